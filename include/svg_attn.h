@@ -1,0 +1,201 @@
+/*
+ * svg_attn.h — C ABI of libsvgattn.so, the MI355X (gfx950) sparse-attention engine that sits behind the
+ * attention-processor / operator API of svg-project/Sparse-VideoGen.
+ *
+ * Every entry point is `extern "C"`, takes raw device pointers + sizes + an opaque hipStream_t (as void*),
+ * launches asynchronously on that stream, never allocates, never synchronises, never throws.  The return
+ * value is 0 on success or a negative SVG_ERR_* code (svg_strerror() gives text).  Tensors are owned by the
+ * caller.  "ref:" lines cite the reference interface (path:line under the Sparse-VideoGen tree) that the
+ * entry point replaces; INTEGRATION.md shows the Python-side binding a maintainer would add.
+ *
+ * Layout conventions (same as the reference): Q/K/V/O are contiguous [cfg*H, S, D] ("BH, S, D"), element
+ * type bf16 or fp16 (dtype code), D in {64, 128}.  Token order along S is the model's: Hunyuan/Wan/Cosmos
+ * video tokens first (frame-major, idx = f*P + p) then text; CogVideoX text first.
+ */
+#ifndef SVG_ATTN_H_
+#define SVG_ATTN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVG_DTYPE_BF16 0
+#define SVG_DTYPE_F16 1
+
+#define SVG_OK 0
+#define SVG_ERR_BAD_ARG (-1)       /* null pointer, negative size, inconsistent geometry          */
+#define SVG_ERR_UNSUPPORTED (-2)   /* head_dim / dtype / size outside what the kernels implement  */
+#define SVG_ERR_WORKSPACE (-3)     /* caller-provided workspace too small                          */
+#define SVG_ERR_LAUNCH (-4)        /* hipLaunchKernel / attribute call failed (see svg_last_hip_error) */
+
+const char* svg_strerror(int code);
+int svg_last_hip_error(void);          /* raw hipError_t of the last failing launch in this thread */
+const char* svg_build_info(void);      /* "libsvgattn gfx950 <date> ..."                           */
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout transformation ("placement").
+ * ref: svg/models/hyvideo/placement.py:124-153 (hunyuan_sparse_head_placement),
+ *      svg/models/hyvideo/placement.py:360-387 (hunyuan_hidden_states_placement),
+ *      svg/models/cog/placement.py:80-82 (text-first variant), svg/models/wan/placement.py (ctx = 0).
+ * For every (cfg, head) with best_mask_idx != 0 ("temporal head") video row f*P+p moves to p*F+f
+ * (forward) or p*F+f moves to f*P+p (inverse); text rows and "spatial" heads are copied unchanged.
+ * best_mask_idx: device int64 [BH].  text_first = 0: text is the last `context_length` rows
+ * (Hunyuan/Wan), 1: the first `context_length` rows (CogVideoX).  n_tensors in {1,2,3}: the same
+ * transformation is applied to up to three tensors in one launch (Q,K,V).
+ * ---------------------------------------------------------------------------------------------- */
+int svg_head_placement(const void* const* src, void* const* dst, int32_t n_tensors, const int64_t* best_mask_idx,
+                       int32_t BH, int32_t S, int32_t D, int32_t dtype, int32_t context_length, int32_t num_frame,
+                       int32_t frame_size, int32_t text_first, int32_t inverse, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token permutation (gather) and inverse permutation (scatter) of rows.
+ * ref: svg/kernels/triton/permute.py:12-43,82-128 (Y[bh,s,:] = X[bh, idx[bh,s], :])
+ *      svg/kernels/triton/permute.py:46-75,131-170 (Y[bh, idx[bh,s], :] = X[bh,s,:])
+ * idx: device int32 [BH, S].
+ * ---------------------------------------------------------------------------------------------- */
+int svg_permute_rows(const void* x, const int32_t* idx, void* y, int32_t BH, int32_t S, int32_t D, int32_t dtype,
+                     void* stream);
+int svg_inverse_permute_rows(const void* x, const int32_t* idx, void* y, int32_t BH, int32_t S, int32_t D,
+                             int32_t dtype, void* stream);
+
+/* Stable argsort of cluster labels (counting sort): sorted_idx[b, :] = argsort(labels[b, :], stable),
+ * counts[b, k] = |{n : labels[b,n] == k}|.  This fixes the tie order the reference leaves unspecified
+ * (torch.argsort without stable=True, ref: svg/kernels/triton/permute.py:113, svg/kmeans_utils.py:396).
+ * labels: device int32 [B, N] with values in [0, K); sorted_idx: int32 [B, N]; counts: int32 [B, K] (may be NULL).
+ * workspace: svg_argsort_workspace_bytes(B, N, K) bytes of device scratch. */
+size_t svg_argsort_workspace_bytes(int32_t B, int32_t N, int32_t K);
+int svg_argsort_labels(const int32_t* labels, int32_t* sorted_idx, int32_t* counts, int32_t B, int32_t N, int32_t K,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SVG1 block-sparse attention (and the dense baseline) — one analytic mask family.
+ * ref: flex_attention(q, k, v, block_mask) at svg/models/hyvideo/attention.py:401-403 with the mask_mod of
+ *      svg/models/hyvideo/utils.py:20-44, svg/models/wan/utils.py:25-41, svg/models/cog/utils.py:30-46;
+ *      dense: flash_attn_varlen_func with cu_seqlens [0, valid, S], svg/models/hyvideo/attention.py:452-470.
+ * allowed(q, k) = (q < real_len && k < real_len &&
+ *                  (|q - k| < band || colfull_lo <= k < colfull_hi || rowfull_lo <= q < rowfull_hi))
+ *              || (q >= real_len && k >= real_len)
+ *   Hunyuan : real_len = V + prompt_len, band = floor(w*P/128)*128, colfull = rowfull = [V, real_len)
+ *   Wan     : real_len = S, band = ceil(w*P/128)*128 + 1 (the reference uses <=), colfull = [0, P), rowfull = {}
+ *   Cog     : real_len = S, band = floor(w*P/128)*128, colfull = [0, Lp (+P if sink)), rowfull = [0, Lp)
+ *   dense   : band = S + 1 (two segments when real_len < S, i.e. cu_seqlens [0, real_len, S])
+ * Rows with no allowed key produce zeros.  The mask is evaluated element-wise on band-edge tiles, exactly as
+ * flex_attention applies mask_mod inside partial blocks.
+ *
+ * Fused layout transformation: when head_perm_flag != NULL, heads with head_perm_flag[bh] != 0 are processed
+ * in token-major order *without* materialising the permuted tensors: logical row i (< perm_V, offset by
+ * perm_vid0) is read from / written to physical row vid0 + (i%F)*P + i/F.  The mask is in logical order.
+ * This equals placement -> attention -> inverse placement of the reference (attention.py:514-520).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svg_band_mask {
+    int32_t real_len;
+    int32_t band;
+    int32_t colfull_lo, colfull_hi;
+    int32_t rowfull_lo, rowfull_hi;
+} svg_band_mask_t;
+
+typedef struct svg_perm_desc {
+    const int64_t* head_perm_flag; /* device int64 [BH] (best_mask_idx) or NULL                 */
+    int32_t vid0;                  /* first video row (0 text-last, context_length text-first)  */
+    int32_t num_frame;             /* F                                                          */
+    int32_t frame_size;            /* P                                                          */
+} svg_perm_desc_t;
+
+int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                       int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                       int32_t variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SVG2 variable-block sparse attention.
+ * ref: dynamic_block_sparse_fwd_flashinfer, svg/kmeans_utils.py:1319-1392 (VariableBlockSparseAttentionWrapper
+ *      plan/run, patch assets/patches/modifications.patch:18-78); semantics = dynamic_block_sparse_fwd_torch,
+ *      svg/kmeans_utils.py:902-995: query rows of block-row i attend exactly the kv rows of block-cols j with
+ *      block_map[h, i, j]; blocks are consecutive ranges of sizes q_sizes[h, :], k_sizes[h, :]; rows with no
+ *      active key (and rows of empty blocks) give zeros.
+ * q/o: [Hq, Sq, D], k/v: [Hkv, Skv, D] (Hq % Hkv == 0: GQA group shares map/sizes of its kv head).
+ * block_map: device uint8/bool [Hkv, QB, KB]; q_sizes int32 [Hkv, QB]; k_sizes int32 [Hkv, KB].
+ * Fused token permutation: q_row_idx (int32 [Hq, Sq]) / kv_row_idx (int32 [Hkv, Skv]) map a *permuted* position
+ * to the physical row of q,o / k,v (the `sorted_indices` of permute_tensor_by_labels); NULL = tensors are
+ * already permuted.  With both given the call equals permute(q,k,v) -> attention -> inverse_permute(o)
+ * (ref: svg/models/hyvideo/attention.py:651-653,778-783).
+ * ---------------------------------------------------------------------------------------------- */
+size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq);
+int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
+                           int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
+                           const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
+                           const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                           size_t workspace_bytes, int32_t variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Online profiler (SVG1): mean-squared error of the two candidate masks on sampled query rows.
+ * ref: sample_mse, svg/models/hyvideo/attention.py:376-399 (wan :211-234, cog :120-145) with the profiling masks
+ *      of get_attention_mask, svg/models/hyvideo/utils.py:47-93 (wan/utils.py:63-110, cog/utils.py:61-88),
+ *      evaluated analytically instead of from two materialised [10000, S] fp32 masks.
+ * rows: device int64 [R] sampled query rows (R <= 64 multiple-of-anything; padded internally).
+ * profile mask (block = 128): |floor(x/128) - floor(y/128)| < band_blocks with x, y the row / column index in
+ * frame-major order (mask 0, "spatial") or in token-major order (mask 1, "temporal"); the per-model quirks of
+ * the reference masks (Wan sink columns, Cog's un-offset spatial band and text-less temporal mask) are expressed
+ * through svg_profile_variant_t.  A sampled row whose mask admits no key yields NaN like the reference's softmax
+ * over all -inf.  out_mse: device float [2, BH].
+ * workspace: svg_sample_mse_workspace_bytes(BH, R, D).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svg_profile_variant {
+    int32_t coord;        /* 0: indices as stored (frame-major); 1: token-major (p*F + f) inside the video range */
+    int32_t origin;       /* subtracted from the coordinate before blocking                                    */
+    int32_t span;         /* band domain: 0 <= x - origin < span                                               */
+    int32_t band_blocks;  /* |floor(x/128) - floor(y/128)| < band_blocks                                       */
+    int32_t sink_cols;    /* keys with y < sink_cols always visible (Wan first-frame sink), in variant coords  */
+    int32_t text_lo, text_hi; /* rows / cols in [text_lo, text_hi) are all-ones (empty when lo >= hi)          */
+} svg_profile_variant_t;
+
+typedef struct svg_profile_desc {
+    int32_t vid0;         /* first video row                                   */
+    int32_t num_frame;    /* F                                                 */
+    int32_t frame_size;   /* P                                                 */
+    int32_t emulate_bf16; /* 1: round scores / outputs to the input dtype like the reference's bf16 torch ops */
+    svg_profile_variant_t variant[2]; /* [0] "spatial" mask, [1] "temporal" mask */
+} svg_profile_desc_t;
+
+size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t D, int32_t S);
+int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S,
+                   int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * flash-kmeans (Euclidean Lloyd iterations, batched over heads).
+ * ref: batch_kmeans_Euclid, svg/kmeans_utils.py:684-733; assign kernel :464-554; sorted centroid update
+ *      :258-322,375-421.  One call = one Lloyd iteration, entirely on device:
+ *   labels[b,n]   = argmin_k max(0, xsq[b,n] + csq[b,k] - 2 <x[b,n], c[b,k]>)   (lowest index wins ties)
+ *   c_new[b,k]    = mean of assigned points (fp32 accumulate, deterministic order), old centroid if empty
+ *   counts[b,k]   = cluster sizes;  sorted_idx = stable argsort(labels);  shift[b] = max_k ||c_new - c||
+ * x: [B, N, D]; centroids_in/out: [B, K, D] (same dtype as x); labels int32 [B, N]; counts int32 [B, K];
+ * sorted_idx int32 [B, N]; shift float [B].  xsq float [B, N] must be pre-computed by svg_kmeans_xsq (it is
+ * constant over iterations, ref :704).
+ * ---------------------------------------------------------------------------------------------- */
+int svg_kmeans_xsq(const void* x, float* xsq, int32_t B, int32_t N, int32_t D, int32_t dtype, void* stream);
+size_t svg_kmeans_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D);
+int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, void* centroids_out, int32_t* labels,
+                    int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N, int32_t K, int32_t D,
+                    int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Top-p block selection.
+ * ref: identify_dynamic_map + weighted_softmax, svg/kmeans_utils.py:852-896.
+ * qc: [BH, QC, D], kc: [BH, KC, D] (dtype), k_sizes int32 [BH, KC]; out_map uint8 [BH, QC, KC].
+ * Ties in the descending sort are broken towards the lower cluster index (stable sort).
+ * ---------------------------------------------------------------------------------------------- */
+int svg_identify_dynamic_map(const void* qc, const void* kc, const int32_t* k_sizes, uint8_t* out_map, int32_t BH,
+                             int32_t QC, int32_t KC, int32_t D, int32_t dtype, float top_p, int32_t preserve_length,
+                             void* stream);
+
+/* density of a dynamic map, ref: density_calculation, svg/kmeans_utils.py:13-31.  out: float [BH] */
+int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out, int32_t BH,
+                    int32_t QB, int32_t KB, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVG_ATTN_H_ */

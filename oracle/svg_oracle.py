@@ -1,0 +1,403 @@
+"""CPU oracle for the sparse-attention hot path of svg-project/Sparse-VideoGen.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under sparse-videogen_amd/ imports this module; only tests/, bench.py's
+`cpu_baseline` leg and __graft_entry__.smoke() may, and only as the checker.  Every function restates (in plain
+torch on CPU, fp32 unless the reference itself computes in the input dtype) what the cited reference code computes.
+Citations are `path:line` under the reference tree (/root/reference).
+
+Pinning status (see tests/golden/make_golden.py, which imports the reference itself to produce the fixtures):
+  pinned by running the reference's own code here : mask_mod masks (hy/wan/cog), flex_attention output on CPU,
+      placement (hy/cog ref fns), torch permute / inverse, weighted_softmax, identify_dynamic_map,
+      dynamic_block_sparse_fwd_torch, density_calculation, sparsity_to_width, get_attention_mask (hy/wan/cog) and
+      sample_mse (Hunyuan processor method).
+  PARITY UNPINNED (reference code is GPU-only / third-party): flash-kmeans (Triton kernels, svg/kmeans_utils.py
+      :258-554 — restated from the commented torch form :631-635 and the update finalisation :416-421) and the
+      flashinfer variable-block kernel (anchored on the reference's own test, svg/kernels/test/
+      test_sparse_attn_dyn_blk_wan.py:38-133, i.e. dense attention under the repeat-interleaved block mask).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------------------
+# sparsity -> band width, mask_mod predicates
+# ----------------------------------------------------------------------------------------------------------
+
+
+def sparsity_to_width(sparsity: float, context_length: int, num_frame: int, frame_size: int) -> float:
+    """ref: svg/models/hyvideo/utils.py:142-151 (identical in wan/utils.py:51-60, cog/utils.py:49-58)"""
+    seq_len = context_length + num_frame * frame_size
+    total = seq_len ** 2
+    s = (sparsity * total - 2 * seq_len * context_length) / total
+    width = seq_len * (1 - math.sqrt(1 - s))
+    return width / frame_size
+
+
+def hy_mask(S: int, context_length: int, prompt_length: int, num_frames: int, P: int, mul: float) -> torch.Tensor:
+    """Dense bool mask of generate_temporal_head_mask_mod, ref: svg/models/hyvideo/utils.py:20-44"""
+    q = torch.arange(S)[:, None]
+    k = torch.arange(S)[None, :]
+    real_length = num_frames * P + prompt_length
+    real = (k < real_length) & (q < real_length)
+    fake = (k >= real_length) & (q >= real_length)
+    two_frame = math.floor(mul * P / 128) * 128
+    band = (q - k).abs() < two_frame
+    text_col = (num_frames * P <= k) & (k < real_length)
+    text_row = (num_frames * P <= q) & (q < real_length)
+    return (real & (band | text_col | text_row)) | fake
+
+
+def wan_mask(S: int, num_frames: int, P: int, mul: float) -> torch.Tensor:
+    """ref: svg/models/wan/utils.py:25-41 (ceil, <=, first-frame sink columns)"""
+    q = torch.arange(S)[:, None]
+    k = torch.arange(S)[None, :]
+    two_frame = math.ceil(mul * P / 128) * 128
+    return ((q - k).abs() <= two_frame) | (k < P)
+
+
+def cog_mask(S: int, prompt_length: int, num_frames: int, P: int, mul: float, attn_sink: bool = False) -> torch.Tensor:
+    """ref: svg/models/cog/utils.py:30-46 (text first)"""
+    q = torch.arange(S)[:, None]
+    k = torch.arange(S)[None, :]
+    first_row = q < prompt_length
+    first_col = k < (prompt_length + P) if attn_sink else k < prompt_length
+    two_frame = math.floor(mul * P / 128) * 128
+    return first_col | first_row | ((q - k).abs() < two_frame)
+
+
+# the six integers of svg_band_mask_t (include/svg_attn.h) for each model
+def hy_band_params(S, context_length, prompt_length, num_frames, P, mul):
+    V = num_frames * P
+    real = V + prompt_length
+    return dict(real_len=real, band=math.floor(mul * P / 128) * 128, colfull_lo=V, colfull_hi=real, rowfull_lo=V,
+                rowfull_hi=real)
+
+
+def wan_band_params(S, num_frames, P, mul):
+    return dict(real_len=S, band=math.ceil(mul * P / 128) * 128 + 1, colfull_lo=0, colfull_hi=P, rowfull_lo=0, rowfull_hi=0)
+
+
+def cog_band_params(S, prompt_length, num_frames, P, mul, attn_sink=False):
+    return dict(real_len=S, band=math.floor(mul * P / 128) * 128, colfull_lo=0,
+                colfull_hi=prompt_length + (P if attn_sink else 0), rowfull_lo=0, rowfull_hi=prompt_length)
+
+
+def dense_band_params(S, valid_len=None):
+    return dict(real_len=S if valid_len is None else valid_len, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0,
+                rowfull_hi=0)
+
+
+def band_mask(S: int, real_len: int, band: int, colfull_lo: int, colfull_hi: int, rowfull_lo: int, rowfull_hi: int):
+    """Dense restatement of the predicate documented in include/svg_attn.h (svg_band_mask_t)."""
+    q = torch.arange(S)[:, None]
+    k = torch.arange(S)[None, :]
+    rq, rk = q < real_len, k < real_len
+    in_band = (q - k).abs() < band
+    colf = (k >= colfull_lo) & (k < colfull_hi)
+    rowf = (q >= rowfull_lo) & (q < rowfull_hi)
+    return (rq & rk & (in_band | colf | rowf)) | (~rq & ~rk)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# attention under an element mask
+# ----------------------------------------------------------------------------------------------------------
+
+
+def masked_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor],
+                     scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(q k^T * scale + mask) v in fp32; q,k,v [..., S, D]; mask bool [Sq, Skv] or broadcastable.
+    Rows without any allowed key give zeros (ref: svg/kmeans_utils.py:993 clamp, flex_attention convention).
+    This is what flex_attention(q,k,v,block_mask) (hyvideo/attention.py:401-403) and the dense-masked reference of
+    svg/kernels/test/test_sparse_attn.py:66-87 compute."""
+    qf, kf, vf = q.float(), k.float(), v.float()
+    scale = 1.0 / math.sqrt(q.shape[-1]) if scale is None else scale
+    s = torch.matmul(qf, kf.transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s.masked_fill(~mask, float("-inf"))
+    m = s.max(dim=-1, keepdim=True).values
+    m = torch.where(torch.isinf(m), torch.zeros_like(m), m)
+    p = torch.exp(s - m)
+    l = p.sum(dim=-1, keepdim=True)
+    o = torch.matmul(p, vf) / l.clamp(min=1e-30)
+    return torch.where(l > 0, o, torch.zeros_like(o))
+
+
+def chunked_masked_attention(q, k, v, mask_fn, scale=None, chunk=2048):
+    """Same as masked_attention but builds the mask chunk-by-chunk: mask_fn(q0, q1) -> bool [q1-q0, Skv]."""
+    outs = []
+    for q0 in range(0, q.shape[-2], chunk):
+        q1 = min(q.shape[-2], q0 + chunk)
+        outs.append(masked_attention(q[..., q0:q1, :], k, v, mask_fn(q0, q1), scale))
+    return torch.cat(outs, dim=-2)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# layout transformation (placement)
+# ----------------------------------------------------------------------------------------------------------
+
+
+def _video_slice(S, context_length, text_first):
+    return (context_length, S) if text_first else (0, S - context_length)
+
+
+def head_placement(x: torch.Tensor, best_mask_idx: torch.Tensor, context_length: int, num_frame: int, frame_size: int,
+                   text_first: bool = False, inverse: bool = False) -> torch.Tensor:
+    """ref: ref_hunyuan_sparse_head_placement svg/models/hyvideo/placement.py:156-184 with
+    hunyuan_token_reorder_to_token_major :6-17 (forward) / ref_hunyuan_hidden_states_placement :390-401 with
+    _to_frame_major :20-31 (inverse); text-first: svg/models/cog/placement.py:6-31.  Correct for context_length == 0
+    (the reference torch helper slices `[:-0]` and breaks there; its Triton kernel does not — SURVEY hazard 6)."""
+    cfg, H, S, D = x.shape
+    lo, hi = _video_slice(S, context_length, text_first)
+    out = x.clone()
+    vid = x[:, :, lo:hi, :]
+    if not inverse:
+        perm = vid.reshape(cfg, H, num_frame, frame_size, D).transpose(2, 3).reshape(cfg, H, hi - lo, D)
+    else:
+        perm = vid.reshape(cfg, H, frame_size, num_frame, D).transpose(2, 3).reshape(cfg, H, hi - lo, D)
+    sel = best_mask_idx.to(torch.bool)
+    out[:, :, lo:hi, :] = torch.where(sel[:, :, None, None], perm, vid)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# token permutation
+# ----------------------------------------------------------------------------------------------------------
+
+
+def stable_argsort(labels: torch.Tensor) -> torch.Tensor:
+    """argsort(labels, stable=True): the tie order the reference leaves open (permute.py:113) fixed to 'by index'."""
+    return torch.argsort(labels, dim=-1, stable=True)
+
+
+def permute_by_labels(t: torch.Tensor, labels: torch.Tensor):
+    """ref: permute_tensor_by_labels svg/kmeans_utils.py:828-838 / permute.py:82-128.  t [B,H,S,D], labels [B*H,S]"""
+    B, H, S, D = t.shape
+    idx = stable_argsort(labels.reshape(B * H, S))
+    out = torch.gather(t.reshape(B * H, S, D), 1, idx[..., None].expand(-1, -1, D)).reshape(B, H, S, D)
+    return out, idx.to(torch.int32)
+
+
+def inverse_permutation(t_perm: torch.Tensor, sorted_indices: torch.Tensor) -> torch.Tensor:
+    """ref: apply_inverse_permutation svg/kmeans_utils.py:841-849 / permute.py:131-170: out[idx[s]] = in[s]"""
+    B, H, S, D = t_perm.shape
+    out = torch.empty_like(t_perm).reshape(B * H, S, D)
+    out.scatter_(1, sorted_indices.long().reshape(B * H, S)[..., None].expand(-1, -1, D), t_perm.reshape(B * H, S, D))
+    return out.reshape(B, H, S, D)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# flash-kmeans (PARITY UNPINNED: restated from the commented torch form; see module docstring)
+# ----------------------------------------------------------------------------------------------------------
+
+
+def kmeans_xsq(x: torch.Tensor) -> torch.Tensor:
+    """ref: svg/kmeans_utils.py:704 `(x**2).sum(dim=-1)` in the input dtype, cast to fp32 inside the kernel (:512)"""
+    return (x ** 2).sum(dim=-1).float()
+
+
+def kmeans_csq(c: torch.Tensor) -> torch.Tensor:
+    """ref: svg/kmeans_utils.py:531 `tl.sum(c_tile * c_tile)`: product rounded to the input dtype, fp32 sum"""
+    return (c * c).float().sum(dim=-1)
+
+
+def kmeans_distances(x, xsq, c):
+    """ref: svg/kmeans_utils.py:533-538 dist = x_sq + cent_sq - 2 x.c (fp32 accumulate), clamped at 0"""
+    cross = torch.einsum("bnd,bkd->bnk", x.float(), c.float())
+    return (xsq[:, :, None] + kmeans_csq(c)[:, None, :] - 2.0 * cross).clamp_min(0.0)
+
+
+def kmeans_assign(x, xsq, c):
+    """argmin with lowest-index tie-break (ref :543-548 strict '<' across chunks, first-index tl.argmin inside)"""
+    return kmeans_distances(x, xsq, c).argmin(dim=-1)
+
+
+def kmeans_update(x, labels, c_old):
+    """ref: triton_centroid_update_sorted_euclid svg/kmeans_utils.py:375-421 (fp32 sums, clamp(count,1), empty
+    cluster keeps the old centroid, cast to x.dtype)"""
+    B, N, D = x.shape
+    K = c_old.shape[1]
+    sums = torch.zeros(B, K, D, dtype=torch.float32)
+    sums.scatter_add_(1, labels[..., None].expand(-1, -1, D), x.float())
+    counts = torch.zeros(B, K, dtype=torch.int64)
+    counts.scatter_add_(1, labels, torch.ones_like(labels))
+    cent = sums / counts.float().clamp(min=1.0)[..., None]
+    cent = torch.where((counts == 0)[..., None], c_old.float(), cent)
+    return cent.to(x.dtype), counts.to(torch.int32)
+
+
+def kmeans_iter(x, xsq, c):
+    """one Lloyd iteration, ref: _euclid_iter svg/kmeans_utils.py:629-643"""
+    labels = kmeans_assign(x, xsq, c)
+    c_new, counts = kmeans_update(x, labels, c)
+    shift = (c_new - c).norm(dim=-1).max()
+    return c_new, shift, labels, counts
+
+
+def batch_kmeans_euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=None):
+    """ref: batch_kmeans_Euclid svg/kmeans_utils.py:684-733 incl. its quirk: returned centroids are one update ahead of
+    the returned labels unless it converged (SURVEY hazard 5).  init_centroids is required (device RNG otherwise)."""
+    assert init_centroids is not None, "pass init_centroids: the reference's random init is device-RNG dependent"
+    B, N, D = x.shape
+    xsq = kmeans_xsq(x)
+    c = init_centroids.view(B, n_clusters, D)
+    for it in range(max_iters):
+        c_new, shift, labels, counts = kmeans_iter(x, xsq, c)
+        if shift < tol:
+            break
+        c = c_new
+    return labels, c, counts, it + 1
+
+
+# ----------------------------------------------------------------------------------------------------------
+# SVG2 block selection and variable-block attention
+# ----------------------------------------------------------------------------------------------------------
+
+
+def weighted_softmax(scores: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """ref: svg/kmeans_utils.py:852-861"""
+    dt = scores.dtype
+    s = scores.float()
+    w = weights.float()
+    e = torch.exp(s - s.max(dim=-1, keepdim=True)[0])
+    we = w * e
+    return (we / we.sum(dim=-1, keepdim=True).clamp(min=1e-12)).to(dt)
+
+
+def identify_dynamic_map(qc, kc, q_sizes, k_sizes, p, min_kc_ratio=0.0):
+    """ref: svg/kmeans_utils.py:864-896, with the sort made stable (ties -> lower cluster index; SURVEY hazard 2)."""
+    B, H, QC, D = qc.shape
+    KC = kc.shape[2]
+    scores = torch.matmul(qc, kc.transpose(-2, -1)) / (D ** 0.5)
+    probs = weighted_softmax(scores, k_sizes.unsqueeze(-2).float())
+    sp, si = torch.sort(probs, dim=-1, descending=True, stable=True)
+    cum = torch.cumsum(sp, dim=-1)
+    rm = cum > p
+    rm[..., 1:] = rm[..., :-1].clone()
+    rm[..., 0] = False
+    if min_kc_ratio > 0:
+        rm[..., : int(min_kc_ratio * KC)] = False
+    out = torch.zeros(B, H, QC, KC, dtype=torch.bool)
+    out.scatter_(-1, si, ~rm)
+    return out
+
+
+def block_mask_to_element_mask(block_map, row_sz, col_sz):
+    """ref: svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:47-58"""
+    r = torch.repeat_interleave(block_map, row_sz.long(), dim=0)
+    return torch.repeat_interleave(r, col_sz.long(), dim=1)
+
+
+def dynamic_block_sparse_fwd(q, k, v, dynamic_map, qc_size, kc_size, scale=None):
+    """ref: dynamic_block_sparse_fwd_torch svg/kmeans_utils.py:902-995 (== dense attention under the expanded block
+    mask, which is how the reference's GPU test checks flashinfer).  q [B,H,Sq,D], k/v [B,H,Skv,D]."""
+    B, H, S, D = q.shape
+    out = torch.zeros(B, H, S, D, dtype=torch.float32)
+    for b in range(B):
+        for h in range(H):
+            em = block_mask_to_element_mask(dynamic_map[b, h], qc_size[b, h], kc_size[b, h])
+            out[b, h] = masked_attention(q[b, h], k[b, h], v[b, h], em, scale)
+    return out
+
+
+def density_calculation(dynamic_map, q_sizes, k_sizes):
+    """ref: svg/kmeans_utils.py:13-31"""
+    blk = q_sizes[:, :, :, None] * k_sizes[:, :, None, :]
+    return (blk * dynamic_map).sum(dim=(2, 3)) / blk.sum(dim=(2, 3))
+
+
+def dynamic_map_post_processing(dyn_map, qc_sz, kc_sz, q_sorted_indices, video_length, context_length, prompt_length):
+    """ref: Hunyuan_SAPAttn_Processor2_0.dynamic_map_post_processing svg/models/hyvideo/attention.py:657-702
+    (the map / sizes / indices part; the q,k,v write-back is a plain slice copy)."""
+    dyn_map = F.pad(dyn_map, (0, 2, 0, 2), value=0)
+    dyn_map[:, :, -2, :-1] = True
+    dyn_map[:, :, :-1, -2] = True
+    dyn_map[:, :, -1, -1] = True
+    unprompt = context_length - prompt_length
+    qc_sz = F.pad(qc_sz, (0, 2), value=0)
+    qc_sz[:, :, -2] = prompt_length
+    qc_sz[:, :, -1] = unprompt
+    kc_sz = F.pad(kc_sz, (0, 2), value=0)
+    kc_sz[:, :, -2] = prompt_length
+    kc_sz[:, :, -1] = unprompt
+    qsi = F.pad(q_sorted_indices, (0, context_length), value=0)
+    qsi[:, video_length:] = torch.arange(video_length, video_length + context_length)
+    return dyn_map, qc_sz, kc_sz, qsi
+
+
+# ----------------------------------------------------------------------------------------------------------
+# online profiler
+# ----------------------------------------------------------------------------------------------------------
+
+
+def _blocked_band(n: int, thres_blocks: float) -> torch.Tensor:
+    nb = math.ceil(n / 128)
+    i = torch.arange(nb)
+    blk = (i[:, None] - i[None, :]).abs() < thres_blocks
+    return blk.repeat_interleave(128, 0).repeat_interleave(128, 1)[:n, :n]
+
+
+def profile_masks(model: str, context_length: int, num_frame: int, frame_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Full [S,S] float profiling masks (spatial, temporal).
+    ref: get_attention_mask hyvideo/utils.py:47-93 (1.5 frames, text rows/cols ones), wan/utils.py:63-110 (2 frames,
+    first-frame sink set BEFORE the token-major permutation, ctx == 0), cog/utils.py:61-88 (text first; the spatial
+    band is applied to the un-offset index range [0, ceil(V/128)*128), the temporal mask has no text rows/cols)."""
+    V = num_frame * frame_size
+    S = V + context_length
+
+    def temporal(pix):
+        return pix.reshape(frame_size, num_frame, frame_size, num_frame).permute(1, 0, 3, 2).reshape(V, V)
+
+    if model == "hy":
+        band = _blocked_band(V, (frame_size * 1.5) // 128)
+        out = []
+        for pix in (band, temporal(band)):
+            m = torch.zeros(S, S)
+            m[:V, :V] = pix.float()
+            m[V:, :] = 1
+            m[:, V:] = 1
+            out.append(m)
+        return out[0], out[1]
+    if model == "wan":
+        assert context_length == 0
+        band = _blocked_band(V, (frame_size * 2) // 128)
+        pix = band.clone()
+        pix[:, :frame_size] = True
+        return pix.float(), temporal(pix).float()
+    if model == "cog":
+        c = context_length
+        sp = torch.zeros(S, S)
+        sp[:c, :] = 1
+        sp[:, :c] = 1
+        band = _blocked_band(V, (frame_size * 1.5) // 128)
+        nb128 = min(S, math.ceil(V / 128) * 128)
+        big = _blocked_band(nb128, (frame_size * 1.5) // 128).float()
+        sp[:nb128, :nb128] = torch.maximum(sp[:nb128, :nb128], big)
+        tp = torch.zeros(S, S)
+        tp[c:, c:] = temporal(band).float()
+        return sp, tp
+    raise ValueError(model)
+
+
+def sample_mse(q, k, v, sampled_rows, masks):
+    """ref: sample_mse svg/models/hyvideo/attention.py:376-399, computed in the input dtype exactly like the reference
+    (bf16 matmul outputs, bf16 softmax outputs).  masks: two [rows_available, S] float masks.  -> [2, cfg, H]"""
+    cfg, H, S, D = q.shape
+    sq = q[:, :, sampled_rows, :]
+    scores = torch.matmul(sq, k.transpose(-2, -1)) / (D ** 0.5)
+    golden = torch.matmul(F.softmax(scores, dim=-1), v)
+    out = torch.zeros(len(masks), cfg, H, dtype=q.dtype)
+    for i, m in enumerate(masks):
+        sm = m[sampled_rows, :]
+        w = F.softmax(scores.masked_fill(sm == 0, float("-inf")), dim=-1)
+        hs = torch.matmul(w, v)
+        out[i] = torch.mean((hs - golden) ** 2, dim=(2, 3))
+    return out
+
+
+def sample_mse_fp32(q, k, v, sampled_rows, masks):
+    """Same quantity in fp32 throughout (what the HIP profiler computes with emulate_bf16 = 0)."""
+    return sample_mse(q.float(), k.float(), v.float(), sampled_rows, masks)

@@ -1,0 +1,477 @@
+// SVG1 band (block-sparse) attention, dense attention and SVG2 variable-block attention for gfx950.
+// The MFMA / LDS / online-softmax machinery is attn_core.h; this file supplies the two scheduling policies
+// (which KV tiles a workgroup visits, where rows live in HBM, which elements are masked) and the C ABI.
+#include "attn_core.h"
+
+namespace svg {
+
+// =====================================================================================================
+// Band policy: analytic mask family (see svg_band_mask_t in svg_attn.h)
+// =====================================================================================================
+template <typename T, int D, int NW>
+struct BandPolicy {
+    static constexpr bool kFixup = false;
+    static constexpr bool kPartialOut = false;
+    static constexpr int BM = NW * 32;
+
+    struct Params {
+        const T* q;
+        const T* k;
+        const T* v;
+        T* o;
+        int S, BH, nqt;
+        float scale_log2;
+        int real_len, band, cf_lo, cf_hi, rf_lo, rf_hi;
+        const int64_t* head_flag;
+        int vid0, F, P, V;
+    };
+    struct Ctx {
+        int head, q0, q_end, nT, perm;
+        int seg_lo[3], seg_n[3];
+    };
+    struct KvCursor {};
+
+    static __device__ __forceinline__ int phys_row(const Params& p, const Ctx& c, int logical) {
+        if (c.perm) {
+            const unsigned i = (unsigned)(logical - p.vid0);
+            if (i < (unsigned)p.V) {
+                const unsigned pp = i / (unsigned)p.F;
+                const unsigned f = i - pp * (unsigned)p.F;
+                return p.vid0 + (int)(f * (unsigned)p.P + pp);
+            }
+        }
+        return logical;
+    }
+
+    static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
+        // XCD-aware work mapping: consecutive dispatch ids round-robin over the 8 XCDs; give every XCD 32
+        // neighbouring q-tiles of the same 256-tile window so their KV windows overlap in that XCD's L2 while
+        // the whole chip stays within one or two heads (KV working set fits the 256 MiB Infinity Cache).
+        const int total = p.nqt * p.BH;
+        const int b = blockIdx.x;
+        const int full = (total / (kNumXCD * 32)) * (kNumXCD * 32);
+        int w = b;
+        if (b < full) {
+            const int xcd = b % kNumXCD, s = b / kNumXCD;
+            w = (s / 32) * (kNumXCD * 32) + xcd * 32 + (s % 32);
+        }
+        c.head = w / p.nqt;
+        const int qt = w - c.head * p.nqt;
+        c.q0 = qt * BM;
+        c.q_end = min(p.S, c.q0 + BM);
+        c.perm = (p.head_flag != nullptr) && (p.head_flag[c.head] != 0);
+
+        // ---- KV schedule: up to three key intervals -> sorted, merged, tile-aligned ranges ----
+        // (explicit scalars, no runtime-indexed arrays: keeps everything in SGPRs, no scratch)
+        constexpr int BIG = 1 << 28;
+        int alo = BIG, ahi = BIG, blo = BIG, bhi = BIG, clo = BIG, chi = BIG;
+        const int real = p.real_len;
+        if (c.q0 < real) {
+            const int qr1 = min(c.q_end, real);
+            if (c.q0 < p.rf_hi && qr1 > p.rf_lo) {
+                alo = 0, ahi = (real + kBN - 1) / kBN;
+            } else {
+                alo = max(0, c.q0 - p.band + 1) / kBN;
+                ahi = (min(real, qr1 - 1 + p.band) + kBN - 1) / kBN;
+                const int ch = min(p.cf_hi, real);
+                if (ch > p.cf_lo) blo = p.cf_lo / kBN, bhi = (ch + kBN - 1) / kBN;
+            }
+        }
+        if (c.q_end > real) clo = real / kBN, chi = (p.S + kBN - 1) / kBN;
+#define SVG_CSWAP(x, xh, y, yh) if (y < x) { int t_ = x; x = y; y = t_; t_ = xh; xh = yh; yh = t_; }
+        SVG_CSWAP(alo, ahi, blo, bhi)
+        SVG_CSWAP(blo, bhi, clo, chi)
+        SVG_CSWAP(alo, ahi, blo, bhi)
+#undef SVG_CSWAP
+        if (blo < BIG && blo <= ahi) {
+            ahi = max(ahi, bhi);
+            blo = clo, bhi = chi, clo = BIG, chi = BIG;
+            if (blo < BIG && blo <= ahi) ahi = max(ahi, bhi), blo = BIG, bhi = BIG;
+        } else if (clo < BIG && clo <= bhi) {
+            bhi = max(bhi, chi), clo = BIG, chi = BIG;
+        }
+        c.seg_lo[0] = alo, c.seg_n[0] = ahi - alo;
+        c.seg_lo[1] = blo, c.seg_n[1] = bhi - blo;
+        c.seg_lo[2] = clo, c.seg_n[2] = chi - clo;
+        c.nT = c.seg_n[0] + c.seg_n[1] + c.seg_n[2];
+        return true;
+    }
+
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.head * p.S * D; }
+
+    static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
+    static __device__ __forceinline__ int q_phys(const Params& p, const Ctx& c, int row) {
+        const int l = c.q0 + row;
+        return l < c.q_end ? phys_row(p, c, l) : -1;
+    }
+    static __device__ __forceinline__ int tile_key0(const Ctx& c, int t) {
+        int tile;
+        if (t < c.seg_n[0]) tile = c.seg_lo[0] + t;
+        else if (t < c.seg_n[0] + c.seg_n[1]) tile = c.seg_lo[1] + (t - c.seg_n[0]);
+        else tile = c.seg_lo[2] + (t - c.seg_n[0] - c.seg_n[1]);
+        return tile * kBN;
+    }
+    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor&, int) {}
+    static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor&, int t, int row) {
+        const int l = tile_key0(c, t) + row;
+        return l < p.S ? phys_row(p, c, l) : -1;
+    }
+
+    static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
+        const int w0 = c.q0 + wrow0;
+        if (w0 >= c.q_end) return TILE_SKIP;
+        const int w1 = min(w0 + 32, c.q_end);       // rows [w0, w1)
+        const int k1 = min(k0 + kBN, p.S);          // keys [k0, k1)
+        const int real = p.real_len;
+        // ---- every pair allowed? ----
+        bool all = false;
+        if (k0 + kBN <= p.S) {
+            if (w1 <= real && k1 <= real) {
+                const bool band_all = (k1 - 1 - w0 < p.band) && (w1 - 1 - k0 < p.band);
+                const bool col_all = (k0 >= p.cf_lo && k1 <= p.cf_hi);
+                const bool row_all = (w0 >= p.rf_lo && w1 <= p.rf_hi);
+                all = band_all || col_all || row_all;
+            } else if (w0 >= real && k0 >= real) {
+                all = true;
+            }
+        }
+        if (all) return TILE_FULL;
+        // ---- any pair allowed? ----
+        bool any = false;
+        if (w0 < real && k0 < real) {
+            const int w1r = min(w1, real), k1r = min(k1, real);
+            const bool band_any = (k0 - (w1r - 1) < p.band) && (w0 - (k1r - 1) < p.band);
+            const bool col_any = (k0 < p.cf_hi && k1r > p.cf_lo);
+            const bool row_any = (w0 < p.rf_hi && w1r > p.rf_lo);
+            any = band_any || col_any || row_any;
+        }
+        if (w1 > real && k1 > real) any = true;
+        return any ? TILE_PARTIAL : TILE_SKIP;
+    }
+    static __device__ __forceinline__ bool allowed(const Params& p, const Ctx&, int q, int k) {
+        const bool rq = q < p.real_len, rk = k < p.real_len;
+        const bool in_band = (unsigned)(q - k + p.band - 1) < (unsigned)(2 * p.band - 1);
+        const bool colf = (unsigned)(k - p.cf_lo) < (unsigned)(p.cf_hi - p.cf_lo);
+        const bool rowf = (unsigned)(q - p.rf_lo) < (unsigned)(p.rf_hi - p.rf_lo);
+        // bitwise on purpose: branch-free, one v_cndmask per element in the caller
+        return ((rq & rk) & (in_band | colf | rowf)) | ((!rq & !rk) & (k < p.S));
+    }
+    static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
+};
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPolicy<T, D, NW>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<T, D, NW, BandPolicy<T, D, NW>>(prm, smem, nullptr);
+}
+
+// =====================================================================================================
+// Variable-block policy (SVG2): q rows of block-row i attend the kv rows of the active block-cols.
+// The active, non-empty column blocks of the workgroup's block-row are compacted into a run list in LDS
+// (start, inclusive prefix of lengths); KV tiles are cut from the *concatenation* of the runs, so tiles are
+// always full except the last one — no per-cluster padding waste on the key side.
+// =====================================================================================================
+constexpr int kVbMaxKB = 4096;
+
+template <typename T, int D, int NW>
+struct VarblockPolicy {
+    static constexpr bool kFixup = false;
+    static constexpr bool kPartialOut = false;
+    static constexpr int BM = NW * 32;
+
+    struct Params {
+        const T* q;
+        const T* k;
+        const T* v;
+        T* o;
+        int Hq, Hkv, group, Sq, Skv, QB, KB, max_tiles, kb_cap;
+        float scale_log2;
+        const uint8_t* block_map;   // [Hkv, QB, KB]
+        const int32_t* q_off;       // [Hkv, QB + 1] exclusive prefix of q_sizes
+        const int32_t* k_off;       // [Hkv, KB + 1]
+        const int32_t* tile_off;    // [Hkv, QB + 1] exclusive prefix of ceil(q_size / BM)
+        const int32_t* q_row_idx;   // [Hq, Sq] or null
+        const int32_t* kv_row_idx;  // [Hkv, Skv] or null
+    };
+    struct Ctx {
+        int hq, hkv, q0, q_end, nT, total;  // q rows [q0, q_end) in permuted coordinates; total = active keys
+        const int32_t* run_start;           // LDS: permuted start position of run j
+        const int32_t* run_pref;            // LDS: inclusive prefix of run lengths (run_pref[j] = end of run j in compact coords)
+        const int32_t* qidx;
+        const int32_t* kidx;
+        int nruns;
+    };
+    struct KvCursor {
+        int j;
+    };
+
+    static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char* plds) {
+        c.hq = blockIdx.y;
+        c.hkv = c.hq / p.group;
+        const int32_t* toff = p.tile_off + (size_t)c.hkv * (p.QB + 1);
+        const int w = blockIdx.x;
+        if (w >= toff[p.QB]) return false;
+        // block-row i with tile_off[i] <= w < tile_off[i+1]
+        int a = 0, bnd = p.QB;
+        while (bnd - a > 1) {
+            const int mid = (a + bnd) >> 1;
+            if (toff[mid] <= w) a = mid; else bnd = mid;
+        }
+        const int i = a;
+        const int32_t* qoff = p.q_off + (size_t)c.hkv * (p.QB + 1);
+        const int sub = w - toff[i];
+        c.q0 = qoff[i] + sub * BM;
+        c.q_end = min(qoff[i + 1], c.q0 + BM);
+        c.qidx = p.q_row_idx ? p.q_row_idx + (size_t)c.hq * p.Sq : nullptr;
+        c.kidx = p.kv_row_idx ? p.kv_row_idx + (size_t)c.hkv * p.Skv : nullptr;
+
+        // ---- compact the active non-empty column blocks of row i into the LDS run list ----
+        int32_t* run_start = (int32_t*)plds;
+        int32_t* run_pref = run_start + p.kb_cap;
+        int32_t* wave_cnt = run_pref + p.kb_cap;      // [NW] counts, [NW] lengths
+        const uint8_t* mrow = p.block_map + ((size_t)c.hkv * p.QB + i) * p.KB;
+        const int32_t* koff = p.k_off + (size_t)c.hkv * (p.KB + 1);
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        constexpr int NT = NW * 64;
+        int base_cnt = 0, base_len = 0;
+        for (int j0 = 0; j0 < p.KB; j0 += NT) {
+            const int j = j0 + tid;
+            int len = 0, st = 0;
+            if (j < p.KB && mrow[j]) {
+                st = koff[j];
+                len = koff[j + 1] - st;
+            }
+            const int flag = len > 0;
+            int icnt = flag, ilen = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t1 = __shfl_up(icnt, o), t2 = __shfl_up(ilen, o);
+                if (lane >= o) icnt += t1, ilen += t2;
+            }
+            __syncthreads();  // previous round's readers of wave_cnt are done
+            if (lane == 63) wave_cnt[wv] = icnt, wave_cnt[NW + wv] = ilen;
+            __syncthreads();
+            int wc = base_cnt, wl = base_len;
+            for (int x = 0; x < wv; ++x) wc += wave_cnt[x], wl += wave_cnt[NW + x];
+            if (flag) {
+                run_start[wc + icnt - 1] = st;
+                run_pref[wc + icnt - 1] = wl + ilen;
+            }
+            for (int x = 0; x < NW; ++x) base_cnt += wave_cnt[x], base_len += wave_cnt[NW + x];
+        }
+        __syncthreads();
+        c.nruns = base_cnt;
+        c.total = base_len;
+        c.run_start = run_start;
+        c.run_pref = run_pref;
+        c.nT = (c.total + kBN - 1) / kBN;
+        return true;
+    }
+
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.hq * p.Sq * D; }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.hkv * p.Skv * D; }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.hkv * p.Skv * D; }
+    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.hq * p.Sq * D; }
+
+    static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
+    static __device__ __forceinline__ int q_phys(const Params&, const Ctx& c, int row) {
+        const int l = c.q0 + row;
+        if (l >= c.q_end) return -1;
+        return c.qidx ? c.qidx[l] : l;
+    }
+    static __device__ __forceinline__ int tile_key0(const Ctx&, int t) { return t * kBN; }
+    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) { cu.j = 0; }
+    static __device__ __forceinline__ int kv_phys(const Params&, const Ctx& c, KvCursor& cu, int t, int row) {
+        const int pos = t * kBN + row;  // compact coordinate
+        if (pos >= c.total) return -1;
+        int j = cu.j;
+        while (c.run_pref[j] <= pos) ++j;  // tiles advance monotonically: amortised O(1)
+        cu.j = j;
+        const int len_before = j > 0 ? c.run_pref[j - 1] : 0;
+        const int perm = c.run_start[j] + (pos - len_before);
+        return c.kidx ? c.kidx[perm] : perm;
+    }
+    static __device__ __forceinline__ int classify(const Params&, const Ctx& c, int k0, int wrow0) {
+        if (c.q0 + wrow0 >= c.q_end) return TILE_SKIP;
+        return (k0 + kBN <= c.total) ? TILE_FULL : TILE_PARTIAL;
+    }
+    static __device__ __forceinline__ bool allowed(const Params&, const Ctx& c, int, int k) { return k < c.total; }
+    static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
+};
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void varblock_attn_kernel(typename VarblockPolicy<T, D, NW>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<T, D, NW, VarblockPolicy<T, D, NW>>(prm, smem, smem + attn_lds_bytes<D, NW>());
+}
+
+static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
+
+// plan: exclusive prefix sums of q_sizes, k_sizes and of the per-block-row tile counts.  grid = (Hkv), block = 256
+__global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __restrict__ q_sizes,
+                                                            const int32_t* __restrict__ k_sizes, int32_t* __restrict__ q_off,
+                                                            int32_t* __restrict__ k_off, int32_t* __restrict__ tile_off,
+                                                            int QB, int KB, int BM) {
+    __shared__ int32_t wtot[4];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto scan = [&](const int32_t* in, int32_t* out, int n, int div) {
+        int carry = 0;
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            const int i = i0 + tid;
+            int v = i < n ? in[i] : 0;
+            if (div > 0) v = (v + div - 1) / div;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            __syncthreads();
+            if (lane == 63) wtot[wv] = incl;
+            __syncthreads();
+            int wb = carry;
+            for (int x = 0; x < wv; ++x) wb += wtot[x];
+            if (i < n) out[i] = wb + incl - v;
+            carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        }
+        if (tid == 0) out[n] = carry;
+        __syncthreads();
+    };
+    scan(q_sizes + (size_t)h * QB, q_off + (size_t)h * (QB + 1), QB, 0);
+    scan(k_sizes + (size_t)h * KB, k_off + (size_t)h * (KB + 1), KB, 0);
+    scan(q_sizes + (size_t)h * QB, tile_off + (size_t)h * (QB + 1), QB, BM);
+}
+
+thread_local int g_last_hip_error = 0;
+
+template <typename K, typename Prm>
+static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds, hipStream_t st) {
+    static thread_local const void* configured[16];
+    static thread_local int nconf = 0;
+    bool seen = false;
+    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
+    if (!seen) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return SVG_ERR_LAUNCH;
+        }
+        if (nconf < 16) configured[nconf++] = (const void*)kernel;
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, st, prm);
+    return launch_status();
+}
+
+template <typename T, int D, int NW>
+static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
+                    const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
+    using Pol = BandPolicy<T, D, NW>;
+    typename Pol::Params p;
+    p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
+    p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
+    p.scale_log2 = sm_scale * 1.4426950408889634f;
+    p.real_len = mask->real_len, p.band = mask->band;
+    p.cf_lo = mask->colfull_lo, p.cf_hi = mask->colfull_hi, p.rf_lo = mask->rowfull_lo, p.rf_hi = mask->rowfull_hi;
+    p.head_flag = nullptr, p.vid0 = 0, p.F = 1, p.P = 1, p.V = 0;
+    if (perm && perm->head_perm_flag) {
+        p.head_flag = perm->head_perm_flag;
+        p.vid0 = perm->vid0, p.F = perm->num_frame, p.P = perm->frame_size, p.V = perm->num_frame * perm->frame_size;
+    }
+    return launch_attn(band_attn_kernel<T, D, NW>, p, dim3(p.nqt * BH), NW * 64, attn_lds_bytes<D, NW>(), st);
+}
+
+}  // namespace svg
+
+using namespace svg;
+
+extern "C" int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                  int32_t dtype, float sm_scale, const svg_band_mask_t* mask,
+                                  const svg_perm_desc_t* perm, int32_t variant, void* stream) {
+    if (!q || !k || !v || !o || !mask || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
+    if (mask->real_len < 0 || mask->real_len > S || mask->band < 1 || mask->band > S + 1) return SVG_ERR_BAD_ARG;
+    if (mask->colfull_lo > mask->colfull_hi || mask->rowfull_lo > mask->rowfull_hi) return SVG_ERR_BAD_ARG;
+    if (perm && perm->head_perm_flag) {
+        if (perm->num_frame <= 0 || perm->frame_size <= 0 || perm->vid0 < 0 ||
+            (int64_t)perm->vid0 + (int64_t)perm->num_frame * perm->frame_size > S)
+            return SVG_ERR_BAD_ARG;
+    }
+    if ((int64_t)BH * S * D >= (1ll << 40)) return SVG_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const bool w4 = (variant == 1);  // variant 0: 8 waves x 32 rows (default); 1: 4 waves x 32 rows, 2 WG / CU
+#define SVG_BAND_DISPATCH(T)                                                                                       \
+    if (D == 128) return w4 ? run_band<T, 128, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                      \
+                            : run_band<T, 128, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);                     \
+    if (D == 64) return w4 ? run_band<T, 64, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                        \
+                           : run_band<T, 64, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+    if (dtype == SVG_DTYPE_BF16) {
+        SVG_BAND_DISPATCH(__bf16)
+    } else if (dtype == SVG_DTYPE_F16) {
+        SVG_BAND_DISPATCH(_Float16)
+    }
+#undef SVG_BAND_DISPATCH
+    return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq) {
+    (void)Hq, (void)Sq;
+    if (Hkv <= 0 || QB <= 0 || KB <= 0) return 0;
+    return (size_t)Hkv * (2 * (size_t)(QB + 1) + (size_t)(KB + 1)) * sizeof(int32_t);
+}
+
+namespace svg {
+template <typename T, int D, int NW>
+static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
+                        float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
+                        int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, hipStream_t st) {
+    using Pol = VarblockPolicy<T, D, NW>;
+    int32_t* q_off = (int32_t*)ws;
+    int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
+    int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
+    hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, QB, KB,
+                       Pol::BM);
+    typename Pol::Params p;
+    p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
+    p.Hq = Hq, p.Hkv = Hkv, p.group = Hq / Hkv, p.Sq = Sq, p.Skv = Skv, p.QB = QB, p.KB = KB;
+    p.max_tiles = Sq / Pol::BM + QB;
+    p.kb_cap = (KB + 63) / 64 * 64;
+    p.scale_log2 = sm_scale * 1.4426950408889634f;
+    p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = tile_off;
+    p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
+    return launch_attn(varblock_attn_kernel<T, D, NW>, p, dim3(p.max_tiles, Hq), NW * 64,
+                       attn_lds_bytes<D, NW>() + vb_policy_lds(p.kb_cap), st);
+}
+}  // namespace svg
+
+extern "C" int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv,
+                                      int32_t Sq, int32_t Skv, int32_t D, int32_t dtype, float sm_scale,
+                                      const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB,
+                                      int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                                      size_t workspace_bytes, int32_t variant, void* stream) {
+    if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
+    if (KB > kVbMaxKB) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool w8 = (variant == 1);  // variant 0: 4 waves (128-row q tiles, less padding on ragged blocks); 1: 8 waves
+#define SVG_VB_DISPATCH(T)                                                                                              \
+    if (D == 128)                                                                                                       \
+        return w8 ? run_varblock<T, 128, 8>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, \
+                                            q_row_idx, kv_row_idx, workspace, st)                                       \
+                  : run_varblock<T, 128, 4>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, \
+                                            q_row_idx, kv_row_idx, workspace, st);                                      \
+    if (D == 64)                                                                                                        \
+        return w8 ? run_varblock<T, 64, 8>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB,  \
+                                           q_row_idx, kv_row_idx, workspace, st)                                        \
+                  : run_varblock<T, 64, 4>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB,  \
+                                           q_row_idx, kv_row_idx, workspace, st);
+    if (dtype == SVG_DTYPE_BF16) {
+        SVG_VB_DISPATCH(__bf16)
+    } else if (dtype == SVG_DTYPE_F16) {
+        SVG_VB_DISPATCH(_Float16)
+    }
+#undef SVG_VB_DISPATCH
+    return SVG_ERR_UNSUPPORTED;
+}

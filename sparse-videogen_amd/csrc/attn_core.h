@@ -1,0 +1,306 @@
+// Flash-attention forward core for gfx950 shared by the SVG1 band kernel, the SVG2 variable-block kernel and the
+// online profiler.  One workgroup = NW waves x 32 query rows; KV tiles of 64 keys are staged through LDS.
+//
+// Both GEMMs are computed "swapped" so that every lane owns ONE query row for the whole kernel
+// (row max / row sum / rescale never cross lanes except one lane<->lane+32 exchange per tile):
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]     A = K tile (LDS, ds_read_b128, XOR-swizzled), B = Q (registers)
+//   O^T[d][q]   = sum_key V[key][d] P[q][key] A = V^T (LDS, ds_read_b64_tr_b16 hardware transpose), B = P (registers)
+// MFMA 32x32x16: a lane holds 8 consecutive-k values of row/col (lane & 31), k-group (lane >> 5); the f32x16
+// accumulator holds column (lane & 31) and rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), r = 0..15.
+// Hence the S^T accumulator of a lane *is* the P operand of the second GEMM (keys 16h + 8u + 4g + [0..3] in
+// registers 8h + 4u + [0..3]) — no LDS round trip, no shuffles.
+//
+// LDS images per stage:  K: [64 keys][D] row-major, 16-B chunk c stored at c ^ swz(row) (conflict-free b128 reads)
+//                        V: [D/32][64 keys][32 cols] sub-tiled so that 4 consecutive keys x 32 cols are 256
+//                           contiguous bytes = one conflict-free ds_read_b64_tr_b16 pass.
+// Staging is register-staged and software-pipelined: global loads for tile t+2 are issued right after the
+// ds_writes of tile t+1, one barrier per tile, two LDS stages.
+#pragma once
+#include "svg_common.h"
+
+namespace svg {
+
+constexpr int kBN = 64;  // keys per tile
+
+enum TileClass : int { TILE_SKIP = 0, TILE_FULL = 1, TILE_PARTIAL = 2 };
+
+template <int D>
+struct LdsLayout {
+    static constexpr int kRowBytes = D * 2;
+    static constexpr int kCPR = D / 8;                 // 16-B chunks per row
+    static constexpr int kKBytes = kBN * kRowBytes;    // K tile bytes
+    static constexpr int kVBytes = kBN * kRowBytes;    // V tile bytes
+    static constexpr int kStageBytes = kKBytes + kVBytes;
+    // byte offset of 16-B chunk c of key row `row` inside the K image
+    static __device__ __forceinline__ int k_off(int row, int c) {
+        const int sw = (D == 128) ? (row & 15) : ((row >> 1) & 7);
+        return row * kRowBytes + ((c ^ sw) << 4);
+    }
+    // byte offset of 16-B chunk c (cols 8c..8c+7) of key row `row` inside the V image
+    static __device__ __forceinline__ int v_off(int row, int c) { return (c >> 2) * (kBN * 64) + row * 64 + ((c & 3) << 4); }
+};
+
+template <int D, int NW>
+constexpr int attn_lds_bytes() {
+    // two stages, or the epilogue staging of NW*32 rows with an 8-byte row pad, whichever is larger
+    constexpr int stages = 2 * LdsLayout<D>::kStageBytes;
+    constexpr int epi = NW * 32 * (D * 2 + 8);
+    return stages > epi ? stages : epi;
+}
+
+__device__ __forceinline__ i16x4 lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p));
+}
+
+// The attention kernel body.  Policy P supplies (all functions static __device__):
+//   struct Params; struct Ctx (workgroup-uniform);
+//   bool init(const Params&, Ctx&, char* policy_lds)            -> false: nothing to do (uniform exit)
+//   const T* q_base/k_base/v_base(const Params&, const Ctx&); T* o_base(...)      head base pointers
+//   int  q_logical(ctx, row_in_wg)  / int q_phys(prm, ctx, row_in_wg)            (-1 = row does not exist)
+//   struct KvCursor; kv_cursor_init(prm, ctx, cur, row_in_tile); int kv_phys(prm, ctx, cur, t, row_in_tile)  (-1 invalid)
+//   int  tile_key0(ctx, t)                                       logical index of the first key of tile t
+//   int  classify(prm, ctx, tile_key0, wave_row0)                wave-uniform TileClass
+//   bool allowed(prm, ctx, q_logical, k_logical)                 element predicate for PARTIAL tiles
+//   float score_fixup(float raw)                                 (profiler: dtype rounding emulation)
+//   epilogue: store(prm, ctx, ...) handled here through P::kPartialOut
+template <typename T, int D, int NW, typename P>
+__device__ __forceinline__ void attn_body(const typename P::Params& prm, char* smem, char* policy_lds) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    using L = LdsLayout<D>;
+    constexpr int NT = NW * 64;
+    constexpr int KS = D / 16;          // k-steps of the S^T GEMM
+    constexpr int DB = D / 32;          // 32-wide d blocks of O^T
+    constexpr int NCH = (kBN * L::kCPR) / NT;  // 16-B chunks per thread per tensor per tile
+    static_assert((kBN * L::kCPR) % NT == 0, "tile chunks must divide evenly");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, policy_lds)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_id();
+    const int g = lane >> 5;
+    const int ql = lane & 31;
+    const int row_in_wg = wave * 32 + ql;
+
+    const T* __restrict__ qb = P::q_base(prm, ctx);
+    const T* __restrict__ kb = P::k_base(prm, ctx);
+    const T* __restrict__ vb = P::v_base(prm, ctx);
+
+    // ---- Q fragments (B operand of S^T): 8 consecutive d of this lane's query row per k-step ----
+    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
+    const int q_log = P::q_logical(ctx, row_in_wg);
+    // (rows that do not exist read row 0 instead: a lane only ever feeds its own query row, and such rows are
+    //  never stored, so no predication is needed — predicated loads cost exec-masked blocks)
+    V8 qf[KS];
+    {
+        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
+    }
+
+    // ---- staging bookkeeping: chunk i of this thread covers (row srow[i], 16-B chunk scol[i]) of the tile ----
+    int srow[NCH], k_dst[NCH], v_dst[NCH], scol[NCH];
+    typename P::KvCursor cur[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = tid + i * NT;
+        srow[i] = id / L::kCPR;
+        scol[i] = id - srow[i] * L::kCPR;
+        k_dst[i] = L::k_off(srow[i], scol[i]);
+        v_dst[i] = L::kKBytes + L::v_off(srow[i], scol[i]);
+        P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
+    }
+    u32x4 kreg[NCH], vreg[NCH];
+
+    // Loads are issued unconditionally (row clamped to 0 when the tile row does not exist) and zeroed at
+    // ds_write time: a predicated load would split the loop body into exec-masked blocks and make hipcc's
+    // waitcnt pass fall back to vmcnt(0) at the loop header.
+    // Physical rows are resolved one tile ahead of the data loads (nphys): for the variable-block policy the
+    // resolve is itself a global index load, and this keeps its latency off the critical path.
+    bool svalid[NCH];
+    int nphys[NCH];
+    auto stage_resolve = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : -1;
+    };
+    auto stage_issue = [&](int t) {  // data loads of tile t (rows resolved earlier), then resolve tile t+1
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int phys = nphys[i];
+            svalid[i] = phys >= 0;
+            const size_t off = (size_t)(phys >= 0 ? phys : 0) * D + scol[i] * 8;
+            kreg[i] = *(const u32x4*)(kb + off);
+            vreg[i] = *(const u32x4*)(vb + off);
+        }
+        stage_resolve(t + 1);
+    };
+    auto stage_write = [&](int buf) {
+        char* base = smem + buf * L::kStageBytes;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *(u32x4*)(base + k_dst[i]) = svalid[i] ? kreg[i] : z;
+            *(u32x4*)(base + v_dst[i]) = svalid[i] ? vreg[i] : z;
+        }
+    };
+
+    // ---- per-lane LDS read offsets ----
+    // K A-fragment (block b, k-step ks): row 32b + ql, chunk 2ks + g
+    // the swizzle is an XOR on the chunk index, so the k-step cannot be a plain byte offset: keep the XOR term
+    const int ksw0 = (D == 128) ? (ql & 15) : ((ql >> 1) & 7);  // same for row ql and 32+ql (32 % 16 == 0, (32>>1)%8==0)
+    // V^T tr-read base: rows 4g + (i>>2), col bytes (16*dhalf + 4*(i&3))*2, i = lane & 15, dhalf = (lane>>4)&1
+    const int vi = lane & 15;
+    const int v_lane_off = L::kKBytes + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
+
+    float m_run = -INFINITY;   // running max, log2 domain (already multiplied by scale*log2e)
+    float l_run = 0.f;         // this lane's partial row sum (its 32 of the 64 keys per tile)
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+
+    const float c_log2 = prm.scale_log2;
+    const int nT = ctx.nT;
+
+    stage_resolve(0);
+    if (nT > 0) stage_issue(0);
+    // Pin the Q fragments: the empty asm makes them "defined here", so hipcc waits for the Q loads at this point
+    // and knows at the loop header that they have landed.  Without it the waitcnt pass emits vmcnt(0) in front of
+    // the first MFMA of EVERY iteration, serialising the tile t+1 prefetch behind the compute of tile t.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    if (nT > 0) {
+        stage_write(0);
+        if (nT > 1) stage_issue(1);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nT; ++t) {
+        const int buf = t & 1;
+        const char* kbuf = smem + buf * L::kStageBytes;
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if (cls != TILE_SKIP) {
+            // ---------------- S^T = K Q^T ----------------
+            f32x16 s[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cch = ((2 * ks + g) ^ ksw0) << 4;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const V8 a = *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + cch);
+                    s[b] = E::mfma(a, qf[ks], s[b]);
+                }
+            }
+            // ---------------- mask + online softmax (lane-local row) ----------------
+            if constexpr (P::kFixup) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
+            }
+            if (cls == TILE_PARTIAL) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx * c_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            float psum = 0.f;
+            V8 pf[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c_log2, -m_use));
+                    psum += p;
+                    pf[b][r >> 3][r & 7] = E::from_float(p);
+                }
+            l_run = l_run * alpha + psum;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+            }
+            // ---------------- O^T += V^T P^T ----------------
+            const char* vbase = kbuf + v_lane_off;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int kb0 = 32 * b + 16 * h;
+                        const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
+                        const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
+                        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
+                    }
+            }
+        }
+        if (t + 1 < nT) stage_write(buf ^ 1);
+        if (t + 2 < nT) stage_issue(t + 2);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if constexpr (P::kPartialOut) {
+        // un-normalised fp32 partial: O^T accumulators, running max and row sum (profiler split-KV)
+        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
+        return;
+    } else {
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    // transpose through LDS (all waves are past the last barrier, stage buffers are free): row stride D*2+8 bytes
+    constexpr int kEpiStride = D * 2 + 8;
+    char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            typename E::v4 o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+            const int d0 = 32 * db + 8 * rq + 4 * g;
+            *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // own-wave LDS writes visible to own-wave reads below
+    __builtin_amdgcn_wave_barrier();
+    T* __restrict__ ob = P::o_base(prm, ctx);
+    constexpr int kLanesPerRow = D * 2 / 8;       // 8 B per lane
+    constexpr int kRowsPerPass = 64 / kLanesPerRow;
+    const int sub = lane / kLanesPerRow;
+    const int colb = (lane - sub * kLanesPerRow) * 8;
+    int ephys[32 / kRowsPerPass];  // resolve all output rows first: keeps the (possibly global) index loads in flight together
+#pragma unroll
+    for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+    for (int i = 0; i < 32 / kRowsPerPass; ++i) {
+        const int rr = i * kRowsPerPass + sub;
+        const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+    }
+    }
+}
+
+}  // namespace svg

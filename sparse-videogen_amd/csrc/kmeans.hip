@@ -1,0 +1,301 @@
+// flash-kmeans for gfx950: one Lloyd iteration of batched Euclidean k-means, entirely on device.
+// ref: batch_kmeans_Euclid / _euclid_iter, svg/kmeans_utils.py:629-643,684-733
+//      assign kernel  _euclid_assign_kernel             svg/kmeans_utils.py:464-554
+//      centroid update (sorted, chunked)                svg/kmeans_utils.py:258-322,375-421
+//
+//   assign : S^T[c][n] = <C[c], X[n]> on MFMA 32x32x16 (A = centroid tile from LDS, B = point fragments in
+//            registers, exactly the S^T half of attn_core.h), dist = max(0, xsq[n] + csq[c] - 2 S), running
+//            (min, argmin) per lane, lowest index wins exact ties like the reference's strict '<' across chunks and
+//            first-index argmin inside a chunk.  The N x K distance matrix is never materialised.
+//   update : stable counting sort of the labels (permute.hip) -> every cluster is a contiguous run of
+//            sorted_idx; one workgroup per (batch, cluster) gathers its rows and reduces them in a FIXED order
+//            (fp32), so centroids are bit-reproducible run to run (the reference's atomics are not).
+#include <algorithm>
+
+#include "attn_core.h"
+
+extern "C" size_t svg_argsort_workspace_bytes(int32_t B, int32_t N, int32_t K);
+extern "C" int svg_argsort_labels(const int32_t* labels, int32_t* sorted_idx, int32_t* counts, int32_t B, int32_t N,
+                                  int32_t K, void* workspace, size_t workspace_bytes, void* stream);
+
+namespace svg {
+
+// ---- ||x||^2 exactly like the reference: (x**2) rounded to the input dtype, summed in fp32, rounded to dtype ----
+// ref: svg/kmeans_utils.py:704 `x_sq = (x**2).sum(dim=-1)` on a bf16 tensor, :512 cast to fp32 in the kernel
+template <typename T>
+__global__ __launch_bounds__(256) void xsq_kernel(const T* __restrict__ x, float* __restrict__ xsq, long long rows, int D) {
+    const int lpr = D / 8;                       // lanes per row (8 elements = 16 B each)
+    const int rpb = 256 / lpr;                   // rows per block pass
+    const int sub = threadIdx.x / lpr, li = threadIdx.x - sub * lpr;
+    for (long long r = (long long)blockIdx.x * rpb + sub; r < rows; r += (long long)gridDim.x * rpb) {
+        const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(x + r * D + li * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = Elt<T>::to_float(v[j]);
+            s += Elt<T>::to_float(Elt<T>::from_float(f * f));
+        }
+        for (int o = lpr >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (li == 0) xsq[r] = Elt<T>::to_float(Elt<T>::from_float(s));
+    }
+}
+
+// ---- ||c||^2: products rounded to the input dtype, fp32 sum (ref: svg/kmeans_utils.py:531) ----
+template <typename T>
+__global__ __launch_bounds__(256) void csq_kernel(const T* __restrict__ c, float* __restrict__ csq, long long rows, int D) {
+    const int lpr = D / 8;
+    const int rpb = 256 / lpr;
+    const int sub = threadIdx.x / lpr, li = threadIdx.x - sub * lpr;
+    for (long long r = (long long)blockIdx.x * rpb + sub; r < rows; r += (long long)gridDim.x * rpb) {
+        const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(c + r * D + li * 8);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = Elt<T>::to_float(v[j]);
+            s += Elt<T>::to_float(Elt<T>::from_float(f * f));
+        }
+        for (int o = lpr >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (li == 0) csq[r] = s;
+    }
+}
+
+// ---- assignment: grid = (ceil(N / (NW*32)), B), block = NW*64 ----
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __restrict__ x, const T* __restrict__ cent,
+                                                                    const float* __restrict__ xsq,
+                                                                    const float* __restrict__ csq, int32_t* __restrict__ labels,
+                                                                    int N, int K) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    using L = LdsLayout<D>;
+    constexpr int NT = NW * 64;
+    constexpr int KS = D / 16;
+    constexpr int NCH = (kBN * L::kCPR) / NT;
+    constexpr int kStage = L::kKBytes + kBN * 4;  // centroid tile + its 64 squared norms
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int g = lane >> 5, ql = lane & 31;
+    const int n = blockIdx.x * (NW * 32) + wave * 32 + ql;
+    const T* xb = x + (size_t)b * N * D;
+    const T* cb = cent + (size_t)b * K * D;
+    const float* csqb = csq + (size_t)b * K;
+
+    V8 xf[KS];
+    {
+        const T* xrow = xb + (size_t)(n < N ? n : 0) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const V8*)(xrow + ks * 16);
+    }
+    const float my_xsq = xsq[(size_t)b * N + (n < N ? n : 0)];
+
+    int srow[NCH], scol[NCH], k_dst[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = tid + i * NT;
+        srow[i] = id / L::kCPR;
+        scol[i] = id - srow[i] * L::kCPR;
+        k_dst[i] = L::k_off(srow[i], scol[i]);
+    }
+    u32x4 creg[NCH];
+    float sreg = 0.f;
+    const int nT = (K + kBN - 1) / kBN;
+    auto issue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = t * kBN + srow[i];
+            creg[i] = *(const u32x4*)(cb + (size_t)(c < K ? c : 0) * D + scol[i] * 8);
+        }
+        if (tid < kBN) {
+            const int c = t * kBN + tid;
+            sreg = csqb[c < K ? c : 0];
+        }
+    };
+    auto write = [&](int buf) {
+        char* base = smem + buf * kStage;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *(u32x4*)(base + k_dst[i]) = creg[i];
+        if (tid < kBN) *(float*)(base + L::kKBytes + tid * 4) = sreg;
+    };
+
+    issue(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
+    write(0);
+    if (nT > 1) issue(1);
+    __syncthreads();
+
+    const int ksw0 = (D == 128) ? (ql & 15) : ((ql >> 1) & 7);
+    float best = 3.4e38f;
+    int best_idx = 0;
+    for (int t = 0; t < nT; ++t) {
+        const int buf = t & 1;
+        const char* kbuf = smem + buf * kStage;
+        f32x16 s[2];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[bb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cch = ((2 * ks + g) ^ ksw0) << 4;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const V8 a = *(const V8*)(kbuf + (32 * bb + ql) * L::kRowBytes + cch);
+                s[bb] = E::mfma(a, xf[ks], s[bb]);
+            }
+        }
+        const float* csq_t = (const float*)(kbuf + L::kKBytes);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 cs4 = *(const f32x4*)(csq_t + 32 * bb + 8 * rq + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = t * kBN + 32 * bb + 8 * rq + 4 * g + j;
+                    float dist = my_xsq + cs4[j] - 2.0f * s[bb][rq * 4 + j];
+                    dist = fmaxf(dist, 0.f);
+                    const bool upd = (c < K) & (dist < best);
+                    best = upd ? dist : best;
+                    best_idx = upd ? c : best_idx;
+                }
+            }
+        if (t + 1 < nT) write(buf ^ 1);
+        if (t + 2 < nT) issue(t + 2);
+        __syncthreads();
+    }
+    // the two lanes of a point cover disjoint centroid subsets: merge, lowest index wins ties
+    const float ob = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(best_idx, 32);
+    if (ob < best || (ob == best && oi < best_idx)) best = ob, best_idx = oi;
+    if (g == 0 && n < N) labels[(size_t)b * N + n] = best_idx;
+}
+
+// ---- centroid update: grid = (K, B), block = 256 = 16 row slots x 16 lanes (D = 128) / 32 x 8 (D = 64) ----
+template <typename T, int D>
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict__ x, const T* __restrict__ c_old,
+                                                            T* __restrict__ c_new, const int32_t* __restrict__ sorted_idx,
+                                                            const int32_t* __restrict__ offsets /* [B][nchunks][K], chunk 0 */,
+                                                            const int32_t* __restrict__ counts, float* __restrict__ shift,
+                                                            int N, int K, size_t off_batch_stride) {
+    constexpr int LPR = D / 8;
+    constexpr int SLOTS = 256 / LPR;
+    __shared__ float red[SLOTS][D + 4];
+    __shared__ float nrm[4];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int slot = tid / LPR, li = tid - slot * LPR;
+    const int cnt = counts[(size_t)b * K + k];
+    const int start = offsets[(size_t)b * off_batch_stride + k];
+    const T* xb = x + (size_t)b * N * D;
+    const int32_t* sidx = sorted_idx + (size_t)b * N + start;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int r = slot; r < cnt; r += SLOTS) {
+        const int row = sidx[r];
+        const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(xb + (size_t)row * D + li * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[slot][li * 8 + j] = acc[j];
+    __syncthreads();
+    float d2 = 0.f;
+    if (tid < D) {
+        float s = 0.f;
+        for (int sl = 0; sl < SLOTS; ++sl) s += red[sl][tid];  // fixed order -> deterministic
+        const size_t o = ((size_t)b * K + k) * D + tid;
+        const float oldv = Elt<T>::to_float(c_old[o]);
+        // ref: svg/kmeans_utils.py:416-421 sums / clamp(count,1), empty cluster keeps the old centroid, cast to x.dtype
+        const T nv = cnt > 0 ? Elt<T>::from_float(s / (float)cnt) : c_old[o];
+        c_new[o] = nv;
+        const float df = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(nv) - oldv));
+        d2 = df * df;
+    }
+    d2 = wave_sum(d2);
+    if ((tid & 63) == 0) nrm[tid >> 6] = d2;
+    __syncthreads();
+    if (tid == 0) {
+        const float nr = sqrtf(nrm[0] + nrm[1] + nrm[2] + nrm[3]);
+        atomicMax((int*)(shift + b), __float_as_int(nr));  // non-negative floats order like ints
+    }
+}
+
+template <typename T, int D>
+static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, void* c_out, int32_t* labels, int32_t* counts,
+                           int32_t* sorted_idx, float* shift, int B, int N, int K, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    constexpr int NW = 8;
+    float* csq = (float*)ws;
+    const size_t csq_bytes = ((size_t)B * K * sizeof(float) + 255) / 256 * 256;
+    char* sort_ws = (char*)ws + csq_bytes;
+    const size_t sort_bytes = svg_argsort_workspace_bytes(B, N, K);
+    hipLaunchKernelGGL((csq_kernel<T>), dim3(std::min<long long>(2048, ((long long)B * K + 15) / 16)), dim3(256), 0, st,
+                       (const T*)c_in, csq, (long long)B * K, D);
+    constexpr int lds = 2 * (LdsLayout<D>::kKBytes + kBN * 4);
+    auto kern = kmeans_assign_kernel<T, D, NW>;
+    hipLaunchKernelGGL(kern, dim3((N + NW * 32 - 1) / (NW * 32), B), dim3(NW * 64), lds, st, (const T*)x, (const T*)c_in, xsq,
+                       csq, labels, N, K);
+    int rc = svg_argsort_labels(labels, sorted_idx, counts, B, N, K, sort_ws, sort_bytes, (void*)st);
+    if (rc) return rc;
+    (void)hipMemsetAsync(shift, 0, (size_t)B * sizeof(float), st);
+    const int nchunks = (N + 1023) / 1024;
+    hipLaunchKernelGGL((kmeans_update_kernel<T, D>), dim3(K, B), dim3(256), 0, st, (const T*)x, (const T*)c_in, (T*)c_out,
+                       sorted_idx, (const int32_t*)sort_ws, counts, shift, N, K, (size_t)nchunks * K);
+    return launch_status();
+}
+
+}  // namespace svg
+
+using namespace svg;
+
+extern "C" int svg_kmeans_xsq(const void* x, float* xsq, int32_t B, int32_t N, int32_t D, int32_t dtype, void* stream) {
+    if (!x || !xsq || B <= 0 || N <= 0) return SVG_ERR_BAD_ARG;
+    if (D != 64 && D != 128) return SVG_ERR_UNSUPPORTED;
+    const long long rows = (long long)B * N;
+    const int rpb = 256 / (D / 8);
+    dim3 grid((unsigned)std::min<long long>(4096, (rows + rpb - 1) / rpb));
+    if (dtype == SVG_DTYPE_BF16)
+        hipLaunchKernelGGL((xsq_kernel<__bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, xsq, rows, D);
+    else if (dtype == SVG_DTYPE_F16)
+        hipLaunchKernelGGL((xsq_kernel<_Float16>), grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, xsq, rows, D);
+    else
+        return SVG_ERR_UNSUPPORTED;
+    return launch_status();
+}
+
+extern "C" size_t svg_kmeans_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D) {
+    (void)D;
+    if (B <= 0 || N <= 0 || K <= 0) return 0;
+    const size_t csq_bytes = ((size_t)B * K * sizeof(float) + 255) / 256 * 256;
+    return csq_bytes + svg_argsort_workspace_bytes(B, N, K);
+}
+
+extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, void* centroids_out,
+                               int32_t* labels, int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N,
+                               int32_t K, int32_t D, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !xsq || !centroids_in || !centroids_out || !labels || !counts || !sorted_idx || !shift || !workspace)
+        return SVG_ERR_BAD_ARG;
+    if (B <= 0 || N <= 0 || K <= 0) return SVG_ERR_BAD_ARG;
+    if (K > 8192) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_kmeans_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SVG_DTYPE_BF16) {
+        if (D == 128)
+            return run_kmeans_iter<__bf16, 128>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
+                                                K, workspace, workspace_bytes, st);
+        if (D == 64)
+            return run_kmeans_iter<__bf16, 64>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K,
+                                               workspace, workspace_bytes, st);
+    } else if (dtype == SVG_DTYPE_F16) {
+        if (D == 128)
+            return run_kmeans_iter<_Float16, 128>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
+                                                  K, workspace, workspace_bytes, st);
+        if (D == 64)
+            return run_kmeans_iter<_Float16, 64>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
+                                                 K, workspace, workspace_bytes, st);
+    }
+    return SVG_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,74 @@
+// Shared helpers for the gfx950 kernels of libsvgattn.  CDNA4 only: wave64, MFMA 32x32x16, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svg_attn.h"
+
+namespace svg {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+using f16x8 = _Float16 __attribute__((ext_vector_type(8)));
+using f16x4 = _Float16 __attribute__((ext_vector_type(4)));
+using i16x4 = short __attribute__((ext_vector_type(4)));
+using i16x8 = short __attribute__((ext_vector_type(8)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+using u32x2 = unsigned __attribute__((ext_vector_type(2)));
+
+extern thread_local int g_last_hip_error;
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return SVG_ERR_LAUNCH;
+    }
+    return SVG_OK;
+}
+
+// Element-type traits: storage vectors + the MFMA builtin for that type.
+template <typename T>
+struct Elt;
+
+template <>
+struct Elt<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_float(__bf16 x) { return (float)x; }
+    static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
+};
+
+template <>
+struct Elt<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_float(_Float16 x) { return (float)x; }
+    static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+};
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr int kNumXCD = 8;
+constexpr int kNumCU = 256;
+
+}  // namespace svg

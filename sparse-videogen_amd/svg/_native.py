@@ -1,0 +1,343 @@
+"""ctypes binding of libsvgattn.so (the C ABI declared in include/svg_attn.h).
+
+PyTorch is only plumbing here: it owns the device memory and the HIP stream; every op below passes raw device
+pointers + sizes + the current stream to the C entry point and raises on a non-zero status.  There is NO CPU
+fallback: calling a native op without the library (or with CPU tensors) raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libsvgattn.so"
+_lib: Optional[C.CDLL] = None
+_load_error: Optional[str] = None
+
+SVG_DTYPE_BF16, SVG_DTYPE_F16 = 0, 1
+
+
+class BandMask(C.Structure):
+    """svg_band_mask_t"""
+
+    _fields_ = [
+        ("real_len", C.c_int32),
+        ("band", C.c_int32),
+        ("colfull_lo", C.c_int32),
+        ("colfull_hi", C.c_int32),
+        ("rowfull_lo", C.c_int32),
+        ("rowfull_hi", C.c_int32),
+    ]
+
+    def as_tuple(self):
+        return (self.real_len, self.band, self.colfull_lo, self.colfull_hi, self.rowfull_lo, self.rowfull_hi)
+
+
+class PermDesc(C.Structure):
+    """svg_perm_desc_t"""
+
+    _fields_ = [
+        ("head_perm_flag", C.c_void_p),
+        ("vid0", C.c_int32),
+        ("num_frame", C.c_int32),
+        ("frame_size", C.c_int32),
+    ]
+
+
+class ProfileVariant(C.Structure):
+    """svg_profile_variant_t"""
+
+    _fields_ = [
+        ("coord", C.c_int32),
+        ("origin", C.c_int32),
+        ("span", C.c_int32),
+        ("band_blocks", C.c_int32),
+        ("sink_cols", C.c_int32),
+        ("text_lo", C.c_int32),
+        ("text_hi", C.c_int32),
+    ]
+
+
+class ProfileDesc(C.Structure):
+    """svg_profile_desc_t"""
+
+    _fields_ = [
+        ("vid0", C.c_int32),
+        ("num_frame", C.c_int32),
+        ("frame_size", C.c_int32),
+        ("emulate_bf16", C.c_int32),
+        ("variant", ProfileVariant * 2),
+    ]
+
+
+_I32, _I64, _F32, _VP, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/svg_attn.h declares (tests check this)
+SIGNATURES = {
+    "svg_strerror": (C.c_char_p, [C.c_int]),
+    "svg_last_hip_error": (C.c_int, []),
+    "svg_build_info": (C.c_char_p, []),
+    "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "svg_inverse_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "svg_argsort_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "svg_argsort_labels": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _SZ, _VP]),
+    "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                     C.POINTER(PermDesc), _I32, _VP]),
+    "svg_varblock_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),
+    "svg_varblock_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP,
+                                         _I32, _I32, _VP, _VP, _VP, _SZ, _I32, _VP]),
+    "svg_sample_mse_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
+    "svg_sample_mse": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
+                                 _SZ, _VP]),
+    "svg_kmeans_xsq": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "svg_kmeans_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
+    "svg_kmeans_iter": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
+    "svg_identify_dynamic_map": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, _I32, _VP]),
+    "svg_map_density": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
+}
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("SVG_ATTN_LIB", str(_LIB_PATH)))
+
+
+def load(strict: bool = True) -> Optional[C.CDLL]:
+    """dlopen the library once and type every entry point.  strict=False returns None instead of raising."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    try:
+        lib = C.CDLL(str(p))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    except (OSError, AttributeError) as e:  # missing .so or missing symbol
+        _load_error = f"{p}: {e}"
+        if strict:
+            raise RuntimeError(
+                f"libsvgattn.so could not be loaded ({_load_error}). Build it with "
+                f"`python sparse-videogen_amd/build.py` (hipcc, gfx950). There is no CPU fallback."
+            ) from e
+        return None
+    return _lib
+
+
+def available() -> bool:
+    return load(strict=False) is not None
+
+
+def build_info() -> str:
+    return load().svg_build_info().decode()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.svg_strerror(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc}, hipError {lib.svg_last_hip_error()})")
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return SVG_DTYPE_BF16
+    if t.dtype == torch.float16:
+        return SVG_DTYPE_F16
+    raise RuntimeError(f"libsvgattn supports bfloat16 / float16 tensors, got {t.dtype}")
+
+
+def _dev(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libsvgattn ops need GPU (HIP) tensors; there is no CPU fallback for the sparse path")
+        if not t.is_contiguous():
+            raise RuntimeError("libsvgattn ops need contiguous tensors")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------
+# typed wrappers (torch tensors in, torch tensors out)
+# ------------------------------------------------------------------------------------------------------
+def head_placement(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor], best_mask_idx: torch.Tensor,
+                   context_length: int, num_frame: int, frame_size: int, text_first: bool, inverse: bool) -> None:
+    lib = load()
+    n = len(srcs)
+    assert 1 <= n <= 3 and len(dsts) == n
+    _dev(*srcs, *dsts, best_mask_idx)
+    x = srcs[0]
+    BH = x.shape[0] * x.shape[1]
+    S, D = x.shape[2], x.shape[3]
+    for t in list(srcs) + list(dsts):
+        assert t.shape == x.shape and t.dtype == x.dtype
+    best = best_mask_idx.to(torch.int64).contiguous()
+    assert best.numel() == BH
+    sp = (C.c_void_p * 3)(*[s.data_ptr() for s in srcs], *([None] * (3 - n)))
+    dp = (C.c_void_p * 3)(*[d.data_ptr() for d in dsts], *([None] * (3 - n)))
+    rc = lib.svg_head_placement(C.cast(sp, _VP), C.cast(dp, _VP), n, best.data_ptr(), BH, S, D, _dtype_code(x),
+                                context_length, num_frame, frame_size, int(text_first), int(inverse), _stream())
+    _check(rc, "svg_head_placement")
+
+
+def permute_rows(x: torch.Tensor, idx: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    lib = load()
+    _dev(x, idx)
+    BH, S, D = x.shape
+    assert idx.dtype == torch.int32 and idx.shape == (BH, S)
+    y = torch.empty_like(x)
+    fn = lib.svg_inverse_permute_rows if inverse else lib.svg_permute_rows
+    _check(fn(x.data_ptr(), idx.data_ptr(), y.data_ptr(), BH, S, D, _dtype_code(x), _stream()), "svg_permute_rows")
+    return y
+
+
+def argsort_labels(labels: torch.Tensor, K: int):
+    """labels int32 [B, N] in [0, K) -> (sorted_idx int32 [B, N] (stable), counts int32 [B, K])"""
+    lib = load()
+    _dev(labels)
+    assert labels.dtype == torch.int32 and labels.dim() == 2
+    B, N = labels.shape
+    ws = torch.empty(lib.svg_argsort_workspace_bytes(B, N, K), dtype=torch.uint8, device=labels.device)
+    sidx = torch.empty((B, N), dtype=torch.int32, device=labels.device)
+    counts = torch.empty((B, K), dtype=torch.int32, device=labels.device)
+    rc = lib.svg_argsort_labels(labels.data_ptr(), sidx.data_ptr(), counts.data_ptr(), B, N, K, ws.data_ptr(),
+                                ws.numel(), _stream())
+    _check(rc, "svg_argsort_labels")
+    return sidx, counts
+
+
+def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
+                   head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1,
+                   frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape."""
+    lib = load()
+    _dev(q, k, v, head_perm_flag)
+    assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    S, D = q.shape[-2], q.shape[-1]
+    BH = q.numel() // (S * D)
+    o = torch.empty_like(q) if out is None else out
+    _dev(o)
+    scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    perm = None
+    if head_perm_flag is not None:
+        flag = head_perm_flag.to(torch.int64).contiguous()
+        assert flag.numel() == BH
+        perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    rc = lib.svg_band_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
+                                C.byref(mask), C.byref(perm) if perm is not None else None, variant, _stream())
+    _check(rc, "svg_band_attention")
+    return o
+
+
+def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
+                       k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
+                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = 0) -> torch.Tensor:
+    """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB]."""
+    lib = load()
+    _dev(q, k, v, block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
+    Hq, Sq, D = q.shape
+    Hkv, Skv, _ = k.shape
+    QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
+    assert block_map.shape == (Hkv, QB, KB) and block_map.dtype in (torch.bool, torch.uint8)
+    assert q_sizes.dtype == torch.int32 and k_sizes.dtype == torch.int32
+    if q_row_idx is not None:
+        assert q_row_idx.dtype == torch.int32 and q_row_idx.shape == (Hq, Sq)
+    if kv_row_idx is not None:
+        assert kv_row_idx.dtype == torch.int32 and kv_row_idx.shape == (Hkv, Skv)
+    o = torch.zeros_like(q) if q_row_idx is None else torch.zeros_like(q)
+    ws = torch.empty(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq), dtype=torch.uint8, device=q.device)
+    scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    rc = lib.svg_varblock_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D,
+                                    _dtype_code(q), scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(),
+                                    QB, KB, _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), variant,
+                                    _stream())
+    _check(rc, "svg_varblock_attention")
+    return o
+
+
+def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,
+               sm_scale: Optional[float] = None) -> torch.Tensor:
+    """q,k,v [BH, S, D]; rows int64 [R] (device) -> mse float32 [2, BH]"""
+    lib = load()
+    _dev(q, k, v, rows)
+    BH, S, D = q.shape
+    R = rows.numel()
+    out = torch.empty((2, BH), dtype=torch.float32, device=q.device)
+    ws = torch.empty(lib.svg_sample_mse_workspace_bytes(BH, R, D, S), dtype=torch.uint8, device=q.device)
+    scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    rc = lib.svg_sample_mse(q.data_ptr(), k.data_ptr(), v.data_ptr(), rows.data_ptr(), R, BH, S, D, _dtype_code(q), scale,
+                            C.byref(prof), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    _check(rc, "svg_sample_mse")
+    return out
+
+
+def kmeans_xsq(x: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    _dev(x)
+    B, N, D = x.shape
+    xsq = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _check(lib.svg_kmeans_xsq(x.data_ptr(), xsq.data_ptr(), B, N, D, _dtype_code(x), _stream()), "svg_kmeans_xsq")
+    return xsq
+
+
+class KmeansBuffers:
+    """Device buffers reused across Lloyd iterations (labels, counts, sorted indices, shift, workspace)."""
+
+    def __init__(self, B: int, N: int, K: int, D: int, device):
+        lib = load()
+        self.labels = torch.empty((B, N), dtype=torch.int32, device=device)
+        self.counts = torch.empty((B, K), dtype=torch.int32, device=device)
+        self.sorted_idx = torch.empty((B, N), dtype=torch.int32, device=device)
+        self.shift = torch.empty((B,), dtype=torch.float32, device=device)
+        self.ws = torch.empty(lib.svg_kmeans_workspace_bytes(B, N, K, D), dtype=torch.uint8, device=device)
+
+
+def kmeans_iter(x: torch.Tensor, xsq: torch.Tensor, c_in: torch.Tensor, c_out: torch.Tensor, buf: KmeansBuffers) -> None:
+    lib = load()
+    _dev(x, xsq, c_in, c_out)
+    B, N, D = x.shape
+    K = c_in.shape[1]
+    assert c_in.shape == (B, K, D) and c_out.shape == (B, K, D) and c_in.dtype == x.dtype == c_out.dtype
+    rc = lib.svg_kmeans_iter(x.data_ptr(), xsq.data_ptr(), c_in.data_ptr(), c_out.data_ptr(), buf.labels.data_ptr(),
+                             buf.counts.data_ptr(), buf.sorted_idx.data_ptr(), buf.shift.data_ptr(), B, N, K, D,
+                             _dtype_code(x), buf.ws.data_ptr(), buf.ws.numel(), _stream())
+    _check(rc, "svg_kmeans_iter")
+
+
+def identify_dynamic_map(qc: torch.Tensor, kc: torch.Tensor, k_sizes: torch.Tensor, top_p: float,
+                         preserve_length: int) -> torch.Tensor:
+    """qc [BH, QC, D], kc [BH, KC, D], k_sizes int32 [BH, KC] -> bool [BH, QC, KC]"""
+    lib = load()
+    _dev(qc, kc, k_sizes)
+    BH, QC, D = qc.shape
+    KC = kc.shape[1]
+    assert k_sizes.dtype == torch.int32 and k_sizes.shape == (BH, KC)
+    out = torch.empty((BH, QC, KC), dtype=torch.uint8, device=qc.device)
+    rc = lib.svg_identify_dynamic_map(qc.data_ptr(), kc.data_ptr(), k_sizes.data_ptr(), out.data_ptr(), BH, QC, KC, D,
+                                      _dtype_code(qc), float(top_p), int(preserve_length), _stream())
+    _check(rc, "svg_identify_dynamic_map")
+    return out.view(torch.bool)
+
+
+def map_density(block_map: torch.Tensor, q_sizes: torch.Tensor, k_sizes: torch.Tensor) -> torch.Tensor:
+    lib = load()
+    _dev(block_map, q_sizes, k_sizes)
+    BH, QB, KB = block_map.shape
+    out = torch.empty((BH,), dtype=torch.float32, device=block_map.device)
+    rc = lib.svg_map_density(block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(), out.data_ptr(), BH, QB, KB,
+                             _stream())
+    _check(rc, "svg_map_density")
+    return out

@@ -1,0 +1,21 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))                           # oracle/, bench.py, __graft_entry__
+sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))   # the `svg` package (reference-compatible module paths)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    return np.load(ROOT / "tests" / "golden" / "reference_golden.npz", allow_pickle=False)

