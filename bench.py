@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SVG1 block-sparse attention of one HunyuanVideo 720p / 129-frame layer-call on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hy720p|hy480p|tiny] [--no-cpu] [--no-dense]
+
+Workload (BASELINE.json configs[1]): q, k, v = randn([1, 24, 119056, 128], bf16) (F=33, P=3600, ctx=256, prompt 64),
+sparsity 0.25 -> band 15616 tokens, half of the heads temporal (fused layout transformation inside the kernel).
+One *step* = one sparse layer-call = online profiler (sample_mse, 64 rows) + band attention with fused placement, i.e.
+exactly what Hunyuan_SVGAttn_Processor2_0.attention_core_logic does per layer in the sparse branch
+(ref: svg/models/hyvideo/attention.py:507-524).  Inputs are resident in HBM before the timed region.
+
+metric  = attention TFLOP/s, algorithmic: 4 * D * H * (#unmasked (q,k) pairs) per layer-call (42.78 TFLOP
+          at L=64) divided by wall time per step; `denoise_steps_per_s` (60 layer-calls per denoise step, attention only)
+          is reported beside it.
+roofline: bound = MFMA (dense bf16 peak 2.5 PFLOP/s); `achieved` = algorithmic FLOPs of the dominant kernel
+          (band_attn_kernel) / its mean launch duration measured with HIP events on the launch stream.
+cpu_baseline: the reference's CPU-capable dense path torch SDPA (ref: svg/models/wan/attention.py:279-281) on the host
+          cores, bf16, on a bounded sample (one head, shortened sequence), scaled — see `sample`.
+N > 1   : heads are independent units; rank r owns heads r::N of the same layer-call (strong scaling), no data-path
+          collective during attention, one all-gather of the attention output per step (the exchange the next op,
+          `to_out`, needs) over RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (H, D, F, P, ctx, prompt_len, sparsity)
+    "hy720p": (24, 128, 33, 3600, 256, 64, 0.25),
+    "hy480p": (24, 128, 33, 1350, 256, 64, 0.25),
+    "tiny": (4, 128, 5, 600, 256, 64, 0.4),
+}
+
+
+def allowed_pairs_hy(V: int, ctx: int, L: int, tf: int) -> int:
+    """#unmasked (q,k) pairs of the Hunyuan mask: band over video + text rows/cols + pad block."""
+    tf = min(tf, V)
+    band = V * (2 * tf - 1) - tf * (tf - 1)
+    return band + 2 * V * L + L * L + (ctx - L) ** 2
+
+
+def cpu_baseline(H: int, D: int, S: int, seconds_target: float = 15.0):
+    """torch SDPA (dense, bf16) on the host cores: one head, sequence shortened so that it runs ~10-30 s."""
+    import torch.nn.functional as F
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    s = 8192
+    q, k, v = (torch.randn(1, 1, s, D, dtype=torch.bfloat16) for _ in range(3))
+    F.scaled_dot_product_attention(q, k, v)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds_target and reps < 64:
+        F.scaled_dot_product_attention(q, k, v)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    tflops = 4.0 * s * s * D / dt / 1e12
+    return {
+        "value": round(tflops, 4),
+        "unit": "TFLOP/s",
+        "cores": cores,
+        "kind": "reference",
+        "sample": f"torch SDPA dense bf16, 1 head, S={s}, D={D}, {reps} reps (reference CPU path "
+                  f"svg/models/wan/attention.py:279-281); a full {H}-head S={S} layer-call is "
+                  f"{4.0 * S * S * D * H / 1e12:.1f} TFLOP dense = {4.0 * S * S * D * H / 1e12 / tflops:.0f} s at this rate",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", type=int, default=0, help="0: 8 waves/WG, 1: 4 waves/WG")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from svg import _native as nat
+    from svg.models.hyvideo.utils import sparsity_to_width
+
+    nat.load()
+    H, D, F_, P_, ctx, L, sparsity = WORKLOADS[a.workload]
+    V = F_ * P_
+    S = V + ctx
+    width = sparsity_to_width(sparsity, ctx, F_, P_)
+    tf = math.floor(width * P_ / 128) * 128
+    mask = nat.BandMask(real_len=V + L, band=tf, colfull_lo=V, colfull_hi=V + L, rowfull_lo=V, rowfull_hi=V + L)
+    pairs = allowed_pairs_hy(V, ctx, L, tf)
+    flops_call = 4.0 * D * H * pairs
+    dense_flops = 4.0 * D * H * S * S
+
+    # heads of this rank (strong scaling: the layer-call is split by heads)
+    my_heads = list(range(rank, H, world))
+    Hl = len(my_heads)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+    o = torch.empty_like(q)
+    best = torch.tensor([[h % 2 for h in my_heads]], device=dev, dtype=torch.int64)  # alternate spatial / temporal
+    rows = torch.randint(0, min(10000, V), (64,), device=dev)
+    bb = int((P_ * 1.5) // 128)
+    prof = nat.ProfileDesc(0, F_, P_, 1)
+    prof.variant[0] = nat.ProfileVariant(0, 0, V, bb, 0, V, S)
+    prof.variant[1] = nat.ProfileVariant(1, 0, V, bb, 0, V, S)
+    gathered = [torch.empty_like(o) for _ in range(world)] if world > 1 else None
+
+    ev_a0, ev_a1 = [], []
+
+    def step(timed: bool):
+        if not a.no_profiler:
+            mse = nat.sample_mse(q[0], k[0], v[0], rows, prof)
+            _ = mse.argmin(0)  # best_mask_idx (kept on device; the bench uses the fixed alternating pattern)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_, variant=a.variant, out=o)
+        e1.record()
+        if timed:
+            ev_a0.append(e0)
+            ev_a1.append(e1)
+        if world > 1:
+            dist.all_gather(gathered, o)
+
+    for _ in range(a.warmup):
+        step(False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    ms_step = dt / a.steps * 1e3
+    attn_ms = sum(x.elapsed_time(y) for x, y in zip(ev_a0, ev_a1)) / len(ev_a0)
+
+    out = None
+    if rank == 0:
+        value = flops_call / (ms_step * 1e-3) / 1e12
+        kern_tf = (flops_call * Hl / H) / (attn_ms * 1e-3) / 1e12
+        out = {
+            "metric": "attn_tflops_svg1_block_sparse",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"HunyuanVideo T2V {a.workload} SVG1 sparse layer-call: sample_mse(64 rows) + band attention with "
+                            f"fused head placement, cfg=1 H={H} D={D} F={F_} P={P_} ctx={ctx} prompt={L} S={S} band={tf} "
+                            f"density={pairs / S / S:.4f}",
+                "parallelism": f"heads/{world}" if world > 1 else "single",
+                "variant": a.variant,
+            },
+            "algorithmic_tflop_per_step": round(flops_call / 1e12, 3),
+            "denoise_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "band_attn_kernel<bf16,128>",
+                "achieved": round(kern_tf, 2),
+                "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(kern_tf / PEAK_BF16_TFLOPS, 4),
+                "kernel_ms": round(attn_ms, 3),
+                "traffic": None,
+            },
+        }
+
+    # ---- extras on rank 0 at N = 1: dense comparator on the same GPU, CPU baseline ----
+    if world == 1 and not a.no_dense:
+        dmask = nat.BandMask(real_len=V + L, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
+        nat.band_attention(q, k, v, dmask, variant=a.variant, out=o)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.band_attention(q, k, v, dmask, variant=a.variant, out=o)
+        e1.record()
+        torch.cuda.synchronize()
+        dms = e0.elapsed_time(e1)
+        dense_pairs = (V + L) ** 2 + (ctx - L) ** 2
+        out["dense_same_gpu"] = {
+            "kernel": "our dense mode (cu_seqlens [0, V+L, S])",
+            "ms": round(dms, 3),
+            "tflops": round(4.0 * D * H * dense_pairs / (dms * 1e-3) / 1e12, 2),
+            "speedup_sparse_vs_dense": round(dms / ms_step, 3),
+        }
+        try:
+            import torch.nn.functional as Fn
+
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+
+            qs, ks, vs = q[:, :4].contiguous(), k[:, :4].contiguous(), v[:, :4].contiguous()
+            # flash backend only: the math fallback would materialise a [4, S, S] score tensor (>100 GB)
+            with sdpa_kernel([SDPBackend.FLASH_ATTENTION]):
+                Fn.scaled_dot_product_attention(qs, ks, vs)
+                torch.cuda.synchronize()
+                e0.record()
+                Fn.scaled_dot_product_attention(qs, ks, vs)
+                e1.record()
+                torch.cuda.synchronize()
+            sms = e0.elapsed_time(e1) * (H / 4)
+            out["dense_same_gpu"]["torch_sdpa_ms_scaled_from_4_heads"] = round(sms, 3)
+            out["dense_same_gpu"]["speedup_sparse_vs_torch_sdpa"] = round(sms / ms_step, 3)
+        except Exception as e:  # noqa: BLE001
+            out["dense_same_gpu"]["torch_sdpa_error"] = str(e)[:200]
+    if world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(H, D, S)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

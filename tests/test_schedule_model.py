@@ -1,0 +1,161 @@
+"""CPU checks of the *scheduling logic* the HIP kernels use (which KV tiles a workgroup visits, how a tile is
+classified, the analytic profiler predicates).  The device code is mirrored line by line in Python here and checked
+exhaustively against the oracle's dense masks on small geometries — this catches logic errors without a GPU.
+Mirrors: BandPolicy::init / classify / allowed (csrc/attention.hip), ProfilePolicy::allowed (csrc/profiler.hip)."""
+import math
+
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+BN = 64
+BIG = 1 << 28
+
+
+def band_schedule(q0, q_end, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
+    alo = ahi = blo = bhi = clo = chi = BIG
+    if q0 < real:
+        qr1 = min(q_end, real)
+        if q0 < rf_hi and qr1 > rf_lo:
+            alo, ahi = 0, (real + BN - 1) // BN
+        else:
+            alo = max(0, q0 - band + 1) // BN
+            ahi = (min(real, qr1 - 1 + band) + BN - 1) // BN
+            ch = min(cf_hi, real)
+            if ch > cf_lo:
+                blo, bhi = cf_lo // BN, (ch + BN - 1) // BN
+    if q_end > real:
+        clo, chi = real // BN, (S + BN - 1) // BN
+    if blo < alo:
+        alo, ahi, blo, bhi = blo, bhi, alo, ahi
+    if clo < blo:
+        blo, bhi, clo, chi = clo, chi, blo, bhi
+    if blo < alo:
+        alo, ahi, blo, bhi = blo, bhi, alo, ahi
+    if blo < BIG and blo <= ahi:
+        ahi = max(ahi, bhi)
+        blo, bhi, clo, chi = clo, chi, BIG, BIG
+        if blo < BIG and blo <= ahi:
+            ahi = max(ahi, bhi)
+            blo, bhi = BIG, BIG
+    elif clo < BIG and clo <= bhi:
+        bhi = max(bhi, chi)
+        clo, chi = BIG, BIG
+    tiles = []
+    for lo, hi in ((alo, ahi), (blo, bhi), (clo, chi)):
+        tiles += list(range(lo, hi)) if lo < BIG else []
+    return tiles
+
+
+def classify(w0, q_end, k0, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
+    if w0 >= q_end:
+        return 0
+    w1 = min(w0 + 32, q_end)
+    k1 = min(k0 + BN, S)
+    all_ = False
+    if k0 + BN <= S:
+        if w1 <= real and k1 <= real:
+            all_ = ((k1 - 1 - w0 < band) and (w1 - 1 - k0 < band)) or (k0 >= cf_lo and k1 <= cf_hi) or \
+                   (w0 >= rf_lo and w1 <= rf_hi)
+        elif w0 >= real and k0 >= real:
+            all_ = True
+    if all_:
+        return 1
+    any_ = False
+    if w0 < real and k0 < real:
+        w1r, k1r = min(w1, real), min(k1, real)
+        any_ = ((k0 - (w1r - 1) < band) and (w0 - (k1r - 1) < band)) or (k0 < cf_hi and k1r > cf_lo) or \
+               (w0 < rf_hi and w1r > rf_lo)
+    if w1 > real and k1 > real:
+        any_ = True
+    return 2 if any_ else 0
+
+
+CASES = []
+for (F_, P_, ctx, L, mul) in [(4, 140, 16, 9, 1.9), (5, 150, 40, 11, 2.3), (3, 100, 300, 120, 1.3), (2, 70, 10, 10, 4.0)]:
+    V = F_ * P_
+    CASES += [
+        ("hy", V + ctx, O.hy_band_params(V + ctx, ctx, L, F_, P_, mul)),
+        ("wan", V, O.wan_band_params(V, F_, P_, mul)),
+        ("cog", V + ctx, O.cog_band_params(V + ctx, ctx, F_, P_, mul)),
+        ("cog_sink", V + ctx, O.cog_band_params(V + ctx, ctx, F_, P_, mul, True)),
+        ("dense", V + ctx, O.dense_band_params(V + ctx)),
+        ("dense2", V + ctx, O.dense_band_params(V + ctx, V + L)),
+    ]
+
+
+@pytest.mark.parametrize("BM", [128, 256])
+@pytest.mark.parametrize("name,S,prm", CASES)
+def test_band_schedule_and_classify(name, S, prm, BM):
+    mask = O.band_mask(S, **prm)
+    p = (prm["real_len"], prm["band"], prm["colfull_lo"], prm["colfull_hi"], prm["rowfull_lo"], prm["rowfull_hi"])
+    for q0 in range(0, S, BM):
+        q_end = min(S, q0 + BM)
+        tiles = band_schedule(q0, q_end, S, *p)
+        assert tiles == sorted(set(tiles)), "tile ranges must be disjoint and ascending"
+        visited = torch.zeros(S, dtype=torch.bool)
+        for t in tiles:
+            visited[t * BN: (t + 1) * BN] = True
+        needed = mask[q0:q_end].any(dim=0)
+        assert not (needed & ~visited).any(), f"{name}: q-tile {q0} misses allowed keys"
+        for w0 in range(q0, q0 + BM, 32):
+            for t in tiles:
+                k0 = t * BN
+                cls = classify(w0, q_end, k0, S, *p)
+                if w0 >= q_end:
+                    assert cls == 0
+                    continue
+                sub = mask[w0:min(w0 + 32, q_end), k0:min(k0 + BN, S)]
+                if cls == 1:
+                    assert sub.all() and sub.shape[1] == BN, f"{name}: FULL tile has a masked element"
+                elif cls == 0:
+                    assert not sub.any(), f"{name}: SKIP tile has an allowed element"
+
+
+# ---- profiler predicate (ProfilePolicy::allowed) ----
+def prof_allowed(q, k, S, vid0, F_, P_, var):
+    coord, origin, span, bb, sink, tlo, thi = var
+    V = F_ * P_
+
+    def co(i):
+        if coord == 1 and 0 <= i - vid0 < V:
+            r = i - vid0
+            f, pp = divmod(r, P_)
+            return vid0 + pp * F_ + f
+        return i
+
+    tq = tlo <= q < thi
+    tk = tlo <= k < thi
+    x, y = co(q) - origin, co(k) - origin
+    dom = 0 <= x < span and 0 <= y < span
+    db = (x >> 7) - (y >> 7)
+    band = db < bb and -db < bb
+    return tq or tk or (dom and (band or y < sink))
+
+
+def prof_variants(model, ctx, F_, P_):
+    V = F_ * P_
+    if model == "hy":
+        bb = int((P_ * 1.5) // 128)
+        return 0, ((0, 0, V, bb, 0, V, V + ctx), (1, 0, V, bb, 0, V, V + ctx))
+    if model == "wan":
+        bb = int((P_ * 2) // 128)
+        return 0, ((0, 0, V, bb, P_, 0, 0), (1, 0, V, bb, P_, 0, 0))
+    bb = int((P_ * 1.5) // 128)
+    span = min(V + ctx, math.ceil(V / 128) * 128)
+    return ctx, ((0, 0, span, bb, 0, 0, ctx), (1, ctx, V, bb, 0, 0, 0))
+
+
+@pytest.mark.parametrize("model,ctx,F_,P_", [("hy", 16, 4, 140), ("wan", 0, 4, 140), ("cog", 16, 4, 140), ("cog", 26, 3, 200),
+                                            ("hy", 40, 5, 100), ("wan", 0, 3, 260)])
+def test_profile_predicates_equal_reference_masks(model, ctx, F_, P_):
+    S = F_ * P_ + ctx
+    vid0, variants = prof_variants(model, ctx, F_, P_)
+    masks = O.profile_masks(model, ctx, F_, P_)
+    gen = torch.Generator().manual_seed(0)
+    rows = torch.randint(0, S, (24,), generator=gen).tolist()
+    for var, m in zip(variants, masks):
+        for q in rows:
+            got = torch.tensor([prof_allowed(q, k, S, vid0, F_, P_, var) for k in range(S)])
+            assert torch.equal(got, m[q] != 0), f"{model} variant coord={var[0]} row {q}"
