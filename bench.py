@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
+    ap.add_argument("--heads", default="alt", choices=["alt", "spatial", "temporal"], help="best_mask_idx pattern")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +127,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
     o = torch.empty_like(q)
-    best = torch.tensor([[h % 2 for h in my_heads]], device=dev, dtype=torch.int64)  # alternate spatial / temporal
+    pat = {"alt": lambda h: h % 2, "spatial": lambda h: 0, "temporal": lambda h: 1}[a.heads]
+    best = torch.tensor([[pat(h) for h in my_heads]], device=dev, dtype=torch.int64)  # default: alternate spatial / temporal
     rows = torch.randint(0, min(10000, V), (64,), device=dev)
     bb = int((P_ * 1.5) // 128)
     prof = nat.ProfileDesc(0, F_, P_, 1)
@@ -196,6 +198,7 @@ def main():
                             f"density={pairs / S / S:.4f}",
                 "parallelism": f"heads/{world}" if world > 1 else "single",
                 "variant": a.variant,
+                "heads": a.heads,
             },
             "algorithmic_tflop_per_step": round(flops_call / 1e12, 3),
             "denoise_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),

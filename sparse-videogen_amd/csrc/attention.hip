@@ -1,6 +1,8 @@
 // SVG1 band (block-sparse) attention, dense attention and SVG2 variable-block attention for gfx950.
 // The MFMA / LDS / online-softmax machinery is attn_core.h; this file supplies the two scheduling policies
 // (which KV tiles a workgroup visits, where rows live in HBM, which elements are masked) and the C ABI.
+#include <algorithm>
+
 #include "attn_core.h"
 
 namespace svg {
@@ -8,10 +10,11 @@ namespace svg {
 // =====================================================================================================
 // Band policy: analytic mask family (see svg_band_mask_t in svg_attn.h)
 // =====================================================================================================
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool PRIO>
 struct BandPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
+    static constexpr bool kSetPrio = PRIO;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -24,12 +27,16 @@ struct BandPolicy {
         int real_len, band, cf_lo, cf_hi, rf_lo, rf_hi;
         const int64_t* head_flag;
         int vid0, F, P, V;
+        int q64, r64;          // 64 / F, 64 % F: tile-to-tile step of the (patch, frame) decomposition
+        int heavy_lo, n_heavy; // q-tiles [heavy_lo, heavy_lo + n_heavy) of every head see ALL keys (text rows): scheduled first
     };
     struct Ctx {
         int head, q0, q_end, nT, perm;
         int seg_lo[3], seg_n[3];
     };
-    struct KvCursor {};
+    struct KvCursor {
+        int pp, f, prev_k0;    // token-major decomposition (row - vid0) = pp * F + f of this thread's row in the previous tile
+    };
 
     static __device__ __forceinline__ int phys_row(const Params& p, const Ctx& c, int logical) {
         if (c.perm) {
@@ -55,8 +62,20 @@ struct BandPolicy {
             const int xcd = b % kNumXCD, s = b / kNumXCD;
             w = (s / 32) * (kNumXCD * 32) + xcd * 32 + (s % 32);
         }
-        c.head = w / p.nqt;
-        const int qt = w - c.head * p.nqt;
+        // longest-processing-time-first: the few q-tiles that contain text rows visit every KV tile (4x the work of a
+        // band tile at Hunyuan 720p); run them first so they do not form the tail of the launch.
+        int qt;
+        const int nh = p.BH * p.n_heavy;
+        if (w < nh) {
+            c.head = w / p.n_heavy;
+            qt = p.heavy_lo + (w - c.head * p.n_heavy);
+        } else {
+            const int nl = p.nqt - p.n_heavy;
+            const int w2 = w - nh;
+            c.head = w2 / nl;
+            const int r = w2 - c.head * nl;
+            qt = r < p.heavy_lo ? r : r + p.n_heavy;
+        }
         c.q0 = qt * BM;
         c.q_end = min(p.S, c.q0 + BM);
         c.perm = (p.head_flag != nullptr) && (p.head_flag[c.head] != 0);
@@ -114,10 +133,33 @@ struct BandPolicy {
         else tile = c.seg_lo[2] + (t - c.seg_n[0] - c.seg_n[1]);
         return tile * kBN;
     }
-    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor&, int) {}
-    static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor&, int t, int row) {
-        const int l = tile_key0(c, t) + row;
-        return l < p.S ? phys_row(p, c, l) : -1;
+    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) {
+        cu.pp = 0, cu.f = 0, cu.prev_k0 = -(1 << 30);
+    }
+    static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor& cu, int t, int row) {
+        const int k0 = tile_key0(c, t);
+        const int l = k0 + row;
+        if (!c.perm) return l < p.S ? l : 0;
+        // token-major head: physical row = vid0 + f * P + pp with (l - vid0) = pp * F + f.  Consecutive tiles advance
+        // by 64 rows, so the decomposition is stepped (4 VALU) instead of divided (~30 VALU); segment jumps re-divide.
+        int pp, f;
+        if (__builtin_amdgcn_readfirstlane((int)(k0 == cu.prev_k0 + kBN))) {
+            f = cu.f + p.r64;
+            pp = cu.pp + p.q64;
+            const bool wrap = f >= p.F;
+            f = wrap ? f - p.F : f;
+            pp = wrap ? pp + 1 : pp;
+        } else {
+            const int i = l - p.vid0;
+            const int a = i >= 0 ? i : -i - 1;              // floor division also for rows in front of the video
+            const int qd = (int)((unsigned)a / (unsigned)p.F);
+            pp = i >= 0 ? qd : -qd - 1;
+            f = i - pp * p.F;
+        }
+        cu.pp = pp, cu.f = f, cu.prev_k0 = k0;
+        const bool in_video = (unsigned)(l - p.vid0) < (unsigned)p.V;
+        const int phys = in_video ? p.vid0 + f * p.P + pp : l;
+        return l < p.S ? phys : 0;
     }
 
     static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
@@ -162,10 +204,10 @@ struct BandPolicy {
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
 };
 
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPolicy<T, D, NW>::Params prm) {
+template <typename T, int D, int NW, bool PRIO>
+__global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPolicy<T, D, NW, PRIO>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body<T, D, NW, BandPolicy<T, D, NW>>(prm, smem, nullptr);
+    attn_body<T, D, NW, BandPolicy<T, D, NW, PRIO>>(prm, smem, nullptr);
 }
 
 // =====================================================================================================
@@ -180,6 +222,7 @@ template <typename T, int D, int NW>
 struct VarblockPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
+    static constexpr bool kSetPrio = false;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -286,7 +329,7 @@ struct VarblockPolicy {
     static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) { cu.j = 0; }
     static __device__ __forceinline__ int kv_phys(const Params&, const Ctx& c, KvCursor& cu, int t, int row) {
         const int pos = t * kBN + row;  // compact coordinate
-        if (pos >= c.total) return -1;
+        if (pos >= c.total) return 0;   // masked by allowed(): reads row 0
         int j = cu.j;
         while (c.run_pref[j] <= pos) ++j;  // tiles advance monotonically: amortised O(1)
         cu.j = j;
@@ -365,10 +408,10 @@ static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool PRIO>
 static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                     const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
-    using Pol = BandPolicy<T, D, NW>;
+    using Pol = BandPolicy<T, D, NW, PRIO>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
@@ -380,7 +423,15 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         p.head_flag = perm->head_perm_flag;
         p.vid0 = perm->vid0, p.F = perm->num_frame, p.P = perm->frame_size, p.V = perm->num_frame * perm->frame_size;
     }
-    return launch_attn(band_attn_kernel<T, D, NW>, p, dim3(p.nqt * BH), NW * 64, attn_lds_bytes<D, NW>(), st);
+    p.q64 = kBN / p.F, p.r64 = kBN % p.F;
+    p.heavy_lo = 0, p.n_heavy = 0;
+    if (p.rf_hi > p.rf_lo && p.rf_lo < p.real_len && p.band <= S) {
+        const int hi = std::min(p.rf_hi, p.real_len);
+        p.heavy_lo = p.rf_lo / Pol::BM;
+        p.n_heavy = (hi + Pol::BM - 1) / Pol::BM - p.heavy_lo;
+        if (p.n_heavy >= p.nqt) p.heavy_lo = 0, p.n_heavy = 0;
+    }
+    return launch_attn(band_attn_kernel<T, D, NW, PRIO>, p, dim3(p.nqt * BH), NW * 64, attn_lds_bytes<D, NW>(), st);
 }
 
 }  // namespace svg
@@ -400,17 +451,20 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     }
     if ((int64_t)BH * S * D >= (1ll << 40)) return SVG_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const bool w4 = (variant == 1);  // variant 0: 8 waves x 32 rows (default); 1: 4 waves x 32 rows, 2 WG / CU
-#define SVG_BAND_DISPATCH(T)                                                                                       \
-    if (D == 128) return w4 ? run_band<T, 128, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                      \
-                            : run_band<T, 128, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);                     \
-    if (D == 64) return w4 ? run_band<T, 64, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                        \
-                           : run_band<T, 64, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+    const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU (default 8 waves x 32 rows)
+    const bool prio = (variant & 2) == 0;  // bit 1: disable s_setprio around the MFMA clusters (A/B switch)
+#define SVG_BAND_RUN(T, DD, NWW)                                                                                  \
+    return prio ? run_band<T, DD, NWW, true>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                         \
+                : run_band<T, DD, NWW, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+#define SVG_BAND_DISPATCH(T)                                                                                      \
+    if (D == 128) { if (w4) { SVG_BAND_RUN(T, 128, 4) } else { SVG_BAND_RUN(T, 128, 8) } }                        \
+    if (D == 64) { if (w4) { SVG_BAND_RUN(T, 64, 4) } else { SVG_BAND_RUN(T, 64, 8) } }
     if (dtype == SVG_DTYPE_BF16) {
         SVG_BAND_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {
         SVG_BAND_DISPATCH(_Float16)
     }
+#undef SVG_BAND_RUN
 #undef SVG_BAND_DISPATCH
     return SVG_ERR_UNSUPPORTED;
 }

@@ -57,7 +57,8 @@ __device__ __forceinline__ i16x4 lds_read_tr16(const char* p) {
 //   bool init(const Params&, Ctx&, char* policy_lds)            -> false: nothing to do (uniform exit)
 //   const T* q_base/k_base/v_base(const Params&, const Ctx&); T* o_base(...)      head base pointers
 //   int  q_logical(ctx, row_in_wg)  / int q_phys(prm, ctx, row_in_wg)            (-1 = row does not exist)
-//   struct KvCursor; kv_cursor_init(prm, ctx, cur, row_in_tile); int kv_phys(prm, ctx, cur, t, row_in_tile)  (-1 invalid)
+//   struct KvCursor; kv_cursor_init(prm, ctx, cur, row_in_tile); int kv_phys(prm, ctx, cur, t, row_in_tile)
+//        (physical row >= 0; rows that do not exist return 0 and MUST be masked by classify/allowed)
 //   int  tile_key0(ctx, t)                                       logical index of the first key of tile t
 //   int  classify(prm, ctx, tile_key0, wave_row0)                wave-uniform TileClass
 //   bool allowed(prm, ctx, q_logical, k_logical)                 element predicate for PARTIAL tiles
@@ -114,23 +115,21 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
     u32x4 kreg[NCH], vreg[NCH];
 
-    // Loads are issued unconditionally (row clamped to 0 when the tile row does not exist) and zeroed at
-    // ds_write time: a predicated load would split the loop body into exec-masked blocks and make hipcc's
-    // waitcnt pass fall back to vmcnt(0) at the loop header.
+    // Loads are issued unconditionally.  A tile row that does not exist (beyond the sequence / beyond the last
+    // active key) reads row 0 instead: its scores are masked to -inf element-wise (such a tile is never FULL) and
+    // p = 0 times the finite V values of row 0 adds nothing, so neither predication nor zero-fill is needed
+    // (predicated loads would cost exec-masked blocks and vmcnt(0) fall-backs in hipcc's waitcnt pass).
     // Physical rows are resolved one tile ahead of the data loads (nphys): for the variable-block policy the
     // resolve is itself a global index load, and this keeps its latency off the critical path.
-    bool svalid[NCH];
     int nphys[NCH];
     auto stage_resolve = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : -1;
+        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
     };
     auto stage_issue = [&](int t) {  // data loads of tile t (rows resolved earlier), then resolve tile t+1
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int phys = nphys[i];
-            svalid[i] = phys >= 0;
-            const size_t off = (size_t)(phys >= 0 ? phys : 0) * D + scol[i] * 8;
+            const size_t off = (size_t)nphys[i] * D + scol[i] * 8;
             kreg[i] = *(const u32x4*)(kb + off);
             vreg[i] = *(const u32x4*)(vb + off);
         }
@@ -140,9 +139,8 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         char* base = smem + buf * L::kStageBytes;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            *(u32x4*)(base + k_dst[i]) = svalid[i] ? kreg[i] : z;
-            *(u32x4*)(base + v_dst[i]) = svalid[i] ? vreg[i] : z;
+            *(u32x4*)(base + k_dst[i]) = kreg[i];
+            *(u32x4*)(base + v_dst[i]) = vreg[i];
         }
     };
 
@@ -185,6 +183,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         const int cls = P::classify(prm, ctx, tk0, wave * 32);
         if (cls != TILE_SKIP) {
             // ---------------- S^T = K Q^T ----------------
+            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
             f32x16 s[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -199,6 +198,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                     s[b] = E::mfma(a, qf[ks], s[b]);
                 }
             }
+            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
             // ---------------- mask + online softmax (lane-local row) ----------------
             if constexpr (P::kFixup) {
 #pragma unroll
@@ -243,6 +243,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                     for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
             }
             // ---------------- O^T += V^T P^T ----------------
+            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
             const char* vbase = kbuf + v_lane_off;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -258,6 +259,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                     }
             }
         }
+        if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
         if (t + 1 < nT) stage_write(buf ^ 1);
         if (t + 2 < nT) stage_issue(t + 2);
         __syncthreads();

@@ -28,6 +28,7 @@ template <typename T, int D>
 struct ProfilePolicy {
     static constexpr bool kFixup = true;
     static constexpr bool kPartialOut = true;
+    static constexpr bool kSetPrio = false;
     static constexpr int NW = kProfNW;
 
     struct Params {
@@ -72,7 +73,7 @@ struct ProfilePolicy {
     static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor&, int) {}
     static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor&, int t, int row) {
         const int l = (c.t0 + t) * kBN + row;
-        return l < p.S ? l : -1;
+        return l < p.S ? l : 0;  // masked by allowed()
     }
     static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
         if (wrow0 >= p.R) return TILE_SKIP;
