@@ -10,11 +10,13 @@ namespace svg {
 // =====================================================================================================
 // Band policy: analytic mask family (see svg_band_mask_t in svg_attn.h)
 // =====================================================================================================
-template <typename T, int D, int NW, bool PRIO>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0>
 struct BandPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
-    static constexpr bool kSetPrio = PRIO;
+    static constexpr int kAbl = ABL;  // > 0 only in the ablation build (attention_abl.hip): timing experiments
+    static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
+    static constexpr bool kSkew = SKEW;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -204,10 +206,10 @@ struct BandPolicy {
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
 };
 
-template <typename T, int D, int NW, bool PRIO>
-__global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPolicy<T, D, NW, PRIO>::Params prm) {
+template <typename T, int D, int NW, bool SKEW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPolicy<T, D, NW, SKEW, ABL>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body<T, D, NW, BandPolicy<T, D, NW, PRIO>>(prm, smem, nullptr);
+    attn_body<T, D, NW, BandPolicy<T, D, NW, SKEW, ABL>>(prm, smem, nullptr);
 }
 
 // =====================================================================================================
@@ -222,7 +224,9 @@ template <typename T, int D, int NW>
 struct VarblockPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
+    static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
+    static constexpr bool kSkew = false;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -408,10 +412,10 @@ static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-template <typename T, int D, int NW, bool PRIO>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0>
 static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                     const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
-    using Pol = BandPolicy<T, D, NW, PRIO>;
+    using Pol = BandPolicy<T, D, NW, SKEW, ABL>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
@@ -431,7 +435,8 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         p.n_heavy = (hi + Pol::BM - 1) / Pol::BM - p.heavy_lo;
         if (p.n_heavy >= p.nqt) p.heavy_lo = 0, p.n_heavy = 0;
     }
-    return launch_attn(band_attn_kernel<T, D, NW, PRIO>, p, dim3(p.nqt * BH), NW * 64, attn_lds_bytes<D, NW>(), st);
+    return launch_attn(band_attn_kernel<T, D, NW, SKEW, ABL>, p, dim3(p.nqt * BH), NW * 64,
+                       attn_lds_bytes<D, NW, attn_stages<NW, Pol>()>(), st);
 }
 
 }  // namespace svg
@@ -451,8 +456,20 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     }
     if ((int64_t)BH * S * D >= (1ll << 40)) return SVG_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // bits 8..11: ablation experiments (timing only, results are wrong): bf16, D = 128, 8 waves, lock-step schedule
+    const int abl = (variant >> 8) & 15;
+    if (abl && dtype == SVG_DTYPE_BF16 && D == 128) {
+        switch (abl) {
+            case 1: return run_band<__bf16, 128, 8, false, 1>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 2: return run_band<__bf16, 128, 8, false, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 3: return run_band<__bf16, 128, 8, false, 3>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 4: return run_band<__bf16, 128, 8, false, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 5: return run_band<__bf16, 128, 8, false, 5>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            default: return SVG_ERR_UNSUPPORTED;
+        }
+    }
     const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU (default 8 waves x 32 rows)
-    const bool prio = (variant & 2) == 0;  // bit 1: disable s_setprio around the MFMA clusters (A/B switch)
+    const bool prio = (variant & 2) != 0;  // bit 1: skewed two-group schedule (experimental; measured 3 % slower than lock-step)
 #define SVG_BAND_RUN(T, DD, NWW)                                                                                  \
     return prio ? run_band<T, DD, NWW, true>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                         \
                 : run_band<T, DD, NWW, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);

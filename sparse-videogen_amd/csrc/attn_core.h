@@ -40,10 +40,16 @@ struct LdsLayout {
     static __device__ __forceinline__ int v_off(int row, int c) { return (c >> 2) * (kBN * 64) + row * 64 + ((c & 3) << 4); }
 };
 
-template <int D, int NW>
+// number of LDS stages: 3 when the policy asks for the skewed two-group schedule (8 waves, one workgroup per CU)
+template <int NW, typename P>
+constexpr int attn_stages() {
+    return (P::kSkew && NW == 8) ? 3 : 2;
+}
+
+template <int D, int NW, int NS = 2>
 constexpr int attn_lds_bytes() {
-    // two stages, or the epilogue staging of NW*32 rows with an 8-byte row pad, whichever is larger
-    constexpr int stages = 2 * LdsLayout<D>::kStageBytes;
+    // NS stages, or the epilogue staging of NW*32 rows with an 8-byte row pad, whichever is larger
+    constexpr int stages = NS * LdsLayout<D>::kStageBytes;
     constexpr int epi = NW * 32 * (D * 2 + 8);
     return stages > epi ? stages : epi;
 }
@@ -176,19 +182,17 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
     __syncthreads();
 
-    for (int t = 0; t < nT; ++t) {
-        const int buf = t & 1;
-        const char* kbuf = smem + buf * L::kStageBytes;
-        const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * 32);
-        if (cls != TILE_SKIP) {
-            // ---------------- S^T = K Q^T ----------------
-            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
-            f32x16 s[2];
+    // The two GEMM phases as lambdas so that the "skewed" schedule below can place them differently per wave group.
+    V8 pf[2][2];  // P^T operand of the current tile (kept across the barrier by the lagging wave group)
+    auto qk_softmax = [&](const char* kbuf, int tk0, int cls) {
+        // ---------------- S^T = K Q^T ----------------
+        if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
+        f32x16 s[2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+        if constexpr (P::kAbl != 3) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cch = ((2 * ks + g) ^ ksw0) << 4;
@@ -198,71 +202,121 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                     s[b] = E::mfma(a, qf[ks], s[b]);
                 }
             }
-            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
-            // ---------------- mask + online softmax (lane-local row) ----------------
-            if constexpr (P::kFixup) {
+        } else {  // ablation: no QK^T (keep the values opaque so that the softmax is not folded away)
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        }
+        if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
+        if constexpr (P::kAbl == 1) {  // ablation: no softmax VALU
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
-            }
-            if (cls == TILE_PARTIAL) {
+                for (int r = 0; r < 16; ++r) pf[b][r >> 3][r & 7] = E::from_float(s[b][r]);
+            return;
+        }
+        // ---------------- mask + online softmax (lane-local row) ----------------
+        if constexpr (P::kFixup) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
-                    }
-            }
-            float mx = s[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx * c_log2);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
-            float psum = 0.f;
-            V8 pf[2][2];
+                for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
+        }
+        if (cls == TILE_PARTIAL) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c_log2, -m_use));
-                    psum += p;
-                    pf[b][r >> 3][r & 7] = E::from_float(p);
+                    const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
                 }
-            l_run = l_run * alpha + psum;
-            if (__any(alpha != 1.f)) {
+        }
+        float mx = s[0][0];
 #pragma unroll
-                for (int db = 0; db < DB; ++db)
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * c_log2);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c_log2, -m_use));
+                psum += p;
+                pf[b][r >> 3][r & 7] = E::from_float(p);
             }
-            // ---------------- O^T += V^T P^T ----------------
-            if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
-            const char* vbase = kbuf + v_lane_off;
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        }
+    };
+    auto pv = [&](const char* kbuf) {
+        if constexpr (P::kAbl == 2) {  // ablation: no PV (keep P alive)
+            asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
+            return;
+        }
+        // ---------------- O^T += V^T P^T ----------------
+        if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
+        const char* vbase = kbuf + v_lane_off;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int kb0 = 32 * b + 16 * h;
-                        const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
-                        const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
-                        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
-                    }
-            }
+        for (int db = 0; db < DB; ++db) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int kb0 = 32 * b + 16 * h;
+                    const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
+                    const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
+                    i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
+                }
         }
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
-        if (t + 1 < nT) stage_write(buf ^ 1);
-        if (t + 2 < nT) stage_issue(t + 2);
-        __syncthreads();
+    };
+
+    // Schedule.  Lock-step (kStages == 2): every wave runs QK -> softmax -> PV per tile; the two waves that share a
+    // SIMD then fight for the matrix pipe in the GEMM phases and for the VALU in the softmax phase (time ~ 4M + 2V).
+    // Skewed (kStages == 3): the second half of the waves (one per SIMD) runs PV one tile late, at the top of the
+    // next iteration — while group A is in its softmax (VALU) group B is in QK (MFMA) and vice versa (time ~ 4M).
+    // The third LDS stage keeps V(t-1) alive for the lagging group while tile t+1 is being written.
+    constexpr int NS = attn_stages<NW, P>();
+    const bool lag = (NS == 3) && (wave >= NW / 2);
+    bool pending = false;
+    int buf = 0, pend_buf = 0;
+    for (int t = 0; t < nT; ++t) {
+        const char* kbuf = smem + buf * L::kStageBytes;
+        if (NS == 3 && lag && pending) {
+            pv(smem + pend_buf * L::kStageBytes);
+            pending = false;
+        }
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if (cls != TILE_SKIP) {
+            qk_softmax(kbuf, tk0, cls);
+            if (NS == 3 && lag) {
+                pending = true;
+                pend_buf = buf;
+            } else {
+                pv(kbuf);
+            }
+        }
+        const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;
+        if constexpr (P::kAbl != 4) {
+            if (t + 1 < nT) stage_write(nbuf);
+            if (t + 2 < nT) stage_issue(t + 2);
+        }
+        if constexpr (P::kAbl != 5) __syncthreads();
+        buf = nbuf;
+    }
+    if (NS == 3) {
+        if (lag && pending) pv(smem + pend_buf * L::kStageBytes);
+        __syncthreads();  // the epilogue below reuses the stage buffers
     }
 
     // ---------------- epilogue ----------------

@@ -28,7 +28,9 @@ template <typename T, int D>
 struct ProfilePolicy {
     static constexpr bool kFixup = true;
     static constexpr bool kPartialOut = true;
+    static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
+    static constexpr bool kSkew = false;
     static constexpr int NW = kProfNW;
 
     struct Params {
