@@ -1,0 +1,178 @@
+"""SVG2 operators — same module path and function names as the reference `svg/kmeans_utils.py`, backed by the HIP
+kernels of libsvgattn (flash-kmeans: csrc/kmeans.hip, top-p block selection: csrc/dynmap.hip, variable-block attention:
+csrc/attention.hip).  No Triton, no flashinfer, no cuVS.
+
+Differences that are deliberate and documented:
+  * all iterations run on device without a host sync per iteration; convergence is checked every `check_every`
+    iterations (default: once, after the last) — the reference syncs every iteration (`center_shift < tol`, :723);
+  * centroid sums are reduced in a fixed order (bit-reproducible), the reference uses fp32 atomics;
+  * `sorted_indices` is the *stable* argsort of the labels (the reference's order inside a cluster is unspecified);
+  * the variable-block attention needs no planning pass, no 4 GiB index buffer and no 512 MB workspace per call.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _native
+from .timer import time_logging_decorator
+
+
+@time_logging_decorator("Level 4- density calculation")
+def density_calculation(dynamic_map, q_cluster_sizes, k_cluster_sizes):
+    """ref: svg/kmeans_utils.py:13-31.  dynamic_map [cfg, H, QC, KC] bool, sizes [cfg, H, QC] / [cfg, H, KC] -> [cfg, H]"""
+    cfg, H, QC, KC = dynamic_map.shape
+    if dynamic_map.is_cuda:
+        d = _native.map_density(dynamic_map.reshape(cfg * H, QC, KC).contiguous(),
+                                q_cluster_sizes.reshape(cfg * H, QC).to(torch.int32).contiguous(),
+                                k_cluster_sizes.reshape(cfg * H, KC).to(torch.int32).contiguous())
+        return d.reshape(cfg, H)
+    blk = q_cluster_sizes[:, :, :, None] * k_cluster_sizes[:, :, None, :]
+    return torch.sum(blk * dynamic_map, dim=(2, 3)) / torch.sum(blk, dim=(2, 3))
+
+
+class KMeansState:
+    """Reusable device buffers of batch_kmeans_Euclid for one (B, N, K, D) shape."""
+
+    def __init__(self, x: torch.Tensor, n_clusters: int):
+        B, N, D = x.shape
+        self.shape = (B, N, n_clusters, D, x.dtype, x.device)
+        self.buf = _native.KmeansBuffers(B, N, n_clusters, D, x.device)
+        self.c = [torch.empty((B, n_clusters, D), dtype=x.dtype, device=x.device) for _ in range(2)]
+
+    def matches(self, x, n_clusters):
+        B, N, D = x.shape
+        return self.shape == (B, N, n_clusters, D, x.dtype, x.device)
+
+
+_STATE_CACHE: dict = {}
+
+
+@time_logging_decorator("Level 4 - batch kmeans euclid")
+def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=None, verbose=False, check_every=0,
+                        return_sorted_indices=False):
+    """ref: batch_kmeans_Euclid, svg/kmeans_utils.py:684-733.
+
+    x: [B, N, D] bf16/fp16 GPU tensor.  Returns (cluster_ids int64 [B, N], centroids [B, K, D], cluster_sizes int32 [B, K],
+    n_iters) — and the stable sorted indices int32 [B, N] when `return_sorted_indices` (they come for free from the
+    centroid update and save the argsort of permute_tensor_by_labels_triton).
+    Like the reference, the returned centroids are one update ahead of the returned labels unless it converged.
+    check_every = n > 0 reads the convergence flag back every n iterations (reference behaviour: n = 1)."""
+    assert x.is_cuda, "batch_kmeans_Euclid requires GPU tensors"
+    assert max_iters >= 1, "max_iters must be >= 1 (the reference raises NameError for 0)"
+    B, N, D = x.shape
+    x = x.contiguous()
+    key = (B, N, n_clusters, D, x.dtype, x.device)
+    st = _STATE_CACHE.get(key)
+    if st is None:
+        st = _STATE_CACHE[key] = KMeansState(x, n_clusters)
+    xsq = _native.kmeans_xsq(x)
+    if init_centroids is None:
+        # ref :706-709 — random points of x as initial centres (device RNG, not reproducible across platforms)
+        indices = torch.randint(0, N, (B, n_clusters), device=x.device)
+        c_in = torch.gather(x, dim=1, index=indices[..., None].expand(-1, -1, D)).contiguous()
+    else:
+        c_in = init_centroids.reshape(B, n_clusters, D).contiguous()
+    n_done = 0
+    cur = c_in
+    for it in range(max_iters):
+        c_out = st.c[it & 1]
+        _native.kmeans_iter(x, xsq, cur, c_out, st.buf)
+        n_done = it + 1
+        if verbose:
+            print(f"Iter {it}, center shift: {st.buf.shift.max().item():.6f}")
+        if check_every and (it + 1) % check_every == 0 and st.buf.shift.max().item() < tol:
+            break  # converged: like the reference, keep the OLD centroids (`cur`)
+        cur = c_out
+    labels = st.buf.labels.to(torch.int64)
+    out = (labels, cur.clone(), st.buf.counts.clone(), n_done)
+    if return_sorted_indices:
+        return out + (st.buf.sorted_idx.clone(),)
+    return out
+
+
+@time_logging_decorator("Level 4 - weighted softmax")
+def weighted_softmax(scores, weights):
+    """ref: svg/kmeans_utils.py:852-861 (torch; kept for API parity — the fused HIP op is identify_dynamic_map)"""
+    input_dtype = scores.dtype
+    scores = scores.float()
+    weights = weights.float()
+    max_score = torch.max(scores, dim=-1, keepdim=True)[0]
+    weighted_exp = weights * torch.exp(scores - max_score)
+    return (weighted_exp / torch.sum(weighted_exp, dim=-1, keepdim=True).clamp(min=1e-12)).to(input_dtype)
+
+
+@time_logging_decorator("Level 4 - identify dynamic map")
+def identify_dynamic_map(query_centroids, key_centroids, q_cluster_sizes, k_cluster_sizes, p, min_kc_ratio=0):
+    """ref: svg/kmeans_utils.py:864-896.  centroids [B, H, QC|KC, D], k_cluster_sizes [B, H, KC] -> bool [B, H, QC, KC]"""
+    B, H, QC, D = query_centroids.shape
+    KC = key_centroids.shape[2]
+    assert query_centroids.is_cuda, "identify_dynamic_map requires GPU tensors"
+    preserve = int(min_kc_ratio * KC) if min_kc_ratio > 0 else 0
+    m = _native.identify_dynamic_map(query_centroids.reshape(B * H, QC, D).contiguous(),
+                                     key_centroids.reshape(B * H, KC, D).contiguous(),
+                                     k_cluster_sizes.reshape(B * H, KC).to(torch.int32).contiguous(), float(p), preserve)
+    return m.reshape(B, H, QC, KC)
+
+
+@time_logging_decorator("Level 3 - dynamic block sparse fwd flashinfer on GPU")
+def dynamic_block_sparse_fwd_flashinfer(q, k, v, block_mask_map, block_row_sz, block_col_sz, is_cpu: bool = True, *,
+                                        q_sorted_indices: Optional[torch.Tensor] = None,
+                                        kv_sorted_indices: Optional[torch.Tensor] = None):
+    """ref: svg/kmeans_utils.py:1319-1392 (name kept for drop-in; there is no flashinfer underneath).
+
+    q, k, v: [B, H, S, D]; block_mask_map bool [B, H, QB, KB]; block_row_sz / block_col_sz int [B, H, QB] / [B, H, KB].
+    `is_cpu` is accepted and ignored (map and sizes may live on either device; they are moved to the GPU).
+    Optional q_sorted_indices / kv_sorted_indices ([B*H, S] int32): q/k/v are then the ORIGINAL (un-permuted) tensors and
+    the permutation / inverse permutation is fused into the kernel."""
+    B, H, S, D = q.shape
+    QB, KB = block_row_sz.shape[-1], block_col_sz.shape[-1]
+    assert block_mask_map.shape == (B, H, QB, KB)
+    dev = q.device
+    bm = block_mask_map.to(dev).reshape(B * H, QB, KB).contiguous()
+    rs = block_row_sz.to(dev).reshape(B * H, QB).to(torch.int32).contiguous()
+    cs = block_col_sz.to(dev).reshape(B * H, KB).to(torch.int32).contiguous()
+    qi = None if q_sorted_indices is None else q_sorted_indices.reshape(B * H, S).to(torch.int32).contiguous()
+    ki = None if kv_sorted_indices is None else kv_sorted_indices.reshape(B * H, k.shape[2]).to(torch.int32).contiguous()
+    with time_logging_decorator("Level 4 - Running"):
+        o = _native.varblock_attention(q.reshape(B * H, S, D).contiguous(), k.reshape(B * H, k.shape[2], D).contiguous(),
+                                       v.reshape(B * H, v.shape[2], D).contiguous(), bm, rs, cs, q_row_idx=qi, kv_row_idx=ki)
+    return o.reshape(B, H, S, D)
+
+
+def dynamic_block_sparse_fwd_torch(q, k, v, dynamic_map, qc_size, kc_size):
+    """ref: svg/kmeans_utils.py:902-995 — plain torch statement of the same attention (any device, slow).  Kept because
+    the reference exposes it; it is dense attention under the block mask expanded to elements."""
+    B, H, S, D = q.shape
+    out = torch.zeros_like(q)
+    for b in range(B):
+        for h in range(H):
+            em = torch.repeat_interleave(torch.repeat_interleave(dynamic_map[b, h], qc_size[b, h].long(), dim=0),
+                                         kc_size[b, h].long(), dim=1)
+            s = (q[b, h].float() @ k[b, h].float().T) * D ** -0.5
+            s = s.masked_fill(~em, float("-inf"))
+            p = torch.softmax(s, dim=-1)
+            p = torch.where(em.any(dim=-1, keepdim=True), p, torch.zeros_like(p))
+            out[b, h] = (p @ v[b, h].float()).to(q.dtype)
+    return out
+
+
+@time_logging_decorator("Level 4 - permute tensor by labels")
+def permute_tensor_by_labels(tensor, labels, dim):
+    """ref: svg/kmeans_utils.py:828-838 (torch version, any device; stable order)"""
+    sorted_indices = torch.argsort(labels.to(tensor.device), dim=-1, stable=True)
+    gi = sorted_indices
+    for _ in range(dim + 1, tensor.dim()):
+        gi = gi.unsqueeze(-1)
+    return torch.gather(tensor, dim, gi.expand(list(tensor.shape))), sorted_indices
+
+
+@time_logging_decorator("Level 4 - inverse permutation")
+def apply_inverse_permutation(permuted_tensor, sorted_indices, dim):
+    """ref: svg/kmeans_utils.py:841-849"""
+    inv = torch.argsort(sorted_indices, dim=-1)
+    gi = inv
+    for _ in range(dim + 1, permuted_tensor.dim()):
+        gi = gi.unsqueeze(-1)
+    return torch.gather(permuted_tensor, dim, gi.expand(permuted_tensor.shape))

@@ -1,0 +1,215 @@
+"""Model-independent attention core of the SVG1 / SVG2 processors.
+
+The three model packages (hyvideo, wan, cog) keep the reference's processor classes and call into these functions from
+their `attention_core_logic`.  On GPU tensors everything below is libsvgattn (HIP); on CPU tensors only the DENSE branch
+exists (torch SDPA — the reference's own CPU-capable path, e.g. svg/models/wan/attention.py:279-281) and the sparse
+branch raises: there is no CPU fallback for the sparse hot path.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import _native
+from ..kmeans_utils import batch_kmeans_Euclid, density_calculation, identify_dynamic_map
+from ..timer import time_logging_decorator
+
+
+@dataclass
+class Geometry:
+    """Token layout of one model: [text?][video F*P][text?]"""
+
+    context_length: int
+    num_frame: int
+    frame_size: int
+    text_first: bool = False
+
+    @property
+    def video_length(self) -> int:
+        return self.num_frame * self.frame_size
+
+    @property
+    def vid0(self) -> int:
+        return self.context_length if self.text_first else 0
+
+    @property
+    def seq_len(self) -> int:
+        return self.context_length + self.video_length
+
+
+def is_full_attention(layer_idx: int, timestep, first_layers_fp, first_times_fp) -> bool:
+    """ref: svg/models/hyvideo/attention.py:491-496 — dense for the first layers and the first (large) timesteps."""
+    if layer_idx < first_layers_fp:
+        return True
+    t0 = timestep[0] if (torch.is_tensor(timestep) and timestep.dim() > 0) or isinstance(timestep, (list, tuple)) else timestep
+    return bool(t0 > first_times_fp)  # one host sync when `timestep` lives on the GPU, exactly like the reference
+
+
+@time_logging_decorator("Level 3 - Dense Flash Attention")
+def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, valid_len: Optional[int] = None) -> torch.Tensor:
+    """Dense attention [cfg, H, S, D].  valid_len < S: two independent segments [0, valid) and [valid, S) — what the
+    reference gets from flash_attn_varlen_func with cu_seqlens [0, valid, S] (hyvideo/attention.py:452-470)."""
+    S = q.shape[2]
+    if q.is_cuda:
+        real = S if valid_len is None else int(valid_len)
+        mask = _native.BandMask(real_len=real, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
+        return _native.band_attention(q.contiguous(), k.contiguous(), v.contiguous(), mask)
+    if valid_len is None or valid_len >= S:
+        return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+    vl = int(valid_len)
+    o = torch.empty_like(q)
+    o[:, :, :vl] = F.scaled_dot_product_attention(q[:, :, :vl], k[:, :, :vl], v[:, :, :vl])
+    o[:, :, vl:] = F.scaled_dot_product_attention(q[:, :, vl:], k[:, :, vl:], v[:, :, vl:])
+    return o
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the sparse path runs only on the GPU through libsvgattn (no CPU fallback); "
+                           f"CPU tensors can only take the dense branch")
+
+
+@time_logging_decorator("Level 3 - sample_mse")
+def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int):
+    """ref: sample_mse svg/models/hyvideo/attention.py:376-399.  Rows are drawn with the CPU generator exactly like the
+    reference (`torch.randint(low=0, high=sample_mse_max_row, size=(n,))` without device=).  -> float32 [2, cfg, H]"""
+    cfg, H, S, D = q.shape
+    n = min(num_sampled_rows, S)
+    rows = torch.randint(low=0, high=sample_max_row, size=(n,))
+    mses = _native.sample_mse(q.reshape(cfg * H, S, D), k.reshape(cfg * H, S, D), v.reshape(cfg * H, S, D),
+                              rows.to(q.device, non_blocking=True), prof)
+    return mses.reshape(2, cfg, H)
+
+
+def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof: "_native.ProfileDesc",
+                          num_sampled_rows: int, sample_max_row: int, fused: bool = True):
+    """The sparse branch of attention_core_logic (ref: hyvideo/attention.py:507-524):
+    online profiling -> best_mask_idx -> placement -> block-sparse attention -> inverse placement.
+    fused=True folds both placements into the attention kernel (bit-identical result, ~5.9 GB less HBM traffic at
+    Hunyuan 720p); fused=False runs the three kernels of the reference pipeline."""
+    _require_gpu(q, "SVG1 sparse attention")
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row)
+    best_mask_idx = torch.argmin(mses, dim=0)  # [cfg, H] int64; NaN wins like torch.argmin in the reference
+    if fused:
+        with time_logging_decorator("Level 3 - sparse_flex_attention"):
+            out = _native.band_attention(q, k, v, mask, head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame,
+                                         frame_size=geo.frame_size)
+        return out, best_mask_idx
+    qo, ko, vo = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    with time_logging_decorator("Level 3 - fast_sparse_head_placement"):
+        _native.head_placement([q, k, v], [qo, ko, vo], best_mask_idx, geo.context_length, geo.num_frame, geo.frame_size,
+                               geo.text_first, inverse=False)
+    with time_logging_decorator("Level 3 - sparse_flex_attention"):
+        hs = _native.band_attention(qo, ko, vo, mask)
+    out = torch.empty_like(hs)
+    with time_logging_decorator("Level 3 - fast_hidden_states_placement"):
+        _native.head_placement([hs], [out], best_mask_idx, geo.context_length, geo.num_frame, geo.frame_size, geo.text_first,
+                               inverse=True)
+    return out, best_mask_idx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SVG2
+# ---------------------------------------------------------------------------------------------------------------
+class CentroidStore:
+    """Per-layer k-means state (ref: class-level dicts of Hunyuan_SAPAttn_Processor2_0, hyvideo/attention.py:566-568).
+    Unlike the reference it can be reset between videos (`clear()`)."""
+
+    def __init__(self):
+        self.q = {}
+        self.k = {}
+
+    def has(self, layer_idx):
+        return layer_idx in self.q
+
+    def clear(self):
+        self.q.clear()
+        self.k.clear()
+
+
+@time_logging_decorator("Level 3.5 - kmeans clustering")
+def kmeans_clustering(store: CentroidStore, layer_idx: int, q_video, k_video, num_q_centroids, num_k_centroids, iter_init,
+                      iter_step):
+    """ref: kmeans_init / kmeans_step / kmeans_clustering, hyvideo/attention.py:576-626: random init from the data on the
+    first call of a layer, warm start from the previous denoise step's centroids afterwards."""
+    cfg, H, N, D = q_video.shape
+    first = not store.has(layer_idx)
+    iters = iter_init if first else iter_step
+    qi = None if first else store.q[layer_idx]
+    ki = None if first else store.k[layer_idx]
+    ql, qc, qs, qit, qidx = batch_kmeans_Euclid(q_video.reshape(cfg * H, N, D), num_q_centroids, max_iters=iters,
+                                                init_centroids=qi, return_sorted_indices=True)
+    kl, kc, ks, kit, kidx = batch_kmeans_Euclid(k_video.reshape(cfg * H, N, D), num_k_centroids, max_iters=iters,
+                                                init_centroids=ki, return_sorted_indices=True)
+    store.q[layer_idx] = qc
+    store.k[layer_idx] = kc
+    if first:
+        print(f"Centroids initialized at layer {layer_idx}. Init step: {iter_init}")
+    return (ql, qc, qs, qit, qidx), (kl, kc, ks, kit, kidx)
+
+
+def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_idx: int, num_q_centroids: int,
+                          num_k_centroids: int, top_p: float, min_kc_ratio: float, iter_init: int, iter_step: int,
+                          prompt_length: int = 0, logging_file: Optional[str] = None, timestep=None):
+    """The sparse branch of the SAP processors (ref: hyvideo/attention.py:747-804, wan/attention.py:529-559):
+    k-means on the video tokens -> top-p block map -> (Hunyuan) two pseudo clusters for prompt / unused prompt ->
+    variable-block attention with the token permutation fused in (the result is already in the original order)."""
+    _require_gpu(q, "SVG2 sparse attention")
+    cfg, H, S, D = q.shape
+    assert cfg == 1, "Batch size must be 1 for kmeans block sparse attention"
+    assert not geo.text_first, "SVG2 is defined for text-last models (Hunyuan, Wan)"
+    V, ctx = geo.video_length, geo.context_length
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    qv = q[:, :, :V].contiguous() if ctx else q
+    kv = k[:, :, :V].contiguous() if ctx else k
+    with time_logging_decorator("Level 3 - semantic aware permutation"):
+        (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = kmeans_clustering(store, layer_idx, qv, kv, num_q_centroids,
+                                                                         num_k_centroids, iter_init, iter_step)
+        q_sizes = qs.view(cfg, H, num_q_centroids)
+        k_sizes = ks.view(cfg, H, num_k_centroids)
+        dyn_map = identify_dynamic_map(qc.view(cfg, H, num_q_centroids, D), kc.view(cfg, H, num_k_centroids, D), q_sizes,
+                                       k_sizes, top_p, min_kc_ratio)
+    if ctx:
+        with time_logging_decorator("Level 3 - dynamic map post processing"):
+            dyn_map, q_sizes, k_sizes, qidx, kidx = dynamic_map_post_processing(dyn_map, q_sizes, k_sizes, qidx, kidx, V, ctx,
+                                                                                prompt_length)
+    QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
+    out = _native.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dyn_map.view(H, QB, KB).contiguous(),
+                                     q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
+                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+    if logging_file is not None:
+        densities = density_calculation(dyn_map, q_sizes, k_sizes)
+        t0 = timestep[0] if torch.is_tensor(timestep) and timestep.dim() > 0 else timestep
+        entry = {"timestep": float(t0) if t0 is not None else None, "layer": layer_idx,
+                 "avg_density": densities.mean().item(), "density": densities.tolist()}
+        with open(logging_file, "a") as f:
+            f.write(json.dumps(entry) + "\n")
+    return out.view(cfg, H, S, D)
+
+
+def dynamic_map_post_processing(dyn_map, qc_sz, kc_sz, q_sorted_indices, k_sorted_indices, video_length, context_length,
+                                prompt_length):
+    """ref: hyvideo/attention.py:657-702 — append the prompt / unused-prompt pseudo clusters.  The q,k,v write-back of
+    the reference (permuted video tokens copied in front of the text tokens) is not needed: the attention kernel
+    gathers rows through the (identity-padded) sorted indices."""
+    dyn_map = F.pad(dyn_map, (0, 2, 0, 2), value=0)
+    dyn_map[:, :, -2, :-1] = True
+    dyn_map[:, :, :-1, -2] = True
+    dyn_map[:, :, -1, -1] = True
+    unprompt = context_length - prompt_length
+    qc_sz = F.pad(qc_sz, (0, 2), value=0)
+    qc_sz[:, :, -2] = prompt_length
+    qc_sz[:, :, -1] = unprompt
+    kc_sz = F.pad(kc_sz, (0, 2), value=0)
+    kc_sz[:, :, -2] = prompt_length
+    kc_sz[:, :, -1] = unprompt
+    tail = torch.arange(video_length, video_length + context_length, device=q_sorted_indices.device, dtype=torch.int32)
+    tail = tail.expand(q_sorted_indices.shape[0], -1)
+    q_sorted_indices = torch.cat([q_sorted_indices, tail], dim=1)
+    k_sorted_indices = torch.cat([k_sorted_indices, tail], dim=1)
+    return dyn_map, qc_sz, kc_sz, q_sorted_indices, k_sorted_indices

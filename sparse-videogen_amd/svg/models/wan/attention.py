@@ -1,0 +1,197 @@
+"""Wan 2.1 attention processors — same class names / class-level configuration / call protocol as the reference module
+svg/models/wan/attention.py (`proc(attn, hidden_states, encoder_hidden_states, attention_mask, rotary_emb, timestep)`
+-> hidden_states).  `attention_core_logic` runs on libsvgattn (HIP)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from ...timer import time_logging_decorator
+from .. import _core
+from .._core import CentroidStore, Geometry
+from .utils import generate_temporal_head_mask_mod, profile_desc
+
+
+def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs):
+    """ref: wan/attention.py:40-66.  `freqs` is either the complex tensor [1, 1, S, D/2] of diffusers or the
+    (real, imag) fp32 pair [S, D/2] the reference's patched model forward produces for its CUDA kernel."""
+    if isinstance(freqs, (tuple, list)):
+        fr, fi = freqs
+        freqs = torch.complex(fr.double(), fi.double())[None, None]
+
+    def rot(x):
+        xc = torch.view_as_complex(x.to(torch.float64).unflatten(3, (-1, 2)))
+        return torch.view_as_real(xc * freqs).flatten(3, 4).type_as(x)
+
+    return rot(query), rot(key)
+
+
+class WanAttn_SVGAttn_Processor2_0:
+    """Sparse VideoGen 1 for Wan 2.1 (ref: wan/attention.py:77-328)."""
+
+    version = None
+    context_length = 0
+    num_frame = 0
+    frame_size = 0
+
+    first_layers_fp = 0
+    first_times_fp = 0
+
+    num_sampled_rows = 32
+    sample_mse_max_row = 10000
+    attention_masks = None
+    sparsity = 0
+
+    block_mask = None
+    temporal_mask_metadata = None
+    fused_placement = True
+
+    def __init__(self, layer_idx):
+        self.layer_idx = layer_idx
+        self.last_best_mask_idx = None
+
+    @classmethod
+    def geometry(cls) -> Geometry:
+        return Geometry(cls.context_length, cls.num_frame, cls.frame_size, text_first=False)
+
+    @time_logging_decorator("Level 2 - qkv")
+    def get_qkv(self, attn, hidden_states, encoder_hidden_states):
+        return attn.to_q(hidden_states), attn.to_k(encoder_hidden_states), attn.to_v(encoder_hidden_states)
+
+    @time_logging_decorator("Level 2 - qk_norm")
+    def get_qk_norm(self, attn, query, key):
+        # Wan normalises across all heads, before the head split (ref :107-121)
+        if getattr(attn, "norm_q", None) is not None:
+            query = attn.norm_q(query)
+        if getattr(attn, "norm_k", None) is not None:
+            key = attn.norm_k(key)
+        return query, key
+
+    @time_logging_decorator("Level 2 - transpose")
+    def get_transpose_qkv(self, attn, query, key, value):
+        return tuple(x.unflatten(2, (attn.heads, -1)).transpose(1, 2).contiguous() for x in (query, key, value))
+
+    @time_logging_decorator("Level 2 - rotary_emb")
+    def get_rotary_emb(self, query, key, rotary_emb):
+        if rotary_emb is not None:
+            query, key = apply_rotary_emb(query, key, rotary_emb)
+        return query, key
+
+    @time_logging_decorator("Level 2 - output")
+    def get_o(self, attn, query, hidden_states, hidden_states_img):
+        hidden_states = hidden_states.transpose(1, 2).flatten(2, 3).type_as(query)
+        if hidden_states_img is not None:
+            hidden_states = hidden_states + hidden_states_img
+        return attn.to_out[1](attn.to_out[0](hidden_states))
+
+    def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, rotary_emb=None, timestep=None):
+        cross = encoder_hidden_states is not None
+        if timestep is None and not cross:
+            from ..context import current_timestep
+
+            timestep = current_timestep()
+        encoder_hidden_states_img = None
+        if getattr(attn, "add_k_proj", None) is not None and encoder_hidden_states is not None:
+            encoder_hidden_states_img = encoder_hidden_states[:, :257]
+            encoder_hidden_states = encoder_hidden_states[:, 257:]
+        if encoder_hidden_states is None:
+            encoder_hidden_states = hidden_states
+        query, key, value = self.get_qkv(attn, hidden_states, encoder_hidden_states)
+        query, key = self.get_qk_norm(attn, query, key)
+        query, key, value = self.get_transpose_qkv(attn, query, key, value)
+        query, key = self.get_rotary_emb(query, key, rotary_emb)
+        hidden_states_img = None
+        if encoder_hidden_states_img is not None:  # I2V: CLIP image tokens, small dense cross attention (ref :174-188)
+            key_img = attn.norm_added_k(attn.add_k_proj(encoder_hidden_states_img))
+            value_img = attn.add_v_proj(encoder_hidden_states_img)
+            key_img = key_img.unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            value_img = value_img.unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            hidden_states_img = F.scaled_dot_product_attention(query, key_img, value_img, attn_mask=None, dropout_p=0.0,
+                                                               is_causal=False)
+            hidden_states_img = hidden_states_img.transpose(1, 2).flatten(2, 3).type_as(query)
+        if timestep is None or cross:  # cross attention in Wan (ref :198-201)
+            hidden_states = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=0.0,
+                                                           is_causal=False)
+        else:
+            hidden_states = self.attention_core_logic(query, key, value, timestep)
+        return self.get_o(attn, query, hidden_states, hidden_states_img)
+
+    @time_logging_decorator("Level 3 - sample mse")
+    def sample_mse(self, query, key, value):
+        geo = self.geometry()
+        return _core.sample_mse(query, key, value, geo, profile_desc(geo.context_length, geo.num_frame, geo.frame_size),
+                                self.num_sampled_rows, min(self.sample_mse_max_row, query.shape[2]))
+
+    @time_logging_decorator("Level 3 - Dense Flash Attention")
+    def flash_attention(self, query, key, value):
+        return _core.dense_attention(query, key, value)
+
+    @time_logging_decorator("Level 2 - attention core logic")
+    def attention_core_logic(self, query, key, value, timestep):
+        cfg, num_heads, seq_len, dim = query.size()
+        geo = self.geometry()
+        assert seq_len == geo.seq_len, (
+            f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
+        if _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
+            return self.flash_attention(query, key, value).reshape(cfg, num_heads, seq_len, dim)
+        if self.block_mask is None:
+            raise RuntimeError("WanAttn_SVGAttn_Processor2_0.block_mask is not set: call replace_wan_attention first")
+        prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
+        out, best = _core.svg1_sparse_attention(query, key, value, geo, self.block_mask, prof, self.num_sampled_rows,
+                                                min(self.sample_mse_max_row, seq_len), fused=self.fused_placement)
+        self.last_best_mask_idx = best
+        return out.reshape(cfg, num_heads, seq_len, dim)
+
+
+def prepare_flexattention(cfg_size, num_head, head_dim, dtype, device, context_length, prompt_length, num_frame, frame_size,
+                          diag_width=1, multiplier=2):
+    """ref: wan/attention.py:331-355 — returns the band-mask descriptor instead of a compiled flex BlockMask."""
+    assert diag_width == multiplier, f"{diag_width} is not equivalent to {multiplier}"
+    return generate_temporal_head_mask_mod(context_length, prompt_length, num_frame, frame_size, mul=multiplier)
+
+
+class WanAttn_SAPAttn_Processor(WanAttn_SVGAttn_Processor2_0):
+    """Sparse VideoGen 2 for Wan 2.1 (ref: wan/attention.py:379-559).  Centroids are kept per processor instance (one
+    per layer), as in the reference."""
+
+    num_layers = 0
+    num_q_centroids = 0
+    num_k_centroids = 0
+    top_p_kmeans = 0
+    min_kc_ratio = 0
+
+    kmeans_iter_init = 0
+    kmeans_iter_step = 0
+    zero_step_kmeans_init = False
+
+    logging_file = None
+
+    def __init__(self, layer_idx):
+        super().__init__(layer_idx)
+        self.centroid_store = CentroidStore()
+
+    def reset_state(self):
+        self.centroid_store.clear()
+
+    @time_logging_decorator("Level 2 - attention core logic")
+    def attention_core_logic(self, query, key, value, timestep):
+        cfg, num_heads, seq_len, dim = query.size()
+        assert cfg == 1, "Batch size must be 1 for kmeans block sparse attention"
+        geo = self.geometry()
+        assert seq_len == geo.seq_len, (
+            f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
+        if _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
+            if self.zero_step_kmeans_init and query.is_cuda:
+                V = geo.video_length
+                _core.kmeans_clustering(self.centroid_store, self.layer_idx, query[:, :, :V].contiguous(),
+                                        key[:, :, :V].contiguous(), self.num_q_centroids, self.num_k_centroids,
+                                        self.kmeans_iter_init, self.kmeans_iter_step)
+            return self.flash_attention(query, key, value).reshape(cfg, num_heads, seq_len, dim)
+        out = _core.svg2_sparse_attention(query, key, value, geo, self.centroid_store, self.layer_idx, self.num_q_centroids,
+                                          self.num_k_centroids, self.top_p_kmeans, self.min_kc_ratio, self.kmeans_iter_init,
+                                          self.kmeans_iter_step, prompt_length=0, logging_file=self.logging_file,
+                                          timestep=timestep)
+        return out.reshape(cfg, num_heads, seq_len, dim)

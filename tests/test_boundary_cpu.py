@@ -1,0 +1,121 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads here (no GPU), exports every symbol include/svg_attn.h
+declares, the ctypes structs match the C layout, argument validation returns error codes without touching the GPU, and
+the Python package exposes the reference's module paths / names."""
+import ctypes
+import importlib
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_functions():
+    src = (ROOT / "include" / "svg_attn.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from svg import _native
+
+    lib = _native.load()
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/svg_attn.h but not exported"
+    assert set(names) == set(_native.SIGNATURES), set(names) ^ set(_native.SIGNATURES)
+    assert "gfx950" in _native.build_info()
+
+
+def test_struct_layouts():
+    from svg import _native
+
+    assert ctypes.sizeof(_native.BandMask) == 24
+    assert ctypes.sizeof(_native.PermDesc) == 24 and _native.PermDesc.vid0.offset == 8
+    assert ctypes.sizeof(_native.ProfileVariant) == 28
+    assert ctypes.sizeof(_native.ProfileDesc) == 16 + 2 * 28
+
+
+def test_argument_validation_returns_error_codes():
+    from svg import _native
+
+    lib = _native.load()
+    assert lib.svg_strerror(0) == b"ok"
+    m = _native.BandMask(10, 3, 0, 0, 0, 0)
+    # null pointers / bad geometry are rejected before any launch
+    assert lib.svg_band_attention(None, None, None, None, 1, 10, 128, 0, 1.0, ctypes.byref(m), None, 0, None) == -1
+    assert lib.svg_permute_rows(None, None, None, 1, 1, 64, 0, None) == -1
+    assert lib.svg_argsort_workspace_bytes(2, 5000, 100) == 2 * 5 * 100 * 4
+    assert lib.svg_varblock_workspace_bytes(4, 4, 10, 20, 1000) > 0
+    assert lib.svg_kmeans_workspace_bytes(2, 5000, 100, 128) >= lib.svg_argsort_workspace_bytes(2, 5000, 100)
+
+
+def test_native_ops_refuse_cpu_tensors():
+    from svg import _native
+
+    x = torch.zeros(1, 4, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.permute_rows(x, torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.band_attention(x[None], x[None], x[None], _native.BandMask(4, 5, 0, 0, 0, 0))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from svg import _native
+
+    monkeypatch.setenv("SVG_ATTN_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_native, "_lib", None)
+    with pytest.raises(RuntimeError, match="could not be loaded"):
+        _native.load()
+    assert not _native.available()
+
+
+REFERENCE_API = {
+    "svg.models.hyvideo.attention": ["HunyuanVideoAttnProcessor2_0_FlashAttention", "Hunyuan_SVGAttn_Processor2_0",
+                                     "Hunyuan_SAPAttn_Processor2_0", "prepare_flexattention"],
+    "svg.models.hyvideo.inference": ["replace_hyvideo_flashattention", "replace_hyvideo_attention"],
+    "svg.models.hyvideo.placement": ["hunyuan_sparse_head_placement", "hunyuan_hidden_states_placement",
+                                     "ref_hunyuan_sparse_head_placement", "ref_hunyuan_hidden_states_placement"],
+    "svg.models.hyvideo.utils": ["generate_temporal_head_mask_mod", "get_attention_mask", "sparsity_to_width"],
+    "svg.models.hyvideo.custom_models": ["replace_sparse_forward"],
+    "svg.models.wan.attention": ["WanAttn_SVGAttn_Processor2_0", "WanAttn_SAPAttn_Processor", "prepare_flexattention"],
+    "svg.models.wan.inference": ["replace_wan_attention"],
+    "svg.models.wan.placement": ["wan_sparse_head_placement", "wan_hidden_states_placement"],
+    "svg.models.wan.utils": ["generate_temporal_head_mask_mod", "get_attention_mask", "sparsity_to_width"],
+    "svg.models.cog.attention": ["CogVideoX_SparseAttn_Processor2_0", "prepare_flexattention"],
+    "svg.models.cog.inference": ["replace_cog_attention"],
+    "svg.models.cog.placement": ["sparse_head_placement", "hidden_states_placement", "ref_sparse_head_placement"],
+    "svg.models.cog.utils": ["generate_temporal_head_mask_mod", "get_attention_mask", "sparsity_to_width"],
+    "svg.kernels.triton.permute": ["permute_tensor_by_labels_triton", "apply_inverse_permutation_triton"],
+    "svg.kmeans_utils": ["batch_kmeans_Euclid", "identify_dynamic_map", "dynamic_block_sparse_fwd_flashinfer",
+                         "dynamic_block_sparse_fwd_torch", "density_calculation", "weighted_softmax"],
+    "svg.timer": ["time_logging_decorator", "TimeLoggingContext", "operator_log_data", "print_operator_log_data"],
+}
+
+
+@pytest.mark.parametrize("module", sorted(REFERENCE_API))
+def test_reference_module_paths_and_names(module):
+    m = importlib.import_module(module)
+    for name in REFERENCE_API[module]:
+        assert hasattr(m, name), f"{module}.{name} missing (reference API)"
+
+
+def test_mask_descriptors_equal_oracle_parameters():
+    from oracle import svg_oracle as O
+    from svg.models.cog.utils import generate_temporal_head_mask_mod as cog_mm
+    from svg.models.hyvideo.utils import generate_temporal_head_mask_mod as hy_mm
+    from svg.models.hyvideo.utils import sparsity_to_width
+    from svg.models.wan.utils import generate_temporal_head_mask_mod as wan_mm
+
+    w = sparsity_to_width(0.25, 256, 33, 3600)
+    assert w == O.sparsity_to_width(0.25, 256, 33, 3600)
+    S = 119056
+    assert hy_mm(256, 64, 33, 3600, w).as_tuple() == tuple(O.hy_band_params(S, 256, 64, 33, 3600, w).values())
+    ww = sparsity_to_width(0.3, 0, 21, 3600)
+    assert wan_mm(0, 0, 21, 3600, ww).as_tuple() == tuple(O.wan_band_params(75600, 21, 3600, ww).values())
+    wc = sparsity_to_width(0.25, 226, 13, 1350)
+    assert cog_mm(226, 13, 1350, wc).as_tuple() == tuple(O.cog_band_params(17776, 226, 13, 1350, wc).values())
+    assert hy_mm(256, 64, 33, 3600, w).band == 15616 and wan_mm(0, 0, 21, 3600, ww).band == 12417

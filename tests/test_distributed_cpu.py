@@ -1,0 +1,52 @@
+"""world_size-2 gloo test of the head-sharded layer-call (svg/distributed.py): every rank computes its heads, one
+all-gather rebuilds [cfg, H, S, D]; the result must be bitwise equal to the single-process result.  The per-head
+attention function here is torch SDPA (CPU) — what is under test is the sharding / exchange, which is device-agnostic."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, H, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import shard_heads, sharded_attention
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(2, H, 96, 32) for _ in range(3))
+    flag = torch.arange(H)[None].expand(2, H) % 2
+
+    def attn(qh, kh, vh, fl):
+        o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh)
+        return o * (1 + fl[:, :, None, None].float())  # a per-head argument must follow its head
+
+    o = sharded_attention(q, k, v, attn, per_head_args=(flag,))
+    ref = attn(q, k, v, flag)
+    ok = torch.equal(o, ref) and sum(len(shard_heads(H, r, world)) for r in range(world)) == H
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [4, 5])  # even and ragged head split
+def test_head_sharded_layer_call_gloo(H):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + H
+    mp.spawn(_worker, args=(world, port, H, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_heads_partition():
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import head_counts, shard_heads
+
+    assert head_counts(24, 8) == [3] * 8 and head_counts(40, 8) == [5] * 8 and head_counts(24, 5) == [5, 5, 5, 5, 4]
+    assert [h for r in range(5) for h in shard_heads(24, r, 5)] == list(range(24))

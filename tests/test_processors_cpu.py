@@ -1,0 +1,113 @@
+"""BASELINE.json configs[0]: CogVideoX, 49 frames 480p geometry (cfg=2, H=48, D=64, text 226 first, F=13, P=1350,
+S=17776), ONE denoise step through a stand-in 2-block stack on CPU with dense torch SDPA — the reference's own CPU-runnable
+case.  It checks the plumbing (install hook, class-level config, timestep hook, processor protocol, dense branch) and that
+the sparse branch refuses CPU tensors instead of silently falling back."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from standins import Attention, Block, Pipe, Transformer
+
+
+def make_cog(heads=48, head_dim=64, layers=2, dtype=torch.bfloat16):
+    torch.manual_seed(0)
+    blocks = [Block(Attention(heads * head_dim, heads, qk_norm="layer", dtype=dtype), "attn1") for _ in range(layers)]
+    return Pipe(Transformer(blocks, "transformer_blocks"))
+
+
+def torch_reference_block(attn, hidden, enc):
+    """CogVideoX attention block in plain torch (text first, LayerNorm QK, no rope) for the dense branch."""
+    x = torch.cat([enc, hidden], dim=1)
+    B = x.shape[0]
+    q, k, v = attn.to_q(x), attn.to_k(x), attn.to_v(x)
+    hd = q.shape[-1] // attn.heads
+    q, k, v = (t.view(B, -1, attn.heads, hd).transpose(1, 2) for t in (q, k, v))
+    q, k = attn.norm_q(q), attn.norm_k(k)
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = o.transpose(1, 2).reshape(B, -1, attn.heads * hd)
+    o = attn.to_out[0](o)
+    return o[:, enc.shape[1]:], o[:, : enc.shape[1]]
+
+
+def test_cog_config1_dense_step_on_cpu():
+    from svg.models.cog.attention import CogVideoX_SparseAttn_Processor2_0
+    from svg.models.cog.inference import replace_cog_attention
+
+    torch.set_num_threads(8)
+    pipe = make_cog()
+    cls = replace_cog_attention(pipe, "v1", num_sampled_rows=32, sparsity=0.25, first_layers_fp=0.025, first_times_fp=0.2)
+    assert cls is CogVideoX_SparseAttn_Processor2_0
+    assert (cls.context_length, cls.num_frame, cls.frame_size) == (226, 13, 1350)
+    assert cls.block_mask.band == math.floor(cls.block_mask.band / 128) * 128 and cls.block_mask.rowfull_hi == 226
+    cfg, S_text, S_vid, dim = 2, 226, 13 * 1350, 48 * 64
+    torch.manual_seed(1)
+    hidden = torch.randn(cfg, S_vid, dim).to(torch.bfloat16) * 0.1
+    enc = torch.randn(cfg, S_text, dim).to(torch.bfloat16) * 0.1
+    t_dense = torch.tensor([999.0])  # > 1000 * (1 - 0.2): warm-up step -> dense branch (ref cog/attention.py:173-176)
+    with torch.no_grad():
+        out_h, out_e = pipe.transformer(hidden, encoder_hidden_states=enc, timestep=t_dense)
+        # plain-torch statement of the same two blocks
+        h, e = hidden, enc
+        for b in pipe.transformer.transformer_blocks:
+            dh, de = torch_reference_block(b.attn1, h, e)
+            h, e = h + dh, e + de
+    torch.testing.assert_close(out_h.float(), h.float(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(out_e.float(), e.float(), atol=2e-2, rtol=2e-2)
+    # a sparse step on CPU tensors must fail loudly: the sparse path exists only as HIP kernels
+    cls.first_layers_fp = 0.0
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        pipe.transformer(hidden, encoder_hidden_states=enc, timestep=torch.tensor([100.0]))
+
+
+def test_timestep_hook_and_explicit_keyword():
+    from svg.models import context
+    from svg.models.cog.inference import replace_cog_attention
+
+    pipe = make_cog(heads=2, head_dim=64, layers=1, dtype=torch.float32)
+    replace_cog_attention(pipe, "v1", 32, 0.25, 0.0, 0.2)
+    seen = []
+    proc = pipe.transformer.transformer_blocks[0].attn1.processor
+    orig = proc.attention_core_logic
+    proc.attention_core_logic = lambda q, k, v, t: (seen.append(t), orig(q, k, v, torch.tensor([1000.0])))[1]
+    S_vid = 13 * 1350
+    with torch.no_grad():
+        pipe.transformer(torch.zeros(1, S_vid, 128), encoder_hidden_states=torch.zeros(1, 226, 128), timestep=torch.tensor([7.0]))
+        assert seen[-1].item() == 7.0 and context.current_timestep() is None
+        attn = pipe.transformer.transformer_blocks[0].attn1
+        attn(torch.zeros(1, S_vid, 128), encoder_hidden_states=torch.zeros(1, 226, 128), timestep=torch.tensor([5.0]))
+        assert seen[-1].item() == 5.0
+
+
+def test_hunyuan_and_wan_install_hooks_set_class_config():
+    from svg.models.hyvideo.attention import Hunyuan_SAPAttn_Processor2_0, Hunyuan_SVGAttn_Processor2_0
+    from svg.models.hyvideo.inference import replace_hyvideo_attention
+    from svg.models.wan.inference import replace_wan_attention
+
+    blocks = [Block(Attention(256, 2, added_kv=(i < 1)), "attn") for i in range(3)]
+    tr = Transformer(blocks[:1], "transformer_blocks")
+    tr.single_transformer_blocks = torch.nn.ModuleList(blocks[1:])
+    pipe = Pipe(tr)
+    cls = replace_hyvideo_attention(pipe, 720, 1280, 129, 64, first_layers_fp=1, first_times_fp=900.0, pattern="SVG",
+                                    num_sampled_rows=64, sparsity=0.25)
+    assert cls is Hunyuan_SVGAttn_Processor2_0
+    assert (cls.context_length, cls.num_frame, cls.frame_size, cls.prompt_length) == (256, 33, 3600, 64)
+    assert cls.block_mask.band == 15616 and cls.block_mask.real_len == 33 * 3600 + 64
+    assert [b.attn.processor.layer_idx for b in blocks] == [0, 1, 2]
+    cls = replace_hyvideo_attention(pipe, 720, 1280, 129, 64, 1, 900.0, pattern="SAP", num_q_centroids=400,
+                                    num_k_centroids=1000, top_p_kmeans=0.9, min_kc_ratio=0.1, kmeans_iter_init=50,
+                                    kmeans_iter_step=2, zero_step_kmeans_init=True)
+    assert cls is Hunyuan_SAPAttn_Processor2_0 and cls.num_k_centroids == 1000 and cls.kmeans_iter_step == 2
+
+    class WanCfg:
+        patch_size = (1, 2, 2)
+
+    wblocks = [Block(Attention(256, 2, across_heads=True), "attn1") for _ in range(2)]
+    wtr = Transformer(wblocks, "blocks")
+    wtr.config = WanCfg()
+    wpipe = Pipe(wtr)
+    wpipe.vae_scale_factor_temporal, wpipe.vae_scale_factor_spatial = 4, 8
+    wcls = replace_wan_attention(wpipe, 720, 1280, 81, first_layers_fp=1, first_times_fp=800.0, pattern="SVG", sparsity=0.3)
+    assert (wcls.context_length, wcls.num_frame, wcls.frame_size) == (0, 21, 3600)
+    assert wcls.block_mask.band == 12417 and wcls.block_mask.colfull_hi == 3600
