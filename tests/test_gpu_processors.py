@@ -1,0 +1,220 @@
+"""GPU end-to-end tests of the attention processors (the drop-in boundary): stand-in diffusers modules, small
+geometries, results compared with the same flow restated with torch + the CPU oracle."""
+import math
+
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+from standins import Attention, Block, Pipe, Transformer
+
+pytestmark = pytest.mark.gpu
+DT = torch.bfloat16
+
+
+def rope_tables(n, d):
+    pos = torch.arange(n)[:, None].float()
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    ang = (pos * inv[None]).repeat_interleave(2, dim=1)
+    return ang.cos(), ang.sin()
+
+
+def hy_reference(attn, hidden, enc, rope, best, single, geo, prm):
+    """Plain-torch statement of Hunyuan_SVGAttn_Processor2_0.__call__ with the oracle attention (fp32)."""
+    from svg.models.hyvideo.attention import apply_rotary_emb
+
+    ctx, F_, P_ = geo
+    a = attn.float()
+    x = torch.cat([hidden, enc], dim=1).float() if single else hidden.float()
+    q, k, v = (m(x).unflatten(2, (attn.heads, -1)).transpose(1, 2) for m in (a.to_q, a.to_k, a.to_v))
+    q, k = a.norm_q(q), a.norm_k(k)
+    n_txt = enc.shape[1]
+    if single:
+        q = torch.cat([apply_rotary_emb(q[:, :, :-n_txt], rope), q[:, :, -n_txt:]], 2)
+        k = torch.cat([apply_rotary_emb(k[:, :, :-n_txt], rope), k[:, :, -n_txt:]], 2)
+    else:
+        q, k = apply_rotary_emb(q, rope), apply_rotary_emb(k, rope)
+        e = enc.float()
+        eq, ek, ev = (m(e).unflatten(2, (attn.heads, -1)).transpose(1, 2) for m in (a.add_q_proj, a.add_k_proj, a.add_v_proj))
+        eq, ek = a.norm_added_q(eq), a.norm_added_k(ek)
+        q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
+    q, k, v = (t.to(DT) for t in (q, k, v))  # the kernel sees bf16 inputs
+    S = q.shape[2]
+    qp, kp, vp = (O.head_placement(t, best, ctx, F_, P_) for t in (q, k, v))
+    o = O.head_placement(O.masked_attention(qp, kp, vp, O.band_mask(S, *prm)), best, ctx, F_, P_, inverse=True)
+    o = o.transpose(1, 2).flatten(2, 3)
+    h, e2 = o[:, :-n_txt], o[:, -n_txt:]
+    h = a.to_out[0](h)
+    if not single:
+        e2 = a.to_add_out(e2)
+    attn.to(DT)
+    return h, e2
+
+
+def test_hunyuan_svg_processor_end_to_end():
+    from svg.models.hyvideo.inference import replace_hyvideo_attention
+
+    torch.manual_seed(0)
+    heads, hd = 4, 128
+    dim = heads * hd
+    blocks = [Block(Attention(dim, heads, added_kv=True, dtype=DT), "attn"), Block(Attention(dim, heads, dtype=DT), "attn")]
+    tr = Transformer(blocks[:1], "transformer_blocks")
+    tr.single_transformer_blocks = torch.nn.ModuleList(blocks[1:])
+    pipe = Pipe(tr)
+    tr.cuda()
+    L = 21
+    cls = replace_hyvideo_attention(pipe, 160, 320, 17, L, first_layers_fp=0, first_times_fp=900.0, pattern="SVG",
+                                    num_sampled_rows=32, sparsity=0.45)
+    ctx, F_, P_ = cls.context_length, cls.num_frame, cls.frame_size
+    assert (ctx, F_, P_) == (256, 5, 200)
+    cls.sample_mse_max_row = F_ * P_
+    V = F_ * P_
+    hidden = (torch.randn(1, V, dim) * 0.3).to(DT).cuda()
+    enc = (torch.randn(1, ctx, dim) * 0.3).to(DT).cuda()
+    amask = torch.zeros(1, V + ctx, dtype=torch.bool)
+    amask[:, : V + L] = True
+    rope = rope_tables(V, hd)
+    prm = cls.block_mask.as_tuple()
+    for blk, single in ((blocks[0], False), (blocks[1], True)):
+        with torch.no_grad():
+            h, e = blk.attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                            timestep=torch.tensor([100.0]))
+            best = blk.attn.processor.last_best_mask_idx.cpu()
+            blk.attn.cpu()
+            rh, re = hy_reference(blk.attn, hidden.cpu(), enc.cpu(), rope, best, single, (ctx, F_, P_), prm)
+            blk.attn.cuda()
+        torch.testing.assert_close(h.float().cpu(), rh, atol=3e-2, rtol=3e-2)
+        torch.testing.assert_close(e.float().cpu(), re, atol=3e-2, rtol=3e-2)
+        # dense warm-up branch (two segments through the attention_mask) against torch
+        with torch.no_grad():
+            hd_, _ = blk.attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                              timestep=torch.tensor([950.0]))
+        assert torch.isfinite(hd_.float()).all()
+    # fused and materialised placement give bit-identical processor outputs
+    cls.fused_placement = False
+    torch.manual_seed(5)
+    with torch.no_grad():
+        h2, _ = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                               timestep=torch.tensor([100.0]))
+    cls.fused_placement = True
+    torch.manual_seed(5)
+    with torch.no_grad():
+        h3, _ = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                               timestep=torch.tensor([100.0]))
+    assert torch.equal(h2, h3)
+
+
+def _clustered(H, N, D, modes, gen):
+    centers = torch.randn(H, modes, D, generator=gen) * 2.0
+    lab = torch.randint(0, modes, (H, N), generator=gen)
+    return torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + 0.4 * torch.randn(H, N, D, generator=gen)
+
+
+@pytest.mark.parametrize("model", ["hy", "wan"])
+def test_svg2_core_against_oracle_and_dense(model):
+    """SVG2 sparse branch: (a) top_p = 1 keeps every block -> must equal dense attention (permutation invariance);
+    (b) top_p < 1: equals oracle attention under the element mask built from the kernels' own labels and block map."""
+    from svg import _native as nat
+    from svg.kmeans_utils import batch_kmeans_Euclid, identify_dynamic_map
+    from svg.models import _core
+
+    gen = torch.Generator().manual_seed(3)
+    H, D, F_, P_ = 3, 128, 6, 150
+    ctx, L = (256, 40) if model == "hy" else (0, 0)
+    V = F_ * P_
+    S = V + ctx
+    q = _clustered(H, S, D, 12, gen)[None].to(DT).cuda()
+    k = _clustered(H, S, D, 20, gen)[None].to(DT).cuda()
+    v = torch.randn(1, H, S, D, generator=gen).to(DT).cuda()
+    geo = _core.Geometry(ctx, F_, P_)
+    QC, KC = 10, 24
+    # (a) everything kept
+    store = _core.CentroidStore()
+    torch.manual_seed(11)
+    o_all = _core.svg2_sparse_attention(q, k, v, geo, store, 0, QC, KC, top_p=1.0, min_kc_ratio=1.0, iter_init=3, iter_step=1,
+                                        prompt_length=L)
+    dense_prm = O.dense_band_params(S, V + L) if ctx else O.dense_band_params(S)
+    ref_dense = O.masked_attention(q.cpu(), k.cpu(), v.cpu(), O.band_mask(S, **dense_prm))
+    torch.testing.assert_close(o_all.float().cpu(), ref_dense, atol=1e-2, rtol=1e-2)
+    # (b) warm-started step with top-p selection, re-derived from the kernels' labels / map
+    qc0, kc0 = store.q[0].clone(), store.k[0].clone()
+    o = _core.svg2_sparse_attention(q, k, v, geo, store, 0, QC, KC, top_p=0.6, min_kc_ratio=0.1, iter_init=3, iter_step=2,
+                                    prompt_length=L)
+    ql, qc, qs, _ = batch_kmeans_Euclid(q[0, :, :V].contiguous(), QC, max_iters=2, init_centroids=qc0)
+    kl, kc, ks, _ = batch_kmeans_Euclid(k[0, :, :V].contiguous(), KC, max_iters=2, init_centroids=kc0)
+    dmap = identify_dynamic_map(qc[None], kc[None], qs[None], ks[None], 0.6, 0.1)[0].cpu()
+    assert 0.05 < dmap.float().mean() < 0.95
+    ql, kl = ql.cpu(), kl.cpu()
+    for h in range(H):
+        em = torch.zeros(S, S, dtype=torch.bool)
+        em[:V, :V] = dmap[h][ql[h]][:, kl[h]]
+        if ctx:
+            em[:V, V:V + L] = True       # everything real sees the prompt
+            em[V:V + L, : V + L] = True  # the prompt sees everything real
+            em[V + L:, V + L:] = True    # unused prompt tokens see only themselves
+        ref = O.masked_attention(q[0, h].cpu(), k[0, h].cpu(), v[0, h].cpu(), em)
+        torch.testing.assert_close(o[0, h].float().cpu(), ref, atol=1e-2, rtol=1e-2)
+
+
+def test_wan_and_cog_svg_processors_run_and_match():
+    from svg.models.cog.attention import CogVideoX_SparseAttn_Processor2_0 as CogP
+    from svg.models.cog.utils import generate_temporal_head_mask_mod as cog_mm
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as WanP
+    from svg.models.wan.utils import generate_temporal_head_mask_mod as wan_mm
+
+    torch.manual_seed(1)
+    heads, hd = 2, 64
+    dim = heads * hd
+    # ---- Cog: text first, LayerNorm qk-norm, returns (hidden, encoder)
+    ctx, F_, P_ = 26, 4, 180
+    CogP.context_length, CogP.num_frame, CogP.frame_size = ctx, F_, P_
+    CogP.first_layers_fp, CogP.first_times_fp, CogP.num_sampled_rows = 0.0, 0.2, 16
+    CogP.block_mask = cog_mm(ctx, F_, P_, mul=1.5)
+    attn = Attention(dim, heads, qk_norm="layer", dtype=DT).cuda()
+    attn.set_processor(CogP(0))
+    hidden = (torch.randn(2, F_ * P_, dim) * 0.3).to(DT).cuda()
+    enc = (torch.randn(2, ctx, dim) * 0.3).to(DT).cuda()
+    with torch.no_grad():
+        h, e = attn(hidden, encoder_hidden_states=enc, image_rotary_emb=None, timestep=torch.tensor([100.0]))
+        best = attn.processor.last_best_mask_idx.cpu()
+        best = torch.where(torch.isnan(best.float()), torch.zeros_like(best), best)
+        a = attn.cpu().float()
+        x = torch.cat([enc, hidden], 1).float().cpu()
+        q, k, v = (m(x).view(2, -1, heads, hd).transpose(1, 2) for m in (a.to_q, a.to_k, a.to_v))
+        q, k = a.norm_q(q), a.norm_k(k)
+        q, k, v = (t.to(DT) for t in (q, k, v))
+        S = ctx + F_ * P_
+        qp, kp, vp = (O.head_placement(t, best, ctx, F_, P_, text_first=True) for t in (q, k, v))
+        o = O.head_placement(O.masked_attention(qp, kp, vp, O.band_mask(S, *CogP.block_mask.as_tuple())), best, ctx, F_, P_,
+                             text_first=True, inverse=True)
+        ref = a.to_out[0](o.transpose(1, 2).reshape(2, -1, dim))
+    torch.testing.assert_close(h.float().cpu(), ref[:, ctx:], atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(e.float().cpu(), ref[:, :ctx], atol=3e-2, rtol=3e-2)
+    # ---- Wan: no text, qk-norm across heads, complex rope as (real, imag)
+    F_, P_ = 5, 160
+    WanP.context_length, WanP.num_frame, WanP.frame_size = 0, F_, P_
+    WanP.first_layers_fp, WanP.first_times_fp, WanP.num_sampled_rows, WanP.sample_mse_max_row = 0, 900.0, 16, 400
+    WanP.block_mask = wan_mm(0, 0, F_, P_, mul=1.2)
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=DT).cuda()
+    attn.set_processor(WanP(0))
+    S = F_ * P_
+    hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
+    ang = torch.rand(S, hd // 2) * 6.28
+    rope = (ang.cos().cuda(), ang.sin().cuda())
+    with torch.no_grad():
+        out = attn(hidden, rotary_emb=rope, timestep=torch.tensor([100.0]))
+        best = attn.processor.last_best_mask_idx.cpu()
+        a = attn.cpu().float()
+        x = hidden.float().cpu()
+        q, k, v = a.to_q(x), a.to_k(x), a.to_v(x)
+        q, k = a.norm_q(q), a.norm_k(k)
+        q, k, v = (t.unflatten(2, (heads, -1)).transpose(1, 2) for t in (q, k, v))
+        fr = torch.complex(ang.cos().double(), ang.sin().double())[None, None]
+        rot = lambda t: torch.view_as_real(torch.view_as_complex(t.double().unflatten(3, (-1, 2))) * fr).flatten(3, 4).float()
+        q, k = rot(q), rot(k)
+        q, k, v = (t.to(DT) for t in (q, k, v))
+        qp, kp, vp = (O.head_placement(t, best, 0, F_, P_) for t in (q, k, v))
+        o = O.head_placement(O.masked_attention(qp, kp, vp, O.band_mask(S, *WanP.block_mask.as_tuple())), best, 0, F_, P_,
+                             inverse=True)
+        ref = a.to_out[0](o.transpose(1, 2).flatten(2, 3))
+    torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
