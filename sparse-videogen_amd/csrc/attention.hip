@@ -212,6 +212,12 @@ __global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPoli
     attn_body<T, D, NW, BandPolicy<T, D, NW, SKEW, ABL>>(prm, smem, nullptr);
 }
 
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pipe_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pipe<T, D, 8, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
+}
+
 // =====================================================================================================
 // Variable-block policy (SVG2): q rows of block-row i attend the kv rows of the active block-cols.
 // The active, non-empty column blocks of the workgroup's block-row are compacted into a run list in LDS
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __res
 }
 
 thread_local int g_last_hip_error = 0;
+static thread_local bool g_band_pipe = false;  // set per call from `variant` bit 2
 
 template <typename K, typename Prm>
 static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds, hipStream_t st) {
@@ -435,6 +442,10 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         p.n_heavy = (hi + Pol::BM - 1) / Pol::BM - p.heavy_lo;
         if (p.n_heavy >= p.nqt) p.heavy_lo = 0, p.n_heavy = 0;
     }
+    if (g_band_pipe && NW == 8 && !SKEW && ABL == 0) {
+        if constexpr (NW == 8 && !SKEW && ABL == 0)
+            return launch_attn(band_attn_pipe_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 3>(), st);
+    }
     return launch_attn(band_attn_kernel<T, D, NW, SKEW, ABL>, p, dim3(p.nqt * BH), NW * 64,
                        attn_lds_bytes<D, NW, attn_stages<NW, Pol>()>(), st);
 }
@@ -465,9 +476,14 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
             case 3: return run_band<__bf16, 128, 8, false, 3>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 4: return run_band<__bf16, 128, 8, false, 4>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 5: return run_band<__bf16, 128, 8, false, 5>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 6: return run_band<__bf16, 128, 8, false, 6>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 7: return run_band<__bf16, 128, 8, false, 7>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 8: return run_band<__bf16, 128, 8, false, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 9: return run_band<__bf16, 128, 8, false, 9>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             default: return SVG_ERR_UNSUPPORTED;
         }
     }
+    g_band_pipe = (variant & 4) != 0;      // bit 2: software-pipelined schedule (attn_body_pipe)
     const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU (default 8 waves x 32 rows)
     const bool prio = (variant & 2) != 0;  // bit 1: skewed two-group schedule (experimental; measured 3 % slower than lock-step)
 #define SVG_BAND_RUN(T, DD, NWW)                                                                                  \

@@ -16,6 +16,8 @@
 // Staging is register-staged and software-pipelined: global loads for tile t+2 are issued right after the
 // ds_writes of tile t+1, one barrier per tile, two LDS stages.
 #pragma once
+#include <type_traits>
+
 #include "svg_common.h"
 
 namespace svg {
@@ -198,15 +200,19 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                 const int cch = ((2 * ks + g) ^ ksw0) << 4;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const V8 a = *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + cch);
-                    s[b] = E::mfma(a, qf[ks], s[b]);
+                    if constexpr (P::kAbl == 6 || P::kAbl >= 8) {  // ablation: MFMAs without the K-fragment LDS reads
+                        s[b] = E::mfma(qf[(ks + b) % KS], qf[ks], s[b]);
+                    } else {
+                        const V8 a = *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + cch);
+                        s[b] = E::mfma(a, qf[ks], s[b]);
+                    }
                 }
             }
         } else {  // ablation: no QK^T (keep the values opaque so that the softmax is not folded away)
             asm volatile("" : "+v"(s[0]), "+v"(s[1]));
         }
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
-        if constexpr (P::kAbl == 1) {  // ablation: no softmax VALU
+        if constexpr (P::kAbl == 1 || P::kAbl == 9) {  // ablation: no softmax VALU
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -271,10 +277,14 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int kb0 = 32 * b + 16 * h;
-                    const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
-                    const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
-                    i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
+                    if constexpr (P::kAbl == 7 || P::kAbl >= 8) {  // ablation: MFMAs without the V transpose reads
+                        acc_o[db] = E::mfma(qf[(db + b + h) % KS], pf[b][h], acc_o[db]);
+                    } else {
+                        const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
+                        const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
+                        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
+                    }
                 }
         }
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
@@ -307,11 +317,11 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
             }
         }
         const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;
-        if constexpr (P::kAbl != 4) {
+        if constexpr (P::kAbl != 4 && P::kAbl < 8) {
             if (t + 1 < nT) stage_write(nbuf);
             if (t + 2 < nT) stage_issue(t + 2);
         }
-        if constexpr (P::kAbl != 5) __syncthreads();
+        if constexpr (P::kAbl != 5 && P::kAbl < 8) __syncthreads();
         buf = nbuf;
     }
     if (NS == 3) {
@@ -356,6 +366,308 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
         if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
     }
+    }
+}
+
+
+// =====================================================================================================================
+// attn_body_pipe — software-pipelined schedule (8 waves, three LDS stages).
+//
+// attn_body runs QK^T -> softmax -> PV per tile; the ablation in profiles/r01_ablation.md shows those phases do not
+// overlap (the two waves of a SIMD sit in the same phase).  Here every wave overlaps them itself: while the matrix pipe
+// executes QK^T of tile t+1, the same wave issues the softmax VALU work of tile t in the shadow of its own MFMAs
+// (an MFMA occupies the pipe for 32 cycles but issues in ~4; independent VALU instructions issue behind it).
+//
+//   iteration t:   phase 1   S(t+1) = K(t+1) Q^T    interleaved, k-step by k-step, with  softmax(S(t)) -> P(t), alpha
+//                  (rare)    O *= alpha             only when a row maximum moved
+//                  phase 2   O^T += V(t)^T P(t)^T   interleaved with ds_write of tile t+2 and the global loads of t+3
+//                  barrier
+// LDS: tile t lives in stage t % 3; iteration t reads K(t+1), V(t) and writes tile t+2 over tile t-1 (dead since the
+// barrier of iteration t-1).  No SKIP class: a tile that a wave does not need is masked (p = 0), band-edge waste ~1 %.
+// =====================================================================================================================
+template <typename T, int D, int NW, typename P>
+__device__ __forceinline__ void attn_body_pipe(const typename P::Params& prm, char* smem, char* policy_lds) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    using L = LdsLayout<D>;
+    constexpr int NT = NW * 64;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int NCH = (kBN * L::kCPR) / NT;
+    constexpr int NS = 3;
+    static_assert(KS == 8 || KS == 4, "softmax interleave is written for 8 or 4 k-steps");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, policy_lds)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_id();
+    const int g = lane >> 5;
+    const int ql = lane & 31;
+    const int row_in_wg = wave * 32 + ql;
+
+    const T* __restrict__ qb = P::q_base(prm, ctx);
+    const T* __restrict__ kb = P::k_base(prm, ctx);
+    const T* __restrict__ vb = P::v_base(prm, ctx);
+
+    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
+    const int q_log = P::q_logical(ctx, row_in_wg);
+    V8 qf[KS];
+    {
+        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
+    }
+
+    int srow[NCH], k_dst[NCH], v_dst[NCH], scol[NCH];
+    typename P::KvCursor cur[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = tid + i * NT;
+        srow[i] = id / L::kCPR;
+        scol[i] = id - srow[i] * L::kCPR;
+        k_dst[i] = L::k_off(srow[i], scol[i]);
+        v_dst[i] = L::kKBytes + L::v_off(srow[i], scol[i]);
+        P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
+    }
+    u32x4 kreg[NCH], vreg[NCH];
+    int nphys[NCH];
+    auto stage_resolve = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
+    };
+    auto stage_issue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)nphys[i] * D + scol[i] * 8;
+            kreg[i] = *(const u32x4*)(kb + off);
+            vreg[i] = *(const u32x4*)(vb + off);
+        }
+        stage_resolve(t + 1);
+    };
+    auto stage_write = [&](int buf) {
+        char* base = smem + buf * L::kStageBytes;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *(u32x4*)(base + k_dst[i]) = kreg[i];
+            *(u32x4*)(base + v_dst[i]) = vreg[i];
+        }
+    };
+
+    const int ksw0 = (D == 128) ? (ql & 15) : ((ql >> 1) & 7);
+    const int vi = lane & 15;
+    const int v_lane_off = L::kKBytes + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    const float c_log2 = prm.scale_log2;
+    const int nT = ctx.nT;
+
+    // ---- prologue: tiles 0 and 1 into LDS, tile 2 into registers, S(0) ----
+    stage_resolve(0);
+    if (nT > 0) stage_issue(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    if (nT > 0) {
+        stage_write(0);
+        if (nT > 1) {
+            stage_issue(1);
+            stage_write(1);
+        }
+        if (nT > 2) stage_issue(2);
+    }
+    __syncthreads();
+
+    f32x16 sc[2], sn[2];  // scores of the current tile / of the next tile (being accumulated)
+    auto zero = [](f32x16 (&x)[2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[b][r] = 0.f;
+    };
+    auto kfrag = [&](const char* kbuf, int b, int ks) -> V8 {
+        return *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + (((2 * ks + g) ^ ksw0) << 4));
+    };
+    zero(sc);
+    if (nT > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) sc[b] = E::mfma(kfrag(smem, b, ks), qf[ks], sc[b]);
+    }
+
+    V8 pf[2][2];
+    int buf = 0;  // stage of tile t
+    // one iteration; HAS_NEXT is a compile-time flag so that phase 1 is a single basic block (a run-time test would put
+    // every k-step into its own block and the scheduler could not interleave the softmax with the MFMAs)
+    auto iteration = [&](int t, auto has_next_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;      // stage of tile t+1
+        const int wbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;    // stage of tile t+2 (= stage of dead tile t-1)
+        const char* kcur = smem + buf * L::kStageBytes;
+        const char* knxt = smem + nbuf * L::kStageBytes;
+
+        // ---- element mask on the current scores (band edges / text boundary / tile tail): rare ----
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if constexpr (P::kFixup) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[b][r] = P::score_fixup(prm, sc[b][r]);
+        }
+        if (cls != TILE_FULL) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const bool ok = (cls == TILE_PARTIAL) && P::allowed(prm, ctx, q_log, tk0 + key);
+                    sc[b][r] = ok ? sc[b][r] : -INFINITY;
+                }
+        }
+
+        // ---- phase 1: S(t+1) = K(t+1) Q^T  ||  softmax(S(t)) ----
+        zero(sn);
+        float mx, m_new, m_use, alpha, psum = 0.f;
+        // K fragments are prefetched one k-step ahead INSIDE the pinned step (reads for step ks+1 are issued before the
+        // MFMAs and the softmax chunk of step ks), so the LDS latency hides behind that chunk instead of adding to it.
+        V8 kf[2][2];  // [parity][block]
+        if constexpr (has_next) {
+            kf[0][0] = kfrag(knxt, 0, 0);
+            kf[0][1] = kfrag(knxt, 1, 0);
+        }
+        auto qk_step = [&](int ks) {
+            if constexpr (has_next) {
+                if (ks + 1 < KS) {
+                    kf[(ks + 1) & 1][0] = kfrag(knxt, 0, ks + 1);
+                    kf[(ks + 1) & 1][1] = kfrag(knxt, 1, ks + 1);
+                }
+                sn[0] = E::mfma(kf[ks & 1][0], qf[ks], sn[0]);
+                sn[1] = E::mfma(kf[ks & 1][1], qf[ks], sn[1]);
+            }
+        };
+        auto sm_max = [&](int b) {  // row max of block b into mx
+            float a = sc[b][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) a = fmaxf(a, sc[b][r]);
+            mx = (b == 0) ? a : fmaxf(mx, a);
+        };
+        auto sm_stats = [&]() {
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_new = fmaxf(m_run, mx * c_log2);
+            m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            asm volatile("" : "+v"(m_use), "+v"(alpha));
+        };
+        auto sm_exp = [&](int b, int h) {  // 8 probabilities: registers 8h..8h+7 of block b
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][8 * h + j], c_log2, -m_use));
+                psum += p;
+                pf[b][h][j] = E::from_float(p);
+            }
+            // anchor: keeps the IR optimiser from sinking this chunk to its first use (the PV phase, another block)
+            asm volatile("" : "+v"(pf[b][h]), "+v"(psum));
+        };
+        if constexpr (KS == 8) {
+            qk_step(0); sm_max(0);              __builtin_amdgcn_sched_barrier(0);
+            qk_step(1); sm_max(1); sm_stats();  __builtin_amdgcn_sched_barrier(0);
+            qk_step(2); sm_exp(0, 0);           __builtin_amdgcn_sched_barrier(0);
+            qk_step(3); sm_exp(0, 1);           __builtin_amdgcn_sched_barrier(0);
+            qk_step(4); sm_exp(1, 0);           __builtin_amdgcn_sched_barrier(0);
+            qk_step(5); sm_exp(1, 1);           __builtin_amdgcn_sched_barrier(0);
+            qk_step(6);                         __builtin_amdgcn_sched_barrier(0);
+            qk_step(7);
+        } else {
+            qk_step(0); sm_max(0); sm_max(1); sm_stats();  __builtin_amdgcn_sched_barrier(0);
+            qk_step(1); sm_exp(0, 0); sm_exp(0, 1);        __builtin_amdgcn_sched_barrier(0);
+            qk_step(2); sm_exp(1, 0); sm_exp(1, 1);        __builtin_amdgcn_sched_barrier(0);
+            qk_step(3);
+        }
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        }
+
+        // ---- phase 2: O^T += V(t)^T P(t)^T  ||  staging of tiles t+2 (LDS write) and t+3 (global loads) ----
+        const char* vbase = kcur + v_lane_off;
+        auto vfrag = [&](int idx) -> V8 {  // idx = db * 4 + b * 2 + h
+            const int db = idx >> 2, kb0 = 32 * ((idx >> 1) & 1) + 16 * (idx & 1);
+            const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
+            const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
+            i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(V8, both);
+        };
+        constexpr int NPV = DB * 4;
+        constexpr int PFD = 2;  // prefetch distance in MFMAs
+        V8 vf[PFD + 1];
+#pragma unroll
+        for (int i = 0; i < PFD; ++i) vf[i] = vfrag(i);
+#pragma unroll
+        for (int idx = 0; idx < NPV; ++idx) {
+            if (idx + PFD < NPV) vf[(idx + PFD) % (PFD + 1)] = vfrag(idx + PFD);
+            acc_o[idx >> 2] = E::mfma(vf[idx % (PFD + 1)], pf[(idx >> 1) & 1][idx & 1], acc_o[idx >> 2]);
+            if (idx == 3) {
+                if (t + 2 < nT) stage_write(wbuf);
+            }
+            if (idx == 7 || (NPV <= 8 && idx == NPV - 1)) {
+                if (t + 3 < nT) stage_issue(t + 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) sc[b] = sn[b];
+        __syncthreads();
+        buf = nbuf;
+    };
+    for (int t = 0; t + 1 < nT; ++t) iteration(t, std::true_type{});
+    if (nT > 0) iteration(nT - 1, std::false_type{});
+
+    // ---------------- epilogue (same as attn_body) ----------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if constexpr (P::kPartialOut) {
+        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
+        return;
+    } else {
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        constexpr int kEpiStride = D * 2 + 8;
+        char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        T* __restrict__ ob = P::o_base(prm, ctx);
+        constexpr int kLanesPerRow = D * 2 / 8;
+        constexpr int kRowsPerPass = 64 / kLanesPerRow;
+        const int sub = lane / kLanesPerRow;
+        const int colb = (lane - sub * kLanesPerRow) * 8;
+        int ephys[32 / kRowsPerPass];
+#pragma unroll
+        for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+        for (int i = 0; i < 32 / kRowsPerPass; ++i) {
+            const int rr = i * kRowsPerPass + sub;
+            const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+        }
     }
 }
 
