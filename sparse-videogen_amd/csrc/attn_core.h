@@ -83,7 +83,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     constexpr int NCH = (kBN * L::kCPR) / NT;  // 16-B chunks per thread per tensor per tile
     static_assert((kBN * L::kCPR) % NT == 0, "tile chunks must divide evenly");
 
-    typename P::Ctx ctx;
+    typename P::Ctx ctx;  // workgroup-uniform, except fields a policy documents as per-wave / per-lane
     if (!P::init(prm, ctx, policy_lds)) return;
 
     const int tid = threadIdx.x;
@@ -397,7 +397,7 @@ __device__ __forceinline__ void attn_body_pipe(const typename P::Params& prm, ch
     constexpr int NS = 3;
     static_assert(KS == 8 || KS == 4, "softmax interleave is written for 8 or 4 k-steps");
 
-    typename P::Ctx ctx;
+    typename P::Ctx ctx;  // workgroup-uniform, except fields a policy documents as per-wave / per-lane
     if (!P::init(prm, ctx, policy_lds)) return;
 
     const int tid = threadIdx.x;

@@ -49,39 +49,14 @@ struct ProfilePolicy {
     struct Ctx {
         int head, variant, chunk, t0, nT;
         ProfVariant pv;
+        // per-lane: this lane's sampled row in mask coordinates; per-wave: block range of the wave's rows
+        int qx, qtext;
+        int xlo_blk, xhi_blk, any_text;
+        // per-tile scratch written by classify(): token-major decomposition of the tile's first key
+        mutable int tk0, f0, p0;
     };
     struct KvCursor {};
 
-    static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
-        c.chunk = blockIdx.x;
-        c.head = blockIdx.y;
-        c.variant = blockIdx.z;
-        const int ntiles = (p.S + kBN - 1) / kBN;
-        c.t0 = c.chunk * p.tiles_per_chunk;
-        c.nT = max(0, min(p.tiles_per_chunk, ntiles - c.t0));
-        c.pv = p.var[c.variant == 2 ? 1 : 0];
-        return true;
-    }
-    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
-
-    // logical q index of a sampled row = its physical row
-    static __device__ __forceinline__ int q_phys(const Params& p, const Ctx&, int row) {
-        return row < p.R ? (int)p.rows[row] : -1;
-    }
-    static __device__ __forceinline__ int q_logical(const Ctx&, int row) { return row; }  // resolved in allowed()
-    static __device__ __forceinline__ int tile_key0(const Ctx& c, int t) { return (c.t0 + t) * kBN; }
-    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor&, int) {}
-    static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor&, int t, int row) {
-        const int l = (c.t0 + t) * kBN + row;
-        return l < p.S ? l : 0;  // masked by allowed()
-    }
-    static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
-        if (wrow0 >= p.R) return TILE_SKIP;
-        if (c.variant == 0) return (k0 + kBN <= p.S) ? TILE_FULL : TILE_PARTIAL;
-        return TILE_PARTIAL;
-    }
     static __device__ __forceinline__ int coord(const Params& p, const ProfVariant& pv, int i) {
         if (pv.coord == 1) {
             const unsigned r = (unsigned)(i - p.vid0);
@@ -93,20 +68,91 @@ struct ProfilePolicy {
         }
         return i;
     }
-    static __device__ __forceinline__ bool allowed(const Params& p, const Ctx& c, int qrow, int k) {
-        if (k >= p.S) return false;
-        if (c.variant == 0) return true;
+
+    static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
+        c.chunk = blockIdx.x;
+        c.head = blockIdx.y;
+        c.variant = blockIdx.z;
+        const int ntiles = (p.S + kBN - 1) / kBN;
+        c.t0 = c.chunk * p.tiles_per_chunk;
+        c.nT = max(0, min(p.tiles_per_chunk, ntiles - c.t0));
+        c.pv = p.var[c.variant == 2 ? 1 : 0];
+        // this lane's query row (rows >= R do not exist) in the coordinates of the variant's mask
+        const int row = (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+        const bool have = row < p.R;
+        const int q = have ? (int)p.rows[row] : 0;
+        c.qx = coord(p, c.pv, q) - c.pv.origin;
+        c.qtext = have && ((unsigned)(q - c.pv.text_lo) < (unsigned)(c.pv.text_hi - c.pv.text_lo));
+        const int blk = c.qx >> 7;
+        int lo = have ? blk : (1 << 28), hi = have ? blk : -(1 << 28), anyt = c.qtext;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+            anyt |= __shfl_xor(anyt, o);
+        }
+        c.xlo_blk = lo, c.xhi_blk = hi, c.any_text = anyt;
+        c.tk0 = 0, c.f0 = 0, c.p0 = 0;
+        return true;
+    }
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
+
+    static __device__ __forceinline__ int q_phys(const Params& p, const Ctx&, int row) {
+        return row < p.R ? (int)p.rows[row] : -1;
+    }
+    static __device__ __forceinline__ int q_logical(const Ctx&, int row) { return row; }
+    static __device__ __forceinline__ int tile_key0(const Ctx& c, int t) { return (c.t0 + t) * kBN; }
+    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor&, int) {}
+    static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor&, int t, int row) {
+        const int l = (c.t0 + t) * kBN + row;
+        return l < p.S ? l : 0;  // masked by allowed()
+    }
+    static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
+        if (wrow0 >= p.R) return TILE_SKIP;
+        if (c.variant == 0) return (k0 + kBN <= p.S) ? TILE_FULL : TILE_PARTIAL;
         const ProfVariant& pv = c.pv;
-        const int q = qrow < p.R ? (int)p.rows[qrow] : 0;
-        const bool tq = (unsigned)(q - pv.text_lo) < (unsigned)(pv.text_hi - pv.text_lo);
+        const int k1 = min(k0 + kBN, p.S);
+        if (pv.coord == 0) {
+            // frame-major mask: drop tiles no row of this wave can see (most of the sequence for the spatial mask)
+            const bool text_keys = (k0 < pv.text_hi) && (k1 > pv.text_lo);
+            if (!c.any_text && !text_keys) {
+                const int y0 = k0 - pv.origin, y1 = k1 - 1 - pv.origin;
+                const bool outside = (y1 < 0) || (y0 >= pv.span);
+                const bool far = ((y0 >> 7) - c.xhi_blk >= pv.band_blocks) || (c.xlo_blk - (y1 >> 7) >= pv.band_blocks);
+                const bool no_sink = y0 >= pv.sink_cols;
+                if (outside || (far && no_sink && y0 >= 0)) return TILE_SKIP;
+            }
+        } else {
+            // token-major mask: one division per tile instead of one per element (keys of a tile are consecutive)
+            const int i0 = max(k0 - p.vid0, 0);
+            c.f0 = (int)((unsigned)i0 / (unsigned)p.P);
+            c.p0 = i0 - c.f0 * p.P;
+        }
+        c.tk0 = k0;
+        return TILE_PARTIAL;
+    }
+    static __device__ __forceinline__ bool allowed(const Params& p, const Ctx& c, int, int k) {
+        if (c.variant == 0) return k < p.S;
+        const ProfVariant& pv = c.pv;
         const bool tk = (unsigned)(k - pv.text_lo) < (unsigned)(pv.text_hi - pv.text_lo);
-        const int x = coord(p, pv, q) - pv.origin;
-        const int y = coord(p, pv, k) - pv.origin;
+        int yc = k;
+        if (pv.coord == 1) {
+            const int off = k - c.tk0;  // 0..63, P >= 64 (checked on the host): at most one wrap into the next frame
+            int pp = c.p0 + off, f = c.f0;
+            const bool wrap = pp >= p.P;
+            pp = wrap ? pp - p.P : pp;
+            f = wrap ? f + 1 : f;
+            const bool in_video = (unsigned)(k - p.vid0) < (unsigned)p.V;
+            yc = in_video ? p.vid0 + pp * p.F + f : k;
+        }
+        const int x = c.qx, y = yc - pv.origin;
         const bool dom = ((unsigned)x < (unsigned)pv.span) & ((unsigned)y < (unsigned)pv.span);
         const int db = (x >> 7) - (y >> 7);
         const bool band = (db < pv.band_blocks) & (-db < pv.band_blocks);
         const bool sink = y < pv.sink_cols;
-        return tq | tk | (dom & (band | sink));
+        return (k < p.S) & (bool)(c.qtext | tk | (dom & (band | sink)));
     }
     static __device__ __forceinline__ float score_fixup(const Params& p, float s) {
         if (!p.emulate) return s;
@@ -139,21 +185,27 @@ __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename 
     attn_body<T, D, kProfNW, ProfilePolicy<T, D>>(prm, smem, nullptr);
 }
 
-// merge the split-KV partials, normalise, and reduce the two MSEs of one head.  grid = (BH), block = 256
+// merge the split-KV partials, normalise, and reduce squared errors.  grid = (kProfRowGroups, BH), block = 256:
+// row group rg of head h -> sq_part[h][rg][0..1] (sum of squared errors of the two masks), [2..3] NaN flags
+constexpr int kProfRowGroups = 8;
+
 template <typename T, int D>
-__global__ __launch_bounds__(256) void profile_combine_kernel(const float* __restrict__ part, float* __restrict__ out_mse, int BH,
+__global__ __launch_bounds__(256) void profile_combine_kernel(const float* __restrict__ part, float* __restrict__ sq_part, int BH,
                                                               int R, int n_chunks, int emulate) {
-    __shared__ float red[2][4];
-    const int h = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red[4][4];
+    const int rg = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int rows_per = (R + kProfRowGroups - 1) / kProfRowGroups;
+    const int r0 = rg * rows_per, r1 = min(R, r0 + rows_per);
     float sq[2] = {0.f, 0.f};
-    bool bad[2] = {false, false};
-    for (int e = tid; e < R * D; e += 256) {
+    float bad[2] = {0.f, 0.f};
+    constexpr int DS = D + 4;
+    for (int e = r0 * D + tid; e < r1 * D; e += 256) {
         const int row = e / D, d = e - row * D;
         float o[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            const float* base = part + ((((size_t)v * BH + h) * n_chunks) * kProfMaxRows + row) * (D + 4);
-            const size_t cs = (size_t)kProfMaxRows * (D + 4);
+            const float* base = part + ((((size_t)v * BH + h) * n_chunks) * kProfMaxRows + row) * DS;
+            const size_t cs = (size_t)kProfMaxRows * DS;
             float M = -INFINITY;
             for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, base[c * cs + D]);
             float L = 0.f, acc = 0.f;
@@ -172,27 +224,37 @@ __global__ __launch_bounds__(256) void profile_combine_kernel(const float* __res
             float diff = o[v + 1] - o[0];
             if (emulate) {
                 diff = Elt<T>::to_float(Elt<T>::from_float(diff));
-                float s2 = diff * diff;
-                s2 = Elt<T>::to_float(Elt<T>::from_float(s2));
-                sq[v] += s2;
+                sq[v] += Elt<T>::to_float(Elt<T>::from_float(diff * diff));
             } else {
                 sq[v] += diff * diff;
             }
-            bad[v] |= (diff != diff);
+            if (diff != diff) bad[v] = 1.f, sq[v] = 0.f;
         }
     }
+    float vals[4] = {bad[0] > 0.f ? 0.f : sq[0], bad[1] > 0.f ? 0.f : sq[1], bad[0], bad[1]};
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        float s = bad[v] ? __builtin_nanf("") : sq[v];
-        s = wave_sum(s);
-        if ((tid & 63) == 0) red[v][tid >> 6] = s;
+    for (int i = 0; i < 4; ++i) {
+        const float s = wave_sum(vals[i]);
+        if ((tid & 63) == 0) red[i][tid >> 6] = s;
     }
     __syncthreads();
-    if (tid < 2) {
-        float s = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    if (tid < 4) sq_part[((size_t)h * kProfRowGroups + rg) * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+// grid = (1), block = 256: out_mse[v][h] = mean over rows and D (NaN when any sampled row had no visible key)
+template <typename T>
+__global__ __launch_bounds__(256) void profile_finalize_kernel(const float* __restrict__ sq_part, float* __restrict__ out_mse,
+                                                               int BH, int R, int D, int emulate) {
+    for (int i = threadIdx.x; i < 2 * BH; i += 256) {
+        const int v = i / BH, h = i - v * BH;
+        float s = 0.f, bad = 0.f;
+        for (int rg = 0; rg < kProfRowGroups; ++rg) {
+            s += sq_part[((size_t)h * kProfRowGroups + rg) * 4 + v];
+            bad += sq_part[((size_t)h * kProfRowGroups + rg) * 4 + 2 + v];
+        }
         s = s / (float)(R * D);
         if (emulate) s = Elt<T>::to_float(Elt<T>::from_float(s));
-        out_mse[(size_t)tid * BH + h] = s;
+        out_mse[(size_t)v * BH + h] = bad > 0.f ? __builtin_nanf("") : s;
     }
 }
 
@@ -238,8 +300,11 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
         return SVG_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3(p.n_chunks, BH, 3), dim3(kProfNW * 64), lds, st, p);
-    hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(BH), dim3(256), 0, st, (const float*)ws, out_mse, BH, R,
-                       p.n_chunks, p.emulate);
+    float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
+    hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
+                       R, p.n_chunks, p.emulate);
+    hipLaunchKernelGGL((profile_finalize_kernel<T>), dim3(1), dim3(256), 0, st, (const float*)sq_part, out_mse, BH, R, D,
+                       p.emulate);
     return launch_status();
 }
 
@@ -249,7 +314,7 @@ using namespace svg;
 
 extern "C" size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t D, int32_t S) {
     if (BH <= 0 || R <= 0 || D <= 0 || S <= 0) return 0;
-    return (size_t)3 * BH * prof_chunks(BH, S) * kProfMaxRows * (D + 4) * sizeof(float);
+    return ((size_t)3 * BH * prof_chunks(BH, S) * kProfMaxRows * (D + 4) + (size_t)BH * kProfRowGroups * 4) * sizeof(float);
 }
 
 extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
@@ -258,6 +323,8 @@ extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const
     if (!q || !k || !v || !rows || !prof || !out_mse || !workspace) return SVG_ERR_BAD_ARG;
     if (R <= 0 || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
     if (R > kProfMaxRows) return SVG_ERR_UNSUPPORTED;
+    for (int i = 0; i < 2; ++i)
+        if (prof->variant[i].coord == 1 && prof->frame_size < kBN) return SVG_ERR_UNSUPPORTED;  // one-wrap stepping
     if (workspace_bytes < svg_sample_mse_workspace_bytes(BH, R, D, S)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SVG_DTYPE_BF16) {
