@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE.json configs[2]): SVG2 semantic-aware permuted attention of one Wan 2.1 T2V 720p layer-call
+(cfg=1, H=40, D=128, F=21, P=3600, S=75600; QC=300, KC=1000, top_p=0.9, min_kc_ratio=0.1, 2 warm-started k-means iterations)
+on one MI355X.  Prints one JSON line with the per-stage times (HIP events), the block-map density and the algorithmic
+FLOPs (attention 4*D*sum_h sum_{(i,j) in map} n(Q_i) n(K_j); k-means 2*N*K*D*BH per iteration).
+
+Synthetic data: per-head mixture of 64 Gaussians for Q and K (iid data would give density ~1), random-init weights n/a.
+    python bench_svg2.py [--workload wan720p|hy720p|small] [--steps K] [--warmup W]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+
+import torch  # noqa: E402
+
+WORKLOADS = {  # H, D, F, P, ctx, prompt, QC, KC
+    "wan720p": (40, 128, 21, 3600, 0, 0, 300, 1000),
+    "hy720p": (24, 128, 33, 3600, 256, 64, 400, 1000),
+    "small": (4, 128, 5, 1000, 0, 0, 40, 100),
+}
+
+
+def clustered(H, N, D, modes, dev, gen, spread=0.35):
+    centers = torch.randn(H, modes, D, device=dev, generator=gen) * 1.5
+    lab = torch.randint(0, modes, (H, N), device=dev, generator=gen)
+    x = torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + spread * torch.randn(H, N, D, device=dev, generator=gen)
+    return x.to(torch.bfloat16)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="wan720p", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    from svg import _native as nat
+    from svg.kmeans_utils import density_calculation
+    from svg.models import _core
+
+    nat.load()
+    dev = torch.device("cuda", 0)
+    H, D, F_, P_, ctx, L, QC, KC = WORKLOADS[a.workload]
+    V = F_ * P_
+    S = V + ctx
+    gen = torch.Generator(device=dev).manual_seed(0)
+    q = clustered(H, S, D, 64, dev, gen)[None]
+    k = clustered(H, S, D, 64, dev, gen)[None]
+    v = torch.randn(1, H, S, D, device=dev, dtype=torch.bfloat16, generator=gen)
+    geo = _core.Geometry(ctx, F_, P_)
+    store = _core.CentroidStore()
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    # first call of a "layer": 50 k-means iterations from random points (reference: kmeans_iter_init = 50)
+    e0, e1 = ev(), ev()
+    e0.record()
+    _core.kmeans_clustering(store, 0, q[:, :, :V].contiguous(), k[:, :, :V].contiguous(), QC, KC, 50, 2)
+    e1.record()
+    torch.cuda.synchronize()
+    init_ms = e0.elapsed_time(e1)
+
+    times = {"kmeans_2it_qk": [], "identify_map": [], "attention": [], "total": []}
+    dens = None
+    for it in range(a.warmup + a.steps):
+        t = [ev() for _ in range(4)]
+        qv = q[:, :, :V].contiguous() if ctx else q
+        kv = k[:, :, :V].contiguous() if ctx else k
+        t[0].record()
+        (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = _core.kmeans_clustering(store, 0, qv, kv, QC, KC, 50, 2)
+        t[1].record()
+        q_sizes, k_sizes = qs.view(1, H, QC), ks.view(1, H, KC)
+        from svg.kmeans_utils import identify_dynamic_map
+
+        dmap = identify_dynamic_map(qc.view(1, H, QC, D), kc.view(1, H, KC, D), q_sizes, k_sizes, 0.9, 0.1)
+        if ctx:
+            dmap, q_sizes, k_sizes, qidx, kidx = _core.dynamic_map_post_processing(dmap, q_sizes, k_sizes, qidx, kidx, V, ctx, L)
+        t[2].record()
+        QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
+        o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
+                                   q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
+                                   q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+        t[3].record()
+        torch.cuda.synchronize()
+        if it >= a.warmup:
+            times["kmeans_2it_qk"].append(t[0].elapsed_time(t[1]))
+            times["identify_map"].append(t[1].elapsed_time(t[2]))
+            times["attention"].append(t[2].elapsed_time(t[3]))
+            times["total"].append(t[0].elapsed_time(t[3]))
+        dens = density_calculation(dmap, q_sizes, k_sizes)
+    ms = {k_: sum(v_) / len(v_) for k_, v_ in times.items()}
+    pairs = (dmap.view(H, QB, KB).float() * q_sizes.view(H, QB, 1).float() * k_sizes.view(H, 1, KB).float()).sum().item()
+    attn_flops = 4.0 * D * pairs
+    km_flops = 2.0 * V * D * H * (QC + KC) * 2  # two iterations, Q and K
+    dense_flops = 4.0 * D * H * S * S
+    out = {
+        "metric": "svg2_layer_call",
+        "workload": f"{a.workload} cfg=1 H={H} D={D} F={F_} P={P_} ctx={ctx} S={S} QC={QC} KC={KC} top_p=0.9 min_kc_ratio=0.1",
+        "ms": {k_: round(v_, 3) for k_, v_ in ms.items()},
+        "kmeans_init_50it_ms": round(init_ms, 2),
+        "density_mean": round(dens.mean().item(), 4),
+        "attention_tflops_algorithmic": round(attn_flops / (ms["attention"] * 1e-3) / 1e12, 1),
+        "kmeans_assign_tflops": round(km_flops / (ms["kmeans_2it_qk"] * 1e-3) / 1e12, 1),
+        "dense_equiv_tflop": round(dense_flops / 1e12, 2),
+        "speedup_vs_dense_at_1000tflops": round((dense_flops / 1e15 * 1e3) / ms["total"], 2),
+        "data": "synthetic (64-mode Gaussian mixture per head)",
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@ struct BandPolicy {
     struct Ctx {
         int head, q0, q_end, nT, perm;
         int seg_lo[3], seg_n[3];
+        int fk_lo, fk_hi;  // per WAVE: tiles with first key in [fk_lo, fk_hi] are FULL for this wave's 32 rows (fast path)
     };
     struct KvCursor {
         int pp, f, prev_k0;    // token-major decomposition (row - vid0) = pp * F + f of this thread's row in the previous tile
@@ -115,6 +116,14 @@ struct BandPolicy {
         c.seg_lo[1] = blo, c.seg_n[1] = bhi - blo;
         c.seg_lo[2] = clo, c.seg_n[2] = chi - clo;
         c.nT = c.seg_n[0] + c.seg_n[1] + c.seg_n[2];
+        // fast-path classification: inside the band, away from its edges, every (row, key) pair of a wave x tile
+        // rectangle is allowed; those tiles (98-99 % of all) are recognised with two scalar compares.
+        const int w0 = c.q0 + wave_id() * 32, w1 = min(w0 + 32, c.q_end);
+        c.fk_lo = 1, c.fk_hi = 0;
+        if (w0 < c.q_end && w1 <= real) {
+            c.fk_lo = max(w1 - p.band, 0);
+            c.fk_hi = min(w0 + p.band - kBN, min(real, p.S) - kBN);
+        }
         return true;
     }
 
@@ -165,6 +174,7 @@ struct BandPolicy {
     }
 
     static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
+        if (k0 >= c.fk_lo && k0 <= c.fk_hi) return TILE_FULL;
         const int w0 = c.q0 + wrow0;
         if (w0 >= c.q_end) return TILE_SKIP;
         const int w1 = min(w0 + 32, c.q_end);       // rows [w0, w1)

@@ -49,6 +49,11 @@ def band_schedule(q0, q_end, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
 
 
 def classify(w0, q_end, k0, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
+    # fast path (BandPolicy::init / classify): per-wave FULL range of first keys
+    w1f = min(w0 + 32, q_end)
+    if w0 < q_end and w1f <= real:
+        if max(w1f - band, 0) <= k0 <= min(w0 + band - BN, min(real, S) - BN):
+            return 1
     if w0 >= q_end:
         return 0
     w1 = min(w0 + 32, q_end)
