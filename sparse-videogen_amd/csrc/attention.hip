@@ -10,14 +10,16 @@ namespace svg {
 // =====================================================================================================
 // Band policy: analytic mask family (see svg_band_mask_t in svg_attn.h)
 // =====================================================================================================
-template <typename T, int D, int NW, bool SKEW, int ABL = 0>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1>
 struct BandPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
-    static constexpr int kAbl = ABL;  // > 0 only in the ablation build (attention_abl.hip): timing experiments
+    static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
     static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
     static constexpr bool kSkew = SKEW;
-    static constexpr int BM = NW * 32;
+    static constexpr int kRowBlocks = RB;    // 32-row blocks per wave
+    static constexpr int kWR = 32 * RB;      // rows per wave
+    static constexpr int BM = NW * kWR;
 
     struct Params {
         const T* q;
@@ -118,7 +120,7 @@ struct BandPolicy {
         c.nT = c.seg_n[0] + c.seg_n[1] + c.seg_n[2];
         // fast-path classification: inside the band, away from its edges, every (row, key) pair of a wave x tile
         // rectangle is allowed; those tiles (98-99 % of all) are recognised with two scalar compares.
-        const int w0 = c.q0 + wave_id() * 32, w1 = min(w0 + 32, c.q_end);
+        const int w0 = c.q0 + wave_id() * kWR, w1 = min(w0 + kWR, c.q_end);
         c.fk_lo = 1, c.fk_hi = 0;
         if (w0 < c.q_end && w1 <= real) {
             c.fk_lo = max(w1 - p.band, 0);
@@ -177,7 +179,7 @@ struct BandPolicy {
         if (k0 >= c.fk_lo && k0 <= c.fk_hi) return TILE_FULL;
         const int w0 = c.q0 + wrow0;
         if (w0 >= c.q_end) return TILE_SKIP;
-        const int w1 = min(w0 + 32, c.q_end);       // rows [w0, w1)
+        const int w1 = min(w0 + kWR, c.q_end);      // rows [w0, w1)
         const int k1 = min(k0 + kBN, p.S);          // keys [k0, k1)
         const int real = p.real_len;
         // ---- every pair allowed? ----
@@ -222,6 +224,14 @@ __global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPoli
     attn_body<T, D, NW, BandPolicy<T, D, NW, SKEW, ABL>>(prm, smem, nullptr);
 }
 
+// 4 waves x 64 query rows, ONE wave per SIMD with the whole 512-entry register file: every K / V fragment read from LDS
+// feeds two MFMAs (LDS operand traffic per FLOP halves), and there is one workgroup of 256 threads per CU.
+template <typename T, int D, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void band_attn_r64_kernel(typename BandPolicy<T, D, 4, false, ABL, 2>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<T, D, 4, BandPolicy<T, D, 4, false, ABL, 2>>(prm, smem, nullptr);
+}
+
 template <typename T, int D>
 __global__ __launch_bounds__(512, 2) void band_attn_pipe_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,6 +253,7 @@ struct VarblockPolicy {
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;
+    static constexpr int kRowBlocks = 1;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -429,10 +440,10 @@ static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-template <typename T, int D, int NW, bool SKEW, int ABL = 0>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1>
 static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                     const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
-    using Pol = BandPolicy<T, D, NW, SKEW, ABL>;
+    using Pol = BandPolicy<T, D, NW, SKEW, ABL, RB>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
@@ -452,12 +463,16 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         p.n_heavy = (hi + Pol::BM - 1) / Pol::BM - p.heavy_lo;
         if (p.n_heavy >= p.nqt) p.heavy_lo = 0, p.n_heavy = 0;
     }
-    if (g_band_pipe && NW == 8 && !SKEW && ABL == 0) {
-        if constexpr (NW == 8 && !SKEW && ABL == 0)
-            return launch_attn(band_attn_pipe_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 3>(), st);
+    if constexpr (RB == 2) {
+        return launch_attn(band_attn_r64_kernel<T, D, ABL>, p, dim3(p.nqt * BH), 256, attn_lds_bytes<D, 4, 2, 2>(), st);
+    } else {
+        if constexpr (NW == 8 && !SKEW && ABL == 0) {
+            if (g_band_pipe)
+                return launch_attn(band_attn_pipe_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 3>(), st);
+        }
+        return launch_attn(band_attn_kernel<T, D, NW, SKEW, ABL>, p, dim3(p.nqt * BH), NW * 64,
+                           attn_lds_bytes<D, NW, attn_stages<NW, Pol>()>(), st);
     }
-    return launch_attn(band_attn_kernel<T, D, NW, SKEW, ABL>, p, dim3(p.nqt * BH), NW * 64,
-                       attn_lds_bytes<D, NW, attn_stages<NW, Pol>()>(), st);
 }
 
 }  // namespace svg
@@ -490,10 +505,19 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
             case 7: return run_band<__bf16, 128, 8, false, 7>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 8: return run_band<__bf16, 128, 8, false, 8>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 9: return run_band<__bf16, 128, 8, false, 9>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 10: return run_band<__bf16, 128, 8, false, 10>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 11: return run_band<__bf16, 128, 8, false, 11>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             default: return SVG_ERR_UNSUPPORTED;
         }
     }
     g_band_pipe = (variant & 4) != 0;      // bit 2: software-pipelined schedule (attn_body_pipe)
+    if (variant & 8) {                     // bit 3: 4 waves x 64 rows, one wave per SIMD (512 registers)
+        if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_BF16 && D == 64) return run_band<__bf16, 64, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 128) return run_band<_Float16, 128, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 64) return run_band<_Float16, 64, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        return SVG_ERR_UNSUPPORTED;
+    }
     const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU (default 8 waves x 32 rows)
     const bool prio = (variant & 2) != 0;  // bit 1: skewed two-group schedule (experimental; measured 3 % slower than lock-step)
 #define SVG_BAND_RUN(T, DD, NWW)                                                                                  \

@@ -48,11 +48,11 @@ constexpr int attn_stages() {
     return (P::kSkew && NW == 8) ? 3 : 2;
 }
 
-template <int D, int NW, int NS = 2>
+template <int D, int NW, int NS = 2, int RB = 1>
 constexpr int attn_lds_bytes() {
-    // NS stages, or the epilogue staging of NW*32 rows with an 8-byte row pad, whichever is larger
+    // NS stages, or the epilogue staging of NW*32*RB rows with an 8-byte row pad, whichever is larger
     constexpr int stages = NS * LdsLayout<D>::kStageBytes;
-    constexpr int epi = NW * 32 * (D * 2 + 8);
+    constexpr int epi = NW * 32 * RB * (D * 2 + 8);
     return stages > epi ? stages : epi;
 }
 
@@ -77,6 +77,9 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     using E = Elt<T>;
     using V8 = typename E::v8;
     using L = LdsLayout<D>;
+    constexpr int RB = P::kRowBlocks;   // 32-row query blocks per wave (2 => 64 rows per wave: every K / V fragment read
+                                        // from LDS feeds two MFMAs, halving LDS operand traffic per FLOP)
+    constexpr int WR = 32 * RB;         // query rows per wave
     constexpr int NT = NW * 64;
     constexpr int KS = D / 16;          // k-steps of the S^T GEMM
     constexpr int DB = D / 32;          // 32-wide d blocks of O^T
@@ -91,22 +94,24 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     const int wave = wave_id();
     const int g = lane >> 5;
     const int ql = lane & 31;
-    const int row_in_wg = wave * 32 + ql;
 
     const T* __restrict__ qb = P::q_base(prm, ctx);
     const T* __restrict__ kb = P::k_base(prm, ctx);
     const T* __restrict__ vb = P::v_base(prm, ctx);
 
-    // ---- Q fragments (B operand of S^T): 8 consecutive d of this lane's query row per k-step ----
-    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
-    const int q_log = P::q_logical(ctx, row_in_wg);
-    // (rows that do not exist read row 0 instead: a lane only ever feeds its own query row, and such rows are
+    // ---- Q fragments (B operand of S^T): 8 consecutive d of this lane's query rows per k-step ----
+    // (rows that do not exist read row 0 instead: a lane only ever feeds its own query rows, and such rows are
     //  never stored, so no predication is needed — predicated loads cost exec-masked blocks)
-    V8 qf[KS];
-    {
+    int q_log[RB];
+    V8 qf[RB][KS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row_in_wg = wave * WR + rb * 32 + ql;
+        const int q_phys = P::q_phys(prm, ctx, row_in_wg);
+        q_log[rb] = P::q_logical(ctx, row_in_wg);
         const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const V8*)(qrow + ks * 16);
     }
 
     // ---- staging bookkeeping: chunk i of this thread covers (row srow[i], 16-B chunk scol[i]) of the tile ----
@@ -160,13 +165,17 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     const int vi = lane & 15;
     const int v_lane_off = L::kKBytes + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
 
-    float m_run = -INFINITY;   // running max, log2 domain (already multiplied by scale*log2e)
-    float l_run = 0.f;         // this lane's partial row sum (its 32 of the 64 keys per tile)
-    f32x16 acc_o[DB];
+    float m_run[RB], l_run[RB];  // running max (log2 domain) / this lane's partial row sum, per owned query row
+    f32x16 acc_o[RB][DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int rb = 0; rb < RB; ++rb) {
+        m_run[rb] = -INFINITY;
+        l_run[rb] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[rb][db][r] = 0.f;
+    }
 
     const float c_log2 = prm.scale_log2;
     const int nT = ctx.nT;
@@ -177,7 +186,9 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     // and knows at the loop header that they have landed.  Without it the waitcnt pass emits vmcnt(0) in front of
     // the first MFMA of EVERY iteration, serialising the tile t+1 prefetch behind the compute of tile t.
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[rb][ks]));
     if (nT > 0) {
         stage_write(0);
         if (nT > 1) stage_issue(1);
@@ -185,90 +196,106 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     __syncthreads();
 
     // The two GEMM phases as lambdas so that the "skewed" schedule below can place them differently per wave group.
-    V8 pf[2][2];  // P^T operand of the current tile (kept across the barrier by the lagging wave group)
+    V8 pf[RB][2][2];  // P^T operand of the current tile (kept across the barrier by the lagging wave group)
     auto qk_softmax = [&](const char* kbuf, int tk0, int cls) {
         // ---------------- S^T = K Q^T ----------------
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
-        f32x16 s[2];
+        f32x16 s[RB][2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[rb][b][r] = 0.f;
+        if constexpr (P::kAbl == 10) __builtin_amdgcn_iglp_opt(0);
+        if constexpr (P::kAbl == 11) __builtin_amdgcn_iglp_opt(1);
         if constexpr (P::kAbl != 3) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int cch = ((2 * ks + g) ^ ksw0) << 4;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    if constexpr (P::kAbl == 6 || P::kAbl >= 8) {  // ablation: MFMAs without the K-fragment LDS reads
-                        s[b] = E::mfma(qf[(ks + b) % KS], qf[ks], s[b]);
+                    if constexpr (P::kAbl == 6 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the K-fragment LDS reads
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(qf[rb][(ks + b) % KS], qf[rb][ks], s[rb][b]);
                     } else {
                         const V8 a = *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + cch);
-                        s[b] = E::mfma(a, qf[ks], s[b]);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(a, qf[rb][ks], s[rb][b]);
                     }
                 }
             }
         } else {  // ablation: no QK^T (keep the values opaque so that the softmax is not folded away)
-            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) asm volatile("" : "+v"(s[rb][0]), "+v"(s[rb][1]));
         }
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
         if constexpr (P::kAbl == 1 || P::kAbl == 9) {  // ablation: no softmax VALU
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pf[b][r >> 3][r & 7] = E::from_float(s[b][r]);
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pf[rb][b][r >> 3][r & 7] = E::from_float(s[rb][b][r]);
             return;
         }
-        // ---------------- mask + online softmax (lane-local row) ----------------
-        if constexpr (P::kFixup) {
+        // ---------------- mask + online softmax (lane-local rows) ----------------
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+        for (int rb = 0; rb < RB; ++rb) {
+            if constexpr (P::kFixup) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
-        }
-        if (cls == TILE_PARTIAL) {
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[rb][b][r] = P::score_fixup(prm, s[rb][b][r]);
+            }
+            if (cls == TILE_PARTIAL) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        s[rb][b][r] = P::allowed(prm, ctx, q_log[rb], tk0 + key) ? s[rb][b][r] : -INFINITY;
+                    }
+            }
+            float mx = s[rb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[rb][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[rb][1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[rb], mx * c_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_use);
+            m_run[rb] = m_new;
+            float psum = 0.f;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][b][r], c_log2, -m_use));
+                    psum += p;
+                    pf[rb][b][r >> 3][r & 7] = E::from_float(p);
                 }
-        }
-        float mx = s[0][0];
+            l_run[rb] = l_run[rb] * alpha + psum;
+            if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+                for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx * c_log2);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c_log2, -m_use));
-                psum += p;
-                pf[b][r >> 3][r & 7] = E::from_float(p);
+                    for (int r = 0; r < 16; ++r) acc_o[rb][db][r] *= alpha;
             }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.f)) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
         }
     };
     auto pv = [&](const char* kbuf) {
         if constexpr (P::kAbl == 2) {  // ablation: no PV (keep P alive)
-            asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                asm volatile("" ::"v"(pf[rb][0][0]), "v"(pf[rb][0][1]), "v"(pf[rb][1][0]), "v"(pf[rb][1][1]));
             return;
         }
         // ---------------- O^T += V^T P^T ----------------
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(1);
+        if constexpr (P::kAbl == 10) __builtin_amdgcn_iglp_opt(0);
+        if constexpr (P::kAbl == 11) __builtin_amdgcn_iglp_opt(1);
         const char* vbase = kbuf + v_lane_off;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
@@ -277,13 +304,17 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int kb0 = 32 * b + 16 * h;
-                    if constexpr (P::kAbl == 7 || P::kAbl >= 8) {  // ablation: MFMAs without the V transpose reads
-                        acc_o[db] = E::mfma(qf[(db + b + h) % KS], pf[b][h], acc_o[db]);
+                    if constexpr (P::kAbl == 7 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the V transpose reads
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            acc_o[rb][db] = E::mfma(qf[rb][(db + b + h) % KS], pf[rb][b][h], acc_o[rb][db]);
                     } else {
                         const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
                         const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
                         i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        acc_o[db] = E::mfma(__builtin_bit_cast(V8, both), pf[b][h], acc_o[db]);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            acc_o[rb][db] = E::mfma(__builtin_bit_cast(V8, both), pf[rb][b][h], acc_o[rb][db]);
                     }
                 }
         }
@@ -306,7 +337,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
             pending = false;
         }
         const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        const int cls = P::classify(prm, ctx, tk0, wave * WR);
         if (cls != TILE_SKIP) {
             qk_softmax(kbuf, tk0, cls);
             if (NS == 3 && lag) {
@@ -317,11 +348,11 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
             }
         }
         const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;
-        if constexpr (P::kAbl != 4 && P::kAbl < 8) {
+        if constexpr (P::kAbl != 4 && P::kAbl != 8 && P::kAbl != 9) {
             if (t + 1 < nT) stage_write(nbuf);
             if (t + 2 < nT) stage_issue(t + 2);
         }
-        if constexpr (P::kAbl != 5 && P::kAbl < 8) __syncthreads();
+        if constexpr (P::kAbl != 5 && P::kAbl != 8 && P::kAbl != 9) __syncthreads();
         buf = nbuf;
     }
     if (NS == 3) {
@@ -330,45 +361,52 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
 
     // ---------------- epilogue ----------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) l_tot[rb] = l_run[rb] + __shfl_xor(l_run[rb], 32);
     if constexpr (P::kPartialOut) {
         // un-normalised fp32 partial: O^T accumulators, running max and row sum (profiler split-KV)
-        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            P::store_partial(prm, ctx, wave * WR + rb * 32 + ql, g, acc_o[rb], m_run[rb], l_tot[rb]);
         return;
     } else {
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     // transpose through LDS (all waves are past the last barrier, stage buffers are free): row stride D*2+8 bytes
     constexpr int kEpiStride = D * 2 + 8;
-    char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+    char* erow = smem + (size_t)(wave * WR) * kEpiStride;
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int rb = 0; rb < RB; ++rb) {
+        const float inv = l_tot[rb] > 0.f ? 1.f / l_tot[rb] : 0.f;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            typename E::v4 o4;
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
-            const int d0 = 32 * db + 8 * rq + 4 * g;
-            *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
-        }
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[rb][db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + (rb * 32 + ql) * kEpiStride + d0 * 2) = o4;
+            }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // own-wave LDS writes visible to own-wave reads below
     __builtin_amdgcn_wave_barrier();
     T* __restrict__ ob = P::o_base(prm, ctx);
     constexpr int kLanesPerRow = D * 2 / 8;       // 8 B per lane
     constexpr int kRowsPerPass = 64 / kLanesPerRow;
+    constexpr int kPasses = WR / kRowsPerPass;
     const int sub = lane / kLanesPerRow;
     const int colb = (lane - sub * kLanesPerRow) * 8;
-    int ephys[32 / kRowsPerPass];  // resolve all output rows first: keeps the (possibly global) index loads in flight together
+    int ephys[kPasses];  // resolve all output rows first: keeps the (possibly global) index loads in flight together
 #pragma unroll
-    for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+    for (int i = 0; i < kPasses; ++i) ephys[i] = P::q_phys(prm, ctx, wave * WR + i * kRowsPerPass + sub);
 #pragma unroll
-    for (int i = 0; i < 32 / kRowsPerPass; ++i) {
+    for (int i = 0; i < kPasses; ++i) {
         const int rr = i * kRowsPerPass + sub;
         const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
         if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
     }
     }
 }
-
 
 // =====================================================================================================================
 // attn_body_pipe — software-pipelined schedule (8 waves, three LDS stages).

@@ -31,6 +31,7 @@ struct ProfilePolicy {
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;
+    static constexpr int kRowBlocks = 1;
     static constexpr int NW = kProfNW;
 
     struct Params {
