@@ -54,6 +54,19 @@ def allowed_pairs_hy(V: int, ctx: int, L: int, tf: int) -> int:
     return band + 2 * V * L + L * L + (ctx - L) ** 2
 
 
+def _pmc_traffic(workload: str):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, tools/gpu_pmc.sh).  PMC collection needs its own rocprofv3 runs, so bench.py reports the value of the
+    committed profile (profiles/r01_pmc_traffic.json) for the headline workload and null otherwise."""
+    p = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if workload != "hy720p" or not p.exists():
+        return None
+    try:
+        return {"bytes": json.loads(p.read_text())["traffic_bytes_per_launch"], "unit": "B/launch", "source": str(p.name)}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(H: int, D: int, S: int, seconds_target: float = 15.0):
     """torch SDPA (dense, bf16) on the host cores: one head, sequence shortened so that it runs ~10-30 s."""
     import torch.nn.functional as F
@@ -210,7 +223,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(kern_tf / PEAK_BF16_TFLOPS, 4),
                 "kernel_ms": round(attn_ms, 3),
-                "traffic": None,
+                "traffic": _pmc_traffic(a.workload),
             },
         }
 

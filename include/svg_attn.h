@@ -104,6 +104,10 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
+/* variant: 0 = shipped schedule (8 waves x 32 query rows, two 64-key tiles per LDS stage).  Non-zero values select the
+ * alternative schedules kept for A/B measurements (all produce the same result): 1 = 4 waves / 128-row q-tiles (2 workgroups
+ * per CU), 2 = skewed two-group schedule, 4 = software-pipelined body, 8 = 4 waves x 64 rows (one wave per SIMD), 16 = 8 waves
+ * with one tile per stage; bits 8..11 = timing-only ablations (wrong results by construction, see profiles/). */
 int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                        int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                        int32_t variant, void* stream);

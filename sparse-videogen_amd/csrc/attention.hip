@@ -10,8 +10,10 @@ namespace svg {
 // =====================================================================================================
 // Band policy: analytic mask family (see svg_band_mask_t in svg_attn.h)
 // =====================================================================================================
-template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1, int SUBS = 1>
 struct BandPolicy {
+    static constexpr int kSubTiles = SUBS;   // 64-key tiles per LDS stage / barrier
+    static constexpr int kPrefetch = (ABL == 12) ? 3 : (ABL == 13 ? 2 : 1);  // operand ring depth (k-steps / MFMA steps ahead)
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
     static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
@@ -32,6 +34,7 @@ struct BandPolicy {
         const int64_t* head_flag;
         int vid0, F, P, V;
         int q64, r64;          // 64 / F, 64 % F: tile-to-tile step of the (patch, frame) decomposition
+        int q128, r128;        // the same for a 128-row step (two tiles per stage)
         int heavy_lo, n_heavy; // q-tiles [heavy_lo, heavy_lo + n_heavy) of every head see ALL keys (text rows): scheduled first
     };
     struct Ctx {
@@ -156,9 +159,10 @@ struct BandPolicy {
         // token-major head: physical row = vid0 + f * P + pp with (l - vid0) = pp * F + f.  Consecutive tiles advance
         // by 64 rows, so the decomposition is stepped (4 VALU) instead of divided (~30 VALU); segment jumps re-divide.
         int pp, f;
-        if (__builtin_amdgcn_readfirstlane((int)(k0 == cu.prev_k0 + kBN))) {
-            f = cu.f + p.r64;
-            pp = cu.pp + p.q64;
+        const int delta = __builtin_amdgcn_readfirstlane(k0 - cu.prev_k0);
+        if (delta == kBN || delta == 2 * kBN) {
+            f = cu.f + (delta == kBN ? p.r64 : p.r128);
+            pp = cu.pp + (delta == kBN ? p.q64 : p.q128);
             const bool wrap = f >= p.F;
             f = wrap ? f - p.F : f;
             pp = wrap ? pp + 1 : pp;
@@ -224,6 +228,13 @@ __global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPoli
     attn_body<T, D, NW, BandPolicy<T, D, NW, SKEW, ABL>>(prm, smem, nullptr);
 }
 
+// 8 waves x 32 rows, two 64-key tiles per LDS stage: one barrier and one staging round per 128 keys
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_s2_kernel(typename BandPolicy<T, D, 8, false, 0, 1, 2>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<T, D, 8, BandPolicy<T, D, 8, false, 0, 1, 2>>(prm, smem, nullptr);
+}
+
 // 4 waves x 64 query rows, ONE wave per SIMD with the whole 512-entry register file: every K / V fragment read from LDS
 // feeds two MFMAs (LDS operand traffic per FLOP halves), and there is one workgroup of 256 threads per CU.
 template <typename T, int D, int ABL = 0>
@@ -254,6 +265,8 @@ struct VarblockPolicy {
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;
     static constexpr int kRowBlocks = 1;
+    static constexpr int kSubTiles = 1;
+    static constexpr int kPrefetch = 1;
     static constexpr int BM = NW * 32;
 
     struct Params {
@@ -440,10 +453,10 @@ static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1>
+template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1, int SUBS = 1>
 static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                     const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
-    using Pol = BandPolicy<T, D, NW, SKEW, ABL, RB>;
+    using Pol = BandPolicy<T, D, NW, SKEW, ABL, RB, SUBS>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
@@ -456,6 +469,7 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         p.vid0 = perm->vid0, p.F = perm->num_frame, p.P = perm->frame_size, p.V = perm->num_frame * perm->frame_size;
     }
     p.q64 = kBN / p.F, p.r64 = kBN % p.F;
+    p.q128 = 2 * kBN / p.F, p.r128 = 2 * kBN % p.F;
     p.heavy_lo = 0, p.n_heavy = 0;
     if (p.rf_hi > p.rf_lo && p.rf_lo < p.real_len && p.band <= S) {
         const int hi = std::min(p.rf_hi, p.real_len);
@@ -465,6 +479,8 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
     }
     if constexpr (RB == 2) {
         return launch_attn(band_attn_r64_kernel<T, D, ABL>, p, dim3(p.nqt * BH), 256, attn_lds_bytes<D, 4, 2, 2>(), st);
+    } else if constexpr (SUBS == 2) {
+        return launch_attn(band_attn_s2_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 2, 1, 2>(), st);
     } else {
         if constexpr (NW == 8 && !SKEW && ABL == 0) {
             if (g_band_pipe)
@@ -507,10 +523,20 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
             case 9: return run_band<__bf16, 128, 8, false, 9>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 10: return run_band<__bf16, 128, 8, false, 10>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 11: return run_band<__bf16, 128, 8, false, 11>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 12: return run_band<__bf16, 128, 8, false, 12>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+            case 13: return run_band<__bf16, 128, 8, false, 13>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             default: return SVG_ERR_UNSUPPORTED;
         }
     }
     g_band_pipe = (variant & 4) != 0;      // bit 2: software-pipelined schedule (attn_body_pipe)
+    // default schedule: 8 waves x 32 rows, two 64-key tiles per LDS stage (one barrier / staging round per 128 keys)
+    if (variant == 0) {
+        if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_BF16 && D == 64) return run_band<__bf16, 64, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 128) return run_band<_Float16, 128, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 64) return run_band<_Float16, 64, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        return SVG_ERR_UNSUPPORTED;
+    }
     if (variant & 8) {                     // bit 3: 4 waves x 64 rows, one wave per SIMD (512 registers)
         if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
         if (dtype == SVG_DTYPE_BF16 && D == 64) return run_band<__bf16, 64, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
@@ -518,7 +544,7 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
         if (dtype == SVG_DTYPE_F16 && D == 64) return run_band<_Float16, 64, 4, false, 0, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
         return SVG_ERR_UNSUPPORTED;
     }
-    const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU (default 8 waves x 32 rows)
+    const bool w4 = (variant & 1) != 0;    // bit 0: 4 waves x 32 rows, 2 WG / CU; bit 4 (16): 8 waves, one tile per stage
     const bool prio = (variant & 2) != 0;  // bit 1: skewed two-group schedule (experimental; measured 3 % slower than lock-step)
 #define SVG_BAND_RUN(T, DD, NWW)                                                                                  \
     return prio ? run_band<T, DD, NWW, true>(q, k, v, o, BH, S, sm_scale, mask, perm, st)                         \

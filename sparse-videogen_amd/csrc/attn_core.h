@@ -48,10 +48,10 @@ constexpr int attn_stages() {
     return (P::kSkew && NW == 8) ? 3 : 2;
 }
 
-template <int D, int NW, int NS = 2, int RB = 1>
+template <int D, int NW, int NS = 2, int RB = 1, int SUBS = 1>
 constexpr int attn_lds_bytes() {
-    // NS stages, or the epilogue staging of NW*32*RB rows with an 8-byte row pad, whichever is larger
-    constexpr int stages = NS * LdsLayout<D>::kStageBytes;
+    // NS stages of SUBS tiles, or the epilogue staging of NW*32*RB rows with an 8-byte row pad, whichever is larger
+    constexpr int stages = NS * SUBS * LdsLayout<D>::kStageBytes;
     constexpr int epi = NW * 32 * RB * (D * 2 + 8);
     return stages > epi ? stages : epi;
 }
@@ -83,8 +83,10 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     constexpr int NT = NW * 64;
     constexpr int KS = D / 16;          // k-steps of the S^T GEMM
     constexpr int DB = D / 32;          // 32-wide d blocks of O^T
-    constexpr int NCH = (kBN * L::kCPR) / NT;  // 16-B chunks per thread per tensor per tile
-    static_assert((kBN * L::kCPR) % NT == 0, "tile chunks must divide evenly");
+    constexpr int SUBS = P::kSubTiles;  // 64-key tiles per LDS stage (2 => one barrier / one staging round per 128 keys)
+    constexpr int NCH = (SUBS * kBN * L::kCPR) / NT;  // 16-B chunks per thread per tensor per stage
+    constexpr int kStage = SUBS * L::kStageBytes;     // a stage is SUBS x [K image | V image]
+    static_assert((SUBS * kBN * L::kCPR) % NT == 0, "stage chunks must divide evenly");
 
     typename P::Ctx ctx;  // workgroup-uniform, except fields a policy documents as per-wave / per-lane
     if (!P::init(prm, ctx, policy_lds)) return;
@@ -115,15 +117,17 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
 
     // ---- staging bookkeeping: chunk i of this thread covers (row srow[i], 16-B chunk scol[i]) of the tile ----
-    int srow[NCH], k_dst[NCH], v_dst[NCH], scol[NCH];
+    int srow[NCH], k_dst[NCH], v_dst[NCH], scol[NCH], ssub[NCH];
     typename P::KvCursor cur[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int id = tid + i * NT;
-        srow[i] = id / L::kCPR;
-        scol[i] = id - srow[i] * L::kCPR;
-        k_dst[i] = L::k_off(srow[i], scol[i]);
-        v_dst[i] = L::kKBytes + L::v_off(srow[i], scol[i]);
+        const int r = id / L::kCPR;      // row inside the stage: sub-tile r / 64, row r % 64
+        ssub[i] = r / kBN;
+        srow[i] = r - ssub[i] * kBN;
+        scol[i] = id - r * L::kCPR;
+        k_dst[i] = ssub[i] * L::kStageBytes + L::k_off(srow[i], scol[i]);
+        v_dst[i] = ssub[i] * L::kStageBytes + L::kKBytes + L::v_off(srow[i], scol[i]);
         P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
     }
     u32x4 kreg[NCH], vreg[NCH];
@@ -135,11 +139,14 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     // Physical rows are resolved one tile ahead of the data loads (nphys): for the variable-block policy the
     // resolve is itself a global index load, and this keeps its latency off the critical path.
     int nphys[NCH];
-    auto stage_resolve = [&](int t) {
+    auto stage_resolve = [&](int st) {  // st = stage index; its tiles are st * SUBS + sub
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
+        for (int i = 0; i < NCH; ++i) {
+            const int t = st * SUBS + ssub[i];
+            nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
+        }
     };
-    auto stage_issue = [&](int t) {  // data loads of tile t (rows resolved earlier), then resolve tile t+1
+    auto stage_issue = [&](int t) {  // data loads of stage t (rows resolved earlier), then resolve stage t+1
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const size_t off = (size_t)nphys[i] * D + scol[i] * 8;
@@ -149,7 +156,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         stage_resolve(t + 1);
     };
     auto stage_write = [&](int buf) {
-        char* base = smem + buf * L::kStageBytes;
+        char* base = smem + buf * kStage;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             *(u32x4*)(base + k_dst[i]) = kreg[i];
@@ -178,7 +185,8 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
 
     const float c_log2 = prm.scale_log2;
-    const int nT = ctx.nT;
+    const int nT64 = ctx.nT;                         // 64-key tiles
+    const int nT = (nT64 + SUBS - 1) / SUBS;         // stages
 
     stage_resolve(0);
     if (nT > 0) stage_issue(0);
@@ -209,21 +217,35 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                 for (int r = 0; r < 16; ++r) s[rb][b][r] = 0.f;
         if constexpr (P::kAbl == 10) __builtin_amdgcn_iglp_opt(0);
         if constexpr (P::kAbl == 11) __builtin_amdgcn_iglp_opt(1);
-        if constexpr (P::kAbl != 3) {
+        if constexpr (P::kAbl == 6 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the K-fragment LDS reads
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(qf[rb][(ks + b) % KS], qf[rb][ks], s[rb][b]);
+        } else if constexpr (P::kAbl != 3) {
+            // K fragments through a register ring, kPF k-steps ahead of the MFMAs that consume them
+            constexpr int kPF = P::kPrefetch;
+            auto kfrag = [&](int b, int ks) -> V8 {
+                return *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + (((2 * ks + g) ^ ksw0) << 4));
+            };
+            V8 ring[kPF + 1][2];
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                ring[i][0] = kfrag(0, i);
+                ring[i][1] = kfrag(1, i);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int cch = ((2 * ks + g) ^ ksw0) << 4;
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if constexpr (P::kAbl == 6 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the K-fragment LDS reads
-#pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(qf[rb][(ks + b) % KS], qf[rb][ks], s[rb][b]);
-                    } else {
-                        const V8 a = *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + cch);
-#pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(a, qf[rb][ks], s[rb][b]);
-                    }
+                if (ks + kPF < KS) {
+                    ring[(ks + kPF) % (kPF + 1)][0] = kfrag(0, ks + kPF);
+                    ring[(ks + kPF) % (kPF + 1)][1] = kfrag(1, ks + kPF);
                 }
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) s[rb][b] = E::mfma(ring[ks % (kPF + 1)][b], qf[rb][ks], s[rb][b]);
             }
         } else {  // ablation: no QK^T (keep the values opaque so that the softmax is not folded away)
 #pragma unroll
@@ -297,26 +319,32 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         if constexpr (P::kAbl == 10) __builtin_amdgcn_iglp_opt(0);
         if constexpr (P::kAbl == 11) __builtin_amdgcn_iglp_opt(1);
         const char* vbase = kbuf + v_lane_off;
+        constexpr int NPV = DB * 4;  // MFMA steps: idx = db * 4 + b * 2 + h
+        if constexpr (P::kAbl == 7 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the V transpose reads
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
+            for (int idx = 0; idx < NPV; ++idx)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int rb = 0; rb < RB; ++rb)
+                    acc_o[rb][idx >> 2] = E::mfma(qf[rb][idx % KS], pf[rb][(idx >> 1) & 1][idx & 1], acc_o[rb][idx >> 2]);
+        } else {
+            constexpr int kPF = P::kPrefetch;
+            auto vfrag = [&](int idx) -> V8 {
+                const int db = idx >> 2, kb0 = 32 * ((idx >> 1) & 1) + 16 * (idx & 1);
+                const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
+                const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
+                i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(V8, both);
+            };
+            V8 ring[kPF + 1];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int kb0 = 32 * b + 16 * h;
-                    if constexpr (P::kAbl == 7 || P::kAbl == 8 || P::kAbl == 9) {  // ablation: MFMAs without the V transpose reads
+            for (int i = 0; i < kPF; ++i) ring[i] = vfrag(i);
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
-                            acc_o[rb][db] = E::mfma(qf[rb][(db + b + h) % KS], pf[rb][b][h], acc_o[rb][db]);
-                    } else {
-                        const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
-                        const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
-                        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int idx = 0; idx < NPV; ++idx) {
+                if (idx + kPF < NPV) ring[(idx + kPF) % (kPF + 1)] = vfrag(idx + kPF);
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
-                            acc_o[rb][db] = E::mfma(__builtin_bit_cast(V8, both), pf[rb][b][h], acc_o[rb][db]);
-                    }
-                }
+                for (int rb = 0; rb < RB; ++rb)
+                    acc_o[rb][idx >> 2] = E::mfma(ring[idx % (kPF + 1)], pf[rb][(idx >> 1) & 1][idx & 1], acc_o[rb][idx >> 2]);
+            }
         }
         if constexpr (P::kSetPrio) __builtin_amdgcn_s_setprio(0);
     };
@@ -331,20 +359,26 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     bool pending = false;
     int buf = 0, pend_buf = 0;
     for (int t = 0; t < nT; ++t) {
-        const char* kbuf = smem + buf * L::kStageBytes;
+        const char* sbuf = smem + buf * kStage;
         if (NS == 3 && lag && pending) {
-            pv(smem + pend_buf * L::kStageBytes);
+            pv(smem + pend_buf * kStage);
             pending = false;
         }
-        const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * WR);
-        if (cls != TILE_SKIP) {
-            qk_softmax(kbuf, tk0, cls);
-            if (NS == 3 && lag) {
-                pending = true;
-                pend_buf = buf;
-            } else {
-                pv(kbuf);
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+            const int t64 = t * SUBS + sub;
+            if (SUBS > 1 && t64 >= nT64) break;
+            const char* kbuf = sbuf + sub * L::kStageBytes;
+            const int tk0 = P::tile_key0(ctx, t64);
+            const int cls = P::classify(prm, ctx, tk0, wave * WR);
+            if (cls != TILE_SKIP) {
+                qk_softmax(kbuf, tk0, cls);
+                if (NS == 3 && lag) {
+                    pending = true;
+                    pend_buf = buf;
+                } else {
+                    pv(kbuf);
+                }
             }
         }
         const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;
@@ -356,7 +390,7 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
         buf = nbuf;
     }
     if (NS == 3) {
-        if (lag && pending) pv(smem + pend_buf * L::kStageBytes);
+        if (lag && pending) pv(smem + pend_buf * kStage);
         __syncthreads();  // the epilogue below reuses the stage buffers
     }
 

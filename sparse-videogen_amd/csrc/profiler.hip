@@ -32,6 +32,8 @@ struct ProfilePolicy {
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;
     static constexpr int kRowBlocks = 1;
+    static constexpr int kSubTiles = 1;
+    static constexpr int kPrefetch = 1;
     static constexpr int NW = kProfNW;
 
     struct Params {
