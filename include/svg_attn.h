@@ -199,6 +199,12 @@ int svg_identify_dynamic_map(const void* qc, const void* kc, const int32_t* k_si
 int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out, int32_t BH,
                     int32_t QB, int32_t KB, void* stream);
 
+/* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedule.
+ * After a svg_band_attention call with variant bits 5 and 6 set (bf16, D = 128) and a synchronised stream, copies 66
+ * counters to the host: out[8 * wave + i], i = 0..7 = s_memtime ticks wave `wave` of one workgroup spent in
+ * [LK work, barrier, QK work, barrier, SV work, barrier, PV work, barrier]; out[64] = KV tiles, out[65] = loop ticks. */
+int svg_debug_pp_trace(uint64_t* out66);
+
 #ifdef __cplusplus
 }
 #endif

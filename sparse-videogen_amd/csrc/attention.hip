@@ -249,6 +249,19 @@ __global__ __launch_bounds__(512, 2) void band_attn_pipe_kernel(typename BandPol
     attn_body_pipe<T, D, 8, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
 
+// ping-pong schedule (attn_body_pp): the two waves of a SIMD alternate matrix and memory / VALU clusters
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp<T, D, BandPolicy<T, D, 8, false>, true>(prm, smem, nullptr);
+}
+
 // =====================================================================================================
 // Variable-block policy (SVG2): q rows of block-row i attend the kv rows of the active block-cols.
 // The active, non-empty column blocks of the workgroup's block-row are compacted into a run list in LDS
@@ -434,6 +447,8 @@ __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __res
 
 thread_local int g_last_hip_error = 0;
 static thread_local bool g_band_pipe = false;  // set per call from `variant` bit 2
+static thread_local bool g_band_pp = false;    // set per call from `variant` bit 5
+static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
 
 template <typename K, typename Prm>
 static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds, hipStream_t st) {
@@ -483,6 +498,12 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
         return launch_attn(band_attn_s2_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 2, 1, 2>(), st);
     } else {
         if constexpr (NW == 8 && !SKEW && ABL == 0) {
+            if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
+                if (g_band_pp && g_band_pp_trace)
+                    return launch_attn(band_attn_pp_trace_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp_lds_bytes<D>(), st);
+            }
+            if (g_band_pp)
+                return launch_attn(band_attn_pp_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp_lds_bytes<D>(), st);
             if (g_band_pipe)
                 return launch_attn(band_attn_pipe_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_lds_bytes<D, 8, 3>(), st);
         }
@@ -494,6 +515,16 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
 }  // namespace svg
 
 using namespace svg;
+
+extern "C" int svg_debug_pp_trace(uint64_t* out66) {
+    if (!out66) return SVG_ERR_BAD_ARG;
+    hipError_t e = hipMemcpyFromSymbol(out66, HIP_SYMBOL(g_pp_trace), 66 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return SVG_ERR_LAUNCH;
+    }
+    return SVG_OK;
+}
 
 extern "C" int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                   int32_t dtype, float sm_scale, const svg_band_mask_t* mask,
@@ -529,6 +560,8 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
         }
     }
     g_band_pipe = (variant & 4) != 0;      // bit 2: software-pipelined schedule (attn_body_pipe)
+    g_band_pp = (variant & 32) != 0;       // bit 5: ping-pong schedule (attn_body_pp)
+    g_band_pp_trace = (variant & 64) != 0; // bit 6 (with bit 5): cycle trace of one workgroup, read with svg_debug_pp_trace
     // default schedule: 8 waves x 32 rows, two 64-key tiles per LDS stage (one barrier / staging round per 128 keys)
     if (variant == 0) {
         if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "svg_strerror": (C.c_char_p, [C.c_int]),
     "svg_last_hip_error": (C.c_int, []),
     "svg_build_info": (C.c_char_p, []),
+    "svg_debug_pp_trace": (C.c_int, [_VP]),
     "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_inverse_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
@@ -341,3 +342,12 @@ def map_density(block_map: torch.Tensor, q_sizes: torch.Tensor, k_sizes: torch.T
                              _stream())
     _check(rc, "svg_map_density")
     return out
+
+
+def debug_pp_trace():
+    """Cycle trace of the ping-pong attention schedule (svg_debug_pp_trace): dict wave -> 8 tick sums, tiles, loop ticks."""
+    buf = (C.c_uint64 * 66)()
+    torch.cuda.synchronize()
+    _check(load().svg_debug_pp_trace(C.cast(buf, C.c_void_p)), "svg_debug_pp_trace")
+    v = list(buf)
+    return {"waves": [v[8 * w: 8 * w + 8] for w in range(8)], "tiles": v[64], "loop_ticks": v[65]}
