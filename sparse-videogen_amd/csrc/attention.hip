@@ -256,10 +256,22 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp_kernel(typename BandPolic
     attn_body_pp<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
 
-template <typename T, int D>
+template <typename T, int D, int ABL>
 __global__ __launch_bounds__(512, 2) void band_attn_pp_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_pp<T, D, BandPolicy<T, D, 8, false>, true>(prm, smem, nullptr);
+    attn_body_pp<T, D, BandPolicy<T, D, 8, false>, true, ABL>(prm, smem, nullptr);
+}
+
+// two-phase ping-pong schedule (attn_body_pp2)
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
+}
+template <typename T, int D, int ABL>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, true, ABL>(prm, smem, nullptr);
 }
 
 // =====================================================================================================
@@ -449,6 +461,8 @@ thread_local int g_last_hip_error = 0;
 static thread_local bool g_band_pipe = false;  // set per call from `variant` bit 2
 static thread_local bool g_band_pp = false;    // set per call from `variant` bit 5
 static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
+static thread_local bool g_band_pp2 = false;       // `variant` bit 7: two-phase ping-pong schedule (attn_body_pp2)
+static thread_local int g_band_pp_abl = 0;         // `variant` bits 8..11 together with bit 6: ablation of the traced kernel
 
 template <typename K, typename Prm>
 static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds, hipStream_t st) {
@@ -499,9 +513,26 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
     } else {
         if constexpr (NW == 8 && !SKEW && ABL == 0) {
             if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
-                if (g_band_pp && g_band_pp_trace)
-                    return launch_attn(band_attn_pp_trace_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp_lds_bytes<D>(), st);
+                if (g_band_pp2 && g_band_pp_trace) {
+#define SVG_PP_TRACE(A) case A: return launch_attn(band_attn_pp2_trace_kernel<T, D, A>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
+                    switch (g_band_pp_abl) {
+                        SVG_PP_TRACE(0) SVG_PP_TRACE(1) SVG_PP_TRACE(2) SVG_PP_TRACE(4) SVG_PP_TRACE(5) SVG_PP_TRACE(6) SVG_PP_TRACE(7)
+                        default: return SVG_ERR_UNSUPPORTED;
+                    }
+#undef SVG_PP_TRACE
+                }
+                if (g_band_pp && g_band_pp_trace) {
+#define SVG_PP_TRACE(A) case A: return launch_attn(band_attn_pp_trace_kernel<T, D, A>, p, dim3(p.nqt * BH), 512, attn_pp_lds_bytes<D>(), st);
+                    switch (g_band_pp_abl) {
+                        SVG_PP_TRACE(0) SVG_PP_TRACE(1) SVG_PP_TRACE(2) SVG_PP_TRACE(3) SVG_PP_TRACE(4) SVG_PP_TRACE(5)
+                        SVG_PP_TRACE(6) SVG_PP_TRACE(7)
+                        default: return SVG_ERR_UNSUPPORTED;
+                    }
+#undef SVG_PP_TRACE
+                }
             }
+            if (g_band_pp2)
+                return launch_attn(band_attn_pp2_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
             if (g_band_pp)
                 return launch_attn(band_attn_pp_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp_lds_bytes<D>(), st);
             if (g_band_pipe)
@@ -516,9 +547,9 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
 
 using namespace svg;
 
-extern "C" int svg_debug_pp_trace(uint64_t* out66) {
-    if (!out66) return SVG_ERR_BAD_ARG;
-    hipError_t e = hipMemcpyFromSymbol(out66, HIP_SYMBOL(g_pp_trace), 66 * sizeof(uint64_t));
+extern "C" int svg_debug_pp_trace(uint64_t* out104) {
+    if (!out104) return SVG_ERR_BAD_ARG;
+    hipError_t e = hipMemcpyFromSymbol(out104, HIP_SYMBOL(g_pp_trace), 104 * sizeof(uint64_t));
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return SVG_ERR_LAUNCH;
@@ -541,7 +572,8 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     hipStream_t st = (hipStream_t)stream;
     // bits 8..11: ablation experiments (timing only, results are wrong): bf16, D = 128, 8 waves, lock-step schedule
     const int abl = (variant >> 8) & 15;
-    if (abl && dtype == SVG_DTYPE_BF16 && D == 128) {
+    g_band_pp_abl = (variant & 64) ? abl : 0;
+    if (abl && !(variant & 64) && dtype == SVG_DTYPE_BF16 && D == 128) {
         switch (abl) {
             case 1: return run_band<__bf16, 128, 8, false, 1>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
             case 2: return run_band<__bf16, 128, 8, false, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
@@ -561,6 +593,7 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     }
     g_band_pipe = (variant & 4) != 0;      // bit 2: software-pipelined schedule (attn_body_pipe)
     g_band_pp = (variant & 32) != 0;       // bit 5: ping-pong schedule (attn_body_pp)
+    g_band_pp2 = (variant & 128) != 0;     // bit 7: two-phase ping-pong schedule (attn_body_pp2)
     g_band_pp_trace = (variant & 64) != 0; // bit 6 (with bit 5): cycle trace of one workgroup, read with svg_debug_pp_trace
     // default schedule: 8 waves x 32 rows, two 64-key tiles per LDS stage (one barrier / staging round per 128 keys)
     if (variant == 0) {

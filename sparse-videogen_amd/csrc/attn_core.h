@@ -792,10 +792,12 @@ constexpr int attn_pp_lds_bytes() {
 
 // cycle trace of the ping-pong clusters (diagnostics, variant bit 6): per wave 8 sums of s_memtime ticks —
 // [LK work, barrier wait, QK work, wait, SV work, wait, PV work, wait] — of workgroup blockIdx.x == kPpTraceBlock
-__device__ unsigned long long g_pp_trace[8 * 8 + 8];
+__device__ unsigned long long g_pp_trace[8 * 8 + 8 + 8 * 4];
 constexpr int kPpTraceBlock = 1000;
 
-template <typename T, int D, typename P, bool TRACE = false>
+// ABL > 0 (trace kernels only, results wrong by construction): 1 no V^T reads, 2 no row maximum / decision, 3 no
+// probabilities of keys 0..31, 4 no probabilities of keys 32..63, 5 no K reads, 6 no DMA, 7 no mask evaluation
+template <typename T, int D, typename P, bool TRACE = false, int ABL = 0>
 __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
     using V8 = typename E::v8;
@@ -847,15 +849,16 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
     const unsigned col_v = (unsigned)(dma_db * 64 + (lane & 3) * 16);   // source byte column of this lane's V chunk
     const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);           // K: slot = chunk ^ ((key >> 2) & 3)
     const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
-    auto dma_issue = [&](int t) {  // request tile t (t < nT) into stage t % NS
+    auto dma_piece = [&](int t, int j) {  // request this wave's piece j of tile t (t < nT) into stage t % NS
         const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
+        const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
+        const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
+        lds_dma16(st + j * 1024, vo ^ k_xor, kb);
+        lds_dma16(st + j * 1024 + kImg, vo, vb);
+    };
+    auto dma_issue = [&](int t) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
-            const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
-            lds_dma16(st + j * 1024, vo ^ k_xor, kb);
-            lds_dma16(st + j * 1024 + kImg, vo, vb);
-        }
+        for (int j = 0; j < NP; ++j) dma_piece(t, j);
     };
     if (nT > 0) dma_issue(0);
     if (nT > 1) dma_issue(1);
@@ -896,13 +899,13 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
     pp_barrier();
     if (lagging) pp_barrier();  // waves 4..7 run one cluster behind
 
-    unsigned tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tr_last = 0, tr_first = 0;
     if constexpr (TRACE) tr_first = tr_last = __builtin_amdgcn_s_memtime();
     auto tick = [&](auto slot_c) {  // close interval `slot`: work intervals end after the wave's own LDS reads have landed
         if constexpr (TRACE) {
             constexpr int slot = decltype(slot_c)::value;
-            if constexpr ((slot & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr ((slot & 1) == 0 && slot < 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             tr_acc[slot] += (unsigned)(now - tr_last);
             tr_last = now;
@@ -926,7 +929,10 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
         V8 pf[2][2];
 
         // ---------------- LK ----------------
-        {
+        if constexpr (ABL == 5) {
+#pragma unroll
+            for (int j = 0; j < NOPR; ++j) opr[j] = qf[j % KS];
+        } else {
             const char* k0 = sbuf + k_lane0;
             const char* k1 = sbuf + k_lane1;
 #pragma unroll
@@ -948,10 +954,21 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             s[0] = E::mfma(opr[0], qf[0], zero);
             s[1] = E::mfma(opr[1], qf[0], zero);
+            // The two accumulator chains leave the issue port idle most of the time (a dependent MFMA waits for its
+            // predecessor): the DMA requests for tile t+2 (address arithmetic + ~60 cycles of issue each) go in between.
+            constexpr int kSeg = KS / (NP + 1);
 #pragma unroll
-            for (int ks = 1; ks < KS; ++ks)
+            for (int ks = 1; ks < KS; ++ks) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) s[b] = E::mfma(opr[ks * 2 + b], qf[ks], s[b]);
+                if constexpr (ABL != 6) {
+                    if (ks % kSeg == kSeg - 1 && ks / kSeg < NP) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) dma_piece(t + 2, ks / kSeg);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
             asm volatile("" : "+v"(s[0]), "+v"(s[1]));  // the scores are produced in this cluster
         }
         tick(std::integral_constant<int, 2>{});
@@ -962,6 +979,10 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
         float m_use, psum = 0.f;
         {
             const char* vbase = sbuf + v_lane_off;
+            if constexpr (ABL == 1) {
+#pragma unroll
+                for (int j = 0; j < NOPR; ++j) asm volatile("" : "+v"(opr[j]));
+            } else
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)          // 16-key step
 #pragma unroll
@@ -977,7 +998,7 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
             }
-            if (cls != TILE_FULL) {
+            if (ABL != 7 && cls != TILE_FULL) {
                 // opaque copies: otherwise LICM hoists the 32 per-element row / key terms out of the tile loop and
                 // they occupy registers for the whole kernel (the budget is 256 with two waves per SIMD)
                 int qv = q_log, kv0 = tk0 + 4 * g;
@@ -992,17 +1013,19 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
                     }
             }
             float mx = s[0][0];
+            if constexpr (ABL != 2) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute
+            }
+            if constexpr (ABL != 2) {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute
                 const unsigned u = __builtin_bit_cast(unsigned, mx);
                 const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                 mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
             }
             m_use = (m_run == -INFINITY) ? 0.f : m_run;
-            if (!__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
+            if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
                 const float m_new = fmaxf(m_run, mx);
                 m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -1021,46 +1044,54 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
                         acc_o[db][r] = x;
                     }
             }
+            if constexpr (ABL == 3) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 8; ++r) pf[0][0][r] = E::from_float(s[0][r]);
+            } else
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {   // keys 0..15 (the first PV step); the rest is computed in the shadow of the PV MFMAs
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], c_log2, -m_use));
                 psum += p;
-                pf[0][r >> 3][r & 7] = E::from_float(p);
+                pf[0][0][r] = E::from_float(p);
             }
-            asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(psum));  // keep this half of the softmax in this cluster
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t+1 (requested in PV(t-1))
+            asm volatile("" : "+v"(pf[0][0]), "+v"(psum));  // keep this part of the softmax in this cluster
+            // this wave's DMA pieces of tile t+1 (requested in QK(t-1)); the pieces of tile t+2 (QK(t)) may stay in flight
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         tick(std::integral_constant<int, 4>{});
         pp_barrier();
         tick(std::integral_constant<int, 5>{});
 
-        // ---------------- PV: keys 0..31 on the matrix pipe while the VALU finishes the probabilities of keys 32..63 ----------------
+        // ---------------- PV: 16-key steps on the matrix pipe while the VALU computes the probabilities of the next step ----------------
         {
+            auto probs = [&](int kk) {  // keys 16 kk .. 16 kk + 15: score registers 8 (kk & 1) .. + 7 of block kk >> 1
+                if constexpr (ABL == 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][r], c_log2, -m_use));
-                psum += p;
-                pf[1][r >> 3][r & 7] = E::from_float(p);
+                    for (int r = 0; r < 8; ++r) pf[kk >> 1][kk & 1][r] = E::from_float(s[kk >> 1][8 * (kk & 1) + r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
+                        psum += p;
+                        pf[kk >> 1][kk & 1][r] = E::from_float(p);
+                    }
+                }
+            };
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) probs(kk + 1);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) acc_o[db] = E::mfma(opr[kk * DB + db], pf[kk >> 1][kk & 1], acc_o[db]);
             }
+            // one MFMA, then its share of the 3 x 28 VALU instructions (8 fma, 8 exp, 8 add, 4 cvt per step)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int db = 0; db < DB; ++db) acc_o[db] = E::mfma(opr[kk * DB + db], pf[0][kk], acc_o[db]);
-            // one MFMA, then its share of the 56 VALU instructions (16 fma, 16 exp, 16 add, 8 cvt)
-#pragma unroll
-            for (int i = 0; i < 2 * DB; ++i) {
+            for (int i = 0; i < 3 * DB; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (56 + 2 * DB - 1) / (2 * DB), 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (28 + DB - 1) / DB, 0);
             }
-            asm volatile("" : "+v"(pf[1][0]), "+v"(pf[1][1]));
             l_run += psum;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) dma_issue(t + 2);  // among bare MFMAs the issue is cheap; its stage was last read in SV(t-1)
-#pragma unroll
-        for (int kk = 2; kk < 4; ++kk)
-#pragma unroll
-            for (int db = 0; db < DB; ++db) acc_o[db] = E::mfma(opr[kk * DB + db], pf[1][kk & 1], acc_o[db]);
         if constexpr (TRACE) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(acc_o[db]));  // the MFMAs have to retire inside the interval
@@ -1073,10 +1104,336 @@ __device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char
         if (blockIdx.x == kPpTraceBlock && lane == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g_pp_trace[wave * 8 + j] = tr_acc[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g_pp_trace[72 + wave * 4 + j] = tr_acc[8 + j];
             if (wave == 0) g_pp_trace[64] = (unsigned long long)nT, g_pp_trace[65] = tr_last - tr_first;
         }
     }
     if (!lagging) pp_barrier();  // matches the lagging group's last barrier; the stage buffers are free afterwards
+
+    // ---------------- epilogue (same as attn_body) ----------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if constexpr (P::kPartialOut) {
+        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
+        return;
+    } else {
+        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+        constexpr int kEpiStride = D * 2 + 8;
+        char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        T* __restrict__ ob = P::o_base(prm, ctx);
+        constexpr int kLanesPerRow = D * 2 / 8;
+        constexpr int kRowsPerPass = 64 / kLanesPerRow;
+        const int sub = lane / kLanesPerRow;
+        const int colb = (lane - sub * kLanesPerRow) * 8;
+        int ephys[32 / kRowsPerPass];
+#pragma unroll
+        for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+        for (int i = 0; i < 32 / kRowsPerPass; ++i) {
+            const int rr = i * kRowsPerPass + sub;
+            const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+        }
+    }
+}
+
+// =====================================================================================================================
+// attn_body_pp2 — two-phase ping-pong: per tile every wave runs ONE matrix phase and ONE vector phase, and the two waves
+// of a SIMD are always in opposite phases (waves 4..7 run one phase behind waves 0..3; two barriers per tile).
+//     M(t+1)  O^T += V(t)^T P(t)^T  (16 MFMAs; the probabilities of keys 16..63 are computed in their shadow)
+//             S(t+1)^T = K(t+1) Q^T (16 MFMAs); operands stream from LDS just ahead of the MFMAs that consume them
+//     N(t+1)  mask, row maximum, (rare) rescale of O, probabilities of keys 0..15 of tile t+1; LDS-DMA requests; DMA wait
+// In M the wave has the matrix pipe to itself (its partner is in N and issues no MFMA), in N it has the VALU to itself.
+// profiles/r01_ablation.md: in the lock-step body both waves of a SIMD sit in the same phase and the phases add up; the
+// four-cluster attn_body_pp separates them but pays four barriers per tile and serialises the LDS operand reads.
+//     slot         2t      2t+1    2t+2     2t+3
+//     waves 0-3    M(t)    N(t)    M(t+1)   N(t+1)          M(t) reads K(t) and V(t-1)
+//     waves 4-7    N(t-1)  M(t)    N(t)     M(t+1)
+// LDS: four stages; tile w is in use during slots 2w .. 2w+3 (K in 2w, 2w+1; V in 2w+2, 2w+3).  Its stage becomes free at
+// slot 2w-4: the leading waves request it in N(w-2) (slot 2w-3), the lagging waves in N(w-3) (slot 2w-4); every wave waits,
+// at the end of a vector phase, for the pieces it requested in the previous one.
+// =====================================================================================================================
+template <int D>
+constexpr int attn_pp2_lds_bytes() {
+    constexpr int stages = 4 * 2 * kBN * D * 2;
+    constexpr int epi = 8 * 32 * (D * 2 + 8);
+    return stages > epi ? stages : epi;
+}
+
+template <typename T, int D, typename P, bool TRACE = false, int ABL = 0>
+__device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, char* smem, char* policy_lds) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    constexpr int NW = 8;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int NS = 4;
+    constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
+    constexpr int kStage = 2 * kImg;
+    constexpr int NP = DB / 2;              // DMA pieces per wave per tensor per tile
+    constexpr float kDefer = 8.f;
+    static_assert(D == 64 || D == 128, "head dim");
+    static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1, "ping-pong body: 32 rows per wave, one tile per stage");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, policy_lds)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_id();
+    const int g = lane >> 5;
+    const int ql = lane & 31;
+    const int row_in_wg = wave * 32 + ql;
+    const bool lagging = wave >= NW / 2;
+    const int nT = ctx.nT;
+
+    const T* __restrict__ qb = P::q_base(prm, ctx);
+    const T* __restrict__ kb = P::k_base(prm, ctx);
+    const T* __restrict__ vb = P::v_base(prm, ctx);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- DMA bookkeeping (same images as attn_body_pp) ----
+    const int dma_db = wave % DB;
+    const int dma_kg0 = (wave / DB) * NP;
+    int krow[NP];
+    typename P::KvCursor cur[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        krow[j] = 16 * (dma_kg0 + j) + (lane >> 2);
+        P::kv_cursor_init(prm, ctx, cur[j], krow[j]);
+    }
+    const unsigned col_v = (unsigned)(dma_db * 64 + (lane & 3) * 16);
+    const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);
+    const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
+    auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT) into stage t % NS
+        const unsigned st = lds_piece + (unsigned)((t & (NS - 1)) * kStage);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
+            const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
+            lds_dma16(st + j * 1024, vo ^ k_xor, kb);
+            lds_dma16(st + j * 1024 + kImg, vo, vb);
+        }
+    };
+    const int dist = lagging ? 3 : 2;   // tiles 0 .. dist-1 are requested here, tile u + dist in N(u)
+    if (nT > 0) dma_issue(0);
+    if (nT > 1) dma_issue(1);
+    if (lagging && nT > 2) dma_issue(2);
+
+    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
+    const int q_log = P::q_logical(ctx, row_in_wg);
+    V8 qf[KS];
+    {
+        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
+    }
+
+    const int k_lane0 = ql * 64 + (((g) ^ ((ql >> 2) & 3)) << 4);   // even k-steps
+    const int k_lane1 = k_lane0 ^ 32;                               // odd k-steps
+    const int vi = lane & 15;
+    const int v_lane_off = kImg + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    const float c_log2 = prm.scale_log2;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (lagging) pp_barrier();  // waves 4..7 run one phase behind
+
+    unsigned tr_acc[4] = {0, 0, 0, 0};
+    unsigned long long tr_last = 0, tr_first = 0;
+    if constexpr (TRACE) tr_first = tr_last = __builtin_amdgcn_s_memtime();
+    auto tick = [&](auto slot_c) {
+        if constexpr (TRACE) {
+            constexpr int slot = decltype(slot_c)::value;
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tr_acc[slot] += (unsigned)(now - tr_last);
+            tr_last = now;
+        }
+    };
+
+    f32x16 sc[2];          // scores: S(t) until the PV steps of the matrix phase have consumed it, then S(t+1) accumulates here
+    V8 pf[2][2];           // probabilities: [32-key block][16-key half]
+    float m_use = 0.f, psum = 0.f;
+
+    auto kfrag = [&](const char* st, int b, int ks) -> V8 {
+        return *(const V8*)(st + ((ks & 1) ? k_lane1 : k_lane0) + (ks >> 1) * (kBN * 64) + b * (32 * 64));
+    };
+    auto vfrag = [&](const char* st, int kk, int db) -> V8 {
+        const char* vbase = st + v_lane_off;
+        const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + (16 * kk) * 64);
+        const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (16 * kk + 8) * 64);
+        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(V8, both);
+    };
+    // probabilities of keys 16 kk + [lo, hi) of the tile in sc
+    auto probs = [&](int kk, int lo, int hi) {
+#pragma unroll
+        for (int r = lo; r < hi; ++r) {
+            if constexpr (ABL == 4) {
+                pf[kk >> 1][kk & 1][r] = E::from_float(sc[kk >> 1][8 * (kk & 1) + r]);
+            } else {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
+                psum += p;
+                pf[kk >> 1][kk & 1][r] = E::from_float(p);
+            }
+        }
+    };
+    // vector phase of tile t on sc: mask, maximum, (rare) rescale, probabilities of keys 0..15, DMA requests, DMA wait
+    auto vector_phase = [&](int t) {
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if constexpr (P::kFixup) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[b][r] = P::score_fixup(prm, sc[b][r]);
+        }
+        if (ABL != 7 && cls != TILE_FULL) {
+            int qv = q_log, kv0 = tk0 + 4 * g;   // opaque copies: keeps LICM from hoisting 32 per-element terms out of the loop
+            asm volatile("" : "+v"(qv), "+v"(kv0));
+            const bool part = (cls == TILE_PARTIAL);  // a tile this wave does not need at all is processed fully masked
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * b + (r & 3) + 8 * (r >> 2);
+                    sc[b][r] = (part & P::allowed(prm, ctx, qv, kv0 + key)) ? sc[b][r] : -INFINITY;
+                }
+        }
+        float mx = sc[0][0];
+        if constexpr (ABL != 2) {
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+            const unsigned u = __builtin_bit_cast(unsigned, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
+        }
+        m_use = (m_run == -INFINITY) ? 0.f : m_run;
+        if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
+            const float m_new = fmaxf(m_run, mx);
+            m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {   // in place (tied operands), see attn_body_pp
+                    float x = acc_o[db][r];
+                    asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(alpha));
+                    acc_o[db][r] = x;
+                }
+        }
+        psum = 0.f;
+        probs(0, 0, 8);
+        asm volatile("" : "+v"(pf[0][0]), "+v"(psum));
+        const bool more = t + dist < nT;
+        if (ABL != 6 && more) dma_issue(t + dist);
+        // pieces requested in the previous vector phase have to be in LDS; the ones just requested may stay in flight
+        if (ABL != 6 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // Matrix phase: O^T += V(t)^T P(t)^T (4 DB MFMAs), then S(t+1)^T = K(t+1) Q^T into sn (2 KS MFMAs).
+    // One step = { LDS read of the operand kPF steps ahead; one MFMA; a 7-instruction slice of the probabilities of the
+    // next 16-key step }; steps are fenced with sched_barrier so the reads stay kPF MFMAs (~kPF x 32 cycles) ahead of their
+    // use — left alone, hipcc puts every read directly in front of its MFMA and the phase runs at LDS latency.
+    auto matrix_phase = [&](int t, auto has_next_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        constexpr int kPF = 4;
+        constexpr int NPV = 4 * DB;
+        constexpr int NALL = has_next ? NPV + 2 * KS : NPV;
+        const char* stv = smem + (t & (NS - 1)) * kStage;
+        const char* stk = smem + ((t + 1) & (NS - 1)) * kStage;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        V8 ring[kPF + 1];
+        auto fetch = [&](int i) {  // operand of step i
+            if (i >= NALL) return;
+            if (i < NPV) {
+                if constexpr (ABL == 1) ring[i % (kPF + 1)] = qf[i % KS];
+                else ring[i % (kPF + 1)] = vfrag(stv, i / DB, i % DB);
+            } else {
+                const int j = i - NPV;
+                if constexpr (ABL == 5) ring[i % (kPF + 1)] = qf[j % KS];
+                else ring[i % (kPF + 1)] = kfrag(stk, j & 1, j >> 1);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) fetch(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NALL; ++i) {
+            fetch(i + kPF);
+            if (i < NPV) {
+                const int kk = i / DB, db = i % DB;
+                acc_o[db] = E::mfma(ring[i % (kPF + 1)], pf[kk >> 1][kk & 1], acc_o[db]);
+                if (kk + 1 < 4) probs(kk + 1, db * (8 / DB), (db + 1) * (8 / DB));
+                if (i == NPV - 1) l_run += psum;
+            } else {
+                const int j = i - NPV, ks = j >> 1, b = j & 1;
+                sc[b] = E::mfma(ring[i % (kPF + 1)], qf[ks], ks == 0 ? zero : sc[b]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (has_next) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    };
+
+    // ---- M(0): only S(0) ----
+    if (nT > 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) sc[b] = E::mfma(kfrag(smem, b, ks), qf[ks], ks == 0 ? zero : sc[b]);
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    }
+    // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc hoist the common VALU work above
+    //  the branch and keep two register sets for O with 32 copies per tile)
+    auto tile = [&](int t, auto has_next_c) {
+        tick(std::integral_constant<int, 0>{});
+        pp_barrier();
+        tick(std::integral_constant<int, 1>{});
+        vector_phase(t);
+        tick(std::integral_constant<int, 2>{});
+        pp_barrier();
+        tick(std::integral_constant<int, 3>{});
+        matrix_phase(t, has_next_c);
+    };
+    for (int t = 0; t + 1 < nT; ++t) tile(t, std::true_type{});
+    if (nT > 0) tile(nT - 1, std::false_type{});
+    // the leading waves wait until the lagging waves have read V of the last tile: the epilogue reuses the stages
+    pp_barrier();
+    if (!lagging) pp_barrier();
+    if constexpr (TRACE) {
+        if (blockIdx.x == kPpTraceBlock && lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g_pp_trace[wave * 8 + j] = tr_acc[j];
+            if (wave == 0) g_pp_trace[64] = (unsigned long long)nT, g_pp_trace[65] = tr_last - tr_first;
+        }
+    }
 
     // ---------------- epilogue (same as attn_body) ----------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);

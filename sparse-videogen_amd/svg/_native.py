@@ -346,8 +346,9 @@ def map_density(block_map: torch.Tensor, q_sizes: torch.Tensor, k_sizes: torch.T
 
 def debug_pp_trace():
     """Cycle trace of the ping-pong attention schedule (svg_debug_pp_trace): dict wave -> 8 tick sums, tiles, loop ticks."""
-    buf = (C.c_uint64 * 66)()
+    buf = (C.c_uint64 * 104)()
     torch.cuda.synchronize()
     _check(load().svg_debug_pp_trace(C.cast(buf, C.c_void_p)), "svg_debug_pp_trace")
     v = list(buf)
-    return {"waves": [v[8 * w: 8 * w + 8] for w in range(8)], "tiles": v[64], "loop_ticks": v[65]}
+    return {"waves": [v[8 * w: 8 * w + 8] for w in range(8)], "sv": [v[72 + 4 * w: 72 + 4 * w + 3] for w in range(8)],
+            "tiles": v[64], "loop_ticks": v[65]}
