@@ -143,11 +143,11 @@ struct BandPolicy {
         return l < c.q_end ? phys_row(p, c, l) : -1;
     }
     static __device__ __forceinline__ int tile_key0(const Ctx& c, int t) {
-        int tile;
-        if (t < c.seg_n[0]) tile = c.seg_lo[0] + t;
-        else if (t < c.seg_n[0] + c.seg_n[1]) tile = c.seg_lo[1] + (t - c.seg_n[0]);
-        else tile = c.seg_lo[2] + (t - c.seg_n[0] - c.seg_n[1]);
-        return tile * kBN;
+        // selects, not branches: this runs once per tile on the scalar unit of every wave
+        const int n01 = c.seg_n[0] + c.seg_n[1];
+        const int a = c.seg_lo[0] + t, b = c.seg_lo[1] + (t - c.seg_n[0]), d = c.seg_lo[2] + (t - n01);
+        const int bd = t < n01 ? b : d;
+        return (t < c.seg_n[0] ? a : bd) * kBN;
     }
     static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) {
         cu.pp = 0, cu.f = 0, cu.prev_k0 = -(1 << 30);

@@ -1179,7 +1179,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     constexpr int NW = 8;
     constexpr int KS = D / 16;
     constexpr int DB = D / 32;
-    constexpr int NS = 4;
+    constexpr bool kDma = true;             // true: LDS-DMA staging (4 stages); false: register staging (3 stages), measured 15 % slower
+    constexpr int kShadow = 2;              // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
+    constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;
     constexpr int NP = DB / 2;              // DMA pieces per wave per tensor per tile
@@ -1218,7 +1220,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);
     const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
     auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT) into stage t % NS
-        const unsigned st = lds_piece + (unsigned)((t & (NS - 1)) * kStage);
+        const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
@@ -1227,10 +1229,43 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             lds_dma16(st + j * 1024 + kImg, vo, vb);
         }
     };
-    const int dist = lagging ? 3 : 2;   // tiles 0 .. dist-1 are requested here, tile u + dist in N(u)
-    if (nT > 0) dma_issue(0);
-    if (nT > 1) dma_issue(1);
-    if (lagging && nT > 2) dma_issue(2);
+    // Register staging (kDma = false, kept for comparison): loads for tile w are issued in N(w - dist) and written in the
+    // following vector phase: slot 2w-1 (leading) / 2w-2 (lagging), after the last read of the stage's previous tenant
+    // (slot 2(w-3)+3) and before the first read of tile w (slot 2w).  Measured 51.0 ms vs 44.7 ms with LDS-DMA: the
+    // ds_write_b128 traffic of the vector phase collides with the operand streaming of the partner's matrix phase.
+    u32x4 kreg[NP], vreg[NP];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
+            const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
+            kreg[j] = *(const u32x4*)((const char*)kb + (vo ^ k_xor));
+            vreg[j] = *(const u32x4*)((const char*)vb + vo);
+        }
+    };
+    char* const piece_ptr = smem + dma_db * (kBN * 64) + dma_kg0 * 1024 + lane * 16;
+    auto stage_store = [&](int t) {
+        char* st = piece_ptr + (t % NS) * kStage;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            *(u32x4*)(st + j * 1024) = kreg[j];
+            *(u32x4*)(st + j * 1024 + kImg) = vreg[j];
+        }
+    };
+    const int dist = kDma ? (lagging ? 3 : 2) : (lagging ? 3 : 2);   // tile u + dist is requested in N(u)
+    if constexpr (kDma) {
+        if (nT > 0) dma_issue(0);
+        if (nT > 1) dma_issue(1);
+        if (lagging && nT > 2) dma_issue(2);
+    } else {
+        // tiles 0 .. dist-2 go to LDS here, tile dist-1 stays in the staging registers (written in N(0))
+        if (nT > 0) { stage_load(0); stage_store(0); }
+        if (nT > 1) stage_load(1);
+        if (lagging) {
+            if (nT > 1) stage_store(1);
+            if (nT > 2) stage_load(2);
+        }
+    }
 
     const int q_phys = P::q_phys(prm, ctx, row_in_wg);
     const int q_log = P::q_logical(ctx, row_in_wg);
@@ -1287,6 +1322,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         return __builtin_bit_cast(V8, both);
     };
     // probabilities of keys 16 kk + [lo, hi) of the tile in sc
+    // (scalar f32 on purpose: the packed forms v_pk_fma_f32 / v_pk_add_f32 measured 48.2 ms vs 42.3 ms here)
     auto probs = [&](int kk, int lo, int hi) {
 #pragma unroll
         for (int r = lo; r < hi; ++r) {
@@ -1349,13 +1385,21 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 }
         }
         psum = 0.f;
-        probs(0, 0, 8);
-        asm volatile("" : "+v"(pf[0][0]), "+v"(psum));
+#pragma unroll
+        for (int kk = 0; kk < 4 - kShadow; ++kk) {
+            probs(kk, 0, 8);
+            asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
+        }
         const bool more = t + dist < nT;
-        if (ABL != 6 && more) dma_issue(t + dist);
-        // pieces requested in the previous vector phase have to be in LDS; the ones just requested may stay in flight
-        if (ABL != 6 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (kDma) {
+            if (ABL != 6 && more) dma_issue(t + dist);
+            // pieces requested in the previous vector phase have to be in LDS; the ones just requested may stay in flight
+            if (ABL != 6 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (ABL != 6) {
+            if (t + dist - 1 < nT) stage_store(t + dist - 1);   // loaded in the previous vector phase (or the prologue)
+            if (more) stage_load(t + dist);
+        }
     };
     // Matrix phase: O^T += V(t)^T P(t)^T (4 DB MFMAs), then S(t+1)^T = K(t+1) Q^T into sn (2 KS MFMAs).
     // One step = { LDS read of the operand kPF steps ahead; one MFMA; a 7-instruction slice of the probabilities of the
@@ -1363,11 +1407,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // use — left alone, hipcc puts every read directly in front of its MFMA and the phase runs at LDS latency.
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
-        constexpr int kPF = 4;
+        constexpr int kPF = 8;
         constexpr int NPV = 4 * DB;
         constexpr int NALL = has_next ? NPV + 2 * KS : NPV;
-        const char* stv = smem + (t & (NS - 1)) * kStage;
-        const char* stk = smem + ((t + 1) & (NS - 1)) * kStage;
+        const char* stv = smem + (t % NS) * kStage;
+        const char* stk = smem + ((t + 1) % NS) * kStage;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         V8 ring[kPF + 1];
         auto fetch = [&](int i) {  // operand of step i
@@ -1390,7 +1434,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             if (i < NPV) {
                 const int kk = i / DB, db = i % DB;
                 acc_o[db] = E::mfma(ring[i % (kPF + 1)], pf[kk >> 1][kk & 1], acc_o[db]);
-                if (kk + 1 < 4) probs(kk + 1, db * (8 / DB), (db + 1) * (8 / DB));
+                // probabilities of a later 16-key step in the shadow of this MFMA (one slice per d-block)
+                if (kk + 1 < 4 && kk + 1 >= 4 - kShadow) probs(kk + 1, db * (8 / DB), (db + 1) * (8 / DB));
                 if (i == NPV - 1) l_run += psum;
             } else {
                 const int j = i - NPV, ks = j >> 1, b = j & 1;
@@ -1420,7 +1465,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         tick(std::integral_constant<int, 2>{});
         pp_barrier();
         tick(std::integral_constant<int, 3>{});
+        __builtin_amdgcn_s_setprio(1);   // the matrix phase wins the VALU / MFMA issue arbitration against the partner's vector phase
         matrix_phase(t, has_next_c);
+        __builtin_amdgcn_s_setprio(0);
     };
     for (int t = 0; t + 1 < nT; ++t) tile(t, std::true_type{});
     if (nT > 0) tile(nT - 1, std::false_type{});
