@@ -217,7 +217,7 @@ def main():
             "denoise_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
             "roofline": {
                 "bound": "mfma",
-                "kernel": "band_attn_kernel<bf16,128>",
+                "kernel": "band_attn_pp2_kernel<bf16,128>" if a.variant in (0, 128) else f"band_attn variant {a.variant}",
                 "achieved": round(kern_tf, 2),
                 "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s",

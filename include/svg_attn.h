@@ -104,10 +104,14 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = shipped schedule (8 waves x 32 query rows, two 64-key tiles per LDS stage).  Non-zero values select the
- * alternative schedules kept for A/B measurements (all produce the same result): 1 = 4 waves / 128-row q-tiles (2 workgroups
- * per CU), 2 = skewed two-group schedule, 4 = software-pipelined body, 8 = 4 waves x 64 rows (one wave per SIMD), 16 = 8 waves
- * with one tile per stage; bits 8..11 = timing-only ablations (wrong results by construction, see profiles/). */
+/* variant: 0 = shipped schedule: two-phase ping-pong, 8 waves x 32 query rows — the two waves that share a SIMD alternate a
+ * matrix phase (PV of tile t + QK^T of tile t+1, operands streamed from LDS) and a vector phase (softmax, LDS-DMA requests),
+ * always in opposite phases.  Non-zero values select the alternative schedules kept for A/B measurements (all produce the same
+ * result up to rounding): 1 = lock-step, 4 waves / 128-row q-tiles (2 workgroups per CU), 2 = skewed two-group schedule,
+ * 4 = intra-wave software-pipelined body, 8 = 4 waves x 64 rows (one wave per SIMD), 16 = lock-step 8 waves, one tile per stage,
+ * 32 = four-cluster ping-pong (register-operand MFMA clusters), 128 = same as 0, 4096 = lock-step 8 waves, two 64-key tiles per
+ * stage (the default before the ping-pong schedule); 64 = with 32 / 128: cycle trace (svg_debug_pp_trace); bits 8..11 =
+ * timing-only ablations (wrong results by construction, see profiles/). */
 int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                        int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                        int32_t variant, void* stream);
@@ -199,11 +203,13 @@ int svg_identify_dynamic_map(const void* qc, const void* kc, const int32_t* k_si
 int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out, int32_t BH,
                     int32_t QB, int32_t KB, void* stream);
 
-/* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedule.
- * After a svg_band_attention call with variant bits 5 and 6 set (bf16, D = 128) and a synchronised stream, copies 66
- * counters to the host: out[8 * wave + i], i = 0..7 = s_memtime ticks wave `wave` of one workgroup spent in
- * [LK work, barrier, QK work, barrier, SV work, barrier, PV work, barrier]; out[64] = KV tiles, out[65] = loop ticks. */
-int svg_debug_pp_trace(uint64_t* out66);
+/* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
+ * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
+ * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in
+ *   variant 32:  i = 0..7  [LK work, barrier, QK work, barrier, SV work, barrier, PV work, barrier]
+ *   variant 128: i = 0..3  [matrix phase, barrier, vector phase, barrier]
+ * out[64] = KV tiles of that workgroup, out[65] = ticks of its tile loop. */
+int svg_debug_pp_trace(uint64_t* out104);
 
 #ifdef __cplusplus
 }

@@ -595,8 +595,17 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     g_band_pp = (variant & 32) != 0;       // bit 5: ping-pong schedule (attn_body_pp)
     g_band_pp2 = (variant & 128) != 0;     // bit 7: two-phase ping-pong schedule (attn_body_pp2)
     g_band_pp_trace = (variant & 64) != 0; // bit 6 (with bit 5): cycle trace of one workgroup, read with svg_debug_pp_trace
-    // default schedule: 8 waves x 32 rows, two 64-key tiles per LDS stage (one barrier / staging round per 128 keys)
+    // default schedule: two-phase ping-pong (attn_body_pp2); bit 12: the previous default — lock-step, 8 waves x 32 rows,
+    // two 64-key tiles per LDS stage (one barrier / staging round per 128 keys)
     if (variant == 0) {
+        g_band_pp2 = true;
+        if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 8, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_BF16 && D == 64) return run_band<__bf16, 64, 8, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 128) return run_band<_Float16, 128, 8, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        if (dtype == SVG_DTYPE_F16 && D == 64) return run_band<_Float16, 64, 8, false>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
+        return SVG_ERR_UNSUPPORTED;
+    }
+    if (variant & 4096) {
         if (dtype == SVG_DTYPE_BF16 && D == 128) return run_band<__bf16, 128, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
         if (dtype == SVG_DTYPE_BF16 && D == 64) return run_band<__bf16, 64, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);
         if (dtype == SVG_DTYPE_F16 && D == 128) return run_band<_Float16, 128, 8, false, 0, 1, 2>(q, k, v, o, BH, S, sm_scale, mask, perm, st);

@@ -118,7 +118,7 @@ def _band_case(model, F_, P_, ctx, L, mul):
                                              (128, torch.float16, 2), (128, torch.bfloat16, 8), (64, torch.float16, 8), (128, torch.bfloat16, 16),
                                              (64, torch.float16, 16), (128, torch.bfloat16, 32), (64, torch.float16, 32),
                                              (128, torch.float16, 32), (64, torch.bfloat16, 32), (128, torch.bfloat16, 128),
-                                             (64, torch.float16, 128), (128, torch.float16, 128), (64, torch.bfloat16, 128)])
+                                             (64, torch.float16, 128), (128, torch.float16, 4096), (64, torch.bfloat16, 4096)])
 def test_band_attention(nat, model, D, dtype, variant):
     torch.manual_seed(2)
     F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3

@@ -26,7 +26,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out+"/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r.get("Kernel_Name","?")
-        if "attn_kernel" not in k: continue
+        if "attn_" not in k or "profile" in k: continue
         agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out+"/summary.txt","w") as fo:
     for k,d in agg.items():
