@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--workload", default="wan720p", choices=sorted(WORKLOADS))
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed)")
+    ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
+                    "(the reference's pipeline) instead of the fused row-index gather")
     a = ap.parse_args()
     from svg import _native as nat
     from svg.kmeans_utils import density_calculation
@@ -81,9 +84,16 @@ def main():
             dmap, q_sizes, k_sizes, qidx, kidx = _core.dynamic_map_post_processing(dmap, q_sizes, k_sizes, qidx, kidx, V, ctx, L)
         t[2].record()
         QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
-        o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
-                                   q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                   q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+        if a.materialize:
+            qi, ki = qidx.view(H, S).contiguous(), kidx.view(H, S).contiguous()
+            qp, kp, vp = nat.permute_rows(q.view(H, S, D), qi), nat.permute_rows(k.view(H, S, D), ki), nat.permute_rows(v.view(H, S, D), ki)
+            op = nat.varblock_attention(qp, kp, vp, dmap.view(H, QB, KB).contiguous(), q_sizes.view(H, QB).contiguous(),
+                                        k_sizes.view(H, KB).contiguous(), variant=a.variant)
+            o = nat.permute_rows(op, qi, inverse=True)
+        else:
+            o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
+                                       q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
+                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant)
         t[3].record()
         torch.cuda.synchronize()
         if it >= a.warmup:

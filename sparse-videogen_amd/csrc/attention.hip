@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename Ba
 // always full except the last one — no per-cluster padding waste on the key side.
 // =====================================================================================================
 constexpr int kVbMaxKB = 4096;
+constexpr int kVbFull = 256;   // mixed tiling: full 256-row tiles go to the 8-wave kernel, the rest of a block-row to 128-row tiles
 
 template <typename T, int D, int NW>
 struct VarblockPolicy {
@@ -300,6 +301,7 @@ struct VarblockPolicy {
         const T* v;
         T* o;
         int Hq, Hkv, group, Sq, Skv, QB, KB, max_tiles, kb_cap;
+        int tile_mode;              // 0: ceil(n / BM) tiles per block-row; 1: only its full 256-row tiles; 2: its rows after them
         float scale_log2;
         const uint8_t* block_map;   // [Hkv, QB, KB]
         const int32_t* q_off;       // [Hkv, QB + 1] exclusive prefix of q_sizes
@@ -335,7 +337,8 @@ struct VarblockPolicy {
         const int i = a;
         const int32_t* qoff = p.q_off + (size_t)c.hkv * (p.QB + 1);
         const int sub = w - toff[i];
-        c.q0 = qoff[i] + sub * BM;
+        const int base = qoff[i] + (p.tile_mode == 2 ? ((qoff[i + 1] - qoff[i]) / kVbFull) * kVbFull : 0);
+        c.q0 = base + sub * BM;
         c.q_end = min(qoff[i + 1], c.q0 + BM);
         c.qidx = p.q_row_idx ? p.q_row_idx + (size_t)c.hq * p.Sq : nullptr;
         c.kidx = p.kv_row_idx ? p.kv_row_idx + (size_t)c.hkv * p.Skv : nullptr;
@@ -426,15 +429,18 @@ static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)si
 __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __restrict__ q_sizes,
                                                             const int32_t* __restrict__ k_sizes, int32_t* __restrict__ q_off,
                                                             int32_t* __restrict__ k_off, int32_t* __restrict__ tile_off,
-                                                            int QB, int KB, int BM) {
+                                                            int32_t* __restrict__ tile_off2, int QB, int KB, int BM) {
     __shared__ int32_t wtot[4];
     const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // div > 0: ceil(v / div); div == -1: number of full kVbFull-row tiles; div == -2: 128-row tiles of the remainder
     auto scan = [&](const int32_t* in, int32_t* out, int n, int div) {
         int carry = 0;
         for (int i0 = 0; i0 < n; i0 += 256) {
             const int i = i0 + tid;
             int v = i < n ? in[i] : 0;
             if (div > 0) v = (v + div - 1) / div;
+            else if (div == -1) v = v / kVbFull;
+            else if (div == -2) v = (v % kVbFull + 127) / 128;
             int incl = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -454,7 +460,12 @@ __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __res
     };
     scan(q_sizes + (size_t)h * QB, q_off + (size_t)h * (QB + 1), QB, 0);
     scan(k_sizes + (size_t)h * KB, k_off + (size_t)h * (KB + 1), KB, 0);
-    scan(q_sizes + (size_t)h * QB, tile_off + (size_t)h * (QB + 1), QB, BM);
+    if (BM > 0) {
+        scan(q_sizes + (size_t)h * QB, tile_off + (size_t)h * (QB + 1), QB, BM);
+    } else {  // mixed tiling
+        scan(q_sizes + (size_t)h * QB, tile_off + (size_t)h * (QB + 1), QB, -1);
+        scan(q_sizes + (size_t)h * QB, tile_off2 + (size_t)h * (QB + 1), QB, -2);
+    }
 }
 
 thread_local int g_last_hip_error = 0;
@@ -640,30 +651,47 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
 extern "C" size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq) {
     (void)Hq, (void)Sq;
     if (Hkv <= 0 || QB <= 0 || KB <= 0) return 0;
-    return (size_t)Hkv * (2 * (size_t)(QB + 1) + (size_t)(KB + 1)) * sizeof(int32_t);
+    return (size_t)Hkv * (3 * (size_t)(QB + 1) + (size_t)(KB + 1)) * sizeof(int32_t);
 }
 
 namespace svg {
+// NW = 4 / 8: uniform tiling (128- / 256-row q tiles).  NW = 0: mixed tiling — the full 256-row tiles of every block-row run
+// on the 8-wave kernel, its remaining rows on 128-row tiles of the 4-wave kernel (two workgroups per CU).  k-means clusters are
+// ragged (Wan 720p bench: mean 252 rows, sigma 161): uniform 256-row tiles keep 68 % of the processed rows real, uniform
+// 128-row tiles 79 % but run the slower 4-wave schedule everywhere; mixed keeps 79 % with most rows on the 8-wave kernel.
 template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, hipStream_t st) {
-    using Pol = VarblockPolicy<T, D, NW>;
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
-    hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, QB, KB,
-                       Pol::BM);
-    typename Pol::Params p;
-    p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
-    p.Hq = Hq, p.Hkv = Hkv, p.group = Hq / Hkv, p.Sq = Sq, p.Skv = Skv, p.QB = QB, p.KB = KB;
-    p.max_tiles = Sq / Pol::BM + QB;
-    p.kb_cap = (KB + 63) / 64 * 64;
-    p.scale_log2 = sm_scale * 1.4426950408889634f;
-    p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = tile_off;
-    p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
-    return launch_attn(varblock_attn_kernel<T, D, NW>, p, dim3(p.max_tiles, Hq), NW * 64,
-                       attn_lds_bytes<D, NW>() + vb_policy_lds(p.kb_cap), st);
+    int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
+    hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
+                       KB, NW * 32);
+    auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
+        constexpr int W = decltype(nw_c)::value;
+        using Pol = VarblockPolicy<T, D, W>;
+        typename Pol::Params p;
+        p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
+        p.Hq = Hq, p.Hkv = Hkv, p.group = Hq / Hkv, p.Sq = Sq, p.Skv = Skv, p.QB = QB, p.KB = KB;
+        p.max_tiles = max_tiles;
+        p.tile_mode = mode;
+        p.kb_cap = (KB + 63) / 64 * 64;
+        p.scale_log2 = sm_scale * 1.4426950408889634f;
+        p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
+        p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
+        return launch_attn(varblock_attn_kernel<T, D, W>, p, dim3(p.max_tiles, Hq), W * 64,
+                           attn_lds_bytes<D, W>() + vb_policy_lds(p.kb_cap), st);
+    };
+    if constexpr (NW == 0) {
+        int rc = SVG_OK;
+        if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
+        if (rc != SVG_OK) return rc;
+        return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
+    } else {
+        return launch(std::integral_constant<int, NW>{}, 0, tile_off, Sq / (NW * 32) + QB);
+    }
 }
 }  // namespace svg
 
@@ -677,23 +705,27 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (KB > kVbMaxKB) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const bool w8 = (variant == 1);  // variant 0: 4 waves (128-row q tiles, less padding on ragged blocks); 1: 8 waves
-#define SVG_VB_DISPATCH(T)                                                                                              \
-    if (D == 128)                                                                                                       \
-        return w8 ? run_varblock<T, 128, 8>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, \
-                                            q_row_idx, kv_row_idx, workspace, st)                                       \
-                  : run_varblock<T, 128, 4>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, \
-                                            q_row_idx, kv_row_idx, workspace, st);                                      \
-    if (D == 64)                                                                                                        \
-        return w8 ? run_varblock<T, 64, 8>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB,  \
-                                           q_row_idx, kv_row_idx, workspace, st)                                        \
-                  : run_varblock<T, 64, 4>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB,  \
-                                           q_row_idx, kv_row_idx, workspace, st);
+    // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
+#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, st
+#define SVG_VB_DISPATCH(T)                                                                       \
+    if (D == 128) {                                                                              \
+        if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
+        return variant == 1 ? run_varblock<T, 128, 8>(SVG_VB_ARGS) : run_varblock<T, 128, 4>(SVG_VB_ARGS); \
+    }                                                                                            \
+    if (D == 64) {                                                                               \
+        if (variant == 2) return run_varblock<T, 64, 0>(SVG_VB_ARGS);                            \
+        return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
+    }
+    if (variant < -1 || variant > 2) return SVG_ERR_BAD_ARG;
+    // -1 (auto): 256-row q tiles once the average block-row is large enough to fill them (Wan 720p, 252-row clusters:
+    // 45.5 ms with 8 waves, 47.7 ms with 4, 46.9 ms mixed), 128-row tiles for small block-rows
+    if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 1 : 0;
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {
         SVG_VB_DISPATCH(_Float16)
     }
+#undef SVG_VB_ARGS
 #undef SVG_VB_DISPATCH
     return SVG_ERR_UNSUPPORTED;
 }

@@ -245,7 +245,7 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
 
 def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
                        k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
-                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = 0) -> torch.Tensor:
+                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1) -> torch.Tensor:
     """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB]."""
     lib = load()
     _dev(q, k, v, block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
