@@ -205,6 +205,40 @@ int svg_identify_dynamic_map(const void* qc, const void* kc, const int32_t* k_si
 int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out, int32_t BH,
                     int32_t QB, int32_t KB, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pre-attention prologue: in-place QK normalisation over head_dim and rotary embedding.
+ * ref: the reference's only native extension, svg/kernels/csrc/ops.h:19-260, bound as `_kernels` in
+ *      svg/kernels/csrc/ops.cu and called from svg/models/hyvideo/attention.py:162-188, wan/attention.py:45-48,
+ *      cog/attention.py:23-34.  Tensors are contiguous [bsz, H, S, D] (norm-only entry points: [m, n] rows), D (n) in
+ *      {32, 64, 128, 256}, bf16 or fp16; weights / biases have the tensor dtype; cos / sin tables are fp32.
+ * Semantics (pinned by the torch references of the reference's tests, svg/kernels/test/test_*.py):
+ *   rms_norm:   y = w * T(x * rsqrt(mean(x^2) + eps))    fp32 statistics, rounded to T before AND after the weight
+ *   layer_norm: y = T((x - mean) * rsqrt(var + 1e-5) * w + b)     fp32, biased variance
+ *   rope cos/sin ("interleaved pairs"): out = T(x * cos + rotate(x) * sin) in fp32, rotate(x)[2i] = -x[2i+1],
+ *               rotate(x)[2i+1] = x[2i]; cos, sin: [S - len_text_prompt, D]
+ *   rope complex: (x[2i] + i x[2i+1]) * (real + i imag) in fp64; real, imag: [S - len_text_prompt, D / 2]
+ *   the first (`cossin`, `complex`) or the last (`txtlast`) len_text_prompt positions are left untouched.
+ * ---------------------------------------------------------------------------------------------- */
+int svg_rms_norm_forward(void* x, const void* weight, int64_t m, int32_t n, int32_t dtype, float eps, void* stream);
+int svg_layer_norm_forward(void* x, const void* weight, const void* bias, int64_t m, int32_t n, int32_t dtype,
+                           void* stream);
+int svg_apply_qk_rope_inplace_cossin(void* q, void* k, const float* cos_cache, const float* sin_cache, int32_t bsz,
+                                     int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t len_text_prompt,
+                                     void* stream);
+int svg_apply_qk_rope_inplace_cossin_txtlast(void* q, void* k, const float* cos_cache, const float* sin_cache,
+                                             int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                             int32_t len_text_prompt, void* stream);
+int svg_apply_qk_rope_inplace_cossin_complex(void* q, void* k, const float* freqs_real, const float* freqs_imag,
+                                             int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                             int32_t len_text_prompt, void* stream);
+/* Fused form: normalisation (norm_kind 0 none / 1 rms / 2 layer) followed by rotary embedding (rope_kind 0 none / 1 cos-sin /
+ * 2 complex) of positions [rope_lo, rope_hi) with table row (position - rope_lo), ONE pass over q and k (either may be NULL).
+ * Bit-identical to the corresponding sequence of the entry points above (the intermediate rounding is kept). */
+int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                     int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias,
+                     float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo,
+                     int32_t rope_hi, void* stream);
+
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
  * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in

@@ -401,3 +401,58 @@ def sample_mse(q, k, v, sampled_rows, masks):
 def sample_mse_fp32(q, k, v, sampled_rows, masks):
     """Same quantity in fp32 throughout (what the HIP profiler computes with emulate_bf16 = 0)."""
     return sample_mse(q.float(), k.float(), v.float(), sampled_rows, masks)
+
+
+# =====================================================================================================================
+# Pre-attention prologue (SURVEY.md §8 f1): QK normalisation + rotary embedding.
+# The reference's CUDA sources (svg/kernels/csrc/include/{norm,rope}/*.cuh) are not part of the checkout; the semantics are
+# the torch references its own tests compare the kernels with.  Pinned: tests/golden/prologue_golden.npz is produced by
+# executing those reference functions themselves (tests/golden/make_golden_prologue.py).
+# =====================================================================================================================
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """ref: replica_host_rms_norm, svg/kernels/test/test_rms_norm.py:31-36 (== diffusers RMSNorm.forward): fp32 variance,
+    the normalised value is rounded to the input dtype before it is multiplied by the weight."""
+    dt = x.dtype
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return weight * xf.to(dt)
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """ref: ref_host_layer_norm, svg/kernels/test/test_layer_norm.py:24-29 — fp32 statistics, one rounding at the end
+    (written out instead of F.layer_norm so that the rounding points are explicit)."""
+    xf = x.to(torch.float32)
+    mean = xf.mean(-1, keepdim=True)
+    var = (xf - mean).pow(2).mean(-1, keepdim=True)
+    y = (xf - mean) * torch.rsqrt(var + eps) * weight.to(torch.float32) + bias.to(torch.float32)
+    return y.to(x.dtype)
+
+
+def rope_cossin(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """ref: ref_host_apply_rope, svg/kernels/test/test_apply_rope.py:24-37 (diffusers apply_rotary_emb, use_real_unbind_dim=-1)"""
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
+
+
+def rope_complex(x: torch.Tensor, freqs_real: torch.Tensor, freqs_imag: torch.Tensor) -> torch.Tensor:
+    """ref: ref_host_apply_rope_complex, svg/kernels/test/test_apply_rope_complex.py:25-36 — complex128 x complex64"""
+    freqs = torch.complex(freqs_real, freqs_imag)
+    xc = torch.view_as_complex(x.to(torch.float64).unflatten(3, (-1, 2)))
+    return torch.view_as_real(xc * freqs.unsqueeze(0).unsqueeze(0)).flatten(3, 4).type_as(x)
+
+
+def apply_qk_rope(q, k, a, b, len_text_prompt: int, kind: str):
+    """kind: 'cossin' (first len_text_prompt positions skipped, ops.h:80-136), 'txtlast' (last ones skipped, :138-196),
+    'complex' (first ones skipped, fp64 complex multiply, :198-260).  Returns new tensors."""
+    S = q.shape[2]
+    L = int(len_text_prompt)
+    lo, hi = (0, S - L) if kind == "txtlast" else (L, S)
+    out = []
+    for x in (q, k):
+        y = x.clone()
+        seg = x[:, :, lo:hi]
+        y[:, :, lo:hi] = rope_complex(seg, a, b) if kind == "complex" else rope_cossin(seg, a, b)
+        out.append(y)
+    return out

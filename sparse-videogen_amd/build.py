@@ -40,6 +40,11 @@ FLAGS = [
 ]
 
 
+# Files whose arithmetic has to reproduce torch's rounding points bit for bit: IEEE semantics, no fma contraction, no
+# folding of double -> float -> half conversions.
+STRICT_FP = {"prologue.hip"}
+
+
 def _newest_header() -> float:
     hs = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
     return max(h.stat().st_mtime for h in hs)
@@ -50,7 +55,10 @@ def _compile(src: Path, force: bool, asm: bool) -> tuple[Path, str]:
     stamp = max(src.stat().st_mtime, _newest_header())
     if not force and obj.exists() and obj.stat().st_mtime >= stamp:
         return obj, ""
-    cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+    flags = list(FLAGS)
+    if src.name in STRICT_FP:
+        flags = [f for f in flags if f not in ("-ffast-math", "-fno-finite-math-only")] + ["-fno-fast-math", "-ffp-contract=off"]
+    cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
     if asm:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(OBJ))

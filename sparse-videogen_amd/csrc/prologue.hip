@@ -1,0 +1,238 @@
+// Pre-attention prologue for gfx950: in-place QK RMSNorm / LayerNorm over head_dim and rotary embedding (three variants),
+// optionally fused into ONE pass over Q and K.  HBM-bound: every element of Q and K is read once and written once
+// (4 * D bytes per token-head at bf16); the cos / sin tables are read once per token position and reused for all heads,
+// both tensors and the whole batch.
+// ref: svg/kernels/csrc/ops.h:19-78 (layer_norm_forward, rms_norm_forward), :80-260 (apply_qk_rope_inplace_cossin,
+//      _txtlast, _complex); semantics = the torch references of the reference's own tests
+//      (svg/kernels/test/test_rms_norm.py:27-36, test_layer_norm.py:24-29, test_apply_rope.py:24-37,
+//      test_apply_rope_txtlast.py:24-37, test_apply_rope_complex.py:25-36).  The CUDA sources behind ops.h
+//      (include/norm/*.cuh, include/rope/*.cuh) are not part of the reference checkout.
+#include "svg_common.h"
+
+#pragma clang fp contract(off)  // the torch references round every product before the add; no fma contraction here
+
+namespace svg {
+
+enum : int { kNormNone = 0, kNormRms = 1, kNormLayer = 2 };
+enum : int { kRopeNone = 0, kRopeCosSin = 1, kRopeComplex = 2 };
+
+struct PrologueParams {
+    void* q;
+    void* k;
+    int Hq, Hkv, S;
+    int norm, rope;
+    const void* qw;   // [D] norm weight for q (dtype of q), may be null (= ones)
+    const void* qb;   // [D] LayerNorm bias for q, may be null (= zeros)
+    const void* kw;
+    const void* kb;
+    float eps;
+    const float* cs;  // cos [rope_hi - rope_lo, D]   (complex: real part [.., D/2])
+    const float* sn;  // sin                           (complex: imaginary part)
+    int rope_lo, rope_hi;  // positions [rope_lo, rope_hi) are rotated with table row (pos - rope_lo)
+};
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {  // sum over the LPR consecutive lanes that hold one row
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One lane = 8 consecutive channels of one (batch, head, position) row; a wave covers 64 / (D / 8) consecutive positions;
+// the workgroup (4 waves) walks over all heads of Q and then of K for its positions, kUnroll rows in flight per lane.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    constexpr int LPR = D / 8;
+    constexpr int RPW = 64 / LPR;
+    constexpr int kUnroll = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, c = lane - sub * LPR;
+    const int pos = (blockIdx.x * 4 + wave) * RPW + sub;
+    const int b = blockIdx.y;
+    const bool valid = pos < p.S;
+    const int spos = valid ? pos : 0;   // invalid lanes load row 0 and store nothing (the shuffles need every lane)
+
+    const bool rot = p.rope != kRopeNone && pos >= p.rope_lo && pos < p.rope_hi;
+    float cs[8], sn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 1.f, sn[j] = 0.f;
+    if (rot) {
+        const size_t r = (size_t)(pos - p.rope_lo);
+        if (p.rope == kRopeCosSin) {
+            const f32x4* pc = (const f32x4*)(p.cs + r * D + c * 8);
+            const f32x4* ps = (const f32x4*)(p.sn + r * D + c * 8);
+            const f32x4 c0 = pc[0], c1 = pc[1], s0 = ps[0], s1 = ps[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = c0[j], cs[4 + j] = c1[j], sn[j] = s0[j], sn[4 + j] = s1[j];
+        } else {  // complex: 4 (real, imag) pairs for this lane's 4 channel pairs
+            const f32x4 fr = *(const f32x4*)(p.cs + r * (D / 2) + c * 4);
+            const f32x4 fi = *(const f32x4*)(p.sn + r * (D / 2) + c * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = fr[j], sn[j] = fi[j];
+        }
+    }
+
+    auto run = [&](T* base, int H, const T* wgt, const T* bias) {
+        float w[8], bs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = 1.f, bs[j] = 0.f;
+        if (p.norm != kNormNone) {
+            if (wgt) {
+                const V8 wv = *(const V8*)(wgt + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = E::to_float(wv[j]);
+            }
+            if (bias) {
+                const V8 bv = *(const V8*)(bias + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bs[j] = E::to_float(bv[j]);
+            }
+        }
+        T* row0 = base + (((size_t)b * H) * p.S + spos) * D + c * 8;
+        const size_t hstride = (size_t)p.S * D;
+        for (int h0 = 0; h0 < H; h0 += kUnroll) {
+            V8 xin[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)   // (heads past H re-read the last head; nothing is stored for them)
+                xin[u] = *(const V8*)(row0 + (size_t)min(h0 + u, H - 1) * hstride);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = E::to_float(xin[u][j]);
+                if (p.norm == kNormRms) {
+                    // diffusers RMSNorm / the reference's "replica": fp32 variance, normalised value rounded to the tensor
+                    // dtype, THEN multiplied by the weight (rounded again)
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+                    ss = group_sum<LPR>(ss);
+                    const float inv = 1.0f / sqrtf(ss / (float)D + p.eps);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float n = E::to_float(E::from_float(x[j] * inv));
+                        x[j] = E::to_float(E::from_float(w[j] * n));
+                    }
+                } else if (p.norm == kNormLayer) {
+                    // torch layer_norm: fp32 statistics (biased variance), one rounding at the end
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s += x[j];
+                    const float mean = group_sum<LPR>(s) / (float)D;
+                    float vs = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vs += (x[j] - mean) * (x[j] - mean);
+                    const float inv = 1.0f / sqrtf(group_sum<LPR>(vs) / (float)D + p.eps);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = E::to_float(E::from_float((x[j] - mean) * inv * w[j] + bs[j]));
+                }
+                V8 out;
+                if (rot && p.rope == kRopeCosSin) {
+                    // out = x * cos + rotate(x) * sin in fp32, rotate(x)[2i] = -x[2i+1], rotate(x)[2i+1] = x[2i]
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = x[2 * i], bq = x[2 * i + 1];
+                        out[2 * i] = E::from_float(a * cs[2 * i] + (-bq) * sn[2 * i]);
+                        out[2 * i + 1] = E::from_float(bq * cs[2 * i + 1] + a * sn[2 * i + 1]);
+                    }
+                } else if (rot) {
+                    // (x[2i] + i x[2i+1]) * (fr + i fi) in fp64 (the reference multiplies complex128 by complex64)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double a = (double)x[2 * i], bq = (double)x[2 * i + 1];
+                        const double fr = (double)cs[i], fi = (double)sn[i];
+                        out[2 * i] = E::from_double(a * fr - bq * fi);
+                        out[2 * i + 1] = E::from_double(a * fi + bq * fr);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] = E::from_float(x[j]);
+                }
+                if (valid && h0 + u < H) *(V8*)(row0 + (size_t)(h0 + u) * hstride) = out;
+            }
+        }
+    };
+    if (p.q) run((T*)p.q, p.Hq, (const T*)p.qw, (const T*)p.qb);
+    if (p.k) run((T*)p.k, p.Hkv, (const T*)p.kw, (const T*)p.kb);
+}
+
+template <typename T>
+static int launch_prologue_t(const PrologueParams& p, int bsz, int D, hipStream_t st) {
+    auto go = [&](auto d_c) -> int {
+        constexpr int DD = decltype(d_c)::value;
+        constexpr int RPB = 4 * (64 / (DD / 8));
+        hipLaunchKernelGGL((qk_prologue_kernel<T, DD>), dim3((p.S + RPB - 1) / RPB, bsz), dim3(256), 0, st, p);
+        return launch_status();
+    };
+    switch (D) {
+        case 32: return go(std::integral_constant<int, 32>{});
+        case 64: return go(std::integral_constant<int, 64>{});
+        case 128: return go(std::integral_constant<int, 128>{});
+        case 256: return go(std::integral_constant<int, 256>{});
+        default: return SVG_ERR_UNSUPPORTED;
+    }
+}
+
+static int launch_prologue(const PrologueParams& p, int bsz, int D, int dtype, hipStream_t st) {
+    if (bsz <= 0 || p.S <= 0) return SVG_ERR_BAD_ARG;
+    if (bsz > 65535) return SVG_ERR_UNSUPPORTED;
+    if (dtype == SVG_DTYPE_BF16) return launch_prologue_t<__bf16>(p, bsz, D, st);
+    if (dtype == SVG_DTYPE_F16) return launch_prologue_t<_Float16>(p, bsz, D, st);
+    return SVG_ERR_UNSUPPORTED;
+}
+
+}  // namespace svg
+
+using namespace svg;
+
+extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight,
+                                const void* k_bias, float eps, int32_t rope_kind, const float* cos_or_real,
+                                const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, void* stream) {
+    if ((!q && !k) || (q && Hq <= 0) || (k && Hkv <= 0)) return SVG_ERR_BAD_ARG;
+    if (norm_kind < 0 || norm_kind > 2 || rope_kind < 0 || rope_kind > 2) return SVG_ERR_BAD_ARG;
+    if (rope_kind != kRopeNone) {
+        if (!cos_or_real || !sin_or_imag || rope_lo < 0 || rope_hi > S || rope_lo > rope_hi) return SVG_ERR_BAD_ARG;
+    }
+    PrologueParams p;
+    p.q = q, p.k = k, p.Hq = Hq, p.Hkv = Hkv, p.S = S, p.norm = norm_kind, p.rope = rope_kind;
+    p.qw = q_weight, p.qb = q_bias, p.kw = k_weight, p.kb = k_bias, p.eps = eps;
+    p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi;
+    return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);
+}
+
+// The five entry points of the reference extension (`_kernels`), same argument meaning.
+extern "C" int svg_rms_norm_forward(void* x, const void* weight, int64_t m, int32_t n, int32_t dtype, float eps, void* stream) {
+    if (!x || !weight || m <= 0 || m > 0x7fffffff) return SVG_ERR_BAD_ARG;
+    return svg_qk_norm_rope(x, nullptr, 1, 1, 0, (int32_t)m, n, dtype, kNormRms, weight, nullptr, nullptr, nullptr, eps, kRopeNone,
+                            nullptr, nullptr, 0, 0, stream);
+}
+extern "C" int svg_layer_norm_forward(void* x, const void* weight, const void* bias, int64_t m, int32_t n, int32_t dtype,
+                                      void* stream) {
+    if (!x || !weight || !bias || m <= 0 || m > 0x7fffffff) return SVG_ERR_BAD_ARG;
+    return svg_qk_norm_rope(x, nullptr, 1, 1, 0, (int32_t)m, n, dtype, kNormLayer, weight, bias, nullptr, nullptr, 1e-5f, kRopeNone,
+                            nullptr, nullptr, 0, 0, stream);
+}
+extern "C" int svg_apply_qk_rope_inplace_cossin(void* q, void* k, const float* cos_cache, const float* sin_cache, int32_t bsz,
+                                                int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                                int32_t len_text_prompt, void* stream) {
+    if (!q || !k || len_text_prompt < 0 || len_text_prompt >= S) return SVG_ERR_BAD_ARG;
+    return svg_qk_norm_rope(q, k, bsz, Hq, Hkv, S, D, dtype, kNormNone, nullptr, nullptr, nullptr, nullptr, 0.f, kRopeCosSin,
+                            cos_cache, sin_cache, len_text_prompt, S, stream);
+}
+extern "C" int svg_apply_qk_rope_inplace_cossin_txtlast(void* q, void* k, const float* cos_cache, const float* sin_cache,
+                                                        int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D,
+                                                        int32_t dtype, int32_t len_text_prompt, void* stream) {
+    if (!q || !k || len_text_prompt < 0 || len_text_prompt >= S) return SVG_ERR_BAD_ARG;
+    return svg_qk_norm_rope(q, k, bsz, Hq, Hkv, S, D, dtype, kNormNone, nullptr, nullptr, nullptr, nullptr, 0.f, kRopeCosSin,
+                            cos_cache, sin_cache, 0, S - len_text_prompt, stream);
+}
+extern "C" int svg_apply_qk_rope_inplace_cossin_complex(void* q, void* k, const float* freqs_real, const float* freqs_imag,
+                                                        int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D,
+                                                        int32_t dtype, int32_t len_text_prompt, void* stream) {
+    if (!q || !k || len_text_prompt < 0 || len_text_prompt >= S) return SVG_ERR_BAD_ARG;
+    return svg_qk_norm_rope(q, k, bsz, Hq, Hkv, S, D, dtype, kNormNone, nullptr, nullptr, nullptr, nullptr, 0.f, kRopeComplex,
+                            freqs_real, freqs_imag, len_text_prompt, S, stream);
+}

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/svg_attn.h"
 
 namespace svg {
@@ -42,6 +44,7 @@ struct Elt<__bf16> {
     }
     static __device__ __forceinline__ float to_float(__bf16 x) { return (float)x; }
     static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
+    static __device__ __forceinline__ __bf16 from_double(double x) { return (__bf16)(float)x; }  // torch: double -> float -> bf16
 };
 
 template <>
@@ -53,6 +56,7 @@ struct Elt<_Float16> {
     }
     static __device__ __forceinline__ float to_float(_Float16 x) { return (float)x; }
     static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+    static __device__ __forceinline__ _Float16 from_double(double x) { return (_Float16)(float)x; }  // torch: double -> float -> half
 };
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -81,6 +81,13 @@ SIGNATURES = {
     "svg_last_hip_error": (C.c_int, []),
     "svg_build_info": (C.c_char_p, []),
     "svg_debug_pp_trace": (C.c_int, [_VP]),
+    "svg_rms_norm_forward": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, C.c_float, _VP]),
+    "svg_layer_norm_forward": (C.c_int, [_VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
+    "svg_apply_qk_rope_inplace_cossin": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_apply_qk_rope_inplace_cossin_txtlast": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_qk_norm_rope": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
+                                   _VP, _I32, _I32, _VP]),
     "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_inverse_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
@@ -352,3 +359,75 @@ def debug_pp_trace():
     v = list(buf)
     return {"waves": [v[8 * w: 8 * w + 8] for w in range(8)], "sv": [v[72 + 4 * w: 72 + 4 * w + 3] for w in range(8)],
             "tiles": v[64], "loop_ticks": v[65]}
+
+
+# ---- pre-attention prologue (svg/kernels/csrc/ops.h of the reference) ----
+def _qk4(q, k):
+    assert q.dim() == 4 and k.dim() == 4 and q.is_contiguous() and k.is_contiguous(), "q, k: contiguous [bsz, H, S, D]"
+    assert q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2] and q.shape[3] == k.shape[3] and q.dtype == k.dtype
+    return q.shape[0], q.shape[1], k.shape[1], q.shape[2], q.shape[3]
+
+
+def rms_norm_forward(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-5) -> None:
+    """in place; x [m, n] (ref: ops.h:52-78)"""
+    lib = load()
+    _dev(x, weight)
+    assert x.dim() == 2 and x.is_contiguous() and weight.shape == (x.shape[1],) and weight.dtype == x.dtype
+    _check(lib.svg_rms_norm_forward(x.data_ptr(), weight.data_ptr(), x.shape[0], x.shape[1], _dtype_code(x), float(eps),
+                                    _stream()), "svg_rms_norm_forward")
+
+
+def layer_norm_forward(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> None:
+    """in place; x [m, n], eps = 1e-5 (ref: ops.h:19-44)"""
+    lib = load()
+    _dev(x, weight, bias)
+    assert x.dim() == 2 and x.is_contiguous() and weight.shape == (x.shape[1],) and bias.shape == weight.shape
+    assert weight.dtype == x.dtype and bias.dtype == x.dtype
+    _check(lib.svg_layer_norm_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), x.shape[0], x.shape[1],
+                                      _dtype_code(x), _stream()), "svg_layer_norm_forward")
+
+
+def _rope(fn_name: str, q, k, a, b, len_text_prompt: int, half: bool) -> None:
+    lib = load()
+    _dev(q, k, a, b)
+    bsz, Hq, Hkv, S, D = _qk4(q, k)
+    valid = S - int(len_text_prompt)
+    assert valid > 0, "len_text_prompt must be smaller than the sequence"
+    cols = D // 2 if half else D
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous()
+    assert a.shape == (valid, cols) and b.shape == (valid, cols), f"rope tables must be [{valid}, {cols}]"
+    _check(getattr(lib, fn_name)(q.data_ptr(), k.data_ptr(), a.data_ptr(), b.data_ptr(), bsz, Hq, Hkv, S, D, _dtype_code(q),
+                                 int(len_text_prompt), _stream()), fn_name)
+
+
+def apply_qk_rope_inplace_cossin(q, k, cos, sin, len_text_prompt: int) -> None:
+    """ref: ops.h:80-136 — the FIRST len_text_prompt positions are skipped"""
+    _rope("svg_apply_qk_rope_inplace_cossin", q, k, cos, sin, len_text_prompt, False)
+
+
+def apply_qk_rope_inplace_cossin_txtlast(q, k, cos, sin, len_text_prompt: int) -> None:
+    """ref: ops.h:138-196 — the LAST len_text_prompt positions are skipped"""
+    _rope("svg_apply_qk_rope_inplace_cossin_txtlast", q, k, cos, sin, len_text_prompt, False)
+
+
+def apply_qk_rope_inplace_cossin_complex(q, k, freqs_real, freqs_imag, len_text_prompt: int) -> None:
+    """ref: ops.h:198-260 — complex multiply in fp64, tables [S - len_text_prompt, D / 2]"""
+    _rope("svg_apply_qk_rope_inplace_cossin_complex", q, k, freqs_real, freqs_imag, len_text_prompt, True)
+
+
+def qk_norm_rope(q, k, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None, k_bias=None, eps: float = 1e-5,
+                 rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0, rope_hi: Optional[int] = None) -> None:
+    """Fused in-place normalisation + rotary embedding of q and k in one pass (svg_qk_norm_rope)."""
+    lib = load()
+    _dev(q, k, q_weight, q_bias, k_weight, k_bias, cos, sin)
+    bsz, Hq, Hkv, S, D = _qk4(q, k)
+    rope_hi = S if rope_hi is None else rope_hi
+    if rope_kind:
+        cols = D // 2 if rope_kind == 2 else D
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+        assert cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
+    for w in (q_weight, q_bias, k_weight, k_bias):
+        assert w is None or (w.dtype == q.dtype and w.shape == (D,) and w.is_contiguous())
+    _check(lib.svg_qk_norm_rope(q.data_ptr(), k.data_ptr(), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
+                                _ptr(q_bias), _ptr(k_weight), _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin),
+                                int(rope_lo), int(rope_hi), _stream()), "svg_qk_norm_rope")

@@ -1,0 +1,178 @@
+"""GPU parity of the pre-attention prologue (svg_rms_norm_forward, svg_layer_norm_forward, svg_apply_qk_rope_inplace_*,
+svg_qk_norm_rope) through the C ABI.  Parameter grids follow the reference's tests (svg/kernels/test/test_rms_norm.py:38,
+test_layer_norm.py:32, test_apply_rope*.py:39); tolerances are the reference's (bf16 rtol 3e-2 / atol 2e-2, fp16 5e-3) —
+and on top of that bit-exactness against the oracle wherever the arithmetic has no reduction."""
+from itertools import product
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(str(Path(__file__).parent / "golden" / "prologue_golden.npz"))
+TOL = {torch.float16: (5e-3, 5e-3), torch.bfloat16: (3e-2, 2e-2)}
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "sparse-videogen_amd"))
+    from svg import _native
+    _native.load()
+    return _native
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(a, b):
+    rtol, atol = TOL[a.dtype]
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=rtol, atol=atol)
+
+
+def ulp_equal(a, b, max_frac, max_ulp=1, abs_ok=0.0):
+    """a, b 16-bit float tensors: identical except for at most max_frac of the elements, which differ by <= max_ulp ulps
+    (or by <= abs_ok in absolute terms: results of a cancellation, where an ulp is meaningless)"""
+    a, b = a.cpu(), b.cpu()
+    ne = a != b
+    ia, ib = a.view(torch.int16).int(), b.view(torch.int16).int()
+    bad = ne & ((ia - ib).abs() > max_ulp) & ((a.float() - b.float()).abs() > abs_ok)
+    assert not bad.any(), f"{int(bad.sum())} elements more than {max_ulp} ulp apart, e.g. {a[bad][:4]} vs {b[bad][:4]}"
+    assert ne.float().mean().item() <= max_frac, f"{ne.float().mean().item():.2e} of the elements differ"
+
+
+@pytest.mark.parametrize("m,n", list(product([1, 7, 31, 55, 95, 128, 512], [32, 64, 128, 256])))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rms_norm(nat, m, n, dtype):
+    torch.manual_seed(m * 1000 + n)
+    x, w = torch.randn(m, n).to(dtype), torch.randn(n).to(dtype)
+    got = dev(x)
+    nat.rms_norm_forward(got, dev(w), 1e-5)
+    # the reduction order (and rsqrt's last bit) differs: the normalised value can land on the other side of a rounding
+    # boundary (1 ulp), which the weight multiply turns into at most 2 ulps of the result
+    ulp_equal(got, O.rms_norm(x, w), 2e-3, 2)
+    close(got, torch.nn.functional.rms_norm(x.float(), [n], w.float(), 1e-5).to(dtype))   # the reference's check
+
+
+@pytest.mark.parametrize("m,n", list(product([1, 7, 31, 55, 95, 128, 512], [32, 64, 128, 256])))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layer_norm(nat, m, n, dtype):
+    torch.manual_seed(m * 1000 + n + 1)
+    x, w, b = torch.randn(m, n).to(dtype), torch.randn(n).to(dtype), torch.randn(n).to(dtype)
+    got = dev(x)
+    nat.layer_norm_forward(got, dev(w), dev(b))
+    ulp_equal(got, O.layer_norm(x, w, b), 5e-3, 2, 1e-4)   # (x - mean) * inv * w + b can cancel
+    close(got, torch.nn.functional.layer_norm(x.float(), [n], w.float(), b.float(), 1e-5).to(dtype))
+
+
+ROPE_GRID = [p for p in product([1, 3], [16], [151, 1037], [64, 128, 256], [15, 77])] + [(1, 32, 6778, 128, 35), (5, 16, 151, 64, 35)]
+
+
+@pytest.mark.parametrize("bsz,H,S,D,L", ROPE_GRID)
+@pytest.mark.parametrize("kind", ["cossin", "txtlast", "complex"])
+def test_apply_rope(nat, kind, bsz, H, S, D, L):
+    torch.manual_seed(S + D + L)
+    dtype = torch.float16 if kind == "complex" else torch.bfloat16      # as in the reference's tests
+    q, k = torch.randn(bsz, H, S, D).to(dtype), torch.randn(bsz, H, S, D).to(dtype)
+    cols = D // 2 if kind == "complex" else D
+    a, b = torch.randn(S - L, cols), torch.randn(S - L, cols)
+    gq, gk = dev(q), dev(k)
+    fn = {"cossin": nat.apply_qk_rope_inplace_cossin, "txtlast": nat.apply_qk_rope_inplace_cossin_txtlast,
+          "complex": nat.apply_qk_rope_inplace_cossin_complex}[kind]
+    fn(gq, gk, dev(a), dev(b), L)
+    rq, rk = O.apply_qk_rope(q, k, a, b, L, kind)
+    assert torch.equal(gq.cpu(), rq) and torch.equal(gk.cpu(), rk), "bit-exact (no reduction in this arithmetic)"
+
+
+def test_rope_gqa_and_bf16_complex(nat):
+    torch.manual_seed(5)
+    bsz, Hq, Hkv, S, D, L = 2, 8, 2, 300, 128, 20
+    q, k = torch.randn(bsz, Hq, S, D).to(torch.bfloat16), torch.randn(bsz, Hkv, S, D).to(torch.bfloat16)
+    fr, fi = torch.randn(S - L, D // 2), torch.randn(S - L, D // 2)
+    gq, gk = dev(q), dev(k)
+    nat.apply_qk_rope_inplace_cossin_complex(gq, gk, dev(fr), dev(fi), L)
+    assert torch.equal(gq.cpu(), O.apply_qk_rope(q, q, fr, fi, L, "complex")[0])
+    assert torch.equal(gk.cpu(), O.apply_qk_rope(k, k, fr, fi, L, "complex")[0])
+
+
+def test_goldens_from_the_reference(nat):
+    """Vectors produced by the reference's own torch reference functions (tests/golden/make_golden_prologue.py)."""
+    def t16(name, dtype=torch.bfloat16):
+        return torch.from_numpy(GOLD[name].copy()).view(dtype)
+    for tag in ["7x32", "31x64", "95x128", "128x256"]:
+        x, w, b = t16(f"norm_x_{tag}"), t16(f"norm_w_{tag}"), t16(f"norm_b_{tag}")
+        g = dev(x); nat.rms_norm_forward(g, dev(w), 1e-5)
+        ulp_equal(g, t16(f"rms_replica_{tag}"), 2e-3, 2)
+        close(g, t16(f"rms_ref_{tag}"))
+        g = dev(x); nat.layer_norm_forward(g, dev(w), dev(b))
+        ulp_equal(g, t16(f"ln_ref_{tag}"), 5e-3, 2, 1e-4)
+    for tag in ["1_2_151_64_15", "2_1_151_128_35", "1_1_151_256_77"]:
+        L = int(tag.split("_")[-1])
+        q, cos, sin = t16(f"rope_q_{tag}"), torch.from_numpy(GOLD[f"rope_cos_{tag}"]), torch.from_numpy(GOLD[f"rope_sin_{tag}"])
+        a, b = dev(q), dev(q)
+        nat.apply_qk_rope_inplace_cossin(a, b, dev(cos), dev(sin), L)
+        assert torch.equal(a.cpu()[:, :, L:], t16(f"rope_first_{tag}")) and torch.equal(a.cpu()[:, :, :L], q[:, :, :L])
+        a, b = dev(q), dev(q)
+        nat.apply_qk_rope_inplace_cossin_txtlast(a, b, dev(cos), dev(sin), L)
+        assert torch.equal(a.cpu()[:, :, :-L], t16(f"rope_last_{tag}")) and torch.equal(a.cpu()[:, :, -L:], q[:, :, -L:])
+        qh = t16(f"cplx_q_{tag}", torch.float16)
+        fr, fi = torch.from_numpy(GOLD[f"cplx_fr_{tag}"]), torch.from_numpy(GOLD[f"cplx_fi_{tag}"])
+        a, b = dev(qh), dev(qh)
+        nat.apply_qk_rope_inplace_cossin_complex(a, b, dev(fr), dev(fi), L)
+        assert torch.equal(a.cpu()[:, :, L:], t16(f"cplx_out_{tag}", torch.float16))
+
+
+@pytest.mark.parametrize("norm,rope", [(1, 1), (2, 1), (1, 2), (1, 0), (0, 1)])
+def test_fused_equals_sequence(nat, norm, rope):
+    """svg_qk_norm_rope == norm entry point followed by rope entry point, bit for bit (Hunyuan: rms + txtlast; Cog: layer +
+    text-first; Wan: rms over the full hidden size is NOT this op, only its rope is)."""
+    torch.manual_seed(11)
+    bsz, Hq, Hkv, S, D, L = 2, 6, 3, 777, 128, 64
+    dt = torch.bfloat16
+    q, k = torch.randn(bsz, Hq, S, D).to(dt), torch.randn(bsz, Hkv, S, D).to(dt)
+    qw, qb, kw, kb = (torch.randn(D).to(dt) for _ in range(4))
+    cols = D // 2 if rope == 2 else D
+    cs, sn = torch.randn(S - L, cols), torch.randn(S - L, cols)
+    fq, fk = dev(q), dev(k)
+    nat.qk_norm_rope(fq, fk, norm, dev(qw), dev(qb) if norm == 2 else None, dev(kw), dev(kb) if norm == 2 else None, 1e-6,
+                     rope, dev(cs) if rope else None, dev(sn) if rope else None, 0, S - L)
+    sq, sk = dev(q), dev(k)
+    if norm == 1:
+        nat.rms_norm_forward(sq.view(-1, D), dev(qw), 1e-6); nat.rms_norm_forward(sk.view(-1, D), dev(kw), 1e-6)
+    elif norm == 2:
+        # the stand-alone layer-norm entry point fixes eps = 1e-5 like the reference; run the fused op without rope instead
+        nat.qk_norm_rope(sq, sk, 2, dev(qw), dev(qb), dev(kw), dev(kb), 1e-6)
+    if rope == 1:
+        nat.apply_qk_rope_inplace_cossin_txtlast(sq, sk, dev(cs), dev(sn), L)
+    elif rope == 2:
+        nat.qk_norm_rope(sq, sk, 0, rope_kind=2, cos=dev(cs), sin=dev(sn), rope_lo=0, rope_hi=S - L)
+    assert torch.equal(fq, sq) and torch.equal(fk, sk)
+
+
+def test_full_size_hunyuan_prologue(nat):
+    """HunyuanVideo 720p shape (H = 24, S = 119056, D = 128): fused rms-norm + text-last rope; spot rows against the oracle,
+    text rows un-rotated, and the fused pass equals the two separate passes."""
+    torch.manual_seed(3)
+    H, S, D, L = 24, 119056, 128, 256
+    dt = torch.bfloat16
+    q = torch.randn(1, H, S, D, device="cuda", dtype=dt)
+    k = torch.randn(1, H, S, D, device="cuda", dtype=dt)
+    qw, kw = torch.randn(D, device="cuda").to(dt), torch.randn(D, device="cuda").to(dt)
+    cos, sin = torch.randn(S - L, D, device="cuda"), torch.randn(S - L, D, device="cuda")
+    q0, k0 = q.clone(), k.clone()
+    nat.qk_norm_rope(q, k, 1, qw, None, kw, None, 1e-6, 1, cos, sin, 0, S - L)
+    a, b = q0.clone(), k0.clone()
+    nat.rms_norm_forward(a.view(-1, D), qw, 1e-6); nat.rms_norm_forward(b.view(-1, D), kw, 1e-6)
+    nat.apply_qk_rope_inplace_cossin_txtlast(a, b, cos, sin, L)
+    assert torch.equal(q, a) and torch.equal(k, b)
+    rows = torch.tensor([0, 1, 63, 64, 4097, 59999, S - L - 1, S - L, S - 1])
+    for x0, x1, w in ((q0, q, qw), (k0, k, kw)):
+        sub = x0[:, :, rows].cpu()
+        ref = O.rms_norm(sub, w.cpu(), 1e-6)
+        pos = rows < S - L
+        ref[:, :, pos] = O.rope_cossin(ref[:, :, pos], cos[rows[pos]].cpu(), sin[rows[pos]].cpu())
+        ulp_equal(x1[:, :, rows], ref, 2e-3, 2)
