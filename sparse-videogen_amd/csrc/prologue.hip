@@ -203,17 +203,27 @@ extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32
     return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);
 }
 
+// Rows of a flat [m, n] tensor are independent: view it as [H, S, n] with the largest H in {16, 8, 4, 2, 1} dividing m so that
+// every lane keeps several rows in flight (the kernel walks "heads" with kUnroll loads outstanding).
+static inline int rows_as_heads(int64_t m) {
+    for (int h = 16; h > 1; h >>= 1)
+        if (m % h == 0) return h;
+    return 1;
+}
+
 // The five entry points of the reference extension (`_kernels`), same argument meaning.
 extern "C" int svg_rms_norm_forward(void* x, const void* weight, int64_t m, int32_t n, int32_t dtype, float eps, void* stream) {
     if (!x || !weight || m <= 0 || m > 0x7fffffff) return SVG_ERR_BAD_ARG;
-    return svg_qk_norm_rope(x, nullptr, 1, 1, 0, (int32_t)m, n, dtype, kNormRms, weight, nullptr, nullptr, nullptr, eps, kRopeNone,
-                            nullptr, nullptr, 0, 0, stream);
+    const int h = rows_as_heads(m);
+    return svg_qk_norm_rope(x, nullptr, 1, h, 0, (int32_t)(m / h), n, dtype, kNormRms, weight, nullptr, nullptr, nullptr, eps,
+                            kRopeNone, nullptr, nullptr, 0, 0, stream);
 }
 extern "C" int svg_layer_norm_forward(void* x, const void* weight, const void* bias, int64_t m, int32_t n, int32_t dtype,
                                       void* stream) {
     if (!x || !weight || !bias || m <= 0 || m > 0x7fffffff) return SVG_ERR_BAD_ARG;
-    return svg_qk_norm_rope(x, nullptr, 1, 1, 0, (int32_t)m, n, dtype, kNormLayer, weight, bias, nullptr, nullptr, 1e-5f, kRopeNone,
-                            nullptr, nullptr, 0, 0, stream);
+    const int h = rows_as_heads(m);
+    return svg_qk_norm_rope(x, nullptr, 1, h, 0, (int32_t)(m / h), n, dtype, kNormLayer, weight, bias, nullptr, nullptr, 1e-5f,
+                            kRopeNone, nullptr, nullptr, 0, 0, stream);
 }
 extern "C" int svg_apply_qk_rope_inplace_cossin(void* q, void* k, const float* cos_cache, const float* sin_cache, int32_t bsz,
                                                 int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,

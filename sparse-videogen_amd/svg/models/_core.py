@@ -213,3 +213,74 @@ def dynamic_map_post_processing(dyn_map, qc_sz, kc_sz, q_sorted_indices, k_sorte
     q_sorted_indices = torch.cat([q_sorted_indices, tail], dim=1)
     k_sorted_indices = torch.cat([k_sorted_indices, tail], dim=1)
     return dyn_map, qc_sz, kc_sz, q_sorted_indices, k_sorted_indices
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pre-attention prologue on libsvgattn (the reference's `_kernels` fast path: hyvideo/attention.py:157-188,
+# wan/attention.py:42-48, cog/attention.py:19-34).  Each helper returns False when the HIP path does not apply (CPU tensors,
+# unsupported head_dim / dtype, a norm module it does not recognise) so that the caller runs the model's own torch modules —
+# exactly the reference's `except ImportError` branch.
+# ---------------------------------------------------------------------------------------------------------------------
+_FAST_DIMS = (32, 64, 128, 256)
+
+
+def _fast_ok(*ts) -> bool:
+    if not all(t.is_cuda for t in ts):
+        return False                      # CPU tensors: the model's own torch modules (the reference's CPU-capable path)
+    _native.load()                        # GPU tensors without the library: raise, never fall back silently
+    return all(t.is_cuda and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float16) and t.dim() == 4
+               and t.shape[-1] in _FAST_DIMS for t in ts)
+
+
+def _norm_desc(norm, D: int, dtype, device):
+    """(kind, weight, bias, eps) of an RMSNorm / LayerNorm over head_dim, or None if the module is something else."""
+    if norm is None:
+        return None
+    w = getattr(norm, "weight", None)
+    if w is not None and tuple(w.shape) != (D,):
+        return None
+    eps = getattr(norm, "eps", None)
+    if eps is None:
+        return None
+    b = getattr(norm, "bias", None)
+    is_layer = isinstance(norm, torch.nn.LayerNorm) or b is not None
+    cast = lambda t: None if t is None else t.detach().to(device=device, dtype=dtype).contiguous()  # noqa: E731
+    return (2 if is_layer else 1), cast(w), cast(b), float(eps)
+
+
+def qk_norm_inplace(norm_q, norm_k, query, key) -> bool:
+    """In-place QK normalisation over head_dim (ref fast path: `_kernels.rms_norm_forward` / `layer_norm_forward`)."""
+    if norm_q is None or norm_k is None or not _fast_ok(query, key):
+        return False
+    D = query.shape[-1]
+    dq, dk = _norm_desc(norm_q, D, query.dtype, query.device), _norm_desc(norm_k, D, key.dtype, key.device)
+    if dq is None or dk is None or dq[0] != dk[0] or dq[3] != dk[3]:
+        return False
+    _native.qk_norm_rope(query, key, dq[0], dq[1], dq[2], dk[1], dk[2], dq[3])
+    return True
+
+
+def _tables(a, b, rows: int, cols: int, device):
+    a = a.detach().to(device=device, dtype=torch.float32).reshape(-1, a.shape[-1]).contiguous()
+    b = b.detach().to(device=device, dtype=torch.float32).reshape(-1, b.shape[-1]).contiguous()
+    return (a, b) if a.shape == (rows, cols) and b.shape == (rows, cols) else None
+
+
+def qk_rope_inplace(query, key, cos, sin, rope_lo: int, rope_hi: int, complex_pairs: bool = False, norm_q=None,
+                    norm_k=None) -> bool:
+    """In-place rotary embedding of positions [rope_lo, rope_hi) — optionally fused with the QK normalisation (one pass over
+    q and k instead of three).  cos / sin: [rope_hi - rope_lo, D] fp32 (complex_pairs: real / imag [.., D / 2])."""
+    if not _fast_ok(query, key) or rope_hi <= rope_lo:
+        return False
+    D = query.shape[-1]
+    tb = _tables(cos, sin, rope_hi - rope_lo, D // 2 if complex_pairs else D, query.device)
+    if tb is None:
+        return False
+    kind, qw, qb, kw, kb, eps = 0, None, None, None, None, 0.0
+    if norm_q is not None or norm_k is not None:
+        dq, dk = _norm_desc(norm_q, D, query.dtype, query.device), _norm_desc(norm_k, D, key.dtype, key.device)
+        if dq is None or dk is None or dq[0] != dk[0] or dq[3] != dk[3]:
+            return False
+        kind, qw, qb, kw, kb, eps = dq[0], dq[1], dq[2], dk[1], dk[2], dq[3]
+    _native.qk_norm_rope(query, key, kind, qw, qb, kw, kb, eps, 2 if complex_pairs else 1, tb[0], tb[1], rope_lo, rope_hi)
+    return True

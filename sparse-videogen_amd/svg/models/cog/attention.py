@@ -13,7 +13,9 @@ from .utils import generate_temporal_head_mask_mod, profile_desc
 
 
 def qk_norm(attn, query, key):
-    """ref: cog/attention.py:40-45 (LayerNorm over head_dim)"""
+    """ref: cog/attention.py:40-45 (LayerNorm over head_dim); HIP fast path = `_kernels.layer_norm_forward` (:23-29)"""
+    if _core.qk_norm_inplace(getattr(attn, "norm_q", None), getattr(attn, "norm_k", None), query, key):
+        return query, key
     if getattr(attn, "norm_q", None) is not None:
         query = attn.norm_q(query)
     if getattr(attn, "norm_k", None) is not None:
@@ -24,6 +26,9 @@ def qk_norm(attn, query, key):
 def rotary_emb(image_rotary_emb, query, key, text_seq_length):
     """ref: cog/attention.py:47-50 — RoPE on the video tokens only (text first)"""
     if image_rotary_emb is not None:
+        cos, sin = image_rotary_emb   # HIP fast path = `_kernels.apply_qk_rope_inplace_cossin` (text first), :31-34
+        if _core.qk_rope_inplace(query, key, cos, sin, text_seq_length, query.shape[2]):
+            return query, key
         query[:, :, text_seq_length:] = apply_rotary_emb(query[:, :, text_seq_length:], image_rotary_emb)
         key[:, :, text_seq_length:] = apply_rotary_emb(key[:, :, text_seq_length:], image_rotary_emb)
     return query, key

@@ -29,6 +29,8 @@ def apply_rotary_emb(x: torch.Tensor, freqs_cis) -> torch.Tensor:
 
 
 def apply_qk_norm(norm_q, norm_k, query, key):
+    if _core.qk_norm_inplace(norm_q, norm_k, query, key):   # HIP, in place (ref: the `_kernels.rms_norm_forward` path :162-170)
+        return query, key
     if norm_q is not None:
         query = norm_q(query)
     if norm_k is not None:
@@ -38,18 +40,26 @@ def apply_qk_norm(norm_q, norm_k, query, key):
 
 def apply_qk_rope_single(query, key, image_rotary_emb, encoder_hidden_states):
     n_txt = encoder_hidden_states.shape[1]
+    cos, sin = image_rotary_emb
+    if _core.qk_rope_inplace(query, key, cos, sin, 0, query.shape[2] - n_txt):   # `apply_qk_rope_inplace_cossin_txtlast` :172-178
+        return query, key
     query = torch.cat([apply_rotary_emb(query[:, :, :-n_txt], image_rotary_emb), query[:, :, -n_txt:]], dim=2)
     key = torch.cat([apply_rotary_emb(key[:, :, :-n_txt], image_rotary_emb), key[:, :, -n_txt:]], dim=2)
     return query, key
 
 
 def apply_qk_rope_double(query, key, image_rotary_emb):
+    cos, sin = image_rotary_emb
+    if _core.qk_rope_inplace(query, key, cos, sin, 0, query.shape[2]):           # txtlast with len_text_prompt = 0, :180-188
+        return query, key
     return apply_rotary_emb(query, image_rotary_emb), apply_rotary_emb(key, image_rotary_emb)
 
 
 class _HunyuanProcessorBase:
     """QKV projection / norm / RoPE / text concat / output projection shared by the three Hunyuan processors
     (ref: hyvideo/attention.py:252-373)."""
+
+    fused_prologue = True   # QK-norm + RoPE in one HIP pass (False: two stages, as in the reference)
 
     def __init__(self, layer_idx: int = 0):
         self.layer_idx = layer_idx
@@ -74,6 +84,20 @@ class _HunyuanProcessorBase:
             else:
                 query, key = apply_qk_rope_double(query, key, image_rotary_emb)
         return query, key
+
+    @time_logging_decorator("Level 2 - get_fused_prologue")
+    def get_fused_prologue(self, attn, query, key, image_rotary_emb, encoder_hidden_states) -> bool:
+        """QK-norm + RoPE in ONE pass over q and k (svg_qk_norm_rope) when both apply and the tensors are on the GPU;
+        bit-identical to get_qk_norm followed by get_rotary_emb on the HIP path.  False: run the two stages."""
+        if not self.fused_prologue or image_rotary_emb is None:
+            return False
+        nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)
+        if nq is None or nk is None:
+            return False
+        single = getattr(attn, "add_q_proj", None) is None and encoder_hidden_states is not None
+        hi = query.shape[2] - (encoder_hidden_states.shape[1] if single else 0)
+        cos, sin = image_rotary_emb
+        return _core.qk_rope_inplace(query, key, cos, sin, 0, hi, norm_q=nq, norm_k=nk)
 
     @time_logging_decorator("Level 2 - get_encoder_condition_and_concat")
     def get_encoder_condition_and_concat(self, attn, query, key, value, encoder_hidden_states):
@@ -118,8 +142,9 @@ class _HunyuanProcessorBase:
             hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
         query, key, value = self.get_qkv(attn, hidden_states)
         query, key, value = self.get_transpose_qkv(attn, query, key, value)
-        query, key = self.get_qk_norm(attn, query, key)
-        query, key = self.get_rotary_emb(attn, query, key, image_rotary_emb, encoder_hidden_states)
+        if not self.get_fused_prologue(attn, query, key, image_rotary_emb, encoder_hidden_states):
+            query, key = self.get_qk_norm(attn, query, key)
+            query, key = self.get_rotary_emb(attn, query, key, image_rotary_emb, encoder_hidden_states)
         query, key, value = self.get_encoder_condition_and_concat(attn, query, key, value, encoder_hidden_states)
         cu_max_seqlens = self.get_cu_max_seqlen(attention_mask, query.device)
         hidden_states = self.attention_core_logic(query, key, value, timestep, self.layer_idx, cu_max_seqlens)

@@ -17,8 +17,15 @@ from .utils import generate_temporal_head_mask_mod, profile_desc
 def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs):
     """ref: wan/attention.py:40-66.  `freqs` is either the complex tensor [1, 1, S, D/2] of diffusers or the
     (real, imag) fp32 pair [S, D/2] the reference's patched model forward produces for its CUDA kernel."""
+    # HIP fast path (ref: `_kernels.apply_qk_rope_inplace_cossin_complex(query, key, freqs_real, freqs_imag, 0)`, :45-48)
+    S = query.shape[2]
     if isinstance(freqs, (tuple, list)):
         fr, fi = freqs
+    else:
+        fr, fi = freqs.real, freqs.imag
+    if _core.qk_rope_inplace(query, key, fr, fi, 0, S, complex_pairs=True):
+        return query, key
+    if isinstance(freqs, (tuple, list)):
         freqs = torch.complex(fr.double(), fi.double())[None, None]
 
     def rot(x):
