@@ -138,6 +138,7 @@ struct BandPolicy {
     static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.head * p.S * D; }
 
     static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
+    static __device__ __forceinline__ bool wave_active(const Ctx& c, int wrow0) { return c.q0 + wrow0 < c.q_end; }
     static __device__ __forceinline__ int q_phys(const Params& p, const Ctx& c, int row) {
         const int l = c.q0 + row;
         return l < c.q_end ? phys_row(p, c, l) : -1;
@@ -392,6 +393,7 @@ struct VarblockPolicy {
     static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.hq * p.Sq * D; }
 
     static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
+    static __device__ __forceinline__ bool wave_active(const Ctx& c, int wrow0) { return c.q0 + wrow0 < c.q_end; }
     static __device__ __forceinline__ int q_phys(const Params&, const Ctx& c, int row) {
         const int l = c.q0 + row;
         if (l >= c.q_end) return -1;
@@ -421,6 +423,13 @@ template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void varblock_attn_kernel(typename VarblockPolicy<T, D, NW>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body<T, D, NW, VarblockPolicy<T, D, NW>>(prm, smem, smem + attn_lds_bytes<D, NW>());
+}
+
+// two-phase ping-pong body for the variable-block policy (256-row q tiles)
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void varblock_attn_pp2_kernel(typename VarblockPolicy<T, D, 8>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, VarblockPolicy<T, D, 8>>(prm, smem, smem + attn_pp2_lds_bytes<D>());
 }
 
 static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
@@ -668,7 +677,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
     int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
     hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
-                       KB, NW * 32);
+                       KB, (NW < 0 ? -NW : NW) * 32);
     auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
         constexpr int W = decltype(nw_c)::value;
         using Pol = VarblockPolicy<T, D, W>;
@@ -681,14 +690,20 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.scale_log2 = sm_scale * 1.4426950408889634f;
         p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
         p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
-        return launch_attn(varblock_attn_kernel<T, D, W>, p, dim3(p.max_tiles, Hq), W * 64,
-                           attn_lds_bytes<D, W>() + vb_policy_lds(p.kb_cap), st);
+        if constexpr (NW == -8)
+            return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
+                               attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+        else
+            return launch_attn(varblock_attn_kernel<T, D, W>, p, dim3(p.max_tiles, Hq), W * 64,
+                               attn_lds_bytes<D, W>() + vb_policy_lds(p.kb_cap), st);
     };
     if constexpr (NW == 0) {
         int rc = SVG_OK;
         if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
         if (rc != SVG_OK) return rc;
         return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
+    } else if constexpr (NW == -8) {   // two-phase ping-pong body, 256-row q tiles
+        return launch(std::integral_constant<int, 8>{}, 0, tile_off, Sq / 256 + QB);
     } else {
         return launch(std::integral_constant<int, NW>{}, 0, tile_off, Sq / (NW * 32) + QB);
     }
@@ -710,16 +725,18 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
+        if (variant == 3) return run_varblock<T, 128, -8>(SVG_VB_ARGS);                          \
         return variant == 1 ? run_varblock<T, 128, 8>(SVG_VB_ARGS) : run_varblock<T, 128, 4>(SVG_VB_ARGS); \
     }                                                                                            \
     if (D == 64) {                                                                               \
         if (variant == 2) return run_varblock<T, 64, 0>(SVG_VB_ARGS);                            \
+        if (variant == 3) return run_varblock<T, 64, -8>(SVG_VB_ARGS);                           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
-    if (variant < -1 || variant > 2) return SVG_ERR_BAD_ARG;
-    // -1 (auto): 256-row q tiles once the average block-row is large enough to fill them (Wan 720p, 252-row clusters:
-    // 45.5 ms with 8 waves, 47.7 ms with 4, 46.9 ms mixed), 128-row tiles for small block-rows
-    if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 1 : 0;
+    if (variant < -1 || variant > 3) return SVG_ERR_BAD_ARG;
+    // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
+    // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
+    if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {

@@ -779,7 +779,8 @@ __device__ __forceinline__ void pp_barrier() {
 // one LDS-DMA piece: lane l's 16 bytes at (base + voff_l) land at LDS byte address lds + 16 * l (probe: tools/probe_dma.hip)
 __device__ __forceinline__ void lds_dma16(unsigned lds, unsigned voff, const void* base) {
     // (s_nop: an SALU write of M0 needs one wait state before an LDS-DMA reads it; hipcc does not look inside inline asm)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(base) : "memory");
+    const unsigned lds_u = __builtin_amdgcn_readfirstlane(lds);   // wave-uniform by construction; make it so for the compiler
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_u), "v"(voff), "s"(base) : "memory");
 }
 
 template <int D>
@@ -1219,12 +1220,22 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const unsigned col_v = (unsigned)(dma_db * 64 + (lane & 3) * 16);
     const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);
     const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
-    auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT) into stage t % NS
+    // Physical rows are resolved one vector phase before they are requested (nnext -> nphys): for the variable-block policy
+    // the resolve is itself a global index load, and this keeps its latency off the critical path.
+    int nphys[NP], nnext[NP];
+    auto resolve = [&](int t) {  // rows of tile t into nnext (tiles are resolved in increasing order: the cursors only move forward)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nnext[j] = (t < nT) ? P::kv_phys(prm, ctx, cur[j], t, krow[j]) : 0;
+    };
+    auto take = [&]() {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) nphys[j] = nnext[j];
+    };
+    auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
         const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
-            const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
+            const unsigned vo = (unsigned)nphys[j] * (unsigned)(2 * D) + col_v;
             lds_dma16(st + j * 1024, vo ^ k_xor, kb);
             lds_dma16(st + j * 1024 + kImg, vo, vb);
         }
@@ -1235,10 +1246,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // ds_write_b128 traffic of the vector phase collides with the operand streaming of the partner's matrix phase.
     u32x4 kreg[NP], vreg[NP];
     auto stage_load = [&](int t) {
+        resolve(t);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
-            const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
+            const unsigned vo = (unsigned)nnext[j] * (unsigned)(2 * D) + col_v;
             kreg[j] = *(const u32x4*)((const char*)kb + (vo ^ k_xor));
             vreg[j] = *(const u32x4*)((const char*)vb + vo);
         }
@@ -1254,9 +1265,12 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     };
     const int dist = kDma ? (lagging ? 3 : 2) : (lagging ? 3 : 2);   // tile u + dist is requested in N(u)
     if constexpr (kDma) {
-        if (nT > 0) dma_issue(0);
-        if (nT > 1) dma_issue(1);
-        if (lagging && nT > 2) dma_issue(2);
+        for (int t = 0; t < dist; ++t) {
+            resolve(t);
+            take();
+            if (t < nT) dma_issue(t);
+        }
+        resolve(dist);   // requested in N(0)
     } else {
         // tiles 0 .. dist-2 go to LDS here, tile dist-1 stays in the staging registers (written in N(0))
         if (nT > 0) { stage_load(0); stage_store(0); }
@@ -1294,6 +1308,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pp_barrier();
     if (lagging) pp_barrier();  // waves 4..7 run one phase behind
+
+    // A wave without query rows (ragged q tiles of the variable-block policy, the last q tile of a sequence) keeps the barrier
+    // and staging protocol but computes nothing: its partner then has the SIMD to itself.  (A separate loop, not a branch
+    // inside the tile loop — see the note on control-flow merges below.)
+    const bool idle = !P::wave_active(ctx, wave * 32);
 
     unsigned tr_acc[4] = {0, 0, 0, 0};
     unsigned long long tr_last = 0, tr_first = 0;
@@ -1335,8 +1354,29 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             }
         }
     };
+    // staging half of a vector phase: resolve the rows of tile t+dist+1 (index loads first: they are older than the DMA
+    // requests below, so the counted wait at the end retires them too), request tile t+dist, wait for tile t+dist-1
+    auto stage_resolve_next = [&](int t) {
+        if constexpr (kDma) {
+            take();
+            resolve(t + dist + 1);
+        }
+    };
+    auto stage_request = [&](int t) {
+        const bool more = t + dist < nT;
+        if constexpr (kDma) {
+            if (ABL != 6 && more) dma_issue(t + dist);
+            // pieces requested in the previous vector phase have to be in LDS; the ones just requested may stay in flight
+            if (ABL != 6 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (ABL != 6) {
+            if (t + dist - 1 < nT) stage_store(t + dist - 1);   // loaded in the previous vector phase (or the prologue)
+            if (more) stage_load(t + dist);
+        }
+    };
     // vector phase of tile t on sc: mask, maximum, (rare) rescale, probabilities of keys 0..15, DMA requests, DMA wait
     auto vector_phase = [&](int t) {
+        stage_resolve_next(t);
         const int tk0 = P::tile_key0(ctx, t);
         const int cls = P::classify(prm, ctx, tk0, wave * 32);
         if constexpr (P::kFixup) {
@@ -1390,16 +1430,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             probs(kk, 0, 8);
             asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
         }
-        const bool more = t + dist < nT;
-        if constexpr (kDma) {
-            if (ABL != 6 && more) dma_issue(t + dist);
-            // pieces requested in the previous vector phase have to be in LDS; the ones just requested may stay in flight
-            if (ABL != 6 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if constexpr (ABL != 6) {
-            if (t + dist - 1 < nT) stage_store(t + dist - 1);   // loaded in the previous vector phase (or the prologue)
-            if (more) stage_load(t + dist);
-        }
+        stage_request(t);
     };
     // Matrix phase: O^T += V(t)^T P(t)^T (4 DB MFMAs), then S(t+1)^T = K(t+1) Q^T into sn (2 KS MFMAs).
     // One step = { LDS read of the operand kPF steps ahead; one MFMA; a 7-instruction slice of the probabilities of the
@@ -1445,6 +1476,18 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         }
         if constexpr (has_next) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
     };
+
+    if (idle) {
+        for (int t = 0; t < nT; ++t) {
+            pp_barrier();
+            stage_resolve_next(t);
+            stage_request(t);
+            pp_barrier();
+        }
+        pp_barrier();
+        if (!lagging) pp_barrier();
+        return;
+    }
 
     // ---- M(0): only S(0) ----
     if (nT > 0) {

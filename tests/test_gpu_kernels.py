@@ -197,8 +197,9 @@ def random_partition_batch(seq_len, num_blocks, bsz, gen):
 
 _VB_SMALL = [(hq, hkv, D, 256, MB, NB, dens, dt, var)
              for (hq, hkv) in [(1, 1), (4, 4), (4, 1), (16, 4)] for D in (64, 128) for (MB, NB) in [(10, 50), (20, 100)]
-             for dens in (0.2, 0.9) for (dt, var) in [(torch.bfloat16, 0), (torch.float16, 1), (torch.bfloat16, 2)]]
-_VB_LARGE = [(4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 2), (4, 1, 64, 8192, 20, 100, 0.5, torch.float16, 2),
+             for dens in (0.2, 0.9) for (dt, var) in [(torch.bfloat16, 0), (torch.float16, 1), (torch.bfloat16, 2), (torch.float16, 3)]]
+_VB_LARGE = [(4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 3), (4, 1, 64, 8192, 20, 100, 0.5, torch.bfloat16, 3),
+             (4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 2), (4, 1, 64, 8192, 20, 100, 0.5, torch.float16, 2),
              (4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 0), (16, 4, 128, 4096, 10, 50, 0.2, torch.float16, 1),
              (4, 1, 64, 8192, 20, 100, 0.9, torch.bfloat16, 1), (1, 1, 128, 8192, 10, 100, 0.7, torch.float16, 0)]
 
