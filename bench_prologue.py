@@ -70,7 +70,27 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.steps
 
+    # the whole pre-attention data movement of a layer-call: projection outputs [bsz, S, H*D] -> head-major q, k (norm + rope) and v
+    qin, kin, vin = (torch.randn(bsz, S, H * D, device=dev, dtype=dt) for _ in range(3))
+
+    def transposing():
+        nat.qk_norm_rope_transpose(qin, kin, H, H, norm, w[0], w[1] if norm == 2 else None, w[2], w[3] if norm == 2 else None,
+                                   1e-6, rk, cs, sn, lo, hi)
+        nat.qk_norm_rope_transpose(vin, None, H, 0)
+
+    def reference_pipeline():
+        qq, kk, _ = (x.unflatten(2, (H, D)).transpose(1, 2).contiguous() for x in (qin, kin, vin))
+        if norm == 1:
+            nat.rms_norm_forward(qq.view(-1, D), w[0], 1e-6)
+            nat.rms_norm_forward(kk.view(-1, D), w[2], 1e-6)
+        elif norm == 2:
+            nat.layer_norm_forward(qq.view(-1, D), w[0], w[1])
+            nat.layer_norm_forward(kk.view(-1, D), w[2], w[3])
+        {"last": nat.apply_qk_rope_inplace_cossin_txtlast, "first": nat.apply_qk_rope_inplace_cossin,
+         "complex": nat.apply_qk_rope_inplace_cossin_complex}[rope](qq, kk, cs, sn, L)
+
     t_f, t_s = timeit(fused), timeit(separate)
+    t_t, t_r = timeit(transposing), timeit(reference_pipeline)
     qk_bytes = 2 * 2 * bsz * H * S * D * 2             # q and k, read + write
     table_bytes = 2 * (S - L) * cols * 4
     alg = qk_bytes + table_bytes
@@ -84,6 +104,10 @@ def main():
                             "bytes_moved": (2 if norm else 1) * qk_bytes + table_bytes,
                             "GBps_moved": round(((2 if norm else 1) * qk_bytes + table_bytes) / t_s / 1e6, 1)},
         "speedup_fused_vs_separate": round(t_s / t_f, 3),
+        "with_transpose": {"ms_one_pass": round(t_t, 4), "GBps": round(3 * qk_bytes / 2 / t_t / 1e6, 1),
+                           "ms_reference_pipeline": round(t_r, 4),
+                           "what": "q, k, v [bsz, S, H*D] -> [bsz, H, S, D] incl. norm + rope: svg_qk_norm_rope_transpose x2 vs "
+                                   "3 x transpose().contiguous() + the reference's three prologue calls", "speedup": round(t_r / t_t, 3)},
     }
     print(json.dumps(out))
 

@@ -240,6 +240,16 @@ int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int
                      float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo,
                      int32_t rope_hi, void* stream);
 
+/* The same pass reading the projection output in token-major layout [bsz, S, H, D] and writing head-major [bsz, H, S, D]:
+ * replaces `x.unflatten(2, (heads, -1)).transpose(1, 2)` + contiguous copy + norm + norm + rope
+ * (ref: svg/models/hyvideo/attention.py:268-286) by one read and one write per element.  norm_kind = rope_kind = 0 is a plain
+ * transpose (use it for V: pass it as q_in / q_out with k_in = NULL). */
+int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz, int32_t Hq,
+                               int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind, const void* q_weight,
+                               const void* q_bias, const void* k_weight, const void* k_bias, float eps, int32_t rope_kind,
+                               const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi,
+                               void* stream);
+
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
  * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in

@@ -19,6 +19,8 @@ enum : int { kRopeNone = 0, kRopeCosSin = 1, kRopeComplex = 2 };
 struct PrologueParams {
     void* q;
     void* k;
+    const void* q_src;   // null: in place.  Otherwise the input in token-major layout [bsz, S, H, D] (the projection output);
+    const void* k_src;   // the result is written head-major [bsz, H, S, D] to q / k: the transpose rides along for free
     int Hq, Hkv, S;
     int norm, rope;
     const void* qw;   // [D] norm weight for q (dtype of q), may be null (= ones)
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
         }
     }
 
-    auto run = [&](T* base, int H, const T* wgt, const T* bias) {
+    auto run = [&](T* base, const T* src, int H, const T* wgt, const T* bias) {
         float w[8], bs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = 1.f, bs[j] = 0.f;
@@ -92,11 +94,14 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
         }
         T* row0 = base + (((size_t)b * H) * p.S + spos) * D + c * 8;
         const size_t hstride = (size_t)p.S * D;
+        // input rows: in place, or token-major [bsz, S, H, D] where the heads of one position are D apart
+        const T* in0 = src ? src + (((size_t)b * p.S + spos) * H) * D + c * 8 : row0;
+        const size_t in_hstride = src ? (size_t)D : hstride;
         for (int h0 = 0; h0 < H; h0 += kUnroll) {
             V8 xin[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u)   // (heads past H re-read the last head; nothing is stored for them)
-                xin[u] = *(const V8*)(row0 + (size_t)min(h0 + u, H - 1) * hstride);
+                xin[u] = *(const V8*)(in0 + (size_t)min(h0 + u, H - 1) * in_hstride);
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 float x[8];
@@ -154,8 +159,8 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
             }
         }
     };
-    if (p.q) run((T*)p.q, p.Hq, (const T*)p.qw, (const T*)p.qb);
-    if (p.k) run((T*)p.k, p.Hkv, (const T*)p.kw, (const T*)p.kb);
+    if (p.q) run((T*)p.q, (const T*)p.q_src, p.Hq, (const T*)p.qw, (const T*)p.qb);
+    if (p.k) run((T*)p.k, (const T*)p.k_src, p.Hkv, (const T*)p.kw, (const T*)p.kb);
 }
 
 template <typename T>
@@ -197,7 +202,27 @@ extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32
         if (!cos_or_real || !sin_or_imag || rope_lo < 0 || rope_hi > S || rope_lo > rope_hi) return SVG_ERR_BAD_ARG;
     }
     PrologueParams p;
+    p.q_src = nullptr, p.k_src = nullptr;
     p.q = q, p.k = k, p.Hq = Hq, p.Hkv = Hkv, p.S = S, p.norm = norm_kind, p.rope = rope_kind;
+    p.qw = q_weight, p.qb = q_bias, p.kw = k_weight, p.kb = k_bias, p.eps = eps;
+    p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi;
+    return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);
+}
+
+extern "C" int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz, int32_t Hq,
+                                          int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind,
+                                          const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias,
+                                          float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag,
+                                          int32_t rope_lo, int32_t rope_hi, void* stream) {
+    if ((!q_in && !k_in) || (q_in && (!q_out || Hq <= 0)) || (k_in && (!k_out || Hkv <= 0))) return SVG_ERR_BAD_ARG;
+    if (q_in == q_out || (k_in && k_in == k_out)) return SVG_ERR_BAD_ARG;   // the layouts differ: not an in-place operation
+    if (norm_kind < 0 || norm_kind > 2 || rope_kind < 0 || rope_kind > 2) return SVG_ERR_BAD_ARG;
+    if (rope_kind != kRopeNone) {
+        if (!cos_or_real || !sin_or_imag || rope_lo < 0 || rope_hi > S || rope_lo > rope_hi) return SVG_ERR_BAD_ARG;
+    }
+    PrologueParams p;
+    p.q = q_in ? q_out : nullptr, p.k = k_in ? k_out : nullptr, p.q_src = q_in, p.k_src = k_in;
+    p.Hq = Hq, p.Hkv = Hkv, p.S = S, p.norm = norm_kind, p.rope = rope_kind;
     p.qw = q_weight, p.qb = q_bias, p.kw = k_weight, p.kb = k_bias, p.eps = eps;
     p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi;
     return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);

@@ -86,6 +86,8 @@ SIGNATURES = {
     "svg_apply_qk_rope_inplace_cossin": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_txtlast": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_qk_norm_rope_transpose": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
+                                             C.c_float, _I32, _VP, _VP, _I32, _I32, _VP]),
     "svg_qk_norm_rope": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
                                    _VP, _I32, _I32, _VP]),
     "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
@@ -431,3 +433,29 @@ def qk_norm_rope(q, k, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=
     _check(lib.svg_qk_norm_rope(q.data_ptr(), k.data_ptr(), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
                                 _ptr(q_bias), _ptr(k_weight), _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin),
                                 int(rope_lo), int(rope_hi), _stream()), "svg_qk_norm_rope")
+
+
+
+def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None,
+                           k_bias=None, eps: float = 1e-5, rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0,
+                           rope_hi: Optional[int] = None):
+    """q_in [bsz, S, Hq * D] (k_in [bsz, S, Hkv * D] or None) token-major -> new head-major tensors [bsz, H, S, D] with
+    normalisation + rotary embedding applied in the same pass (svg_qk_norm_rope_transpose)."""
+    lib = load()
+    _dev(q_in, k_in, q_weight, q_bias, k_weight, k_bias, cos, sin)
+    bsz, S, HD = q_in.shape
+    D = HD // heads_q
+    q_out = torch.empty((bsz, heads_q, S, D), dtype=q_in.dtype, device=q_in.device)
+    k_out = None
+    if k_in is not None:
+        assert k_in.shape == (bsz, S, heads_k * D) and k_in.dtype == q_in.dtype
+        k_out = torch.empty((bsz, heads_k, S, D), dtype=q_in.dtype, device=q_in.device)
+    rope_hi = S if rope_hi is None else rope_hi
+    if rope_kind:
+        cols = D // 2 if rope_kind == 2 else D
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
+    _check(lib.svg_qk_norm_rope_transpose(q_in.data_ptr(), _ptr(k_in), q_out.data_ptr(), _ptr(k_out), bsz, heads_q, heads_k, S, D,
+                                          _dtype_code(q_in), int(norm_kind), _ptr(q_weight), _ptr(q_bias), _ptr(k_weight),
+                                          _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin), int(rope_lo),
+                                          int(rope_hi), _stream()), "svg_qk_norm_rope_transpose")
+    return q_out, k_out

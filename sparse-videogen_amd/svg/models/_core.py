@@ -284,3 +284,33 @@ def qk_rope_inplace(query, key, cos, sin, rope_lo: int, rope_hi: int, complex_pa
         kind, qw, qb, kw, kb, eps = dq[0], dq[1], dq[2], dk[1], dk[2], dq[3]
     _native.qk_norm_rope(query, key, kind, qw, qb, kw, kb, eps, 2 if complex_pairs else 1, tb[0], tb[1], rope_lo, rope_hi)
     return True
+
+
+def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin, rope_lo: int, rope_hi: int,
+                         complex_pairs: bool = False):
+    """Projection outputs [bsz, S, heads * D] -> head-major q, k, v [bsz, heads, S, D] with QK-norm + RoPE applied to q, k in
+    the same pass (svg_qk_norm_rope_transpose): replaces three transpose copies + norm + norm + rope.  None: not applicable."""
+    ts = (query, key, value)
+    if not all(t.is_cuda for t in ts):
+        return None
+    _native.load()
+    if not all(t.dim() == 3 and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float16) for t in ts):
+        return None
+    D = query.shape[-1] // heads
+    if D not in _FAST_DIMS or query.shape != key.shape or value.shape != query.shape:
+        return None
+    kind, qw, qb, kw, kb, eps = 0, None, None, None, None, 0.0
+    if norm_q is not None or norm_k is not None:
+        dq, dk = _norm_desc(norm_q, D, query.dtype, query.device), _norm_desc(norm_k, D, key.dtype, key.device)
+        if dq is None or dk is None or dq[0] != dk[0] or dq[3] != dk[3]:
+            return None
+        kind, qw, qb, kw, kb, eps = dq[0], dq[1], dq[2], dk[1], dk[2], dq[3]
+    rk, tb = 0, (None, None)
+    if cos is not None:
+        tb = _tables(cos, sin, rope_hi - rope_lo, D // 2 if complex_pairs else D, query.device)
+        if tb is None:
+            return None
+        rk = 2 if complex_pairs else 1
+    q, k = _native.qk_norm_rope_transpose(query, key, heads, heads, kind, qw, qb, kw, kb, eps, rk, tb[0], tb[1], rope_lo, rope_hi)
+    v, _ = _native.qk_norm_rope_transpose(value, None, heads, 0)
+    return q, k, v

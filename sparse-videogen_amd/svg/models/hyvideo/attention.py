@@ -85,6 +85,19 @@ class _HunyuanProcessorBase:
                 query, key = apply_qk_rope_double(query, key, image_rotary_emb)
         return query, key
 
+    @time_logging_decorator("Level 2 - get_transpose_norm_rope")
+    def get_transpose_norm_rope(self, attn, query, key, value, image_rotary_emb, encoder_hidden_states):
+        """get_transpose_qkv + get_qk_norm + get_rotary_emb in one read and one write per element
+        (svg_qk_norm_rope_transpose); None when the HIP path does not apply."""
+        if not self.fused_prologue:
+            return None
+        single = getattr(attn, "add_q_proj", None) is None and encoder_hidden_states is not None
+        S = query.shape[1]
+        hi = S - (encoder_hidden_states.shape[1] if single else 0)
+        cos, sin = image_rotary_emb if image_rotary_emb is not None else (None, None)
+        return _core.qkv_from_projections(query, key, value, attn.heads, getattr(attn, "norm_q", None),
+                                          getattr(attn, "norm_k", None), cos, sin, 0, hi)
+
     @time_logging_decorator("Level 2 - get_fused_prologue")
     def get_fused_prologue(self, attn, query, key, image_rotary_emb, encoder_hidden_states) -> bool:
         """QK-norm + RoPE in ONE pass over q and k (svg_qk_norm_rope) when both apply and the tensors are on the GPU;
@@ -141,10 +154,14 @@ class _HunyuanProcessorBase:
         if getattr(attn, "add_q_proj", None) is None and encoder_hidden_states is not None:
             hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
         query, key, value = self.get_qkv(attn, hidden_states)
-        query, key, value = self.get_transpose_qkv(attn, query, key, value)
-        if not self.get_fused_prologue(attn, query, key, image_rotary_emb, encoder_hidden_states):
-            query, key = self.get_qk_norm(attn, query, key)
-            query, key = self.get_rotary_emb(attn, query, key, image_rotary_emb, encoder_hidden_states)
+        fused = self.get_transpose_norm_rope(attn, query, key, value, image_rotary_emb, encoder_hidden_states)
+        if fused is not None:
+            query, key, value = fused
+        else:
+            query, key, value = self.get_transpose_qkv(attn, query, key, value)
+            if not self.get_fused_prologue(attn, query, key, image_rotary_emb, encoder_hidden_states):
+                query, key = self.get_qk_norm(attn, query, key)
+                query, key = self.get_rotary_emb(attn, query, key, image_rotary_emb, encoder_hidden_states)
         query, key, value = self.get_encoder_condition_and_concat(attn, query, key, value, encoder_hidden_states)
         cu_max_seqlens = self.get_cu_max_seqlen(attention_mask, query.device)
         hidden_states = self.attention_core_logic(query, key, value, timestep, self.layer_idx, cu_max_seqlens)

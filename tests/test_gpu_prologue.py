@@ -153,6 +153,28 @@ def test_fused_equals_sequence(nat, norm, rope):
     assert torch.equal(fq, sq) and torch.equal(fk, sk)
 
 
+@pytest.mark.parametrize("norm,rope,D", [(1, 1, 128), (2, 1, 64), (0, 2, 128), (0, 0, 256)])
+def test_transposing_form_equals_transpose_then_in_place(nat, norm, rope, D):
+    """svg_qk_norm_rope_transpose([bsz, S, H*D]) == transpose(1, 2).contiguous() followed by svg_qk_norm_rope, bit for bit."""
+    torch.manual_seed(13)
+    bsz, Hq, Hkv, S, L = 2, 6, 3, 533, 40
+    dt = torch.bfloat16
+    q_in, k_in = torch.randn(bsz, S, Hq * D).to(dt).cuda(), torch.randn(bsz, S, Hkv * D).to(dt).cuda()
+    qw, qb, kw, kb = (torch.randn(D).to(dt).cuda() for _ in range(4))
+    cols = D // 2 if rope == 2 else D
+    cs, sn = torch.randn(S - L, cols).cuda(), torch.randn(S - L, cols).cuda()
+    args = (norm, qw, qb if norm == 2 else None, kw, kb if norm == 2 else None, 1e-6, rope, cs if rope else None,
+            sn if rope else None, L, S)
+    q_out, k_out = nat.qk_norm_rope_transpose(q_in, k_in, Hq, Hkv, *args)
+    q_ref = q_in.unflatten(2, (Hq, D)).transpose(1, 2).contiguous()
+    k_ref = k_in.unflatten(2, (Hkv, D)).transpose(1, 2).contiguous()
+    if norm or rope:
+        nat.qk_norm_rope(q_ref, k_ref, *args)
+    assert torch.equal(q_out, q_ref) and torch.equal(k_out, k_ref)
+    v_out, none = nat.qk_norm_rope_transpose(k_in, None, Hkv, 0)       # plain transpose of one tensor (V)
+    assert none is None and torch.equal(v_out, k_in.unflatten(2, (Hkv, D)).transpose(1, 2).contiguous())
+
+
 def test_full_size_hunyuan_prologue(nat):
     """HunyuanVideo 720p shape (H = 24, S = 119056, D = 128): fused rms-norm + text-last rope; spot rows against the oracle,
     text rows un-rotated, and the fused pass equals the two separate passes."""
