@@ -7,6 +7,7 @@ are the model's own torch modules, as in the reference's torch fall-back path (h
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -60,6 +61,7 @@ class _HunyuanProcessorBase:
     (ref: hyvideo/attention.py:252-373)."""
 
     fused_prologue = True   # QK-norm + RoPE in one HIP pass (False: two stages, as in the reference)
+    _valid_len_cache: dict = {}
 
     def __init__(self, layer_idx: int = 0):
         self.layer_idx = layer_idx
@@ -132,7 +134,18 @@ class _HunyuanProcessorBase:
         """ref :308-316.  Returns (valid_len, seq_len): the two dense segments are [0, valid) and [valid, S)."""
         if attention_mask is None:
             return None, None
-        return int(attention_mask.sum()), attention_mask.numel()
+        # The mask is the same tensor object for every layer of a forward pass: its popcount is read back to the host once per
+        # tensor object (the reference synchronises on it in every layer-call).  Keyed by object identity, guarded by a weak
+        # reference and the in-place version counter, so a recycled address or an edited mask never hits.
+        cache = _HunyuanProcessorBase._valid_len_cache
+        ent = cache.get(id(attention_mask))
+        if ent is not None and ent[0]() is attention_mask and ent[1] == attention_mask._version:
+            return ent[2], attention_mask.numel()
+        if len(cache) > 8:
+            cache.clear()
+        n = int(attention_mask.sum())
+        cache[id(attention_mask)] = (weakref.ref(attention_mask), attention_mask._version, n)
+        return n, attention_mask.numel()
 
     @time_logging_decorator("Level 2 - get_o")
     def get_o(self, attn, hidden_states, encoder_hidden_states):
