@@ -24,6 +24,7 @@ extern "C" {
 
 #define SVG_DTYPE_BF16 0
 #define SVG_DTYPE_F16 1
+#define SVG_DTYPE_F32 2   /* only where an entry point says so (block glue: fp32 LayerNorm outputs, fp32 weights) */
 
 #define SVG_OK 0
 #define SVG_ERR_BAD_ARG (-1)       /* null pointer, negative size, inconsistent geometry          */
@@ -249,6 +250,27 @@ int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, 
                                const void* q_bias, const void* k_weight, const void* k_bias, float eps, int32_t rope_kind,
                                const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi,
                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Transformer-block glue of the Wan blocks, rows of [M, N], N % 8 == 0, N <= 8192; dtypes per tensor
+ * (SVG_DTYPE_BF16 / F16 / F32); scale, shift, gate are fp32 [M / rows_per_batch, N] (one row per batch element).
+ * ref: triton_layernorm_forward svg/kernels/triton/layernorm.py:204-216 (fp32 statistics; the reference writes fp32),
+ *      triton_modulate_shift_forward svg/kernels/triton/modulate.py:45-85      y = x * (1 + scale) + shift,
+ *      triton_modulate_gate_residual_forward modulate.py:125-164               y = residual + x * gate,
+ *      call sites svg/models/wan/custom_models.py:37-111.
+ * svg_layernorm_modulate_forward fuses the first two (one read, one write of the 16-bit hidden states instead of
+ * read 2 + write 4 + read 4 + write 2 bytes per element); weight / bias NULL = no affine, scale / shift NULL = no modulate.
+ * ---------------------------------------------------------------------------------------------- */
+int svg_layernorm_forward(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N, int32_t x_dtype,
+                          int32_t y_dtype, int32_t w_dtype, float eps, void* stream);
+int svg_modulate_shift_forward(const void* x, void* y, const float* scale, const float* shift, int64_t M, int32_t N,
+                               int64_t rows_per_batch, int32_t x_dtype, int32_t y_dtype, void* stream);
+int svg_modulate_gate_residual_forward(const void* residual, const void* x, const float* gate, void* y, int64_t M, int32_t N,
+                                       int64_t rows_per_batch, int32_t r_dtype, int32_t x_dtype, int32_t y_dtype,
+                                       void* stream);
+int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, const void* bias, const float* scale,
+                                   const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
+                                   int32_t y_dtype, int32_t w_dtype, float eps, void* stream);
 
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised

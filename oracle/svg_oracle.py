@@ -456,3 +456,24 @@ def apply_qk_rope(q, k, a, b, len_text_prompt: int, kind: str):
         y[:, :, lo:hi] = rope_complex(seg, a, b) if kind == "complex" else rope_cossin(seg, a, b)
         out.append(y)
     return out
+
+
+# =====================================================================================================================
+# Transformer-block glue of the Wan blocks.  The semantics are the torch fall-back branches of the
+# reference's block forward (svg/models/wan/custom_models.py:44-108), which its Triton kernels replace.
+# =====================================================================================================================
+def fp32_layernorm(x: torch.Tensor, weight=None, bias=None, eps: float = 1e-5) -> torch.Tensor:
+    """ref: `self.norm1(hidden_states.float())` with diffusers FP32LayerNorm, custom_models.py:44-47 — fp32 in, fp32 out"""
+    w = weight.float() if weight is not None else None
+    b = bias.float() if bias is not None else None
+    return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps)
+
+
+def modulate_shift(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, out_dtype) -> torch.Tensor:
+    """ref: `(norm_hidden_states * (1 + scale_msa) + shift_msa).type_as(hidden_states)`, custom_models.py:58"""
+    return (x.float() * (1 + scale.float()) + shift.float()).to(out_dtype)
+
+
+def modulate_gate_residual(residual: torch.Tensor, x: torch.Tensor, gate: torch.Tensor, out_dtype) -> torch.Tensor:
+    """ref: `(hidden_states.float() + attn_output * gate_msa).type_as(hidden_states)`, custom_models.py:69"""
+    return (residual.float() + x.float() * gate.float()).to(out_dtype)

@@ -42,7 +42,7 @@ FLAGS = [
 
 # Files whose arithmetic has to reproduce torch's rounding points bit for bit: IEEE semantics, no fma contraction, no
 # folding of double -> float -> half conversions.
-STRICT_FP = {"prologue.hip"}
+STRICT_FP = {"prologue.hip", "glue.hip"}
 
 
 def _newest_header() -> float:

@@ -86,6 +86,11 @@ SIGNATURES = {
     "svg_apply_qk_rope_inplace_cossin": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_txtlast": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_layernorm_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "svg_modulate_shift_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _VP]),
+    "svg_modulate_gate_residual_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32, _VP]),
+    "svg_layernorm_modulate_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32,
+                                                 C.c_float, _VP]),
     "svg_qk_norm_rope_transpose": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                              C.c_float, _I32, _VP, _VP, _I32, _I32, _VP]),
     "svg_qk_norm_rope": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
@@ -459,3 +464,80 @@ def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: in
                                           _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin), int(rope_lo),
                                           int(rope_hi), _stream()), "svg_qk_norm_rope_transpose")
     return q_out, k_out
+
+
+# ---- transformer-block glue (svg/kernels/triton/{layernorm,modulate}.py of the reference) ----
+_GLUE_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def _rows(x: torch.Tensor):
+    assert x.dim() in (2, 3) and x.is_contiguous(), "expected contiguous [M, N] or [B, S, N]"
+    N = x.shape[-1]
+    return x.numel() // N, N, (x.shape[1] if x.dim() == 3 else x.numel() // N)
+
+
+def _per_batch(t: torch.Tensor, x: torch.Tensor, N: int) -> torch.Tensor:
+    """scale / shift / gate: fp32, one row of N per batch element ([N], [1, N], [B, 1, N], [B, N])"""
+    B = x.shape[0] if x.dim() == 3 else 1
+    t = t.detach().to(torch.float32).reshape(-1, N)
+    if t.shape[0] == 1 and B > 1:
+        t = t.expand(B, N)
+    assert t.shape == (B, N), f"modulation tensor must broadcast to [{B}, {N}]"
+    return t.contiguous()
+
+
+def layernorm_forward(x, weight=None, bias=None, eps: float = 1e-5, out_dtype=torch.float32) -> torch.Tensor:
+    lib = load()
+    _dev(x, weight, bias)
+    M, N, _ = _rows(x)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    wdt = _GLUE_DT[weight.dtype] if weight is not None else 2
+    if weight is not None:
+        assert bias is not None and weight.shape == (N,) and bias.shape == (N,) and bias.dtype == weight.dtype
+    _check(lib.svg_layernorm_forward(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), M, N, _GLUE_DT[x.dtype],
+                                     _GLUE_DT[out_dtype], wdt, float(eps), _stream()), "svg_layernorm_forward")
+    return y
+
+
+def modulate_shift_forward(x, scale, shift, out_dtype=torch.float32) -> torch.Tensor:
+    lib = load()
+    _dev(x)
+    M, N, rpb = _rows(x)
+    sc, sh = _per_batch(scale, x, N), _per_batch(shift, x, N)
+    _dev(sc, sh)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _check(lib.svg_modulate_shift_forward(x.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), M, N, rpb, _GLUE_DT[x.dtype],
+                                          _GLUE_DT[out_dtype], _stream()), "svg_modulate_shift_forward")
+    return y
+
+
+def modulate_gate_residual_forward(residual, x, gate, out_dtype=torch.float32) -> torch.Tensor:
+    lib = load()
+    _dev(residual, x)
+    assert residual.shape == x.shape
+    M, N, rpb = _rows(x)
+    _rows(residual)
+    g = _per_batch(gate, x, N)
+    _dev(g)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _check(lib.svg_modulate_gate_residual_forward(residual.data_ptr(), x.data_ptr(), g.data_ptr(), y.data_ptr(), M, N, rpb,
+                                                  _GLUE_DT[residual.dtype], _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], _stream()),
+           "svg_modulate_gate_residual_forward")
+    return y
+
+
+def layernorm_modulate_forward(x, weight=None, bias=None, scale=None, shift=None, eps: float = 1e-5, out_dtype=None) -> torch.Tensor:
+    """Fused fp32 LayerNorm (+ affine) (+ y * (1 + scale) + shift), one pass; out_dtype defaults to x.dtype."""
+    lib = load()
+    _dev(x, weight, bias)
+    M, N, rpb = _rows(x)
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    sc = _per_batch(scale, x, N) if scale is not None else None
+    sh = _per_batch(shift, x, N) if shift is not None else None
+    _dev(sc, sh)
+    wdt = _GLUE_DT[weight.dtype] if weight is not None else 2
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _check(lib.svg_layernorm_modulate_forward(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), _ptr(sc), _ptr(sh), M, N, rpb,
+                                              _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], wdt, float(eps), _stream()),
+           "svg_layernorm_modulate_forward")
+    return y
