@@ -203,6 +203,16 @@ int svg_identify_dynamic_map(const void* qc, const void* kc, const int32_t* k_si
                              int32_t QC, int32_t KC, int32_t D, int32_t dtype, float top_p, int32_t preserve_length,
                              void* stream);
 
+/* Uniform-block (BSR) front end of the variable-block kernel — the reference's alternative backend
+ * (flashinfer.BlockSparseAttentionWrapper plan/run + text merge, svg/kernels/ops/attention_ops.py:107-197, wan variant
+ * attention_ops_wan.py): expands (indptr [MB + 1], indices) over MB x NB blocks of row_block x col_block tokens into the dense
+ * map [heads, MB + 1, NB + 1] and the size arrays [heads, MB + 1] / [heads, NB + 1] that svg_varblock_attention takes; block-row 0
+ * / block-column 0 hold the len_text text tokens (text first) and are always active: video rows see their BSR blocks and all
+ * text, text rows see everything — the merge_state of the reference in one kernel. */
+int svg_bsr_to_block_map(const int32_t* indptr, const int32_t* indices, int32_t MB, int32_t NB, int32_t row_block,
+                         int32_t col_block, int32_t len_text, int32_t heads, uint8_t* block_map, int32_t* q_sizes,
+                         int32_t* k_sizes, void* stream);
+
 /* density of a dynamic map, ref: density_calculation, svg/kmeans_utils.py:13-31.  out: float [BH] */
 int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out, int32_t BH,
                     int32_t QB, int32_t KB, void* stream);

@@ -32,7 +32,45 @@ __global__ __launch_bounds__(256) void map_density_kernel(const uint8_t* __restr
     }
 }
 
+// BSR (indptr, indices) of MB x NB uniform blocks -> the dense per-head block map + size arrays the variable-block kernel
+// takes, with one extra leading block-row / block-column for the text tokens (always active).  grid = (MB + 1), block = 256.
+__global__ __launch_bounds__(256) void bsr_to_map_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                         uint8_t* __restrict__ map, int32_t* __restrict__ q_sizes,
+                                                         int32_t* __restrict__ k_sizes, int MB, int NB, int R, int Cc, int text,
+                                                         int heads) {
+    const int i = blockIdx.x, tid = threadIdx.x;   // block-row i of the extended map (0 = text)
+    const int KB = NB + 1, QB = MB + 1;
+    for (int h = 0; h < heads; ++h) {
+        uint8_t* row = map + ((size_t)h * QB + i) * KB;
+        for (int j = tid; j < KB; j += 256) row[j] = (i == 0 || j == 0) ? 1 : 0;
+        if (tid == 0) q_sizes[(size_t)h * QB + i] = i == 0 ? text : R;
+        if (i == 0)
+            for (int j = tid; j < KB; j += 256) k_sizes[(size_t)h * KB + j] = j == 0 ? text : Cc;
+    }
+    __syncthreads();
+    if (i > 0) {
+        const int lo = indptr[i - 1], hi = indptr[i];
+        for (int h = 0; h < heads; ++h) {
+            uint8_t* row = map + ((size_t)h * QB + i) * KB;
+            for (int p = lo + tid; p < hi; p += 256) {
+                const int j = indices[p];
+                if (j >= 0 && j < NB) row[1 + j] = 1;
+            }
+        }
+    }
+}
+
 }  // namespace svg
+
+extern "C" int svg_bsr_to_block_map(const int32_t* indptr, const int32_t* indices, int32_t MB, int32_t NB, int32_t row_block,
+                                    int32_t col_block, int32_t len_text, int32_t heads, uint8_t* block_map, int32_t* q_sizes,
+                                    int32_t* k_sizes, void* stream) {
+    if (!indptr || !indices || !block_map || !q_sizes || !k_sizes) return SVG_ERR_BAD_ARG;
+    if (MB <= 0 || NB <= 0 || row_block <= 0 || col_block <= 0 || len_text < 0 || heads <= 0) return SVG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(svg::bsr_to_map_kernel, dim3(MB + 1), dim3(256), 0, (hipStream_t)stream, indptr, indices, block_map, q_sizes,
+                       k_sizes, MB, NB, row_block, col_block, len_text, heads);
+    return svg::launch_status();
+}
 
 extern "C" const char* svg_strerror(int code) {
     switch (code) {

@@ -86,6 +86,7 @@ SIGNATURES = {
     "svg_apply_qk_rope_inplace_cossin": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_txtlast": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "svg_bsr_to_block_map": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
     "svg_layernorm_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "svg_modulate_shift_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _VP]),
     "svg_modulate_gate_residual_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32, _VP]),
@@ -541,3 +542,19 @@ def layernorm_modulate_forward(x, weight=None, bias=None, scale=None, shift=None
                                               _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], wdt, float(eps), _stream()),
            "svg_layernorm_modulate_forward")
     return y
+
+
+def bsr_to_block_map(indptr: torch.Tensor, indices: torch.Tensor, MB: int, NB: int, row_block: int, col_block: int,
+                     len_text: int, heads: int):
+    """BSR over uniform blocks -> (block_map uint8 [heads, MB+1, NB+1], q_sizes int32 [heads, MB+1], k_sizes int32 [heads, NB+1])
+    with the text block in front (svg_bsr_to_block_map)."""
+    lib = load()
+    _dev(indptr, indices)
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == MB + 1
+    dev = indptr.device
+    bm = torch.empty((heads, MB + 1, NB + 1), dtype=torch.uint8, device=dev)
+    qs = torch.empty((heads, MB + 1), dtype=torch.int32, device=dev)
+    ks = torch.empty((heads, NB + 1), dtype=torch.int32, device=dev)
+    _check(lib.svg_bsr_to_block_map(indptr.data_ptr(), indices.data_ptr(), MB, NB, row_block, col_block, len_text, heads,
+                                    bm.data_ptr(), qs.data_ptr(), ks.data_ptr(), _stream()), "svg_bsr_to_block_map")
+    return bm, qs, ks

@@ -1,0 +1,66 @@
+"""Uniform-block (BSR) sparse attention ops (svg/kernels/ops/attention_ops.py mirror) on the GPU: the reference's test
+(svg/kernels/test/test_sparse_attn.py:181-260) compares sparse_attn_forward with dense attention under the element mask its own
+generators produce; those masks are the goldens here (tests/golden/make_golden_bsr.py)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(str(Path(__file__).parent / "golden" / "bsr_golden.npz"))
+P = 40
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "sparse-videogen_amd"))
+    from svg.kernels.ops import attention_ops
+    return attention_ops
+
+
+def golden_mask(kind, F, L, mul):
+    S = F * P + L
+    return torch.from_numpy(np.unpackbits(GOLD[f"{kind}_{F}_{L}_{mul}"])[: S * S].reshape(S, S).astype(bool))
+
+
+def close(a, b):
+    rtol, atol = {torch.float16: (5e-3, 5e-3), torch.bfloat16: (3e-2, 2e-2)}[a.dtype]   # test_sparse_attn.py:91-96
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("F,L", [(5, 16), (13, 77), (5, 0)])
+@pytest.mark.parametrize("heads,D", [(4, 64), (2, 128)])
+@pytest.mark.parametrize("kind,mul", [("spatial", 0), ("spatial", 1), ("spatial", 2), ("temporal", 0.5), ("temporal", 1),
+                                      ("temporal", 1.4), ("temporal", 1.8)])
+def test_sparse_attn_forward(ops, kind, mul, F, L, heads, D):
+    torch.manual_seed(F + L)
+    S = F * P + L
+    dt = torch.float16
+    q, k, v = (torch.randn(S, heads, D).to(dt) for _ in range(3))
+    gen = ops._gen_spatial_mask if kind == "spatial" else ops._gen_temporal_mask
+    md = gen(F, P, mul)
+    meta = ops.FAMetadata(L, F, P, md if kind == "temporal" else None, md if kind == "spatial" else None, None)
+    o = ops.sparse_attn_forward(q.cuda(), k.cuda(), v.cuda(), meta, kind)
+    mask = golden_mask(kind, F, L, mul)
+    qh, kh, vh = (x.permute(1, 0, 2)[None] for x in (q, k, v))
+    ref = O.masked_attention(qh, kh, vh, mask)[0].permute(1, 0, 2)
+    close(o, ref.to(dt))
+
+
+def test_init_sparse_attn_and_gqa(ops):
+    torch.manual_seed(1)
+    F, L, Hq, Hkv, D = 5, 16, 8, 2, 128
+    S = F * P + L
+    meta = ops.init_sparse_attn(L, F, P, 1.4, 1)
+    q = torch.randn(S, Hq, D).to(torch.bfloat16)
+    k, v = torch.randn(S, Hkv, D).to(torch.bfloat16), torch.randn(S, Hkv, D).to(torch.bfloat16)
+    for kind, mul in (("temporal", 1.4), ("spatial", 1)):
+        o = ops.sparse_attn_forward(q.cuda(), k.cuda(), v.cuda(), meta, kind)
+        mask = golden_mask(kind, F, L, mul)
+        kr, vr = k.repeat_interleave(Hq // Hkv, dim=1), v.repeat_interleave(Hq // Hkv, dim=1)
+        ref = O.masked_attention(q.permute(1, 0, 2)[None], kr.permute(1, 0, 2)[None], vr.permute(1, 0, 2)[None], mask)[0]
+        close(o, ref.permute(1, 0, 2).to(torch.bfloat16))
