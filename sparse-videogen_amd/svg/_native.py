@@ -423,12 +423,16 @@ def apply_qk_rope_inplace_cossin_complex(q, k, freqs_real, freqs_imag, len_text_
     _rope("svg_apply_qk_rope_inplace_cossin_complex", q, k, freqs_real, freqs_imag, len_text_prompt, True)
 
 
-def qk_norm_rope(q, k, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None, k_bias=None, eps: float = 1e-5,
+def qk_norm_rope(q, k=None, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None, k_bias=None, eps: float = 1e-5,
                  rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0, rope_hi: Optional[int] = None) -> None:
-    """Fused in-place normalisation + rotary embedding of q and k in one pass (svg_qk_norm_rope)."""
+    """Fused in-place normalisation + rotary embedding of q and (optionally) k in one pass (svg_qk_norm_rope)."""
     lib = load()
     _dev(q, k, q_weight, q_bias, k_weight, k_bias, cos, sin)
-    bsz, Hq, Hkv, S, D = _qk4(q, k)
+    if k is not None:
+        bsz, Hq, Hkv, S, D = _qk4(q, k)
+    else:
+        assert q.dim() == 4 and q.is_contiguous()
+        (bsz, Hq, S, D), Hkv = q.shape, 0
     rope_hi = S if rope_hi is None else rope_hi
     if rope_kind:
         cols = D // 2 if rope_kind == 2 else D
@@ -436,10 +440,9 @@ def qk_norm_rope(q, k, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=
         assert cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
     for w in (q_weight, q_bias, k_weight, k_bias):
         assert w is None or (w.dtype == q.dtype and w.shape == (D,) and w.is_contiguous())
-    _check(lib.svg_qk_norm_rope(q.data_ptr(), k.data_ptr(), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
+    _check(lib.svg_qk_norm_rope(q.data_ptr(), _ptr(k), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
                                 _ptr(q_bias), _ptr(k_weight), _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin),
                                 int(rope_lo), int(rope_hi), _stream()), "svg_qk_norm_rope")
-
 
 
 def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None,

@@ -256,7 +256,11 @@ def qk_norm_inplace(norm_q, norm_k, query, key) -> bool:
     dq, dk = _norm_desc(norm_q, D, query.dtype, query.device), _norm_desc(norm_k, D, key.dtype, key.device)
     if dq is None or dk is None or dq[0] != dk[0] or dq[3] != dk[3]:
         return False
-    _native.qk_norm_rope(query, key, dq[0], dq[1], dq[2], dk[1], dk[2], dq[3])
+    if query.shape[0] == key.shape[0] and query.shape[2] == key.shape[2]:
+        _native.qk_norm_rope(query, key, dq[0], dq[1], dq[2], dk[1], dk[2], dq[3])
+    else:   # cross attention: different sequence lengths, one call per tensor
+        _native.qk_norm_rope(query, None, dq[0], dq[1], dq[2], None, None, dq[3])
+        _native.qk_norm_rope(key, None, dk[0], dk[1], dk[2], None, None, dk[3])
     return True
 
 

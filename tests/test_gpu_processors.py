@@ -218,3 +218,45 @@ def test_wan_and_cog_svg_processors_run_and_match():
                              inverse=True)
         ref = a.to_out[0](o.transpose(1, 2).flatten(2, 3))
     torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+
+
+def test_cosmos_svg_processor_matches_torch():
+    """Cosmos (4th model family): per-head RMS qk-norm after the head split, half-split RoPE, no text; sparse core = Wan's."""
+    from svg.models.cosmos.attention import Cosmos_SVG_AttnProcessor2_0 as CosP, apply_rotary_emb_half
+    from svg.models.cosmos.inference import replace_cosmos_attention
+    from svg.models.cosmos.utils import generate_temporal_head_mask_mod as mm
+
+    torch.manual_seed(4)
+    heads, hd = 2, 128
+    dim = heads * hd
+    F_, P_ = 5, 160
+    CosP.context_length, CosP.num_frame, CosP.frame_size = 0, F_, P_
+    CosP.first_layers_fp, CosP.first_times_fp, CosP.num_sampled_rows, CosP.sample_mse_max_row = 0, 900.0, 16, 400
+    CosP.block_mask = mm(0, 0, F_, P_, mul=1.2)
+    attn = Attention(dim, heads, qk_norm="rms", dtype=DT).cuda()      # per-head RMSNorm(hd)
+    attn.set_processor(CosP(0))
+    S = F_ * P_
+    hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
+    ang = torch.rand(S, hd // 2) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1), torch.cat([ang.sin(), ang.sin()], -1)
+    with torch.no_grad():
+        out = attn(hidden, image_rotary_emb=(cos.cuda(), sin.cuda()), timestep=torch.tensor([100.0]))
+        best = attn.processor.last_best_mask_idx.cpu()
+        a = attn.cpu().float()
+        x = hidden.float().cpu()
+        q, k, v = (m(x).unflatten(2, (heads, -1)).transpose(1, 2) for m in (a.to_q, a.to_k, a.to_v))
+        q, k = a.norm_q(q), a.norm_k(k)
+        q, k = apply_rotary_emb_half(q, (cos, sin)), apply_rotary_emb_half(k, (cos, sin))
+        q, k, v = (t.to(DT) for t in (q, k, v))
+        qp, kp, vp = (O.head_placement(t, best, 0, F_, P_) for t in (q, k, v))
+        o = O.head_placement(O.masked_attention(qp, kp, vp, O.band_mask(S, *CosP.block_mask.as_tuple())), best, 0, F_, P_,
+                             inverse=True)
+        ref = a.to_out[0](o.transpose(1, 2).reshape(1, -1, dim))
+    torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+    # dense warm-up branch and the cross-attention branch stay finite
+    attn.cuda().to(DT)
+    with torch.no_grad():
+        d = attn(hidden, image_rotary_emb=(cos.cuda(), sin.cuda()), timestep=torch.tensor([950.0]))
+        c = attn(hidden, encoder_hidden_states=hidden[:, :77], timestep=None)
+    assert torch.isfinite(d.float()).all() and torch.isfinite(c.float()).all()
+    assert callable(replace_cosmos_attention)
