@@ -45,8 +45,9 @@ def is_full_attention(layer_idx: int, timestep, first_layers_fp, first_times_fp)
     """ref: svg/models/hyvideo/attention.py:491-496 — dense for the first layers and the first (large) timesteps."""
     if layer_idx < first_layers_fp:
         return True
-    t0 = timestep[0] if (torch.is_tensor(timestep) and timestep.dim() > 0) or isinstance(timestep, (list, tuple)) else timestep
-    return bool(t0 > first_times_fp)  # one host sync when `timestep` lives on the GPU, exactly like the reference
+    from .context import timestep_value
+
+    return timestep_value(timestep) > first_times_fp   # read back once per transformer forward, not once per layer
 
 
 @time_logging_decorator("Level 3 - Dense Flash Attention")

@@ -11,7 +11,7 @@ import functools
 import inspect
 from typing import Any, Optional
 
-_CURRENT: dict = {"timestep": None}
+_CURRENT: dict = {"timestep": None, "host": None}
 
 
 def current_timestep() -> Optional[Any]:
@@ -20,6 +20,21 @@ def current_timestep() -> Optional[Any]:
 
 def set_timestep(t) -> None:
     _CURRENT["timestep"] = t
+    _CURRENT["host"] = None
+
+
+def timestep_value(t) -> float:
+    """`timestep[0]` as a Python float.  For the tensor published by the forward hook the device-to-host read happens once per
+    transformer forward (the reference compares the GPU tensor in every layer: one sync per layer-call)."""
+    import torch
+
+    if t is _CURRENT["timestep"] and _CURRENT["host"] is not None:
+        return _CURRENT["host"]
+    t0 = t[0] if (torch.is_tensor(t) and t.dim() > 0) or isinstance(t, (list, tuple)) else t
+    val = float(t0)
+    if t is _CURRENT["timestep"]:
+        _CURRENT["host"] = val
+    return val
 
 
 def install_timestep_hook(transformer) -> None:
@@ -36,12 +51,12 @@ def install_timestep_hook(transformer) -> None:
             t = bound.arguments.get("timestep", None)
         except TypeError:
             t = kwargs.get("timestep", None)
-        prev = _CURRENT["timestep"]
-        _CURRENT["timestep"] = t
+        prev = (_CURRENT["timestep"], _CURRENT["host"])
+        _CURRENT["timestep"], _CURRENT["host"] = t, None
         try:
             return orig(*args, **kwargs)
         finally:
-            _CURRENT["timestep"] = prev
+            _CURRENT["timestep"], _CURRENT["host"] = prev
 
     transformer.forward = forward
     transformer._svg_timestep_hook = True
