@@ -1231,14 +1231,15 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
 #pragma unroll
         for (int j = 0; j < NP; ++j) nphys[j] = nnext[j];
     };
-    auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
+    auto dma_piece = [&](int t, int j) {
         const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
+        const unsigned vo = (unsigned)nphys[j] * (unsigned)(2 * D) + col_v;
+        lds_dma16(st + j * 1024, vo ^ k_xor, kb);
+        lds_dma16(st + j * 1024 + kImg, vo, vb);
+    };
+    auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const unsigned vo = (unsigned)nphys[j] * (unsigned)(2 * D) + col_v;
-            lds_dma16(st + j * 1024, vo ^ k_xor, kb);
-            lds_dma16(st + j * 1024 + kImg, vo, vb);
-        }
+        for (int j = 0; j < NP; ++j) dma_piece(t, j);
     };
     // Register staging (kDma = false, kept for comparison): loads for tile w are issued in N(w - dist) and written in the
     // following vector phase: slot 2w-1 (leading) / 2w-2 (lagging), after the last read of the stage's previous tenant
@@ -1377,6 +1378,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // vector phase of tile t on sc: mask, maximum, (rare) rescale, probabilities of keys 0..15, DMA requests, DMA wait
     auto vector_phase = [&](int t) {
         stage_resolve_next(t);
+        constexpr bool kSpread = kDma && ABL != 6;   // requests spread over the phase instead of back to back at its end
+        if (kSpread && t + dist < nT) dma_piece(t + dist, 0);
         const int tk0 = P::tile_key0(ctx, t);
         const int cls = P::classify(prm, ctx, tk0, wave * 32);
         if constexpr (P::kFixup) {
@@ -1424,13 +1427,21 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                     acc_o[db][r] = x;
                 }
         }
+        if constexpr (kSpread && NP > 1) {
+            if (t + dist < nT) dma_piece(t + dist, 1);
+        }
         psum = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4 - kShadow; ++kk) {
             probs(kk, 0, 8);
             asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
         }
-        stage_request(t);
+        if constexpr (kSpread) {
+            if (t + dist < nT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            stage_request(t);
+        }
     };
     // Matrix phase: O^T += V(t)^T P(t)^T (4 DB MFMAs), then S(t+1)^T = K(t+1) Q^T into sn (2 KS MFMAs).
     // One step = { LDS read of the operand kPF steps ahead; one MFMA; a 7-instruction slice of the probabilities of the
