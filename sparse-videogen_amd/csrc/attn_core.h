@@ -1207,35 +1207,28 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const T* __restrict__ vb = P::v_base(prm, ctx);
     const unsigned lds0 = (unsigned)(size_t)smem;
 
-    // ---- DMA bookkeeping (same images as attn_body_pp) ----
-    const int dma_db = wave % DB;
-    const int dma_kg0 = (wave / DB) * NP;
-    int krow[NP];
-    typename P::KvCursor cur[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        krow[j] = 16 * (dma_kg0 + j) + (lane >> 2);
-        P::kv_cursor_init(prm, ctx, cur[j], krow[j]);
-    }
-    const unsigned col_v = (unsigned)(dma_db * 64 + (lane & 3) * 16);
+    // ---- DMA bookkeeping (same images as attn_body_pp).  A wave's NP pieces per tensor are the d-blocks dma_db0 .. + NP - 1 of
+    //      ONE 16-key group: every lane resolves a single key row per tile (one cursor, one index load) ----
+    const int dma_kg = wave / 2;
+    const int dma_db0 = (wave % 2) * NP;
+    const int krow = 16 * dma_kg + (lane >> 2);
+    typename P::KvCursor cur;
+    P::kv_cursor_init(prm, ctx, cur, krow);
+    const unsigned col_v = (unsigned)(dma_db0 * 64 + (lane & 3) * 16);
     const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);
-    const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
+    const unsigned lds_piece = lds0 + (unsigned)(dma_db0 * (kBN * 64) + dma_kg * 1024);
     // Physical rows are resolved one vector phase before they are requested (nnext -> nphys): for the variable-block policy
     // the resolve is itself a global index load, and this keeps its latency off the critical path.
-    int nphys[NP], nnext[NP];
-    auto resolve = [&](int t) {  // rows of tile t into nnext (tiles are resolved in increasing order: the cursors only move forward)
-#pragma unroll
-        for (int j = 0; j < NP; ++j) nnext[j] = (t < nT) ? P::kv_phys(prm, ctx, cur[j], t, krow[j]) : 0;
+    int nphys = 0, nnext = 0;
+    auto resolve = [&](int t) {  // row of tile t into nnext (tiles are resolved in increasing order: the cursor only moves forward)
+        nnext = (t < nT) ? P::kv_phys(prm, ctx, cur, t, krow) : 0;
     };
-    auto take = [&]() {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) nphys[j] = nnext[j];
-    };
+    auto take = [&]() { nphys = nnext; };
     auto dma_piece = [&](int t, int j) {
         const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
-        const unsigned vo = (unsigned)nphys[j] * (unsigned)(2 * D) + col_v;
-        lds_dma16(st + j * 1024, vo ^ k_xor, kb);
-        lds_dma16(st + j * 1024 + kImg, vo, vb);
+        const unsigned vo = (unsigned)nphys * (unsigned)(2 * D) + col_v + (unsigned)(j * 64);
+        lds_dma16(st + j * (kBN * 64), vo ^ k_xor, kb);
+        lds_dma16(st + j * (kBN * 64) + kImg, vo, vb);
     };
     auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
 #pragma unroll
@@ -1250,18 +1243,18 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         resolve(t);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const unsigned vo = (unsigned)nnext[j] * (unsigned)(2 * D) + col_v;
+            const unsigned vo = (unsigned)nnext * (unsigned)(2 * D) + col_v + (unsigned)(j * 64);
             kreg[j] = *(const u32x4*)((const char*)kb + (vo ^ k_xor));
             vreg[j] = *(const u32x4*)((const char*)vb + vo);
         }
     };
-    char* const piece_ptr = smem + dma_db * (kBN * 64) + dma_kg0 * 1024 + lane * 16;
+    char* const piece_ptr = smem + dma_db0 * (kBN * 64) + dma_kg * 1024 + lane * 16;
     auto stage_store = [&](int t) {
         char* st = piece_ptr + (t % NS) * kStage;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            *(u32x4*)(st + j * 1024) = kreg[j];
-            *(u32x4*)(st + j * 1024 + kImg) = vreg[j];
+            *(u32x4*)(st + j * (kBN * 64)) = kreg[j];
+            *(u32x4*)(st + j * (kBN * 64) + kImg) = vreg[j];
         }
     };
     const int dist = kDma ? (lagging ? 3 : 2) : (lagging ? 3 : 2);   // tile u + dist is requested in N(u)
