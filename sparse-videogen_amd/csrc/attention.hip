@@ -160,10 +160,12 @@ struct BandPolicy {
         // token-major head: physical row = vid0 + f * P + pp with (l - vid0) = pp * F + f.  Consecutive tiles advance
         // by 64 rows, so the decomposition is stepped (4 VALU) instead of divided (~30 VALU); segment jumps re-divide.
         int pp, f;
+        // a cursor advances by one stage per call: 64 keys, or 128 with two tiles per stage (each chunk keeps its sub-tile)
+        constexpr int kStep = kBN * SUBS;
         const int delta = __builtin_amdgcn_readfirstlane(k0 - cu.prev_k0);
-        if (delta == kBN || delta == 2 * kBN) {
-            f = cu.f + (delta == kBN ? p.r64 : p.r128);
-            pp = cu.pp + (delta == kBN ? p.q64 : p.q128);
+        if (delta == kStep) {
+            f = cu.f + (SUBS == 1 ? p.r64 : p.r128);
+            pp = cu.pp + (SUBS == 1 ? p.q64 : p.q128);
             const bool wrap = f >= p.F;
             f = wrap ? f - p.F : f;
             pp = wrap ? pp + 1 : pp;
