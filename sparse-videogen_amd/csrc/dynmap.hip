@@ -21,12 +21,13 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
                                                              int QC, int KC, float sqrt_d, float top_p,
                                                              int preserve) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* prob = (float*)smem;              // [KC]  probabilities (already rounded to T), later reused
-    float* sorted = prob + KC;               // [KC]  probabilities in descending order
-    uint8_t* keep = (uint8_t*)(sorted + KC); // [KC]  keep flag per sorted position
-    int* ranks_w = (int*)smem + 2 * KC + ((KC + 3) / 4);  // [KC] rank of cluster j in the descending order
+    // LDS: keys[N2] u64 (sort keys; N2 = KC rounded up to a power of two), prob[KC] f32
+    const int N2 = 1 << (32 - __builtin_clz(max(KC, 2) - 1));
+    unsigned long long* keys = (unsigned long long*)smem;
+    float* prob = (float*)(keys + N2);
     __shared__ float qrow[D];
     __shared__ float red[4];
+    __shared__ int cut_s;
     const int row = blockIdx.x, bh = blockIdx.y, tid = threadIdx.x;
     const T* q = qc + ((size_t)bh * QC + row) * D;
     const T* kb = kc + (size_t)bh * KC * D;
@@ -66,37 +67,49 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
     if ((tid & 63) == 0) red[tid >> 6] = lsum;
     __syncthreads();
     const float gsum = fmaxf(red[0] + red[1] + red[2] + red[3], 1e-12f);
-    for (int j = tid; j < KC; j += kDynThreads) prob[j] = Elt<T>::to_float(Elt<T>::from_float(prob[j] / gsum));
-    __syncthreads();
-    // 3. rank of every element in the stable descending order
-    for (int j = tid; j < KC; j += kDynThreads) {
-        const float pj = prob[j];
-        int rank = 0;
-        for (int i = 0; i < KC; ++i) {
-            const float pi = prob[i];
-            rank += (pi > pj) | ((pi == pj) & (i < j));
+    // 3. stable descending order: sort the unique keys (inverted probability bits, cluster index) ascending — probabilities
+    //    are >= 0, so their bit patterns order like the values; ties fall back to the lower index like a stable sort.
+    //    Bitonic network in LDS: O(N log^2 N) compare-exchanges instead of the N^2 rank counting this kernel started with.
+    for (int j = tid; j < N2; j += kDynThreads) {
+        unsigned long long key = ~0ull;
+        if (j < KC) {
+            const float pj = Elt<T>::to_float(Elt<T>::from_float(prob[j] / gsum));
+            key = ((unsigned long long)(0xffffffffu - __float_as_uint(pj)) << 32) | (unsigned)j;
         }
-        sorted[rank] = pj;
-        ranks_w[j] = rank;
+        keys[j] = key;
     }
     __syncthreads();
-    // 4. sequential cumsum (one lane), keep flags per sorted position
+    for (int k = 2; k <= N2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < N2 / 2; t += kDynThreads) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const unsigned long long a = keys[lo], b2 = keys[hi];
+                const bool asc = (lo & k) == 0;
+                if ((a > b2) == asc) keys[lo] = b2, keys[hi] = a;
+            }
+            __syncthreads();
+        }
+    }
+    // 4. cumulative sum in sorted order: sequential, fp32 accumulator, every prefix rounded to the input dtype (torch cumsum
+    //    on a 16-bit tensor).  The prefix is non-decreasing, so everything after the first position whose previous prefix
+    //    exceeds p is dropped: one lane walks only that far.
     if (tid == 0) {
         const float p_cmp = Elt<T>::to_float(Elt<T>::from_float(top_p));
         float acc = 0.f, prev_cum = 0.f;
-        for (int r = 0; r < KC; ++r) {
-            bool rm = (r > 0) && (prev_cum > p_cmp);
-            if (r < preserve) rm = false;
-            keep[r] = rm ? 0 : 1;
-            acc += sorted[r];
+        int r = 0;
+        for (; r < KC; ++r) {
+            if (r > 0 && prev_cum > p_cmp) break;   // position r (and all later ones) is removed unless r < preserve
+            acc += __uint_as_float(0xffffffffu - (unsigned)(keys[r] >> 32));
             prev_cum = Elt<T>::to_float(Elt<T>::from_float(acc));
         }
+        cut_s = max(r, preserve);
     }
     __syncthreads();
     // 5. scatter back to cluster order
+    const int cut = cut_s;
     uint8_t* orow = out + ((size_t)bh * QC + row) * KC;
-    const int* ranks = (const int*)smem + 2 * KC + ((KC + 3) / 4);
-    for (int j = tid; j < KC; j += kDynThreads) orow[j] = keep[ranks[j]];
+    for (int r = tid; r < KC; r += kDynThreads) orow[(unsigned)keys[r]] = r < cut ? 1 : 0;
 }
 
 }  // namespace svg
@@ -108,8 +121,10 @@ extern "C" int svg_identify_dynamic_map(const void* qc, const void* kc, const in
                                         int32_t preserve_length, void* stream) {
     if (!qc || !kc || !k_sizes || !out_map || BH <= 0 || QC <= 0 || KC <= 0) return SVG_ERR_BAD_ARG;
     if (KC > 4096) return SVG_ERR_UNSUPPORTED;
-    // LDS: prob[KC] f32, sorted[KC] f32, keep[KC] u8 (padded to 4), ranks[KC] i32
-    const size_t lds = (size_t)KC * 4 * 2 + ((KC + 3) / 4) * 4 + (size_t)KC * 4;
+    // LDS: keys[N2] u64 (N2 = KC rounded up to a power of two) + prob[KC] f32
+    int n2 = 2;
+    while (n2 < KC) n2 <<= 1;
+    const size_t lds = (size_t)n2 * 8 + (size_t)KC * 4;
     const float inv = sqrtf((float)D);  // scores are divided by sqrt(D) like the reference
     dim3 grid(QC, BH);
     hipStream_t st = (hipStream_t)stream;
