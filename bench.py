@@ -62,7 +62,7 @@ def _pmc_traffic(workload: str):
     if workload != "hy720p" or not p.exists():
         return None
     try:
-        return {"bytes": json.loads(p.read_text())["traffic_bytes_per_launch"], "unit": "B/launch", "source": str(p.name)}
+        return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
     except Exception:  # noqa: BLE001
         return None
 
@@ -223,7 +223,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(kern_tf / PEAK_BF16_TFLOPS, 4),
                 "kernel_ms": round(attn_ms, 3),
-                "traffic": _pmc_traffic(a.workload),
+                "traffic": _pmc_traffic(a.workload),          # HBM bytes per launch (PMC), profiles/r01_pmc_traffic.json
+                "traffic_unit": "B/launch",
+                "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
             },
         }
 
