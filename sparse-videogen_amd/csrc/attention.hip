@@ -591,6 +591,7 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
             return SVG_ERR_BAD_ARG;
     }
     if ((int64_t)BH * S * D >= (1ll << 40)) return SVG_ERR_UNSUPPORTED;
+    if ((int64_t)S * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;   // the LDS-DMA requests carry 32-bit byte offsets per head
     hipStream_t st = (hipStream_t)stream;
     // bits 8..11: ablation experiments (timing only, results are wrong): bf16, D = 128, 8 waves, lock-step schedule
     const int abl = (variant >> 8) & 15;
@@ -720,6 +721,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
     if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
     if (KB > kVbMaxKB) return SVG_ERR_UNSUPPORTED;
+    if ((int64_t)Skv * D * 2 >= (1ll << 32) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
