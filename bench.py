@@ -134,8 +134,13 @@ def main():
     flops_call = 4.0 * D * H * pairs
     dense_flops = 4.0 * D * H * S * S
 
-    # heads of this rank (strong scaling: the layer-call is split by heads)
-    my_heads = list(range(rank, H, world))
+    # heads of this rank (strong scaling: the layer-call is split by heads).  The heads are taken in super-groups of
+    # world * n consecutive heads, n per rank, so that the all-gather of one local chunk of n heads lands as ONE contiguous,
+    # naturally ordered slice of the full [H, S, D] output — no reordering copy — and the gather of chunk c overlaps the
+    # attention of chunk c + 1 ("overlappable").
+    from svg.distributed import chunked_head_layout, gather_chunk
+
+    n_chunks, n_per, my_heads = chunked_head_layout(H, rank, world)
     Hl = len(my_heads)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
@@ -147,7 +152,7 @@ def main():
     prof = nat.ProfileDesc(0, F_, P_, 1)
     prof.variant[0] = nat.ProfileVariant(0, 0, V, bb, 0, V, S)
     prof.variant[1] = nat.ProfileVariant(1, 0, V, bb, 0, V, S)
-    gathered = [torch.empty_like(o) for _ in range(world)] if world > 1 else None
+    full = torch.empty(H, S, D, device=dev, dtype=torch.bfloat16) if world > 1 else None   # every rank ends with all heads
 
     ev_a0, ev_a1 = [], []
 
@@ -158,13 +163,19 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_, variant=a.variant, out=o)
+        works = []
+        for c in range(n_chunks):
+            sl = slice(c * n_per, (c + 1) * n_per)
+            nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), vid0=0, num_frame=F_,
+                               frame_size=P_, variant=a.variant, out=o[:, sl])
+            if world > 1:   # RCCL all-gather of this chunk on the communicator's stream, while the next chunk computes
+                works.append(gather_chunk(full, o[0, sl], c, n_per, world))
         e1.record()
         if timed:
             ev_a0.append(e0)
             ev_a1.append(e1)
-        if world > 1:
-            dist.all_gather(gathered, o)
+        for w in works:
+            w.wait()
 
     for _ in range(a.warmup):
         step(False)

@@ -1259,12 +1259,14 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     };
     const int dist = kDma ? (lagging ? 3 : 2) : (lagging ? 3 : 2);   // tile u + dist is requested in N(u)
     if constexpr (kDma) {
-        for (int t = 0; t < dist; ++t) {
+        // (ablation 6 — no DMA inside the loop — fills all four stages here so that the loop computes on finite stale data)
+        const int npro = (ABL == 6) ? NS : dist;
+        for (int t = 0; t < npro; ++t) {
             resolve(t);
             take();
             if (t < nT) dma_issue(t);
         }
-        resolve(dist);   // requested in N(0)
+        resolve(npro);   // requested in N(0)
     } else {
         // tiles 0 .. dist-2 go to LDS here, tile dist-1 stays in the staging registers (written in N(0))
         if (nT > 0) { stage_load(0); stage_store(0); }

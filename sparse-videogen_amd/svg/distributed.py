@@ -56,3 +56,21 @@ def sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_fn
     sl = slice(mine[0], mine[-1] + 1) if mine else slice(0, 0)
     o_local = attn_fn(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(), *[a[:, sl] for a in per_head_args])
     return all_gather_heads(o_local, H, group)
+
+
+def chunked_head_layout(num_heads: int, rank: int, world: int, max_chunks: int = 3):
+    """Head ownership for overlapping the output all-gather with compute: heads are taken in super-groups of world * n
+    consecutive heads, n per rank, so the all-gather of local chunk c (n heads per rank) is the contiguous, naturally ordered
+    slice [c * world * n, (c + 1) * world * n) of the full [H, ...] output.  Returns (n_chunks, n_per_chunk, my_heads)."""
+    assert num_heads % world == 0, f"{num_heads} heads do not split over {world} ranks"
+    local = num_heads // world
+    n_chunks = 1 if world == 1 else max(c for c in range(max_chunks, 0, -1) if local % c == 0)
+    n_per = local // n_chunks
+    mine = [c * world * n_per + rank * n_per + i for c in range(n_chunks) for i in range(n_per)]
+    return n_chunks, n_per, mine
+
+
+def gather_chunk(full: torch.Tensor, o_chunk: torch.Tensor, chunk: int, n_per: int, world: int, group=None, async_op: bool = True):
+    """All-gather local chunk `chunk` ([n_per, S, D] on every rank) into its slice of `full` [H, S, D]; returns the work handle."""
+    dst = full[chunk * world * n_per:(chunk + 1) * world * n_per]
+    return dist.all_gather_into_tensor(dst, o_chunk.contiguous(), group=group, async_op=async_op)

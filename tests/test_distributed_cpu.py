@@ -50,3 +50,50 @@ def test_shard_heads_partition():
 
     assert head_counts(24, 8) == [3] * 8 and head_counts(40, 8) == [5] * 8 and head_counts(24, 5) == [5, 5, 5, 5, 4]
     assert [h for r in range(5) for h in shard_heads(24, r, 5)] == list(range(24))
+
+
+def _worker_chunked(rank, world, port, H, ret):
+    """the bench's N > 1 scheme: per-chunk attention + asynchronous all-gather into contiguous slices of the full output"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import chunked_head_layout, gather_chunk
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, D = 40, 8
+    n_chunks, n_per, mine = chunked_head_layout(H, rank, world)
+    torch.manual_seed(0)
+    q_all = torch.randn(H, S, D)                      # every rank derives the same global tensor, then keeps its heads
+    fn = lambda x: torch.tanh(x) * 2.0                # noqa: E731  stand-in for the per-head attention
+    o = fn(q_all[mine])
+    full = torch.empty(H, S, D)
+    works = [gather_chunk(full, o[c * n_per:(c + 1) * n_per], c, n_per, world) for c in range(n_chunks)]
+    for w in works:
+        w.wait()
+    owners = sorted(h for r in range(world) for h in chunked_head_layout(H, r, world)[2])
+    ret[rank] = bool(torch.equal(full, fn(q_all)) and owners == list(range(H)) and len(mine) == H // world)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [24, 8, 6])   # 24 heads / 2 ranks -> 3 chunks of 4; 8 -> 2 chunks of 2; 6 -> 3 chunks of 1
+def test_chunked_overlapped_gather_gloo(H):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000) + H
+    mp.spawn(_worker_chunked, args=(world, port, H, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_chunked_head_layout_partitions():
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import chunked_head_layout
+
+    for H, world in ((24, 8), (24, 4), (24, 2), (24, 1), (40, 8), (48, 8)):
+        seen = []
+        for r in range(world):
+            n_chunks, n_per, mine = chunked_head_layout(H, r, world)
+            assert n_chunks * n_per == H // world
+            seen += mine
+        assert sorted(seen) == list(range(H))
+    assert chunked_head_layout(24, 3, 8) == (3, 1, [3, 11, 19])
+    assert chunked_head_layout(24, 1, 2) == (3, 4, [4, 5, 6, 7, 12, 13, 14, 15, 20, 21, 22, 23])
