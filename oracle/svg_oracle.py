@@ -10,10 +10,14 @@ Pinning status (see tests/golden/make_golden.py, which imports the reference its
       placement (hy/cog ref fns), torch permute / inverse, weighted_softmax, identify_dynamic_map,
       dynamic_block_sparse_fwd_torch, density_calculation, sparsity_to_width, get_attention_mask (hy/wan/cog) and
       sample_mse (Hunyuan processor method).
-  PARITY UNPINNED (reference code is GPU-only / third-party): flash-kmeans (Triton kernels, svg/kmeans_utils.py
-      :258-554 — restated from the commented torch form :631-635 and the update finalisation :416-421) and the
-      flashinfer variable-block kernel (anchored on the reference's own test, svg/kernels/test/
-      test_sparse_attn_dyn_blk_wan.py:38-133, i.e. dense attention under the repeat-interleaved block mask).
+  pinned at loop level: flash-kmeans — tests/golden/make_golden_kmeans.py runs the reference's own batch_kmeans_Euclid /
+      _euclid_iter / host half of triton_centroid_update_sorted_euclid on CPU with only the two Triton kernel LAUNCHES replaced
+      (svg/kmeans_utils.py:258-554; their bodies are restated here from the Triton source and the commented torch form :631-635).
+  pinned by the reference's own torch references / generators: QK-norm + RoPE prologue (make_golden_prologue.py), BSR masks of
+      the uniform-block ops (make_golden_bsr.py).
+  PARITY UNPINNED (third-party, GPU-only): the Triton kernel BODIES of flash-kmeans and the flashinfer variable-block kernel
+      (anchored on the reference's own test, svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:38-133, i.e. dense attention
+      under the repeat-interleaved block mask).
 """
 from __future__ import annotations
 
@@ -190,7 +194,9 @@ def inverse_permutation(t_perm: torch.Tensor, sorted_indices: torch.Tensor) -> t
 
 
 # ----------------------------------------------------------------------------------------------------------
-# flash-kmeans (PARITY UNPINNED: restated from the commented torch form; see module docstring)
+# flash-kmeans (kernel bodies restated from the Triton source and its commented torch form; the LOOP — finalisation, empty
+# clusters, shift / tol break, return convention — is pinned against the reference's own batch_kmeans_Euclid run on CPU with only
+# the two Triton launches replaced: tests/golden/make_golden_kmeans.py, tests/test_oracle_golden.py)
 # ----------------------------------------------------------------------------------------------------------
 
 

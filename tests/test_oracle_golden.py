@@ -3,6 +3,7 @@
 import hashlib
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import svg_oracle as O
@@ -174,3 +175,27 @@ def test_kmeans_oracle_properties():
         inertia = O.kmeans_distances(x, xsq, cc).min(dim=-1).values.sum()
         assert prev is None or inertia <= prev * 1.001
         prev = inertia
+
+
+# ---- flash-kmeans: loop-level pin (tests/golden/make_golden_kmeans.py runs the reference's own batch_kmeans_Euclid loop,
+#      _euclid_iter and the host half of triton_centroid_update_sorted_euclid; only the two Triton launches are replaced) ----
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_kmeans_loop_equals_reference_loop(tag):
+    import numpy as np
+    from pathlib import Path
+
+    G = np.load(str(Path(__file__).parent / "golden" / "kmeans_loop_golden.npz"))
+    B, N, D, K, iters, dtc = (int(v) for v in G[f"{tag}_meta"])
+    dt = {0: torch.bfloat16, 2: torch.float32}[dtc]
+    x = torch.from_numpy(G[f"{tag}_x"]).to(dt)
+    init = torch.from_numpy(G[f"{tag}_init"]).to(dt)
+    ids, cent, sizes, n_it = O.batch_kmeans_euclid(x, K, max_iters=iters, tol=1e-4, init_centroids=init)
+    assert n_it == int(G[f"{tag}_iters"])
+    assert torch.equal(ids.to(torch.int32), torch.from_numpy(G[f"{tag}_ids"]))
+    assert torch.equal(sizes.to(torch.int32), torch.from_numpy(G[f"{tag}_sizes"]))
+    if dt == torch.float32:   # fp32 centroids keep the accumulation order (the reference kernel uses atomics: unordered)
+        torch.testing.assert_close(cent.float(), torch.from_numpy(G[f"{tag}_centroids"]), rtol=2e-6, atol=2e-6)
+    else:
+        assert torch.equal(cent.float(), torch.from_numpy(G[f"{tag}_centroids"]))
+    if tag == "b":
+        assert (sizes == 0).any(), "the case is built to contain empty clusters (they keep their old centroid)"
