@@ -1186,6 +1186,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;
     constexpr int NP = DB / 2;              // DMA pieces per wave per tensor per tile
+    constexpr bool kPrioM = true;
     constexpr float kDefer = 8.f;
     static_assert(D == 64 || D == 128, "head dim");
     static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1, "ping-pong body: 32 rows per wave, one tile per stage");
@@ -1514,9 +1515,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         tick(std::integral_constant<int, 2>{});
         pp_barrier();
         tick(std::integral_constant<int, 3>{});
-        __builtin_amdgcn_s_setprio(1);   // the matrix phase wins the VALU / MFMA issue arbitration against the partner's vector phase
+        if (kPrioM) __builtin_amdgcn_s_setprio(1);   // the matrix phase wins the VALU / MFMA issue arbitration against the partner's vector phase
         matrix_phase(t, has_next_c);
-        __builtin_amdgcn_s_setprio(0);
+        if (kPrioM) __builtin_amdgcn_s_setprio(0);
     };
     for (int t = 0; t + 1 < nT; ++t) tile(t, std::true_type{});
     if (nT > 0) tile(nT - 1, std::false_type{});
