@@ -290,6 +290,10 @@ int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, c
  * out[64] = KV tiles of that workgroup, out[65] = ticks of its tile loop. */
 int svg_debug_pp_trace(uint64_t* out104);
 
+/* Launch timeline of the same traced kernel (variant 128 | 64): for each of the first n_workgroups (<= 16384) workgroups
+ * out[6 * b + ..] = [s_memtime at entry, at the start of the tile loop, at its end, after the last store of O, HW_ID, XCC_ID]. */
+int svg_debug_wg_trace(uint64_t* out, int32_t n_workgroups);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,27 +59,30 @@ struct BandPolicy {
     }
 
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
-        // XCD-aware work mapping: consecutive dispatch ids round-robin over the 8 XCDs; give every XCD 32
-        // neighbouring q-tiles of the same 256-tile window so their KV windows overlap in that XCD's L2 while
-        // the whole chip stays within one or two heads (KV working set fits the 256 MiB Infinity Cache).
-        const int total = p.nqt * p.BH;
-        const int b = blockIdx.x;
-        const int full = (total / (kNumXCD * 32)) * (kNumXCD * 32);
-        int w = b;
-        if (b < full) {
-            const int xcd = b % kNumXCD, s = b / kNumXCD;
-            w = (s / 32) * (kNumXCD * 32) + xcd * 32 + (s % 32);
-        }
-        // longest-processing-time-first: the few q-tiles that contain text rows visit every KV tile (4x the work of a
-        // band tile at Hunyuan 720p); run them first so they do not form the tail of the launch.
+        // Work mapping.  The hardware hands dispatch id b to XCD b % 8 and each XCD schedules its share on its own 32 CUs, so the
+        // load has to be balanced across XCDs by construction.
+        //  * longest-processing-time-first: the few q-tiles that contain text rows visit every KV tile, all of them on the
+        //    masked path (~11x the time of a band tile at Hunyuan 720p).  They take the first dispatch ids, un-swizzled:
+        //    first so that they do not form the tail of the launch, round-robin so that every XCD gets its share (with the
+        //    swizzle below applied to them they all landed on XCD 0, which then ran 16 % longer than the other seven).
+        //  * the remaining q-tiles: every XCD gets 32 neighbouring q-tiles of the same 256-tile window, so their KV windows
+        //    overlap in that XCD's L2 while the whole chip stays within one or two heads (KV working set fits the 256 MiB
+        //    Infinity Cache).
         int qt;
         const int nh = p.BH * p.n_heavy;
-        if (w < nh) {
-            c.head = w / p.n_heavy;
-            qt = p.heavy_lo + (w - c.head * p.n_heavy);
+        const int b = blockIdx.x;
+        if (b < nh) {
+            c.head = b / p.n_heavy;
+            qt = p.heavy_lo + (b - c.head * p.n_heavy);
         } else {
+            const int b2 = b - nh;
+            const int full = ((p.nqt * p.BH - nh) / (kNumXCD * 32)) * (kNumXCD * 32);
+            int w2 = b2;
+            if (b2 < full) {
+                const int xcd = b2 % kNumXCD, s = b2 / kNumXCD;
+                w2 = (s / 32) * (kNumXCD * 32) + xcd * 32 + (s % 32);
+            }
             const int nl = p.nqt - p.n_heavy;
-            const int w2 = w - nh;
             c.head = w2 / nl;
             const int r = w2 - c.head * nl;
             qt = r < p.heavy_lo ? r : r + p.n_heavy;
@@ -568,6 +571,16 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
 }  // namespace svg
 
 using namespace svg;
+
+extern "C" int svg_debug_wg_trace(uint64_t* out, int n_workgroups) {
+    if (!out || n_workgroups < 0 || n_workgroups > kWgTraceMax) return SVG_ERR_BAD_ARG;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_trace), (size_t)n_workgroups * 6 * sizeof(uint64_t));
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return SVG_ERR_LAUNCH;
+    }
+    return SVG_OK;
+}
 
 extern "C" int svg_debug_pp_trace(uint64_t* out104) {
     if (!out104) return SVG_ERR_BAD_ARG;

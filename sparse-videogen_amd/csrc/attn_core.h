@@ -795,6 +795,10 @@ constexpr int attn_pp_lds_bytes() {
 // [LK work, barrier wait, QK work, wait, SV work, wait, PV work, wait] — of workgroup blockIdx.x == kPpTraceBlock
 __device__ unsigned long long g_pp_trace[8 * 8 + 8 + 8 * 4];
 constexpr int kPpTraceBlock = 1000;
+// Launch timeline of the traced two-phase kernel: per workgroup [s_memtime at entry, at loop start, at loop end, at exit, HW_ID, XCC_ID]
+// (wave 0), read with svg_debug_wg_trace; tools/wg_timeline.py turns it into per-CU occupancy and launch gaps.
+constexpr int kWgTraceMax = 16384;
+__device__ unsigned long long g_wg_trace[kWgTraceMax * 6];
 
 // ABL > 0 (trace kernels only, results wrong by construction): 1 no V^T reads, 2 no row maximum / decision, 3 no
 // probabilities of keys 0..31, 4 no probabilities of keys 32..63, 5 no K reads, 6 no DMA, 7 no mask evaluation
@@ -1191,6 +1195,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     static_assert(D == 64 || D == 128, "head dim");
     static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1, "ping-pong body: 32 rows per wave, one tile per stage");
 
+    unsigned long long wg_t0 = 0;
+    if constexpr (TRACE) wg_t0 = __builtin_amdgcn_s_memtime();
     typename P::Ctx ctx;
     if (!P::init(prm, ctx, policy_lds)) return;
 
@@ -1532,6 +1538,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         }
     }
 
+    unsigned long long wg_t2 = 0;
+    if constexpr (TRACE) wg_t2 = __builtin_amdgcn_s_memtime();
     // ---------------- epilogue (same as attn_body) ----------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if constexpr (P::kPartialOut) {
@@ -1566,6 +1574,15 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             const int rr = i * kRowsPerPass + sub;
             const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
             if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+        }
+        if constexpr (TRACE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave == 0 && lane == 0 && blockIdx.x < (unsigned)kWgTraceMax) {
+                unsigned long long* w = g_wg_trace + (size_t)blockIdx.x * 6;
+                w[0] = wg_t0, w[1] = tr_first, w[2] = wg_t2, w[3] = __builtin_amdgcn_s_memtime();
+                w[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+                w[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+            }
         }
     }
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "svg_last_hip_error": (C.c_int, []),
     "svg_build_info": (C.c_char_p, []),
     "svg_debug_pp_trace": (C.c_int, [_VP]),
+    "svg_debug_wg_trace": (C.c_int, [_VP, _I32]),
     "svg_rms_norm_forward": (C.c_int, [_VP, _VP, C.c_int64, _I32, _I32, C.c_float, _VP]),
     "svg_layer_norm_forward": (C.c_int, [_VP, _VP, _VP, C.c_int64, _I32, _I32, _VP]),
     "svg_apply_qk_rope_inplace_cossin": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
@@ -367,6 +368,17 @@ def debug_pp_trace():
     v = list(buf)
     return {"waves": [v[8 * w: 8 * w + 8] for w in range(8)], "sv": [v[72 + 4 * w: 72 + 4 * w + 3] for w in range(8)],
             "tiles": v[64], "loop_ticks": v[65]}
+
+
+def debug_wg_trace(n_workgroups: int):
+    """Launch timeline of the traced two-phase kernel (svg_debug_wg_trace): int64 array [n, 6] =
+    [entry, loop start, loop end, exit (s_memtime ticks), HW_ID, XCC_ID] per workgroup."""
+    import numpy as np
+
+    buf = np.zeros((n_workgroups, 6), dtype=np.uint64)
+    torch.cuda.synchronize()
+    _check(load().svg_debug_wg_trace(C.c_void_p(buf.ctypes.data), n_workgroups), "svg_debug_wg_trace")
+    return buf
 
 
 # ---- pre-attention prologue (svg/kernels/csrc/ops.h of the reference) ----
