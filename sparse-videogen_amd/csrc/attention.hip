@@ -225,6 +225,23 @@ struct BandPolicy {
         // bitwise on purpose: branch-free, one v_cndmask per element in the caller
         return ((rq & rk) & (in_band | colf | rowf)) | ((!rq & !rk) & (k < p.S));
     }
+    // The same predicate as two key intervals of one query row, [a0, a0 + alen) u [b0, b0 + blen) (unsigned lengths, 0 = empty):
+    // the two-phase body keeps them per lane across the tile loop, so a masked element costs 2 x (add, compare) + or + select.
+    //   real row, not a full row:  band n [0, real)  u  full columns n [0, real)
+    //   full row (text):           [0, real)
+    //   row behind real_len:       [real_len, S)
+    static __device__ __forceinline__ void row_intervals(const Params& p, const Ctx&, int q, int& a0, unsigned& alen, int& b0,
+                                                         unsigned& blen) {
+        const int real = p.real_len;
+        const bool rq = q < real;
+        const bool rowf = (unsigned)(q - p.rf_lo) < (unsigned)(p.rf_hi - p.rf_lo);
+        const int band_lo = max(q - p.band + 1, 0), band_hi = min(q + p.band, real);
+        const int lo = rq ? (rowf ? 0 : band_lo) : real;
+        const int hi = rq ? (rowf ? real : band_hi) : p.S;
+        a0 = lo, alen = (unsigned)max(hi - lo, 0);
+        const int ch = min(p.cf_hi, real);
+        b0 = p.cf_lo, blen = (rq && !rowf) ? (unsigned)max(ch - p.cf_lo, 0) : 0u;
+    }
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
 };
 
@@ -421,6 +438,10 @@ struct VarblockPolicy {
         return (k0 + kBN <= c.total) ? TILE_FULL : TILE_PARTIAL;
     }
     static __device__ __forceinline__ bool allowed(const Params&, const Ctx& c, int, int k) { return k < c.total; }
+    static __device__ __forceinline__ void row_intervals(const Params&, const Ctx& c, int, int& a0, unsigned& alen, int& b0,
+                                                         unsigned& blen) {
+        a0 = 0, alen = (unsigned)c.total, b0 = 0, blen = 0u;
+    }
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
 };
 

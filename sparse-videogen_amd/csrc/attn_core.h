@@ -70,6 +70,7 @@ __device__ __forceinline__ i16x4 lds_read_tr16(const char* p) {
 //   int  tile_key0(ctx, t)                                       logical index of the first key of tile t
 //   int  classify(prm, ctx, tile_key0, wave_row0)                wave-uniform TileClass
 //   bool allowed(prm, ctx, q_logical, k_logical)                 element predicate for PARTIAL tiles
+//   void row_intervals(prm, ctx, q_logical, a0, alen, b0, blen)  the same predicate as two key intervals of a row (two-phase body)
 //   float score_fixup(float raw)                                 (profiler: dtype rounding emulation)
 //   epilogue: store(prm, ctx, ...) handled here through P::kPartialOut
 template <typename T, int D, int NW, typename P>
@@ -771,6 +772,17 @@ __device__ __forceinline__ void attn_body_pipe(const typename P::Params& prm, ch
 // Online softmax uses a deferred maximum: while no row's tile maximum exceeds the running maximum by more than 2^kDefer
 // the old maximum is kept (p <= 2^kDefer, harmless in bf16 relative precision) and O is not rescaled.
 // =====================================================================================================================
+// v_max3_f32 / v_max_f32 without the input canonicalisation hipcc attaches to fmaxf()
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void pp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1227,19 +1239,40 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // Physical rows are resolved one vector phase before they are requested (nnext -> nphys): for the variable-block policy
     // the resolve is itself a global index load, and this keeps its latency off the critical path.
     int nphys = 0, nnext = 0;
-    auto resolve = [&](int t) {  // row of tile t into nnext (tiles are resolved in increasing order: the cursor only moves forward)
-        nnext = (t < nT) ? P::kv_phys(prm, ctx, cur, t, krow) : 0;
+    // (`guard` = false in the steady-state loop, where every tile index touched by a phase is known to be < nT: the "is there
+    //  such a tile" tests and their scalar mask bookkeeping cost ~20 instructions per tile, each an issue slot of the wave)
+    auto resolve = [&](int t, auto guard_c) {  // row of tile t into nnext (tiles are resolved in increasing order: the cursor only moves forward)
+        if constexpr (decltype(guard_c)::value) nnext = (t < nT) ? P::kv_phys(prm, ctx, cur, t, krow) : 0;
+        else nnext = P::kv_phys(prm, ctx, cur, t, krow);
     };
+    constexpr std::true_type kGuarded{};
     auto take = [&]() { nphys = nnext; };
-    auto dma_piece = [&](int t, int j) {
-        const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
-        const unsigned vo = (unsigned)nphys * (unsigned)(2 * D) + col_v + (unsigned)(j * 64);
-        lds_dma16(st + j * (kBN * 64), vo ^ k_xor, kb);
-        lds_dma16(st + j * (kBN * 64) + kImg, vo, vb);
+    // One piece = the K and the V request of d-block dma_db0 + j.  (One asm block per pair: the swizzle XOR of the K source
+    // address doubles as the wait state M0 needs after an SALU write and the V request reuses M0 + kImg: 6 issue slots per
+    // tile less than two independent lds_dma16 calls.)
+    auto dma_piece = [&](int t, auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        static_assert(2 * D >= 256 || NP == 1, "row offset | column offset");
+        const unsigned st = __builtin_amdgcn_readfirstlane(lds_piece + (unsigned)((t % NS) * kStage) + j * (kBN * 64));
+        const unsigned vo = ((unsigned)nphys * (unsigned)(2 * D)) | col_v;
+        unsigned kvo;
+        const unsigned kx = k_xor;   // (locals: asm operands of a generic lambda do not capture implicitly)
+        // (the d-block offset goes into the scalar base, loop-invariant — an instruction offset would also move the LDS address)
+        const char* const kbp = (const char*)kb + j * 64;
+        const char* const vbp = (const char*)vb + j * 64;
+        asm volatile("s_mov_b32 m0, %1\n\t"
+                     "v_xor_b32 %0, %2, %3\n\t"
+                     "global_load_lds_dwordx4 %0, %4\n\t"
+                     "s_add_u32 m0, m0, %6\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %5"
+                     : "=&v"(kvo)
+                     : "s"(st), "v"(vo), "v"(kx), "s"(kbp), "s"(vbp), "n"(kImg)
+                     : "memory", "scc");
     };
     auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
-#pragma unroll
-        for (int j = 0; j < NP; ++j) dma_piece(t, j);
+        dma_piece(t, std::integral_constant<int, 0>{});
+        if constexpr (NP > 1) dma_piece(t, std::integral_constant<int, 1>{});
     };
     // Register staging (kDma = false, kept for comparison): loads for tile w are issued in N(w - dist) and written in the
     // following vector phase: slot 2w-1 (leading) / 2w-2 (lagging), after the last read of the stage's previous tenant
@@ -1247,7 +1280,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // ds_write_b128 traffic of the vector phase collides with the operand streaming of the partner's matrix phase.
     u32x4 kreg[NP], vreg[NP];
     auto stage_load = [&](int t) {
-        resolve(t);
+        resolve(t, kGuarded);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const unsigned vo = (unsigned)nnext * (unsigned)(2 * D) + col_v + (unsigned)(j * 64);
@@ -1269,11 +1302,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         // (ablation 6 — no DMA inside the loop — fills all four stages here so that the loop computes on finite stale data)
         const int npro = (ABL == 6) ? NS : dist;
         for (int t = 0; t < npro; ++t) {
-            resolve(t);
+            resolve(t, kGuarded);
             take();
             if (t < nT) dma_issue(t);
         }
-        resolve(npro);   // requested in N(0)
+        resolve(npro, kGuarded);   // requested in N(0)
     } else {
         // tiles 0 .. dist-2 go to LDS here, tile dist-1 stays in the staging registers (written in N(0))
         if (nT > 0) { stage_load(0); stage_store(0); }
@@ -1297,6 +1330,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const int k_lane1 = k_lane0 ^ 32;                               // odd k-steps
     const int vi = lane & 15;
     const int v_lane_off = kImg + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
+
+    int m_a0, m_b0;
+    unsigned m_alen, m_blen;
+    P::row_intervals(prm, ctx, q_log, m_a0, m_alen, m_b0, m_blen);
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 acc_o[DB];
@@ -1359,10 +1396,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     };
     // staging half of a vector phase: resolve the rows of tile t+dist+1 (index loads first: they are older than the DMA
     // requests below, so the counted wait at the end retires them too), request tile t+dist, wait for tile t+dist-1
-    auto stage_resolve_next = [&](int t) {
+    auto stage_resolve_next = [&](int t, auto guard_c) {
         if constexpr (kDma) {
             take();
-            resolve(t + dist + 1);
+            resolve(t + dist + 1, guard_c);
         }
     };
     auto stage_request = [&](int t) {
@@ -1378,10 +1415,12 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         }
     };
     // vector phase of tile t on sc: mask, maximum, (rare) rescale, probabilities of keys 0..15, DMA requests, DMA wait
-    auto vector_phase = [&](int t) {
-        stage_resolve_next(t);
+    auto vector_phase = [&](int t, auto guard_c) {
+        constexpr bool guard = decltype(guard_c)::value;
+        stage_resolve_next(t, guard_c);
         constexpr bool kSpread = kDma && ABL != 6;   // requests spread over the phase instead of back to back at its end
-        if (kSpread && t + dist < nT) dma_piece(t + dist, 0);
+        const bool more = !guard || t + dist < nT;
+        if (kSpread && more) dma_piece(t + dist, std::integral_constant<int, 0>{});
         const int tk0 = P::tile_key0(ctx, t);
         const int cls = P::classify(prm, ctx, tk0, wave * 32);
         if constexpr (P::kFixup) {
@@ -1391,26 +1430,27 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 for (int r = 0; r < 16; ++r) sc[b][r] = P::score_fixup(prm, sc[b][r]);
         }
         if (ABL != 7 && cls != TILE_FULL) {
-            int qv = q_log, kv0 = tk0 + 4 * g;   // opaque copies: keeps LICM from hoisting 32 per-element terms out of the loop
-            asm volatile("" : "+v"(qv), "+v"(kv0));
+            // the row's allowed keys are [m_a0, +m_alen) u [m_b0, +m_blen) (per lane, loop-invariant)
+            int ka = tk0 + 4 * g - m_a0, kb_ = tk0 + 4 * g - m_b0;
+            asm volatile("" : "+v"(ka), "+v"(kb_));   // opaque: keeps LICM from hoisting 64 per-element terms out of the loop
             const bool part = (cls == TILE_PARTIAL);  // a tile this wave does not need at all is processed fully masked
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = 32 * b + (r & 3) + 8 * (r >> 2);
-                    sc[b][r] = (part & P::allowed(prm, ctx, qv, kv0 + key)) ? sc[b][r] : -INFINITY;
+                    const bool ok = ((unsigned)(ka + key) < m_alen) | ((unsigned)(kb_ + key) < m_blen);
+                    sc[b][r] = (part & ok) ? sc[b][r] : -INFINITY;
                 }
         }
         float mx = sc[0][0];
         if constexpr (ABL != 2) {
+            // (asm: fmaxf() makes hipcc canonicalise every input with a v_max_f32 x, x — 8 extra issue slots per tile)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
-            const unsigned u = __builtin_bit_cast(unsigned, mx);
+            for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+            const unsigned u = __builtin_bit_cast(unsigned, vmax2(mx, sc[1][15]));
             const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
-            mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
+            mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
         }
         m_use = (m_run == -INFINITY) ? 0.f : m_run;
         if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
@@ -1430,7 +1470,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 }
         }
         if constexpr (kSpread && NP > 1) {
-            if (t + dist < nT) dma_piece(t + dist, 1);
+            if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
         }
         psum = 0.f;
 #pragma unroll
@@ -1439,7 +1479,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
         }
         if constexpr (kSpread) {
-            if (t + dist < nT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             stage_request(t);
@@ -1449,15 +1489,26 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // One step = { LDS read of the operand kPF steps ahead; one MFMA; a 7-instruction slice of the probabilities of the
     // next 16-key step }; steps are fenced with sched_barrier so the reads stay kPF MFMAs (~kPF x 32 cycles) ahead of their
     // use — left alone, hipcc puts every read directly in front of its MFMA and the phase runs at LDS latency.
+    // (Requesting the first kPF operands — all V(t), visible since the barrier in front of M(t-1) — at the end of the vector phase,
+    //  in front of the barrier, so that the matrix phase opens with an MFMA, measured 1.1 % slower: the 16 reads lengthen the
+    //  vector phase by more than the matrix phase gains.)
+    constexpr int kPF = 8;
+    constexpr int NPV = 4 * DB;
+    V8 ring[kPF + 1];
+    auto matrix_prefetch = [&](int t) {
+        const char* stv = smem + (t % NS) * kStage;
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) {
+            if constexpr (ABL == 1) ring[i % (kPF + 1)] = qf[i % KS];
+            else ring[i % (kPF + 1)] = vfrag(stv, i / DB, i % DB);
+        }
+    };
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
-        constexpr int kPF = 8;
-        constexpr int NPV = 4 * DB;
         constexpr int NALL = has_next ? NPV + 2 * KS : NPV;
         const char* stv = smem + (t % NS) * kStage;
         const char* stk = smem + ((t + 1) % NS) * kStage;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        V8 ring[kPF + 1];
         auto fetch = [&](int i) {  // operand of step i
             if (i >= NALL) return;
             if (i < NPV) {
@@ -1469,8 +1520,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 else ring[i % (kPF + 1)] = kfrag(stk, j & 1, j >> 1);
             }
         };
-#pragma unroll
-        for (int i = 0; i < kPF; ++i) fetch(i);
+        matrix_prefetch(t);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NALL; ++i) {
@@ -1493,7 +1543,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     if (idle) {
         for (int t = 0; t < nT; ++t) {
             pp_barrier();
-            stage_resolve_next(t);
+            stage_resolve_next(t, kGuarded);
             stage_request(t);
             pp_barrier();
         }
@@ -1513,11 +1563,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     }
     // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc hoist the common VALU work above
     //  the branch and keep two register sets for O with 32 copies per tile)
-    auto tile = [&](int t, auto has_next_c) {
+    auto tile = [&](int t, auto has_next_c, auto guard_c) {
         tick(std::integral_constant<int, 0>{});
         pp_barrier();
         tick(std::integral_constant<int, 1>{});
-        vector_phase(t);
+        vector_phase(t, guard_c);
         tick(std::integral_constant<int, 2>{});
         pp_barrier();
         tick(std::integral_constant<int, 3>{});
@@ -1525,8 +1575,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         matrix_phase(t, has_next_c);
         if (kPrioM) __builtin_amdgcn_s_setprio(0);
     };
-    for (int t = 0; t + 1 < nT; ++t) tile(t, std::true_type{});
-    if (nT > 0) tile(nT - 1, std::false_type{});
+    // steady state: every tile a phase of tile t touches (t + dist + 1 at most) exists; then the guarded tail; then the peeled last tile
+    int t = 0;
+    for (const int n_main = nT - dist - 1; t < n_main; ++t) tile(t, std::true_type{}, std::false_type{});
+    for (; t + 1 < nT; ++t) tile(t, std::true_type{}, kGuarded);
+    if (nT > 0) tile(nT - 1, std::false_type{}, kGuarded);
     // the leading waves wait until the lagging waves have read V of the last tile: the epilogue reuses the stages
     pp_barrier();
     if (!lagging) pp_barrier();

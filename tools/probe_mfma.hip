@@ -106,6 +106,63 @@ __global__ __launch_bounds__(512) void k_ring(float* out, unsigned long long* ti
     if (lane == 0) ticks[wave] = t1 - t0;
 }
 
+// the intra-wave pipelined regime: BOTH waves of every SIMD run { ring fetch, MFMA, NV VALU (every third one a v_exp) } per step
+template <int NV>
+__global__ __launch_bounds__(512) void k_both(float* out, unsigned long long* ticks, int nwaves) {
+    __shared__ __attribute__((aligned(16))) short lds[32768];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 32768; i += blockDim.x) lds[i] = (short)(i * 7);
+    __syncthreads();
+    if (wave >= nwaves) return;
+    float a0 = threadIdx.x * 0.001f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    typedef short i16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 B = {1, 1, 2, 2, 3, 3, 4, 4};
+    f32x16 c[4] = {{0}, {0}, {0}, {0}};
+    const char* p = (const char*)lds + lane * 8;
+    constexpr int PF = 8;
+    bf16x8 ring[PF + 1];
+    auto fetch = [&](int i) {
+        const int off = (i & 31) * 1024;
+        i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p + off));
+        i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(p + off + 512));
+        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        ring[i % (PF + 1)] = __builtin_bit_cast(bf16x8, both);
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 64; ++it) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fetch(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            if (i + PF < 36) fetch(i + PF);
+            c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i % (PF + 1)], B, c[i & 3], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v % 3 == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(a1));
+                else if (v % 3 == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a0) : "v"(0.999f), "v"(0.001f));
+                else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a2) : "v"(0.001f));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3] + a0 + a1 + a2 + a3;
+    if (lane == 0) ticks[wave] = t1 - t0;
+}
+
+template <int NV>
+void run_both(float* out, unsigned long long* ticks) {
+    for (int nw = 4; nw <= 8; nw += 4) {
+        hipLaunchKernelGGL((k_both<NV>), dim3(1), dim3(512), 0, 0, out, ticks, nw);
+        hipDeviceSynchronize();
+        unsigned long long h[8];
+        hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
+        printf("both-waves regime, %d VALU per step, %d waves per SIMD: %.1f ticks per MFMA per wave (wave 0), %.1f (wave %d)\n", NV, nw / 4,
+               h[0] / (64.0 * 36), h[nw - 1] / (64.0 * 36), nw - 1);
+    }
+}
+
 template <int VALU, bool C>
 void run_ring(const char* name, float* out, unsigned long long* ticks) {
     for (int partner = 0; partner < 2; ++partner) {
@@ -140,5 +197,9 @@ int main() {
     run_ring<0, false>("ring: MFMA + 2 tr reads 8 ahead", out, ticks);
     run_ring<1, false>("ring: + 4 VALU", out, ticks);
     run_ring<1, true>("ring: + 4 VALU, partner also reads LDS", out, ticks);
+    run_both<0>(out, ticks);
+    run_both<4>(out, ticks);
+    run_both<6>(out, ticks);
+    run_both<8>(out, ticks);
     return 0;
 }
