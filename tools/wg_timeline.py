@@ -34,7 +34,7 @@ nat.band_attention(q, k, v, mask, variant=128 | 64, **kw)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-nwg = H * ((S + 255) // 256)
+nwg = H * (-(-V // 256) + -(-L // 256) + -(-(ctx - L) // 256))   # q-tiles never straddle the video | prompt | pad boundaries
 tr = nat.debug_wg_trace(min(nwg, 16384)).astype(np.int64)
 t0, t1, t2, t3, hw, xcc = (tr[:, i] for i in range(6))
 ok = t3 > 0
