@@ -130,6 +130,31 @@ def test_band_attention(nat, model, D, dtype, variant):
     check_attn(o, ref, dtype)
 
 
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 0), (64, torch.float16, 0), (128, torch.float16, 4096)])
+def test_band_attention_random_mask_family(nat, seed, D, dtype, variant):
+    """Random members of the svg_band_mask_t family (include/svg_attn.h) against the dense restatement of the predicate:
+    full rows / full columns anywhere (also empty, also overlapping real_len, also at q-tile boundaries), real_len <= S, bands
+    from 1 to S + 1.  Guards the per-row interval form of the mask and the q-tile row regions of the two-phase kernel."""
+    import random
+
+    rng = random.Random(1000 + seed)
+    S = rng.choice([300, 513, 777, 1024, 1301])
+    real = rng.choice([S, S, rng.randint(1, S), max(1, S - rng.randint(0, 300))])
+    band = rng.choice([1, rng.randint(2, 200), rng.randint(100, S), S + 1])
+    lo = min(S, rng.choice([0, 256, rng.randint(0, S - 1)]))
+    cf = (lo, min(S, lo + rng.choice([0, 1, 64, rng.randint(1, 300)])))
+    lo = min(S, rng.choice([0, 256, 512, rng.randint(0, S - 1)]))
+    rf = (lo, min(S, lo + rng.choice([0, 1, 30, 256, rng.randint(1, 400)])))
+    prm = dict(real_len=real, band=band, colfull_lo=cf[0], colfull_hi=cf[1], rowfull_lo=rf[0], rowfull_hi=rf[1])
+    torch.manual_seed(seed)
+    H = 2
+    q, k, v = (torch.randn(1, H, S, D).to(dtype) for _ in range(3))
+    o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), variant=variant)
+    ref = O.masked_attention(q, k, v, O.band_mask(S, **prm))
+    check_attn(o, ref, dtype)
+
+
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])
 def test_band_attention_fused_placement(nat, model):
     """head_perm_flag path == placement -> attention -> inverse placement of the reference (attention.py:514-520)."""
