@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *(const V8*)(xrow + ks * 16);
     }
-    const float my_xsq = xsq[(size_t)b * N + (n < N ? n : 0)];
+    (void)xsq;   // |x|^2 does not change the argmin; the parameter stays for the callers that keep the distance form
 
     int srow[NCH], scol[NCH], k_dst[NCH];
 #pragma unroll
@@ -107,9 +107,9 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
             const int c = t * kBN + srow[i];
             creg[i] = *(const u32x4*)(cb + (size_t)(c < K ? c : 0) * D + scol[i] * 8);
         }
-        if (tid < kBN) {
+        if (tid < kBN) {   // -|c|^2 / 2 (the accumulator's start value, see below); centroids behind K can never win
             const int c = t * kBN + tid;
-            sreg = csqb[c < K ? c : 0];
+            sreg = c < K ? -0.5f * csqb[c] : -INFINITY;
         }
     };
     auto write = [&](int buf) {
@@ -127,16 +127,24 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     __syncthreads();
 
     const int ksw0 = (D == 128) ? (ql & 15) : ((ql >> 1) & 7);
-    float best = 3.4e38f;
+    // argmin_c |x - c|^2 = argmax_c (x.c - |c|^2 / 2): the accumulators start at -|c|^2 / 2, so an element of the epilogue is a
+    // compare and two selects (the distance form — fma, clamp, bounds test, compare, two selects — made this kernel VALU-bound:
+    // 192 VALU against 16 MFMAs per tile).  Ties keep the lowest index, like argmin.
+    float best = -INFINITY;
     int best_idx = 0;
     for (int t = 0; t < nT; ++t) {
         const int buf = t & 1;
         const char* kbuf = smem + buf * kStage;
+        const float* h_t = (const float*)(kbuf + L::kKBytes);
         f32x16 s[2];
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[bb][r] = 0.f;
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 h4 = *(const f32x4*)(h_t + 32 * bb + 8 * rq + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[bb][rq * 4 + j] = h4[j];
+            }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cch = ((2 * ks + g) ^ ksw0) << 4;
@@ -146,22 +154,20 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
                 s[bb] = E::mfma(a, xf[ks], s[bb]);
             }
         }
-        const float* csq_t = (const float*)(kbuf + L::kKBytes);
+        float tb = s[0][0];
+        int ti = 4 * g;
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 cs4 = *(const f32x4*)(csq_t + 32 * bb + 8 * rq + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = t * kBN + 32 * bb + 8 * rq + 4 * g + j;
-                    float dist = my_xsq + cs4[j] - 2.0f * s[bb][rq * 4 + j];
-                    dist = fmaxf(dist, 0.f);
-                    const bool upd = (c < K) & (dist < best);
-                    best = upd ? dist : best;
-                    best_idx = upd ? c : best_idx;
-                }
+            for (int r = (bb == 0 ? 1 : 0); r < 16; ++r) {
+                const int c = 32 * bb + 8 * (r >> 2) + (r & 3);   // + 4 g: tile-local centroid index, ascending in (bb, r)
+                const bool upd = s[bb][r] > tb;
+                tb = upd ? s[bb][r] : tb;
+                ti = upd ? c + 4 * g : ti;
             }
+        const bool upd = tb > best;
+        best = upd ? tb : best;
+        best_idx = upd ? t * kBN + ti : best_idx;
         if (t + 1 < nT) write(buf ^ 1);
         if (t + 2 < nT) issue(t + 2);
         __syncthreads();
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     // the two lanes of a point cover disjoint centroid subsets: merge, lowest index wins ties
     const float ob = __shfl_xor(best, 32);
     const int oi = __shfl_xor(best_idx, 32);
-    if (ob < best || (ob == best && oi < best_idx)) best = ob, best_idx = oi;
+    if (ob > best || (ob == best && oi < best_idx)) best = ob, best_idx = oi;
     if (g == 0 && n < N) labels[(size_t)b * N + n] = best_idx;
 }
 
