@@ -4,10 +4,12 @@
 // profiling masks of get_attention_mask (hyvideo/utils.py:47-93, wan/utils.py:63-110, cog/utils.py:61-88).
 //
 // The reference materialises two [10000, S] fp32 masks (4.8 GB each) and runs three full softmaxes in torch.
-// Here the masks are analytic predicates and the three variants are three workgroup roles of ONE launch that
-// share attn_core.h: grid = (kv_chunks, BH, 3); every workgroup streams its chunk of K/V once (split-KV), emits
-// un-normalised fp32 partials (O, m, l) per sampled row, and a small second kernel merges the chunks, normalises
-// and reduces the MSE.  K/V of a head are therefore read once from HBM and twice more from L2/MALL.
+// Here the masks are analytic predicates and the three variants are three wave roles of ONE workgroup that shares
+// attn_core.h: grid = (kv_chunks, BH); waves 0-1 compute the golden rows, waves 2-3 the rows under mask 1, waves 4-5 under
+// mask 0 (waves 6-7 only help staging) on the SAME staged K/V tiles, so a chunk of K/V is read and staged once (split-KV);
+// every role emits un-normalised fp32 partials (O, m, l) per sampled row, and a small second kernel merges the chunks,
+// normalises and reduces the MSE.  (The first version ran the roles as three workgroups, grid.z = 3: K/V staged three times,
+// 1.26 ms per call at Hunyuan 720p.)
 #include "attn_core.h"
 
 namespace svg {
@@ -21,8 +23,9 @@ struct ProfVariant {
     int text_lo, text_hi;  // rows / cols in [text_lo, text_hi) are all-ones (empty when lo >= hi)
 };
 
-constexpr int kProfNW = 4;      // waves per workgroup (rows 64.. of the 128-row tile simply do not exist)
+constexpr int kProfNW = 8;      // waves per workgroup: 3 roles x 2 waves x 32 sampled rows, the last two waves have no rows
 constexpr int kProfMaxRows = 64;
+constexpr int kProfRoleRows = 3 * kProfMaxRows;   // workgroup rows [64 v, 64 v + 64) belong to role v
 
 template <typename T, int D>
 struct ProfilePolicy {
@@ -75,15 +78,18 @@ struct ProfilePolicy {
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
         c.chunk = blockIdx.x;
         c.head = blockIdx.y;
-        c.variant = blockIdx.z;
+        // two waves per role; a wave lives on SIMD (wave % 4): the golden rows (waves 0-1) and the token-major mask (waves 2-3, the
+        // expensive predicate) get a SIMD each, the frame-major mask (waves 4-5, skips most tiles) shares with the golden waves
+        const int role = (int)(threadIdx.x >> 7);
+        c.variant = role == 0 ? 0 : (role == 1 ? 2 : 1);
         const int ntiles = (p.S + kBN - 1) / kBN;
         c.t0 = c.chunk * p.tiles_per_chunk;
         c.nT = max(0, min(p.tiles_per_chunk, ntiles - c.t0));
         c.pv = p.var[c.variant == 2 ? 1 : 0];
         // this lane's query row (rows >= R do not exist) in the coordinates of the variant's mask
         const int row = (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
-        const bool have = row < p.R;
-        const int q = have ? (int)p.rows[row] : 0;
+        const bool have = exists(p, row);
+        const int q = have ? (int)p.rows[row & (kProfMaxRows - 1)] : 0;
         c.qx = coord(p, c.pv, q) - c.pv.origin;
         c.qtext = have && ((unsigned)(q - c.pv.text_lo) < (unsigned)(c.pv.text_hi - c.pv.text_lo));
         const int blk = c.qx >> 7;
@@ -102,8 +108,12 @@ struct ProfilePolicy {
     static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
     static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
 
+    // workgroup row -> sampled row of its role
+    static __device__ __forceinline__ bool exists(const Params& p, int row) {
+        return row < kProfRoleRows && (row & (kProfMaxRows - 1)) < p.R;
+    }
     static __device__ __forceinline__ int q_phys(const Params& p, const Ctx&, int row) {
-        return row < p.R ? (int)p.rows[row] : -1;
+        return exists(p, row) ? (int)p.rows[row & (kProfMaxRows - 1)] : -1;
     }
     static __device__ __forceinline__ int q_logical(const Ctx&, int row) { return row; }
     static __device__ __forceinline__ int tile_key0(const Ctx& c, int t) { return (c.t0 + t) * kBN; }
@@ -113,7 +123,7 @@ struct ProfilePolicy {
         return l < p.S ? l : 0;  // masked by allowed()
     }
     static __device__ __forceinline__ int classify(const Params& p, const Ctx& c, int k0, int wrow0) {
-        if (wrow0 >= p.R) return TILE_SKIP;
+        if (!exists(p, wrow0)) return TILE_SKIP;
         if (c.variant == 0) return (k0 + kBN <= p.S) ? TILE_FULL : TILE_PARTIAL;
         const ProfVariant& pv = c.pv;
         const int k1 = min(k0 + kBN, p.S);
@@ -165,8 +175,9 @@ struct ProfilePolicy {
     }
     static __device__ __forceinline__ void store_partial(const Params& p, const Ctx& c, int row, int g, const f32x16* acc,
                                                          float m, float l) {
-        if (row >= p.R) return;
-        float* dst = p.part + ((((size_t)c.variant * p.BH + c.head) * p.n_chunks + c.chunk) * kProfMaxRows + row) * (D + 4);
+        if (!exists(p, row)) return;
+        float* dst = p.part + ((((size_t)c.variant * p.BH + c.head) * p.n_chunks + c.chunk) * kProfMaxRows +
+                               (row & (kProfMaxRows - 1))) * (D + 4);
 #pragma unroll
         for (int db = 0; db < D / 32; ++db)
 #pragma unroll
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void profile_finalize_kernel(const float* __re
 
 static int prof_chunks(int BH, int S) {
     const int ntiles = (S + kBN - 1) / kBN;
-    int n = (4 * kNumCU + 3 * BH - 1) / (3 * BH);
+    int n = (2 * kNumCU) / BH;   // two 512-thread workgroups fit a CU: one round of the launch
     n = n < 1 ? 1 : n;
     n = n > ntiles ? ntiles : n;
     n = n > 64 ? 64 : n;
@@ -302,7 +313,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
         g_last_hip_error = (int)e;
         return SVG_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_chunks, BH, 3), dim3(kProfNW * 64), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.n_chunks, BH), dim3(kProfNW * 64), lds, st, p);
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
                        R, p.n_chunks, p.emulate);
