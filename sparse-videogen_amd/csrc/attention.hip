@@ -16,6 +16,7 @@ struct BandPolicy {
     static constexpr int kPrefetch = (ABL == 12) ? 3 : (ABL == 13 ? 2 : 1);  // operand ring depth (k-steps / MFMA steps ahead)
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
+    static constexpr bool kIntervalMask = true;   // row_intervals() describes the mask (two-phase body)
     static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
     static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
     static constexpr bool kSkew = SKEW;
@@ -319,6 +320,7 @@ template <typename T, int D, int NW>
 struct VarblockPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
+    static constexpr bool kIntervalMask = true;
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;

@@ -1331,9 +1331,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const int vi = lane & 15;
     const int v_lane_off = kImg + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
 
-    int m_a0, m_b0;
-    unsigned m_alen, m_blen;
-    P::row_intervals(prm, ctx, q_log, m_a0, m_alen, m_b0, m_blen);
+    int m_a0 = 0, m_b0 = 0;
+    unsigned m_alen = 0, m_blen = 0;
+    if constexpr (P::kIntervalMask) P::row_intervals(prm, ctx, q_log, m_a0, m_alen, m_b0, m_blen);
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 acc_o[DB];
@@ -1430,18 +1430,30 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 for (int r = 0; r < 16; ++r) sc[b][r] = P::score_fixup(prm, sc[b][r]);
         }
         if (ABL != 7 && cls != TILE_FULL) {
-            // the row's allowed keys are [m_a0, +m_alen) u [m_b0, +m_blen) (per lane, loop-invariant)
-            int ka = tk0 + 4 * g - m_a0, kb_ = tk0 + 4 * g - m_b0;
-            asm volatile("" : "+v"(ka), "+v"(kb_));   // opaque: keeps LICM from hoisting 64 per-element terms out of the loop
             const bool part = (cls == TILE_PARTIAL);  // a tile this wave does not need at all is processed fully masked
+            if constexpr (P::kIntervalMask) {
+                // the row's allowed keys are [m_a0, +m_alen) u [m_b0, +m_blen) (per lane, loop-invariant)
+                int ka = tk0 + 4 * g - m_a0, kb_ = tk0 + 4 * g - m_b0;
+                asm volatile("" : "+v"(ka), "+v"(kb_));   // opaque: keeps LICM from hoisting 64 per-element terms out of the loop
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * b + (r & 3) + 8 * (r >> 2);
-                    const bool ok = ((unsigned)(ka + key) < m_alen) | ((unsigned)(kb_ + key) < m_blen);
-                    sc[b][r] = (part & ok) ? sc[b][r] : -INFINITY;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2);
+                        const bool ok = ((unsigned)(ka + key) < m_alen) | ((unsigned)(kb_ + key) < m_blen);
+                        sc[b][r] = (part & ok) ? sc[b][r] : -INFINITY;
+                    }
+            } else {   // general element predicate (profiler masks)
+                int qv = q_log, kv0 = tk0 + 4 * g;
+                asm volatile("" : "+v"(qv), "+v"(kv0));
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2);
+                        sc[b][r] = (part & P::allowed(prm, ctx, qv, kv0 + key)) ? sc[b][r] : -INFINITY;
+                    }
+            }
         }
         float mx = sc[0][0];
         if constexpr (ABL != 2) {
