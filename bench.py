@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", type=int, default=0, help="0: 8 waves/WG, 1: 4 waves/WG")
+    ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
@@ -141,6 +142,9 @@ def main():
     from svg.distributed import chunked_head_layout, gather_chunk
 
     n_chunks, n_per, my_heads = chunked_head_layout(H, rank, world)
+    if world == 1 and a.chunks > 1:   # exercise the chunked two-stream launch path on one GPU (no collective)
+        assert H % a.chunks == 0
+        n_chunks, n_per = a.chunks, H // a.chunks
     Hl = len(my_heads)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
@@ -155,6 +159,10 @@ def main():
     full = torch.empty(H, S, D, device=dev, dtype=torch.bfloat16) if world > 1 else None   # every rank ends with all heads
 
     ev_a0, ev_a1 = [], []
+    # The chunk launches alternate between two streams: a launch of 467-934 workgroups on 256 CUs ends with a partly idle
+    # round (1.8 / 3.6 rounds at N = 8 / 4), and the next chunk's workgroups fill those CUs instead of waiting for the
+    # kernel boundary.  The all-gather of a chunk is enqueued behind its own stream.
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)] if n_chunks > 1 and not os.environ.get("SVG_BENCH_ONE_STREAM") else None
 
     def step(timed: bool):
         if not a.no_profiler:
@@ -164,12 +172,20 @@ def main():
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         works = []
+        main = torch.cuda.current_stream()
         for c in range(n_chunks):
             sl = slice(c * n_per, (c + 1) * n_per)
-            nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), vid0=0, num_frame=F_,
-                               frame_size=P_, variant=a.variant, out=o[:, sl])
-            if world > 1:   # RCCL all-gather of this chunk on the communicator's stream, while the next chunk computes
-                works.append(gather_chunk(full, o[0, sl], c, n_per, world))
+            st = side[c % 2] if side else main
+            if side:
+                st.wait_stream(main)   # inputs and the profiler's result are produced on the main stream
+            with torch.cuda.stream(st):
+                nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), vid0=0,
+                                   num_frame=F_, frame_size=P_, variant=a.variant, out=o[:, sl])
+                if world > 1:   # RCCL all-gather of this chunk behind its kernel, while the next chunk computes
+                    works.append(gather_chunk(full, o[0, sl], c, n_per, world))
+        if side:
+            for st in side:
+                main.wait_stream(st)
         e1.record()
         if timed:
             ev_a0.append(e0)
