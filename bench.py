@@ -114,12 +114,19 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); the HIP path has no CPU fallback")
+    # (SVG_BENCH_SMOKE=1: all ranks on cuda:0 over gloo — a control-flow smoke test of the N > 1 path on a one-GPU box, not a measurement)
+    smoke = bool(os.environ.get("SVG_BENCH_SMOKE"))
+    if smoke:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if smoke:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from svg import _native as nat
     from svg.models.hyvideo.utils import sparsity_to_width

@@ -1,0 +1,46 @@
+"""bench.py contract on a GPU box: one JSON line with the driver's keys at N = 1, and the N > 1 control flow (head sharding,
+chunk launches on two streams, per-chunk all-gather, max-over-ranks timing) as a 2-process smoke run — both ranks on cuda:0 over
+gloo (SVG_BENCH_SMOKE), because a gpurun box has one GPU; RCCL itself is exercised by the driver's 8-GPU run."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out: str):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_json_line():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d), sorted(KEYS - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["dtype"] == "bf16"
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_two_rank_control_flow_smoke():
+    env = dict(os.environ, SVG_BENCH_SMOKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "heads/2"
+    assert d["value"] > 0 and d["cpu_baseline"] is None
