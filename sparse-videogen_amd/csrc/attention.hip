@@ -16,7 +16,8 @@ struct BandPolicy {
     static constexpr int kPrefetch = (ABL == 12) ? 3 : (ABL == 13 ? 2 : 1);  // operand ring depth (k-steps / MFMA steps ahead)
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
-    static constexpr bool kIntervalMask = true;   // row_intervals() describes the mask (two-phase body)
+    static constexpr bool kIntervalMask = true;
+    static constexpr bool kFastPartial = false;   // row_intervals() describes the mask (two-phase body)
     static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
     static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
     static constexpr bool kSkew = SKEW;
@@ -321,6 +322,7 @@ struct VarblockPolicy {
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
     static constexpr bool kIntervalMask = true;
+    static constexpr bool kFastPartial = false;
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;

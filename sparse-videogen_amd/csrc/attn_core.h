@@ -24,7 +24,9 @@ namespace svg {
 
 constexpr int kBN = 64;  // keys per tile
 
-enum TileClass : int { TILE_SKIP = 0, TILE_FULL = 1, TILE_PARTIAL = 2 };
+// TILE_PARTIAL_FAST: lock-step body only, policies with kFastPartial — a cheaper element predicate that holds on tiles the policy
+// recognises (allowed_fast(prm, ctx, key offset inside the tile without the lane part))
+enum TileClass : int { TILE_SKIP = 0, TILE_FULL = 1, TILE_PARTIAL = 2, TILE_PARTIAL_FAST = 3 };
 
 template <int D>
 struct LdsLayout {
@@ -279,6 +281,15 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
                         const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
                         s[rb][b][r] = P::allowed(prm, ctx, q_log[rb], tk0 + key) ? s[rb][b][r] : -INFINITY;
                     }
+            }
+            if constexpr (P::kFastPartial) {
+                if (cls == TILE_PARTIAL_FAST) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            s[rb][b][r] = P::allowed_fast(prm, ctx, 32 * b + (r & 3) + 8 * (r >> 2)) ? s[rb][b][r] : -INFINITY;
+                }
             }
             float mx = s[rb][0][0];
 #pragma unroll

@@ -5,7 +5,7 @@
 //
 // The reference materialises two [10000, S] fp32 masks (4.8 GB each) and runs three full softmaxes in torch.
 // Here the masks are analytic predicates and the three variants are three wave roles of ONE workgroup that shares
-// attn_core.h: grid = (kv_chunks, BH); waves 0-1 compute the golden rows, waves 2-3 the rows under mask 1, waves 4-5 under
+// attn_core.h: grid = (BH, kv_chunks); waves 0-1 compute the golden rows, waves 2-3 the rows under mask 1, waves 4-5 under
 // mask 0 (waves 6-7 only help staging) on the SAME staged K/V tiles, so a chunk of K/V is read and staged once (split-KV);
 // every role emits un-normalised fp32 partials (O, m, l) per sampled row, and a small second kernel merges the chunks,
 // normalises and reduces the MSE.  (The first version ran the roles as three workgroups, grid.z = 3: K/V staged three times,
@@ -31,7 +31,8 @@ template <typename T, int D>
 struct ProfilePolicy {
     static constexpr bool kFixup = true;
     static constexpr bool kPartialOut = true;
-    static constexpr bool kIntervalMask = false;   // the profiling masks are general element predicates (allowed())
+    static constexpr bool kIntervalMask = false;
+    static constexpr bool kFastPartial = true;     // token-major mask: tiles inside one frame row block, see classify()   // the profiling masks are general element predicates (allowed())
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;
@@ -61,6 +62,11 @@ struct ProfilePolicy {
         int xlo_blk, xhi_blk, any_text;
         // per-tile scratch written by classify(): token-major decomposition of the tile's first key
         mutable int tk0, f0, p0;
+        // token-major fast tiles (TILE_PARTIAL_FAST): the keys of the tile are y = ybase + off * F in mask coordinates (one frame,
+        // no text keys), and this lane's row sees y in [fa0, fa0 + falen) u [0, fblen): band blocks n domain, sink columns n domain
+        mutable int ybase;
+        int fa0, g4F;
+        unsigned falen, fblen;
     };
     struct KvCursor {};
     static __device__ __forceinline__ bool wave_active(const Ctx&, int wrow0) { return wrow0 < kProfRoleRows; }
@@ -78,8 +84,11 @@ struct ProfilePolicy {
     }
 
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
-        c.chunk = blockIdx.x;
-        c.head = blockIdx.y;
+        // chunk-major dispatch: the sampled rows are low (< sample_mse_max_row), so the frame-major mask only has work in the first
+        // chunks of every head, on the expensive element predicate; dispatching all heads' chunk 0, 1, ... first puts the long
+        // workgroups at the front of the launch instead of into its tail
+        c.chunk = blockIdx.y;
+        c.head = blockIdx.x;
         // two waves per role; a wave lives on SIMD (wave % 4): the golden rows (waves 0-1) and the token-major mask (waves 2-3, the
         // expensive predicate) get a SIMD each, the frame-major mask (waves 4-5, skips most tiles) shares with the golden waves
         const int role = (int)(threadIdx.x >> 7);
@@ -104,6 +113,16 @@ struct ProfilePolicy {
         }
         c.xlo_blk = lo, c.xhi_blk = hi, c.any_text = anyt;
         c.tk0 = 0, c.f0 = 0, c.p0 = 0;
+        c.ybase = 0, c.g4F = 4 * (int)((threadIdx.x >> 5) & 1) * p.F;
+        {
+            const int x = c.qx, span = c.pv.span;
+            const bool xdom = have && ((unsigned)x < (unsigned)span);
+            const int ylo = ((x >> 7) - c.pv.band_blocks + 1) * 128, yhi = ((x >> 7) + c.pv.band_blocks) * 128;
+            const int a0 = max(ylo, 0), a1 = min(yhi, span);
+            c.fa0 = a0, c.falen = xdom ? (unsigned)max(a1 - a0, 0) : 0u;
+            c.fblen = (xdom && c.pv.sink_cols > 0) ? (unsigned)min(c.pv.sink_cols, span) : 0u;
+            if (c.qtext) c.fa0 = -(1 << 30), c.falen = 0xFFFFFFFFu;   // a text row sees every key
+        }
         return true;
     }
     static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
@@ -144,6 +163,14 @@ struct ProfilePolicy {
             const int i0 = max(k0 - p.vid0, 0);
             c.f0 = (int)((unsigned)i0 / (unsigned)p.P);
             c.p0 = i0 - c.f0 * p.P;
+            // all 64 keys inside the video, inside one frame, none of them a text column: the general predicate collapses to
+            // two interval tests on y = ybase + off * F (6 instead of ~25 instructions per element)
+            const bool text_keys = (k0 < pv.text_hi) && (k0 + kBN > pv.text_lo);
+            if (k0 >= p.vid0 && k0 + kBN <= p.vid0 + p.V && k0 + kBN <= p.S && c.p0 + kBN <= p.P && !text_keys) {
+                c.tk0 = k0;
+                c.ybase = p.vid0 + c.p0 * p.F + c.f0 - pv.origin;
+                return TILE_PARTIAL_FAST;
+            }
         }
         c.tk0 = k0;
         return TILE_PARTIAL;
@@ -168,6 +195,10 @@ struct ProfilePolicy {
         const bool band = (db < pv.band_blocks) & (-db < pv.band_blocks);
         const bool sink = y < pv.sink_cols;
         return (k < p.S) & (bool)(c.qtext | tk | (dom & (band | sink)));
+    }
+    static __device__ __forceinline__ bool allowed_fast(const Params& p, const Ctx& c, int off) {
+        const int y = c.ybase + c.g4F + off * p.F;   // off: key offset inside the tile without the lane's 4 g
+        return ((unsigned)(y - c.fa0) < c.falen) | ((unsigned)y < c.fblen);
     }
     static __device__ __forceinline__ float score_fixup(const Params& p, float s) {
         if (!p.emulate) return s;
@@ -317,7 +348,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
         g_last_hip_error = (int)e;
         return SVG_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.n_chunks, BH), dim3(kProfNW * 64), lds, st, p);
+    hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
                        R, p.n_chunks, p.emulate);
