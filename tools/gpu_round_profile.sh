@@ -1,13 +1,13 @@
-mkdir -p gpurun_out/i
-python bench.py > gpurun_out/i/bench.json 2> gpurun_out/i/bench.err
+mkdir -p gpurun_out/k
+python bench.py > gpurun_out/k/bench.json 2> gpurun_out/k/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/i/kt -o r01i -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-dense > $GRAFT_REPO_ROOT/gpurun_out/i/bench_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/k/kt -o r01k -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-dense > $GRAFT_REPO_ROOT/gpurun_out/k/bench_rocprof.json 2>/dev/null
 cd $GRAFT_REPO_ROOT
-python tools/rocprof_summary.py $(find gpurun_out/i/kt -name "*.db" | head -1) gpurun_out/i/kernel_trace.txt
-bash tools/gpu_pmc.sh i > gpurun_out/i/pmc.log 2>&1
-cp gpurun_out/pmc_i/summary.txt gpurun_out/i/pmc_summary.txt
-python tools/wg_timeline.py 15616 alt > gpurun_out/i/wg_timeline.txt 2>&1
-python tools/svg1_models.py > gpurun_out/i/svg1_models.md 2>&1
-python bench_svg2.py > gpurun_out/i/svg2_wan.json 2>gpurun_out/i/svg2_wan.err
-python bench_svg2.py --workload hy720p > gpurun_out/i/svg2_hy.json 2>gpurun_out/i/svg2_hy.err
-tail -c 400 gpurun_out/i/bench.json; head -4 gpurun_out/i/kernel_trace.txt | cut -c1-180; cat gpurun_out/i/svg1_models.md; tail -2 gpurun_out/i/svg2_wan.json
+python tools/rocprof_summary.py $(find gpurun_out/k/kt -name "*.db" | head -1) gpurun_out/k/kernel_trace.txt
+bash tools/gpu_pmc.sh k > gpurun_out/k/pmc.log 2>&1
+cp gpurun_out/pmc_k/summary.txt gpurun_out/k/pmc_summary.txt
+python tools/wg_timeline.py 15616 alt > gpurun_out/k/wg_timeline.txt 2>&1
+python tools/svg1_models.py > gpurun_out/k/svg1_models.md 2>&1
+python bench_svg2.py > gpurun_out/k/svg2_wan.json 2>gpurun_out/k/svg2_wan.err
+python bench_svg2.py --workload hy720p > gpurun_out/k/svg2_hy.json 2>gpurun_out/k/svg2_hy.err
+tail -c 400 gpurun_out/k/bench.json; head -4 gpurun_out/k/kernel_trace.txt | cut -c1-180; cat gpurun_out/k/svg1_models.md; tail -2 gpurun_out/k/svg2_wan.json
