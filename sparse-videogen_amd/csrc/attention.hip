@@ -17,8 +17,9 @@ struct BandPolicy {
     static constexpr int kPrefetch = (ABL == 12) ? 3 : (ABL == 13 ? 2 : 1);  // operand ring depth (k-steps / MFMA steps ahead)
     static constexpr bool kFixup = false;
     static constexpr bool kPartialOut = false;
-    static constexpr bool kIntervalMask = true;
-    static constexpr bool kFastPartial = false;   // row_intervals() describes the mask (two-phase body)
+    static constexpr bool kIntervalMask = true;   // row_intervals() describes the mask (two-phase body)
+    static constexpr bool kFastPartial = false;
+    static constexpr int kShadow128 = 1;   // two-phase body, D = 128: probability steps in the MFMA shadow (measured best)
     static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
     static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
     static constexpr bool kSkew = SKEW;
@@ -324,6 +325,7 @@ struct VarblockPolicy {
     static constexpr bool kPartialOut = false;
     static constexpr bool kIntervalMask = true;
     static constexpr bool kFastPartial = false;
+    static constexpr int kShadow128 = 2;   // the vector phase also resolves rows through the run list and the index arrays
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;

@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     constexpr int KS = D / 16;
     constexpr int DB = D / 32;
     constexpr bool kDma = true;             // true: LDS-DMA staging (4 stages); false: register staging (3 stages), measured 15 % slower
-    constexpr int kShadow = (D == 64) ? 2 : 1;              // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
+    constexpr int kShadow = (D == 64) ? 2 : P::kShadow128;              // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
     constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;

@@ -32,6 +32,7 @@ struct ProfilePolicy {
     static constexpr bool kFixup = true;
     static constexpr bool kPartialOut = true;
     static constexpr bool kIntervalMask = false;
+    static constexpr int kShadow128 = 1;
     static constexpr bool kFastPartial = true;     // token-major mask: tiles inside one frame row block, see classify()   // the profiling masks are general element predicates (allowed())
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
