@@ -39,6 +39,8 @@ struct BandPolicy {
         int vid0, F, P, V;
         int q64, r64;          // 64 / F, 64 % F: tile-to-tile step of the (patch, frame) decomposition
         int q128, r128;        // the same for a 128-row step (two tiles per stage)
+        int sp64, sp128;       // physical-row step of a token-major head: q + r * P (the patch index advances by q, the frame by r)
+        int wrap_phys;         // 1 - F * P: correction when the frame index wraps
         int heavy_lo, n_heavy; // q-tiles [heavy_lo, heavy_lo + n_heavy) of every head see ALL keys (text rows): scheduled first
         // Row regions: q-tiles never straddle rowfull_lo / rowfull_hi / real_len, so every q-tile is homogeneous (band rows, full
         // rows or rows behind real_len).  Region r = rows [reg_lo[r], reg_hi[r]), its first q-tile is reg_t0[r].
@@ -50,8 +52,8 @@ struct BandPolicy {
         int fk_lo, fk_hi;  // per WAVE: tiles with first key in [fk_lo, fk_hi] are FULL for this wave's 32 rows (fast path)
     };
     struct KvCursor {
-        int pp, f, prev_k0;    // token-major decomposition (row - vid0) = pp * F + f of this thread's row in the previous tile
-    };
+        int physv, f, prev_k0;  // token-major head: frame f and physical row vid0 + f * P + pp of this thread's row in the previous tile,
+    };                          // with (row - vid0) = pp * F + f
 
     static __device__ __forceinline__ int phys_row(const Params& p, const Ctx& c, int logical) {
         if (c.perm) {
@@ -167,34 +169,37 @@ struct BandPolicy {
         return (t < c.seg_n[0] ? a : bd) * kBN;
     }
     static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) {
-        cu.pp = 0, cu.f = 0, cu.prev_k0 = -(1 << 30);
+        cu.physv = 0, cu.f = 0, cu.prev_k0 = -(1 << 30);
     }
     static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor& cu, int t, int row) {
         const int k0 = tile_key0(c, t);
         const int l = k0 + row;
         if (!c.perm) return l < p.S ? l : 0;
-        // token-major head: physical row = vid0 + f * P + pp with (l - vid0) = pp * F + f.  Consecutive tiles advance
-        // by 64 rows, so the decomposition is stepped (4 VALU) instead of divided (~30 VALU); segment jumps re-divide.
-        int pp, f;
+        // token-major head: physical row = vid0 + f * P + pp with (l - vid0) = pp * F + f.  Consecutive tiles advance by 64 rows,
+        // so the frame and the physical row are stepped (5 VALU, no multiply) instead of divided (~30 VALU); segment jumps re-divide.
+        // A tile that lies inside the video range (scalar test) needs neither the range selects nor the bounds test.
+        int f, physv;
         // a cursor advances by one stage per call: 64 keys, or 128 with two tiles per stage (each chunk keeps its sub-tile)
         constexpr int kStep = kBN * SUBS;
         const int delta = __builtin_amdgcn_readfirstlane(k0 - cu.prev_k0);
         if (delta == kStep) {
             f = cu.f + (SUBS == 1 ? p.r64 : p.r128);
-            pp = cu.pp + (SUBS == 1 ? p.q64 : p.q128);
+            physv = cu.physv + (SUBS == 1 ? p.sp64 : p.sp128);
             const bool wrap = f >= p.F;
             f = wrap ? f - p.F : f;
-            pp = wrap ? pp + 1 : pp;
+            physv = wrap ? physv + p.wrap_phys : physv;
         } else {
             const int i = l - p.vid0;
             const int a = i >= 0 ? i : -i - 1;              // floor division also for rows in front of the video
             const int qd = (int)((unsigned)a / (unsigned)p.F);
-            pp = i >= 0 ? qd : -qd - 1;
+            const int pp = i >= 0 ? qd : -qd - 1;
             f = i - pp * p.F;
+            physv = p.vid0 + f * p.P + pp;
         }
-        cu.pp = pp, cu.f = f, cu.prev_k0 = k0;
+        cu.physv = physv, cu.f = f, cu.prev_k0 = k0;
+        if (k0 >= p.vid0 && k0 + kStep <= p.vid0 + p.V) return physv;
         const bool in_video = (unsigned)(l - p.vid0) < (unsigned)p.V;
-        const int phys = in_video ? p.vid0 + f * p.P + pp : l;
+        const int phys = in_video ? physv : l;
         return l < p.S ? phys : 0;
     }
 
@@ -643,6 +648,8 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
     }
     p.q64 = kBN / p.F, p.r64 = kBN % p.F;
     p.q128 = 2 * kBN / p.F, p.r128 = 2 * kBN % p.F;
+    p.sp64 = p.q64 + p.r64 * p.P, p.sp128 = p.q128 + p.r128 * p.P;
+    p.wrap_phys = 1 - p.F * p.P;
     // row regions (see Params): cut at rowfull_lo, rowfull_hi (inside [0, real_len)) and real_len; unused slots are empty regions
     // behind the last tile.  A q-tile of full rows visits every key tile on the unmasked fast path (with the text rows sharing a
     // tile with band rows or rows behind real_len, all 1861 tiles of it took the per-element masked path: 9.5 ms instead of 3.2).
