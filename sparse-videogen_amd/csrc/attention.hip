@@ -3,7 +3,6 @@
 // (which KV tiles a workgroup visits, where rows live in HBM, which elements are masked) and the C ABI.
 #include <algorithm>
 
-#include <cstdlib>
 #include "attn_core.h"
 
 namespace svg {
@@ -611,6 +610,7 @@ static thread_local bool g_band_pipe = false;  // set per call from `variant` bi
 static thread_local bool g_band_pp = false;    // set per call from `variant` bit 5
 static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
 static thread_local bool g_band_pp2 = false;       // `variant` bit 7: two-phase ping-pong schedule (attn_body_pp2)
+static thread_local bool g_vb_block_row_order = false;  // svg_varblock_attention variant 4: two-phase kernel in block-row order (A/B)
 static thread_local int g_band_pp_abl = 0;         // `variant` bits 8..11 together with bit 6: ablation of the traced kernel
 
 template <typename K, typename Prm>
@@ -855,8 +855,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.order = nullptr;
         if constexpr (NW == -8) {
             const int group = Hq / Hkv;
-            static const bool no_order = getenv("SVG_VB_NO_ORDER") != nullptr;   // A/B switch: block-row order
-            if (!no_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
+            if (!g_vb_block_row_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
                 int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);
                 int32_t* hist = work + (size_t)Hkv * QB;
                 const int nb = Hkv * kVbBuckets;
@@ -902,16 +901,17 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
+    g_vb_block_row_order = (variant == 4);
 #define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, st
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
-        if (variant == 3) return run_varblock<T, 128, -8>(SVG_VB_ARGS);                          \
+        if (variant == 3 || variant == 4) return run_varblock<T, 128, -8>(SVG_VB_ARGS);          \
         return variant == 1 ? run_varblock<T, 128, 8>(SVG_VB_ARGS) : run_varblock<T, 128, 4>(SVG_VB_ARGS); \
     }                                                                                            \
     if (D == 64) {                                                                               \
         if (variant == 2) return run_varblock<T, 64, 0>(SVG_VB_ARGS);                            \
-        if (variant == 3) return run_varblock<T, 64, -8>(SVG_VB_ARGS);                           \
+        if (variant == 3 || variant == 4) return run_varblock<T, 64, -8>(SVG_VB_ARGS);           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
     if (variant < -1 || variant > 3) return SVG_ERR_BAD_ARG;
