@@ -226,7 +226,8 @@ _VB_SMALL = [(hq, hkv, D, 256, MB, NB, dens, dt, var)
 _VB_LARGE = [(4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 3), (4, 1, 64, 8192, 20, 100, 0.5, torch.bfloat16, 3),
              (4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 2), (4, 1, 64, 8192, 20, 100, 0.5, torch.float16, 2),
              (4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 0), (16, 4, 128, 4096, 10, 50, 0.2, torch.float16, 1),
-             (4, 1, 64, 8192, 20, 100, 0.9, torch.bfloat16, 1), (1, 1, 128, 8192, 10, 100, 0.7, torch.float16, 0)]
+             (4, 1, 64, 8192, 20, 100, 0.9, torch.bfloat16, 1), (1, 1, 128, 8192, 10, 100, 0.7, torch.float16, 0),
+             (4, 4, 128, 4096, 20, 100, 0.7, torch.bfloat16, 4), (16, 4, 64, 4096, 10, 50, 0.5, torch.float16, 4)]
 
 
 @pytest.mark.parametrize("hq,hkv,D,S,MB,NB,density,dtype,variant", _VB_SMALL + _VB_LARGE)
