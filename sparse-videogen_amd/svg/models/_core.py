@@ -184,13 +184,59 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
                                      q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
                                      q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
     if logging_file is not None:
+        from .context import timestep_value
+
         densities = density_calculation(dyn_map, q_sizes, k_sizes)
-        t0 = timestep[0] if torch.is_tensor(timestep) and timestep.dim() > 0 else timestep
-        entry = {"timestep": float(t0) if t0 is not None else None, "layer": layer_idx,
-                 "avg_density": densities.mean().item(), "density": densities.tolist()}
-        with open(logging_file, "a") as f:
-            f.write(json.dumps(entry) + "\n")
+        DENSITY_LOG.push(logging_file, {"timestep": timestep_value(timestep) if timestep is not None else None, "layer": layer_idx},
+                         densities)
     return out.view(cfg, H, S, D)
+
+
+class _DensityLog:
+    """Density logging off the critical path.  The reference reads `densities.mean().item()` / `.tolist()` back in
+    every sparse layer-call (hyvideo/attention.py:786-802): one device synchronisation per layer.  Here the per-head densities are
+    copied to pinned host memory asynchronously and the JSON lines (same fields, same order) are written once their copy has
+    completed — opportunistically on later calls, and in any case by `flush()` (registered with atexit; call it before reading
+    the file)."""
+
+    def __init__(self):
+        self.pending = []   # (path, meta, pinned host tensor, event)
+
+    def push(self, path: str, meta: dict, densities: torch.Tensor) -> None:
+        host = torch.empty(densities.shape, dtype=torch.float32, pin_memory=densities.is_cuda)
+        host.copy_(densities.float(), non_blocking=True)
+        ev = None
+        if densities.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.pending.append((path, meta, host, ev))
+        self.flush(wait=False)
+
+    def flush(self, wait: bool = True) -> None:
+        while self.pending:
+            path, meta, host, ev = self.pending[0]
+            if ev is not None:
+                if wait:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            entry = dict(meta, avg_density=float(host.mean()), density=host.tolist())
+            with open(path, "a") as f:
+                f.write(json.dumps(entry) + "\n")
+            self.pending.pop(0)
+
+
+DENSITY_LOG = _DensityLog()
+
+
+def flush_density_log() -> None:
+    """Write every pending density record (see _DensityLog)."""
+    DENSITY_LOG.flush(wait=True)
+
+
+import atexit  # noqa: E402
+
+atexit.register(flush_density_log)
 
 
 def dynamic_map_post_processing(dyn_map, qc_sz, kc_sz, q_sorted_indices, k_sorted_indices, video_length, context_length,

@@ -111,3 +111,21 @@ def test_hunyuan_and_wan_install_hooks_set_class_config():
     wcls = replace_wan_attention(wpipe, 720, 1280, 81, first_layers_fp=1, first_times_fp=800.0, pattern="SVG", sparsity=0.3)
     assert (wcls.context_length, wcls.num_frame, wcls.frame_size) == (0, 21, 3600)
     assert wcls.block_mask.band == 12417 and wcls.block_mask.colfull_hi == 3600
+
+
+def test_density_log_is_deferred_and_flushable(tmp_path):
+    """density records are written off the critical path (no per-layer .item()); same fields as the reference's
+    JSON lines (hyvideo/attention.py:786-802)."""
+    import json
+
+    from svg.models import _core
+
+    path = tmp_path / "density.jsonl"
+    _core.DENSITY_LOG.push(str(path), {"timestep": 981.0, "layer": 7}, torch.tensor([[0.25, 0.5, 0.75]]))
+    _core.DENSITY_LOG.push(str(path), {"timestep": 981.0, "layer": 8}, torch.tensor([[1.0, 0.0, 0.5]]))
+    _core.flush_density_log()
+    lines = [json.loads(l) for l in path.read_text().splitlines()]
+    assert [l["layer"] for l in lines] == [7, 8]
+    assert list(lines[0]) == ["timestep", "layer", "avg_density", "density"]
+    assert lines[0]["avg_density"] == pytest.approx(0.5) and lines[1]["density"] == [[1.0, 0.0, 0.5]]
+    assert not _core.DENSITY_LOG.pending
