@@ -284,6 +284,20 @@ int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, c
                                    const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
                                    int32_t y_dtype, int32_t w_dtype, float eps, void* stream);
 
+/* Device-side dense / sparse switch.  The reference decides per layer on the host,
+ * `timestep[0] > first_times_fp` (svg/models/hyvideo/attention.py:491-496), which reads the GPU tensor back in every layer-call.
+ * Here the caller turns that comparison into a device flag (one torch op, no synchronisation) and both kernels read it:
+ *   svg_band_attention_switch: use_alt_flag[0] != 0 -> attention under alt_mask (the dense warm-up mask) without the layout
+ *       transformation of `perm`; otherwise exactly svg_band_attention(mask, perm).  Two-phase kernel only (variant 0).
+ *   svg_sample_mse_flagged: skip_flag[0] != 0 -> every kernel of the call returns at once (out_mse is left untouched: the
+ *       profiler's result is not used on a dense step); skip_flag == NULL -> svg_sample_mse. */
+int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                              int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                              const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream);
+int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S,
+                           int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
+                           void* workspace, size_t workspace_bytes, const int32_t* skip_flag, void* stream);
+
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
  * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in

@@ -79,6 +79,7 @@ struct BandPolicy {
         int qt;
         const int nh = p.BH * p.n_heavy;
         const int b = blockIdx.x;
+        if (b >= p.nqt * p.BH) return false;   // (the device-switched launch is sized for the larger of its two masks)
         if (b < nh) {
             c.head = b / p.n_heavy;
             qt = p.heavy_lo + (b - c.head * p.n_heavy);
@@ -307,6 +308,17 @@ template <typename T, int D>
 __global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
+}
+// Device-side switch between two masks: `flag[0] != 0` selects prm_alt (the dense warm-up mask, no layout
+// transformation) — the dense / sparse decision of attention_core_logic (hyvideo/attention.py:491-496) without reading the
+// timestep back to the host.
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2_switch_kernel(typename BandPolicy<T, D, 8, false>::Params prm,
+                                                                      typename BandPolicy<T, D, 8, false>::Params prm_alt,
+                                                                      const int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (flag[0] != 0) attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm_alt, smem, nullptr);
+    else attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
 template <typename T, int D, int ABL>
 __global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
@@ -631,10 +643,9 @@ static int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1, int SUBS = 1>
-static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
-                    const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
-    using Pol = BandPolicy<T, D, NW, SKEW, ABL, RB, SUBS>;
+template <typename Pol, typename T>
+static typename Pol::Params make_band_params(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
+                                             const svg_band_mask_t* mask, const svg_perm_desc_t* perm) {
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
@@ -675,6 +686,14 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
             if (p.n_heavy >= p.nqt) p.heavy_lo = 0, p.n_heavy = 0;
         }
     }
+    return p;
+}
+
+template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1, int SUBS = 1>
+static int run_band(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
+                    const svg_band_mask_t* mask, const svg_perm_desc_t* perm, hipStream_t st) {
+    using Pol = BandPolicy<T, D, NW, SKEW, ABL, RB, SUBS>;
+    const typename Pol::Params p = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
     if constexpr (RB == 2) {
         return launch_attn(band_attn_r64_kernel<T, D, ABL>, p, dim3(p.nqt * BH), 256, attn_lds_bytes<D, 4, 2, 2>(), st);
     } else if constexpr (SUBS == 2) {
@@ -715,6 +734,56 @@ static int run_band(const void* q, const void* k, const void* v, void* o, int BH
 }  // namespace svg
 
 using namespace svg;
+
+namespace svg {
+template <typename T, int D>
+static int run_band_switch(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
+                           const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const svg_band_mask_t* alt_mask,
+                           const int32_t* flag, hipStream_t st) {
+    using Pol = BandPolicy<T, D, 8, false>;
+    const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
+    const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
+    auto kern = band_attn_pp2_switch_kernel<T, D>;
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pp2_lds_bytes<D>());
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return SVG_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<D>(), st, a, b, flag);
+    return launch_status();
+}
+}  // namespace svg
+
+extern "C" int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                         int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                         const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream) {
+    if (!q || !k || !v || !o || !mask || !alt_mask || !use_alt_flag || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
+    for (const svg_band_mask_t* m : {mask, alt_mask}) {
+        if (m->real_len < 0 || m->real_len > S || m->band < 1 || m->band > S + 1) return SVG_ERR_BAD_ARG;
+        if (m->colfull_lo > m->colfull_hi || m->rowfull_lo > m->rowfull_hi) return SVG_ERR_BAD_ARG;
+    }
+    if (perm && perm->head_perm_flag) {
+        if (perm->num_frame <= 0 || perm->frame_size <= 0 || perm->vid0 < 0 ||
+            (int64_t)perm->vid0 + (int64_t)perm->num_frame * perm->frame_size > S)
+            return SVG_ERR_BAD_ARG;
+    }
+    if ((int64_t)BH * S * D >= (1ll << 40) || (int64_t)S * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+#define SVG_SW_ARGS q, k, v, o, BH, S, sm_scale, mask, perm, alt_mask, use_alt_flag, st
+    if (dtype == SVG_DTYPE_BF16) {
+        if (D == 128) return run_band_switch<__bf16, 128>(SVG_SW_ARGS);
+        if (D == 64) return run_band_switch<__bf16, 64>(SVG_SW_ARGS);
+    } else if (dtype == SVG_DTYPE_F16) {
+        if (D == 128) return run_band_switch<_Float16, 128>(SVG_SW_ARGS);
+        if (D == 64) return run_band_switch<_Float16, 64>(SVG_SW_ARGS);
+    }
+#undef SVG_SW_ARGS
+    return SVG_ERR_UNSUPPORTED;
+}
 
 extern "C" int svg_debug_wg_trace(uint64_t* out, int n_workgroups) {
     if (!out || n_workgroups < 0 || n_workgroups > kWgTraceMax) return SVG_ERR_BAD_ARG;

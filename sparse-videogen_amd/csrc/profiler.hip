@@ -54,6 +54,7 @@ struct ProfilePolicy {
         int vid0, F, P, V;
         ProfVariant var[2];
         float* part;        // [3][BH][n_chunks][kProfMaxRows][D + 4]
+        const int32_t* skip; // device flag (or nullptr): non-zero = this call is not needed (dense step), every kernel returns at once
     };
     struct Ctx {
         int head, variant, chunk, t0, nT;
@@ -85,6 +86,7 @@ struct ProfilePolicy {
     }
 
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char*) {
+        if (p.skip && p.skip[0] != 0) return false;
         // chunk-major dispatch: the sampled rows are low (< sample_mse_max_row), so the frame-major mask only has work in the first
         // chunks of every head, on the expensive element predicate; dispatching all heads' chunk 0, 1, ... first puts the long
         // workgroups at the front of the launch instead of into its tail
@@ -241,8 +243,9 @@ constexpr int kProfRowGroups = 8;
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void profile_combine_kernel(const float* __restrict__ part, float* __restrict__ sq_part, int BH,
-                                                              int R, int n_chunks, int emulate) {
+                                                              int R, int n_chunks, int emulate, const int32_t* __restrict__ skip) {
     __shared__ float red[4][4];
+    if (skip && skip[0] != 0) return;
     const int rg = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
     const int rows_per = (R + kProfRowGroups - 1) / kProfRowGroups;
     const int r0 = rg * rows_per, r1 = min(R, r0 + rows_per);
@@ -294,7 +297,8 @@ __global__ __launch_bounds__(256) void profile_combine_kernel(const float* __res
 // grid = (1), block = 256: out_mse[v][h] = mean over rows and D (NaN when any sampled row had no visible key)
 template <typename T>
 __global__ __launch_bounds__(256) void profile_finalize_kernel(const float* __restrict__ sq_part, float* __restrict__ out_mse,
-                                                               int BH, int R, int D, int emulate) {
+                                                               int BH, int R, int D, int emulate, const int32_t* __restrict__ skip) {
+    if (skip && skip[0] != 0) return;
     for (int i = threadIdx.x; i < 2 * BH; i += 256) {
         const int v = i / BH, h = i - v * BH;
         float s = 0.f, bad = 0.f;
@@ -319,7 +323,7 @@ static int prof_chunks(int BH, int S) {
 
 template <typename T, int D>
 static int run_profile(const void* q, const void* k, const void* v, const int64_t* rows, int R, int BH, int S, float sm_scale,
-                       const svg_profile_desc_t* pd, float* out_mse, void* ws, hipStream_t st) {
+                       const svg_profile_desc_t* pd, float* out_mse, void* ws, const int32_t* skip, hipStream_t st) {
     using Pol = ProfilePolicy<T, D>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v;
@@ -342,6 +346,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
         p.var[i].text_hi = pd->variant[i].text_hi;
     }
     p.part = (float*)ws;
+    p.skip = skip;
     const int lds = attn_lds_bytes<D, kProfNW>();
     auto kern = profile_attn_kernel<T, D>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -352,9 +357,9 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
-                       R, p.n_chunks, p.emulate);
+                       R, p.n_chunks, p.emulate, skip);
     hipLaunchKernelGGL((profile_finalize_kernel<T>), dim3(1), dim3(256), 0, st, (const float*)sq_part, out_mse, BH, R, D,
-                       p.emulate);
+                       p.emulate, skip);
     return launch_status();
 }
 
@@ -367,9 +372,10 @@ extern "C" size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t 
     return ((size_t)3 * BH * prof_chunks(BH, S) * kProfMaxRows * (D + 4) + (size_t)BH * kProfRowGroups * 4) * sizeof(float);
 }
 
-extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
-                              int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
-                              float* out_mse, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
+                                      int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
+                                      float* out_mse, void* workspace, size_t workspace_bytes, const int32_t* skip_flag,
+                                      void* stream) {
     if (!q || !k || !v || !rows || !prof || !out_mse || !workspace) return SVG_ERR_BAD_ARG;
     if (R <= 0 || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
     if (R > kProfMaxRows) return SVG_ERR_UNSUPPORTED;
@@ -378,11 +384,18 @@ extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const
     if (workspace_bytes < svg_sample_mse_workspace_bytes(BH, R, D, S)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SVG_DTYPE_BF16) {
-        if (D == 128) return run_profile<__bf16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, st);
-        if (D == 64) return run_profile<__bf16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, st);
+        if (D == 128) return run_profile<__bf16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
+        if (D == 64) return run_profile<__bf16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
     } else if (dtype == SVG_DTYPE_F16) {
-        if (D == 128) return run_profile<_Float16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, st);
-        if (D == 64) return run_profile<_Float16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, st);
+        if (D == 128) return run_profile<_Float16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
+        if (D == 64) return run_profile<_Float16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
     }
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
+                              int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
+                              float* out_mse, void* workspace, size_t workspace_bytes, void* stream) {
+    return svg_sample_mse_flagged(q, k, v, rows, R, BH, S, D, dtype, sm_scale, prof, out_mse, workspace, workspace_bytes, nullptr,
+                                  stream);
 }

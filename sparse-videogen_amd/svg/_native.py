@@ -104,6 +104,10 @@ SIGNATURES = {
     "svg_argsort_labels": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                      C.POINTER(PermDesc), _I32, _VP]),
+    "svg_band_attention_switch": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                            C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
+    "svg_sample_mse_flagged": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
+                                         _SZ, _VP, _VP]),
     "svg_varblock_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32]),
     "svg_varblock_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP,
                                          _I32, _I32, _VP, _VP, _VP, _SZ, _I32, _VP]),
@@ -259,6 +263,33 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
     return o
 
 
+def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, alt_mask: BandMask,
+                          use_alt_flag: torch.Tensor, sm_scale: Optional[float] = None,
+                          head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1, frame_size: int = 1,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """band_attention with a device-side switch: `use_alt_flag` (int32 [1] on the GPU) != 0 selects `alt_mask` without the head
+    placement, otherwise `mask` with it (svg_band_attention_switch) — no host read of the flag."""
+    lib = load()
+    _dev(q, k, v, head_perm_flag, use_alt_flag)
+    assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    assert use_alt_flag.dtype == torch.int32 and use_alt_flag.numel() >= 1
+    S, D = q.shape[-2], q.shape[-1]
+    BH = q.numel() // (S * D)
+    o = torch.empty_like(q) if out is None else out
+    _dev(o)
+    scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    perm = None
+    if head_perm_flag is not None:
+        flag = head_perm_flag.to(torch.int64).contiguous()
+        assert flag.numel() == BH
+        perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    rc = lib.svg_band_attention_switch(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
+                                       C.byref(mask), C.byref(perm) if perm is not None else None, C.byref(alt_mask),
+                                       use_alt_flag.data_ptr(), _stream())
+    _check(rc, "svg_band_attention_switch")
+    return o
+
+
 def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
                        k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
                        kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1) -> torch.Tensor:
@@ -286,15 +317,24 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
 
 
 def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,
-               sm_scale: Optional[float] = None) -> torch.Tensor:
-    """q,k,v [BH, S, D]; rows int64 [R] (device) -> mse float32 [2, BH]"""
+               sm_scale: Optional[float] = None, skip_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q,k,v [BH, S, D]; rows int64 [R] (device) -> mse float32 [2, BH].  skip_flag (int32 [1] on the GPU) != 0: the kernels
+    return at once and the result is undefined (a dense step does not use it)."""
     lib = load()
-    _dev(q, k, v, rows)
+    _dev(q, k, v, rows, skip_flag)
     BH, S, D = q.shape
     R = rows.numel()
     out = torch.empty((2, BH), dtype=torch.float32, device=q.device)
     ws = torch.empty(lib.svg_sample_mse_workspace_bytes(BH, R, D, S), dtype=torch.uint8, device=q.device)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    if skip_flag is not None:
+        assert skip_flag.dtype == torch.int32
+        out.zero_()
+        rc = lib.svg_sample_mse_flagged(q.data_ptr(), k.data_ptr(), v.data_ptr(), rows.data_ptr(), R, BH, S, D, _dtype_code(q),
+                                        scale, C.byref(prof), out.data_ptr(), ws.data_ptr(), ws.numel(), skip_flag.data_ptr(),
+                                        _stream())
+        _check(rc, "svg_sample_mse_flagged")
+        return out
     rc = lib.svg_sample_mse(q.data_ptr(), k.data_ptr(), v.data_ptr(), rows.data_ptr(), R, BH, S, D, _dtype_code(q), scale,
                             C.byref(prof), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
     _check(rc, "svg_sample_mse")

@@ -75,15 +75,37 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 
 
 @time_logging_decorator("Level 3 - sample_mse")
-def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int):
+def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, skip_flag=None):
     """ref: sample_mse svg/models/hyvideo/attention.py:376-399.  Rows are drawn with the CPU generator exactly like the
     reference (`torch.randint(low=0, high=sample_mse_max_row, size=(n,))` without device=).  -> float32 [2, cfg, H]"""
     cfg, H, S, D = q.shape
     n = min(num_sampled_rows, S)
     rows = torch.randint(low=0, high=sample_max_row, size=(n,))
     mses = _native.sample_mse(q.reshape(cfg * H, S, D), k.reshape(cfg * H, S, D), v.reshape(cfg * H, S, D),
-                              rows.to(q.device, non_blocking=True), prof)
+                              rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag)
     return mses.reshape(2, cfg, H)
+
+
+def dense_flag_on_device(timestep, first_times_fp):
+    """int32 [1] on the timestep's device: 1 = this denoise step is a dense warm-up step (`timestep[0] > first_times_fp`,
+    ref hyvideo/attention.py:495) — the comparison stays on the GPU; None when the timestep is not a GPU tensor."""
+    if not (torch.is_tensor(timestep) and timestep.is_cuda):
+        return None
+    return (timestep.reshape(-1)[:1] > first_times_fp).to(torch.int32)
+
+
+def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask", dense_mask: "_native.BandMask",
+                                 prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, dense_flag):
+    """Dense warm-up step or sparse step, decided on the device: the profiler and the attention kernel read
+    `dense_flag`; on a dense step the profiler returns at once and the kernel runs `dense_mask` without the head placement.
+    Same results as the host-side branch of attention_core_logic (ref: hyvideo/attention.py:491-524)."""
+    _require_gpu(q, "SVG1 attention")
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag)
+    best_mask_idx = torch.argmin(mses, dim=0)
+    out = _native.band_attention_switch(q, k, v, mask, dense_mask, dense_flag, head_perm_flag=best_mask_idx, vid0=geo.vid0,
+                                        num_frame=geo.num_frame, frame_size=geo.frame_size)
+    return out, best_mask_idx
 
 
 def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof: "_native.ProfileDesc",

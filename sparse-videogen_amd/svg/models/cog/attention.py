@@ -9,7 +9,7 @@ import torch
 from .. import _core
 from .._core import Geometry
 from ..hyvideo.attention import apply_rotary_emb
-from .utils import generate_temporal_head_mask_mod, profile_desc
+from .utils import dense_mask, generate_temporal_head_mask_mod, profile_desc
 
 
 def qk_norm(attn, query, key):
@@ -49,6 +49,7 @@ class CogVideoX_SparseAttn_Processor2_0:
     attention_masks = None
     block_mask = None
     fused_placement = True
+    device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor
 
     def __init__(self, layer_idx):
         self.layer_idx = layer_idx
@@ -94,11 +95,21 @@ class CogVideoX_SparseAttn_Processor2_0:
         assert seq_len == geo.seq_len, (
             f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
         # ref :173-176 — Cog's warm-up thresholds are fractions of 42 layers / 1000 timesteps
-        if _core.is_full_attention(self.layer_idx, timestep, 42 * self.first_layers_fp, 1000 * (1 - self.first_times_fp)):
+        first_layers, first_times = 42 * self.first_layers_fp, 1000 * (1 - self.first_times_fp)
+        dense_flag = None   # (device-side dense / sparse switch, see the Hunyuan processor)
+        if self.device_switch and self.fused_placement and self.layer_idx >= first_layers and self.block_mask is not None \
+                and query.is_cuda:
+            dense_flag = _core.dense_flag_on_device(timestep, first_times)
+        if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, first_layers, first_times):
             return self.flash_attention(query, key, value).reshape(cfg, num_heads, seq_len, dim)
         if self.block_mask is None:
             raise RuntimeError("CogVideoX_SparseAttn_Processor2_0.block_mask is not set: call replace_cog_attention first")
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
+        if dense_flag is not None:
+            out, best = _core.svg1_attention_device_switch(query, key, value, geo, self.block_mask, dense_mask(seq_len), prof,
+                                                           self.num_sampled_rows, seq_len, dense_flag)
+            self.last_best_mask_idx = best
+            return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, self.block_mask, prof, self.num_sampled_rows, seq_len,
                                                 fused=self.fused_placement)
         self.last_best_mask_idx = best

@@ -212,6 +212,7 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
     sample_mse_max_row = 10000
     block_mask = None      # svg_band_mask_t descriptor (what the reference's flex BlockMask encodes)
     fused_placement = True  # fold both layout transformations into the attention kernel (bit-identical result)
+    device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor (no read-back per forward)
 
     def __init__(self, layer_idx):
         super().__init__(layer_idx)
@@ -234,14 +235,24 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
         geo = self.geometry()
         assert seq_len == geo.seq_len, (
             f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
-        if _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
-            valid = cu_max_seqlens[0] if cu_max_seqlens is not None and cu_max_seqlens[0] is not None else (
-                geo.video_length + self.prompt_length)
+        valid = cu_max_seqlens[0] if cu_max_seqlens is not None and cu_max_seqlens[0] is not None else (
+            geo.video_length + self.prompt_length)
+        # the layer test is host data; the timestep test stays on the device when the timestep is a GPU tensor (device_switch)
+        dense_flag = None
+        if self.device_switch and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
+                and query.is_cuda:
+            dense_flag = _core.dense_flag_on_device(timestep, self.first_times_fp)
+        if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
             return _core.dense_attention(query, key, value, valid).reshape(cfg, num_heads, seq_len, dim)
         mask = self.block_mask
         if mask is None:
             raise RuntimeError("Hunyuan_SVGAttn_Processor2_0.block_mask is not set: call replace_hyvideo_attention first")
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
+        if dense_flag is not None:
+            out, best = _core.svg1_attention_device_switch(query, key, value, geo, mask, dense_mask(seq_len, int(valid)), prof,
+                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag)
+            self.last_best_mask_idx = best
+            return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, mask, prof, self.num_sampled_rows,
                                                 min(self.sample_mse_max_row, seq_len), fused=self.fused_placement)
         self.last_best_mask_idx = best

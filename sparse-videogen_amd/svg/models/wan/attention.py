@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from ...timer import time_logging_decorator
 from .. import _core
 from .._core import CentroidStore, Geometry
-from .utils import generate_temporal_head_mask_mod, profile_desc
+from .utils import dense_mask, generate_temporal_head_mask_mod, profile_desc
 
 
 def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs):
@@ -48,6 +48,7 @@ class WanAttn_SVGAttn_Processor2_0:
 
     num_sampled_rows = 32
     sample_mse_max_row = 10000
+    device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor
     attention_masks = None
     sparsity = 0
 
@@ -142,11 +143,20 @@ class WanAttn_SVGAttn_Processor2_0:
         geo = self.geometry()
         assert seq_len == geo.seq_len, (
             f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
-        if _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
+        dense_flag = None   # (device-side dense / sparse switch, see the Hunyuan processor)
+        if self.device_switch and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
+                and query.is_cuda:
+            dense_flag = _core.dense_flag_on_device(timestep, self.first_times_fp)
+        if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
             return self.flash_attention(query, key, value).reshape(cfg, num_heads, seq_len, dim)
         if self.block_mask is None:
             raise RuntimeError("WanAttn_SVGAttn_Processor2_0.block_mask is not set: call replace_wan_attention first")
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
+        if dense_flag is not None:
+            out, best = _core.svg1_attention_device_switch(query, key, value, geo, self.block_mask, dense_mask(seq_len), prof,
+                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag)
+            self.last_best_mask_idx = best
+            return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, self.block_mask, prof, self.num_sampled_rows,
                                                 min(self.sample_mse_max_row, seq_len), fused=self.fused_placement)
         self.last_best_mask_idx = best

@@ -155,6 +155,39 @@ def test_band_attention_random_mask_family(nat, seed, D, dtype, variant):
     check_attn(o, ref, dtype)
 
 
+@pytest.mark.parametrize("D,dtype", [(128, torch.bfloat16), (64, torch.float16)])
+def test_band_attention_device_switch(nat, D, dtype):
+    """svg_band_attention_switch / svg_sample_mse_flagged: the device flag selects the dense mask without placement, or the
+    sparse mask with it — the same results as the two plain calls; a flagged profiler call leaves its output untouched."""
+    torch.manual_seed(3)
+    F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3
+    S, prm, _, vid0 = _band_case("hy", F_, P_, ctx, L, mul)
+    H = 4
+    q, k, v = (dev(torch.randn(1, H, S, D).to(dtype)) for _ in range(3))
+    mask = nat.BandMask(**prm)
+    dense = nat.BandMask(real_len=F_ * P_ + L, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
+    best = dev(torch.tensor([[0, 1, 1, 0]]))
+    kw = dict(head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_)
+    sparse_ref = nat.band_attention(q, k, v, mask, **kw)
+    dense_ref = nat.band_attention(q, k, v, dense)
+    for flag, ref in ((0, sparse_ref), (1, dense_ref)):
+        f = dev(torch.tensor([flag], dtype=torch.int32))
+        o = nat.band_attention_switch(q, k, v, mask, dense, f, **kw)
+        # (another instantiation of the same body: the compiler may associate the row sums differently, so rounding-level)
+        torch.testing.assert_close(o.float(), ref.float(), atol=4e-3, rtol=1e-2)
+        assert (o.float() - ref.float()).abs().mean() < 1e-4
+    # profiler: flag 0 == unflagged call, flag 1 == untouched (zero-initialised) output
+    rows = dev(torch.randint(0, F_ * P_, (32,)))
+    prof = nat.ProfileDesc(0, F_, P_, 1)
+    bb = max(1, int((P_ * 1.5) // 128))
+    prof.variant[0] = nat.ProfileVariant(0, 0, F_ * P_, bb, 0, F_ * P_, S)
+    prof.variant[1] = nat.ProfileVariant(1, 0, F_ * P_, bb, 0, F_ * P_, S)
+    base = nat.sample_mse(q[0], k[0], v[0], rows, prof)
+    same = nat.sample_mse(q[0], k[0], v[0], rows, prof, skip_flag=dev(torch.tensor([0], dtype=torch.int32)))
+    skipped = nat.sample_mse(q[0], k[0], v[0], rows, prof, skip_flag=dev(torch.tensor([1], dtype=torch.int32)))
+    assert torch.equal(base, same) and torch.count_nonzero(skipped) == 0
+
+
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])
 def test_band_attention_fused_placement(nat, model):
     """head_perm_flag path == placement -> attention -> inverse placement of the reference (attention.py:514-520)."""

@@ -102,6 +102,19 @@ def test_hunyuan_svg_processor_end_to_end():
         h3, _ = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
                                timestep=torch.tensor([100.0]))
     assert torch.equal(h2, h3)
+    # device-side dense / sparse switch (GPU timestep tensor): the same result as the host-side decision on both kinds of step
+    for t in (100.0, 950.0):
+        outs = []
+        for dev_switch, ts in ((False, torch.tensor([t])), (True, torch.tensor([t]).cuda())):
+            cls.device_switch = dev_switch
+            torch.manual_seed(11)
+            with torch.no_grad():
+                hh, ee = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                                        timestep=ts)
+            outs.append((hh, ee))
+        cls.device_switch = True
+        torch.testing.assert_close(outs[0][0].float(), outs[1][0].float(), atol=1e-2, rtol=1e-2)
+        torch.testing.assert_close(outs[0][1].float(), outs[1][1].float(), atol=1e-2, rtol=1e-2)
 
 
 def _clustered(H, N, D, modes, gen):
