@@ -983,7 +983,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
         if (variant == 3 || variant == 4) return run_varblock<T, 64, -8>(SVG_VB_ARGS);           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
-    if (variant < -1 || variant > 3) return SVG_ERR_BAD_ARG;
+    if (variant < -1 || variant > 4) return SVG_ERR_BAD_ARG;
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
