@@ -74,3 +74,45 @@ def gather_chunk(full: torch.Tensor, o_chunk: torch.Tensor, chunk: int, n_per: i
     """All-gather local chunk `chunk` ([n_per, S, D] on every rank) into its slice of `full` [H, S, D]; returns the work handle."""
     dst = full[chunk * world * n_per:(chunk + 1) * world * n_per]
     return dist.all_gather_into_tensor(dst, o_chunk.contiguous(), group=group, async_op=async_op)
+
+
+def overlapped_sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_fn: Callable[..., torch.Tensor],
+                                 per_head_args: Sequence[torch.Tensor] = (), group=None, max_chunks: int = 3) -> torch.Tensor:
+    """`sharded_attention` with the exchange hidden behind compute (what `bench.py --gpus N` times): this rank's heads are
+    processed in up to `max_chunks` chunks (`chunked_head_layout`); the all-gather of chunk c runs on the communicator's stream
+    while chunk c + 1 computes, and on CUDA the chunk launches alternate between two streams so that the next chunk's workgroups
+    fill the idle CUs of a launch's last round.  Needs num_heads % world == 0 and cfg == 1 (one contiguous [H, S, D] output).
+    attn_fn(q_c, k_c, v_c, *args_c) -> [1, n, S, D] for tensors sliced to the chunk's n heads."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    cfg, H, S, D = q.shape
+    assert cfg == 1, "overlapped_sharded_attention: cfg must be 1 (use sharded_attention otherwise)"
+    n_chunks, n_per, _ = chunked_head_layout(H, rank, world, max_chunks)
+    full = torch.empty((H, S, D), dtype=q.dtype, device=q.device)
+    cuda = q.is_cuda
+    main = torch.cuda.current_stream() if cuda else None
+    side = [torch.cuda.Stream(device=q.device) for _ in range(2)] if cuda and n_chunks > 1 else None
+    works = []
+    for c in range(n_chunks):
+        h0 = c * world * n_per + rank * n_per
+        sl = slice(h0, h0 + n_per)
+        st = side[c % 2] if side else main
+        if side:
+            st.wait_stream(main)
+        ctx = torch.cuda.stream(st) if cuda else _NullCtx()
+        with ctx:
+            o_c = attn_fn(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(), *[a[:, sl] for a in per_head_args])
+            works.append((gather_chunk(full, o_c[0], c, n_per, world, group), o_c))   # keep o_c alive until its gather is done
+    if side:
+        for st in side:
+            main.wait_stream(st)
+    for w, _ in works:
+        w.wait()
+    return full.unsqueeze(0)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

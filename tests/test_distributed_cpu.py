@@ -97,3 +97,34 @@ def test_chunked_head_layout_partitions():
         assert sorted(seen) == list(range(H))
     assert chunked_head_layout(24, 3, 8) == (3, 1, [3, 11, 19])
     assert chunked_head_layout(24, 1, 2) == (3, 4, [4, 5, 6, 7, 12, 13, 14, 15, 20, 21, 22, 23])
+
+
+def _worker_overlapped(rank, world, port, H, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import overlapped_sharded_attention
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, H, 48, 16) for _ in range(3))
+    scale_h = torch.arange(H, dtype=torch.float32)[None]          # a per-head argument, sliced like the heads
+
+    def attn(qh, kh, vh, sc):
+        return torch.nn.functional.scaled_dot_product_attention(qh, kh, vh) * (1.0 + sc[:, :, None, None])
+
+    out = overlapped_sharded_attention(q, k, v, attn, per_head_args=(scale_h,))
+    ref = attn(q, k, v, scale_h)
+    ret[rank] = bool(torch.equal(out, ref))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [24, 6])
+def test_overlapped_sharded_attention_gloo(H):
+    """library form of the bench's N > 1 scheme: chunked heads, per-chunk asynchronous all-gather, full output on every rank"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000) + H
+    mp.spawn(_worker_overlapped, args=(world, port, H, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
