@@ -134,7 +134,7 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
  * (8 waves, lock-step), 2 = mixed (full 256-row tiles on 8 waves, the rest of each block-row on 128-row tiles; two launches),
  * 3 = 256-row q tiles with the two-phase ping-pong body of svg_band_attention (waves without query rows idle), workgroups
  * launched longest-first inside every kv head (device-side counting sort on the active keys of the block-rows);
- * 4 = the same kernel in block-row order (A/B measurements).
+ * 4 = the same kernel in block-row order (A/B measurements); 5 = variant 3 recording the launch timeline (svg_debug_wg_trace).
  * ---------------------------------------------------------------------------------------------- */
 size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq);
 int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,

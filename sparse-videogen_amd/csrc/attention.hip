@@ -501,6 +501,13 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_pp2_kernel(typename Varb
     attn_body_pp2<T, D, VarblockPolicy<T, D, 8>>(prm, smem, smem + attn_pp2_lds_bytes<D>());
 }
 
+// the same kernel with the launch timeline of svg_debug_wg_trace (variant 5)
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void varblock_attn_pp2_trace_kernel(typename VarblockPolicy<T, D, 8>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, VarblockPolicy<T, D, 8>, true>(prm, smem, smem + attn_pp2_lds_bytes<D>());
+}
+
 static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
 
 // plan: exclusive prefix sums of q_sizes, k_sizes and of the per-block-row tile counts.  grid = (Hkv), block = 256
@@ -622,6 +629,7 @@ static thread_local bool g_band_pipe = false;  // set per call from `variant` bi
 static thread_local bool g_band_pp = false;    // set per call from `variant` bit 5
 static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
 static thread_local bool g_band_pp2 = false;       // `variant` bit 7: two-phase ping-pong schedule (attn_body_pp2)
+static thread_local bool g_vb_trace = false;            // svg_varblock_attention variant 5: variant 3 with the launch timeline (bf16, D = 128)
 static thread_local bool g_vb_block_row_order = false;  // svg_varblock_attention variant 4: two-phase kernel in block-row order (A/B)
 static thread_local int g_band_pp_abl = 0;         // `variant` bits 8..11 together with bit 6: ablation of the traced kernel
 
@@ -936,6 +944,11 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, toff, work, hist, order, Hkv,
                                    QB, group);
                 p.order = order;
+                if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
+                    if (g_vb_trace)
+                        return launch_attn(varblock_attn_pp2_trace_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
+                                           attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+                }
                 return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
                                    attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
             }
@@ -971,19 +984,20 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
     g_vb_block_row_order = (variant == 4);
+    g_vb_trace = (variant == 5);
 #define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, st
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
-        if (variant == 3 || variant == 4) return run_varblock<T, 128, -8>(SVG_VB_ARGS);          \
+        if (variant >= 3) return run_varblock<T, 128, -8>(SVG_VB_ARGS);                          \
         return variant == 1 ? run_varblock<T, 128, 8>(SVG_VB_ARGS) : run_varblock<T, 128, 4>(SVG_VB_ARGS); \
     }                                                                                            \
     if (D == 64) {                                                                               \
         if (variant == 2) return run_varblock<T, 64, 0>(SVG_VB_ARGS);                            \
-        if (variant == 3 || variant == 4) return run_varblock<T, 64, -8>(SVG_VB_ARGS);           \
+        if (variant >= 3) return run_varblock<T, 64, -8>(SVG_VB_ARGS);                           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
-    if (variant < -1 || variant > 4) return SVG_ERR_BAD_ARG;
+    if (variant < -1 || variant > 5) return SVG_ERR_BAD_ARG;
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
