@@ -166,10 +166,15 @@ def main():
     full = torch.empty(H, S, D, device=dev, dtype=torch.bfloat16) if world > 1 else None   # every rank ends with all heads
 
     ev_a0, ev_a1 = [], []
-    # The chunk launches alternate between two streams: a launch of 467-934 workgroups on 256 CUs ends with a partly idle
-    # round (1.8 / 3.6 rounds at N = 8 / 4), and the next chunk's workgroups fill those CUs instead of waiting for the
-    # kernel boundary.  The all-gather of a chunk is enqueued behind its own stream.
-    side = [torch.cuda.Stream(device=dev) for _ in range(2)] if n_chunks > 1 and not os.environ.get("SVG_BENCH_ONE_STREAM") else None
+    # N > 1: ONE launch over this rank's heads that counts completions per head (svg_band_attention_notify; the dispatch is
+    # head-major, so heads finish in order); for every chunk of heads a one-wave kernel on a side stream returns once the chunk's
+    # counters are full, and the chunk's all-gather is enqueued behind it — the exchange of chunk c runs while the launch is
+    # still working on chunks c + 1 ...  (Chunked launches instead — SVG_BENCH_CHUNK_LAUNCHES=1, kept for A/B — cost
+    # 5.7 ms per rank at N = 8 against 4.9 ms for the single launch: every launch ends with a partly idle round.)
+    chunk_launches = bool(os.environ.get("SVG_BENCH_CHUNK_LAUNCHES"))
+    side = [torch.cuda.Stream(device=dev) for _ in range(2)] if n_chunks > 1 else None
+    done = torch.zeros(Hl, device=dev, dtype=torch.int32) if n_chunks > 1 else None
+    target = nat.band_notify_target(S, mask)
 
     def step(timed: bool):
         if not a.no_profiler:
@@ -180,16 +185,31 @@ def main():
         e0.record()
         works = []
         main = torch.cuda.current_stream()
-        for c in range(n_chunks):
-            sl = slice(c * n_per, (c + 1) * n_per)
-            st = side[c % 2] if side else main
-            if side:
+        kw = dict(vid0=0, num_frame=F_, frame_size=P_, variant=a.variant)
+        if side is None:
+            nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, **kw)
+        elif chunk_launches:
+            for c in range(n_chunks):
+                sl = slice(c * n_per, (c + 1) * n_per)
+                st = side[c % 2]
                 st.wait_stream(main)   # inputs and the profiler's result are produced on the main stream
-            with torch.cuda.stream(st):
-                nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), vid0=0,
-                                   num_frame=F_, frame_size=P_, variant=a.variant, out=o[:, sl])
-                if world > 1:   # RCCL all-gather of this chunk behind its kernel, while the next chunk computes
-                    works.append(gather_chunk(full, o[0, sl], c, n_per, world))
+                with torch.cuda.stream(st):
+                    nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), out=o[:, sl], **kw)
+                    if world > 1:
+                        works.append(gather_chunk(full, o[0, sl], c, n_per, world))
+        else:
+            done.zero_()
+            zeroed = torch.cuda.Event()
+            zeroed.record()
+            nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, done=done, **kw)
+            for c in range(n_chunks):
+                sl = slice(c * n_per, (c + 1) * n_per)
+                st = side[c % 2]
+                st.wait_event(zeroed)          # NOT the launch itself: the waiter runs beside it
+                with torch.cuda.stream(st):
+                    nat.wait_counters(done[sl], target)
+                    if world > 1:   # RCCL all-gather of this chunk as soon as its heads are complete
+                        works.append(gather_chunk(full, o[0, sl], c, n_per, world))
         if side:
             for st in side:
                 main.wait_stream(st)
@@ -219,6 +239,9 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    if smoke and world > 1:   # the gathered output must hold this rank's heads as they are after the launch (an early gather would not)
+        mine_idx = torch.tensor(my_heads, device=dev)
+        assert torch.equal(full.index_select(0, mine_idx), o[0]), "all-gather ran ahead of the attention kernel"
     ms_step = dt / a.steps * 1e3
     attn_ms = sum(x.elapsed_time(y) for x, y in zip(ev_a0, ev_a1)) / len(ev_a0)
 

@@ -298,6 +298,18 @@ int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const in
                            int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
                            void* workspace, size_t workspace_bytes, const int32_t* skip_flag, void* stream);
 
+/* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
+ * also counts completions: every wave adds 1 to done_per_head[h] (int32 [BH], zeroed by the caller) after its last store of head
+ * h, so done_per_head[h] == svg_band_attention_notify_target(S, mask) means head h of `o` is complete and visible.  The launch is
+ * head-major, so heads complete in order; svg_wait_counters enqueues a one-wave kernel on another stream that returns once
+ * `n` counters have reached `target` — the all-gather of those heads goes behind it and runs while the launch is still working
+ * on the next heads (no chunked launches: at N = 8 three launches of one head cost 5.7 ms, one launch of three heads 4.9 ms). */
+int32_t svg_band_attention_notify_target(int32_t S, const svg_band_mask_t* mask);
+int svg_band_attention_notify(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                              int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                              int32_t* done_per_head, void* stream);
+int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream);
+
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
  * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in

@@ -44,6 +44,10 @@ struct BandPolicy {
         // Row regions: q-tiles never straddle rowfull_lo / rowfull_hi / real_len, so every q-tile is homogeneous (band rows, full
         // rows or rows behind real_len).  Region r = rows [reg_lo[r], reg_hi[r]), its first q-tile is reg_t0[r].
         int reg_lo[4], reg_hi[4], reg_t0[4];
+        // completion counters (or nullptr): every wave of a workgroup adds 1 to done[head] after its last store, so done[h] ==
+        // 8 * (q-tiles of a head) means head h of O is complete and visible — a consumer on another stream (svg_wait_counters) can
+        // start exchanging it while the launch is still working on the next heads (dispatch is head-major)
+        int32_t* done;
     };
     struct Ctx {
         int head, q0, q_end, nT, perm;
@@ -261,6 +265,13 @@ struct BandPolicy {
         b0 = p.cf_lo, blen = (rq && !rowf) ? (unsigned)max(ch - p.cf_lo, 0) : 0u;
     }
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
+    static __device__ __forceinline__ void notify(const Params& p, const Ctx& c) {
+        if (p.done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence();
+            if ((threadIdx.x & 63) == 0) atomicAdd(p.done + c.head, 1);
+        }
+    }
 };
 
 template <typename T, int D, int NW, bool SKEW, int ABL = 0>
@@ -485,6 +496,7 @@ struct VarblockPolicy {
                                                          unsigned& blen) {
         a0 = 0, alen = (unsigned)c.total, b0 = 0, blen = 0u;
     }
+    static __device__ __forceinline__ void notify(const Params&, const Ctx&) {}
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
 };
 
@@ -629,6 +641,7 @@ static thread_local bool g_band_pipe = false;  // set per call from `variant` bi
 static thread_local bool g_band_pp = false;    // set per call from `variant` bit 5
 static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
 static thread_local bool g_band_pp2 = false;       // `variant` bit 7: two-phase ping-pong schedule (attn_body_pp2)
+static thread_local int32_t* g_band_done = nullptr;     // svg_band_attention_notify: per-head completion counters of this call
 static thread_local bool g_vb_trace = false;            // svg_varblock_attention variant 5: variant 3 with the launch timeline (bf16, D = 128)
 static thread_local bool g_vb_block_row_order = false;  // svg_varblock_attention variant 4: two-phase kernel in block-row order (A/B)
 static thread_local int g_band_pp_abl = 0;         // `variant` bits 8..11 together with bit 6: ablation of the traced kernel
@@ -660,6 +673,7 @@ static typename Pol::Params make_band_params(const void* q, const void* k, const
     p.scale_log2 = sm_scale * 1.4426950408889634f;
     p.real_len = mask->real_len, p.band = mask->band;
     p.cf_lo = mask->colfull_lo, p.cf_hi = mask->colfull_hi, p.rf_lo = mask->rowfull_lo, p.rf_hi = mask->rowfull_hi;
+    p.done = g_band_done;
     p.head_flag = nullptr, p.vid0 = 0, p.F = 1, p.P = 1, p.V = 0;
     if (perm && perm->head_perm_flag) {
         p.head_flag = perm->head_perm_flag;
@@ -765,6 +779,36 @@ static int run_band_switch(const void* q, const void* k, const void* v, void* o,
     return launch_status();
 }
 }  // namespace svg
+
+// one wave: spin until every counter has reached `target` (see BandPolicy::Params::done)
+__global__ __launch_bounds__(64) void wait_counters_kernel(const int32_t* __restrict__ counters, int n, int target) {
+    for (int i = threadIdx.x; i < n; i += 64) {
+        while (__hip_atomic_load(counters + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+extern "C" int32_t svg_band_attention_notify_target(int32_t S, const svg_band_mask_t* mask) {
+    if (!mask || S <= 0) return -1;
+    using Pol = svg::BandPolicy<__bf16, 128, 8, false>;
+    const auto p = svg::make_band_params<Pol, __bf16>(nullptr, nullptr, nullptr, nullptr, 1, S, 1.f, mask, nullptr);
+    return p.nqt * 8;   // every wave of every q-tile of a head reports once
+}
+
+extern "C" int svg_band_attention_notify(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                         int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                         int32_t* done_per_head, void* stream) {
+    if (!done_per_head) return SVG_ERR_BAD_ARG;
+    g_band_done = done_per_head;
+    const int rc = svg_band_attention(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, 0, stream);
+    g_band_done = nullptr;
+    return rc;
+}
+
+extern "C" int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream) {
+    if (!counters || n <= 0) return SVG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(wait_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, n, target);
+    return launch_status();
+}
 
 extern "C" int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                          int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,

@@ -73,6 +73,7 @@ __device__ __forceinline__ i16x4 lds_read_tr16(const char* p) {
 //   int  classify(prm, ctx, tile_key0, wave_row0)                wave-uniform TileClass
 //   bool allowed(prm, ctx, q_logical, k_logical)                 element predicate for PARTIAL tiles
 //   void row_intervals(prm, ctx, q_logical, a0, alen, b0, blen)  the same predicate as two key intervals of a row (two-phase body)
+//   void notify(prm, ctx)                                        called by every wave of the two-phase body after its last store
 //   float score_fixup(float raw)                                 (profiler: dtype rounding emulation)
 //   epilogue: store(prm, ctx, ...) handled here through P::kPartialOut
 template <typename T, int D, int NW, typename P>
@@ -1573,6 +1574,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         }
         pp_barrier();
         if (!lagging) pp_barrier();
+        P::notify(prm, ctx);
         return;
     }
 
@@ -1653,6 +1655,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
             if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
         }
+        P::notify(prm, ctx);   // completion counter of the policy (band attention: per head, for an exchange that overlaps the launch)
         if constexpr (TRACE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (wave == 0 && lane == 0 && blockIdx.x < (unsigned)kWgTraceMax) {

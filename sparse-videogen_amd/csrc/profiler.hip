@@ -227,6 +227,7 @@ struct ProfilePolicy {
         }
     }
     static __device__ __forceinline__ T* o_base(const Params&, const Ctx&) { return nullptr; }
+    static __device__ __forceinline__ void notify(const Params&, const Ctx&) {}
 };
 
 // (The two-phase ping-pong body was tried here and is slower, 1.89 ms vs 1.22 ms: it walks every wave through every tile, and a

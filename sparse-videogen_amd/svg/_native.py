@@ -104,6 +104,10 @@ SIGNATURES = {
     "svg_argsort_labels": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                      C.POINTER(PermDesc), _I32, _VP]),
+    "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
+    "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                            C.POINTER(PermDesc), _VP, _VP]),
+    "svg_wait_counters": (C.c_int, [_VP, _I32, _I32, _VP]),
     "svg_band_attention_switch": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
     "svg_sample_mse_flagged": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
@@ -242,8 +246,10 @@ def argsort_labels(labels: torch.Tensor, K: int):
 
 def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
                    head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1,
-                   frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape."""
+                   frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None,
+                   done: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape.
+    done: int32 [BH] zeroed completion counters (svg_band_attention_notify; see band_notify_target / wait_counters)."""
     lib = load()
     _dev(q, k, v, head_perm_flag)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
@@ -257,10 +263,31 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    if done is not None:
+        _dev(done)
+        assert done.dtype == torch.int32 and done.numel() == BH and variant == 0
+        rc = lib.svg_band_attention_notify(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
+                                           C.byref(mask), C.byref(perm) if perm is not None else None, done.data_ptr(), _stream())
+        _check(rc, "svg_band_attention_notify")
+        return o
     rc = lib.svg_band_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
                                 C.byref(mask), C.byref(perm) if perm is not None else None, variant, _stream())
     _check(rc, "svg_band_attention")
     return o
+
+
+def band_notify_target(S: int, mask: BandMask) -> int:
+    """Value a head's completion counter reaches when the head is done (svg_band_attention_notify_target)."""
+    t = load().svg_band_attention_notify_target(int(S), C.byref(mask))
+    assert t > 0
+    return int(t)
+
+
+def wait_counters(counters: torch.Tensor, target: int) -> None:
+    """Enqueue, on the current stream, a one-wave kernel that returns once every element of `counters` (int32, GPU) >= target."""
+    _dev(counters)
+    assert counters.dtype == torch.int32 and counters.is_contiguous()
+    _check(load().svg_wait_counters(counters.data_ptr(), counters.numel(), int(target), _stream()), "svg_wait_counters")
 
 
 def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, alt_mask: BandMask,
