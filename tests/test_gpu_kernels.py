@@ -188,6 +188,33 @@ def test_band_attention_device_switch(nat, D, dtype):
     assert torch.equal(base, same) and torch.count_nonzero(skipped) == 0
 
 
+@pytest.mark.parametrize("model", ["hy", "cog", "dense2"])
+def test_band_attention_notify_counters(nat, model):
+    """svg_band_attention_notify: same output as the plain call, every head's counter ends at svg_band_attention_notify_target,
+    and a waiter enqueued on another stream before the launch has finished returns (svg_wait_counters)."""
+    torch.manual_seed(4)
+    F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3
+    S, prm, _, vid0 = _band_case(model, F_, P_, ctx, L, mul)
+    H, D = 5, 128
+    q, k, v = (dev(torch.randn(1, H, S, D).to(torch.bfloat16)) for _ in range(3))
+    mask = nat.BandMask(**prm)
+    ref = nat.band_attention(q, k, v, mask)
+    done = torch.zeros(H, dtype=torch.int32, device=q.device)
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    o = nat.band_attention(q, k, v, mask, done=done)
+    side.wait_event(ev)
+    target = nat.band_notify_target(S, mask)
+    with torch.cuda.stream(side):
+        nat.wait_counters(done[1:4], target)
+        seen = done.clone()          # runs behind the waiter: heads 1..3 are complete here
+    torch.cuda.synchronize()
+    assert torch.equal(o, ref)
+    assert (done.cpu() == target).all(), (done.cpu(), target)
+    assert (seen.cpu()[1:4] == target).all()
+
+
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])
 def test_band_attention_fused_placement(nat, model):
     """head_perm_flag path == placement -> attention -> inverse placement of the reference (attention.py:514-520)."""
