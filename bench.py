@@ -148,7 +148,9 @@ def main():
     # attention of chunk c + 1 ("overlappable").
     from svg.distributed import chunked_head_layout, gather_chunk
 
-    n_chunks, n_per, my_heads = chunked_head_layout(H, rank, world)
+    # (one head per chunk: with one launch + completion counters a chunk costs a waiter and an all-gather call, not a kernel
+    #  launch, and the exposed gather at the end of the step is that of ONE head instead of a third of the rank's heads)
+    n_chunks, n_per, my_heads = chunked_head_layout(H, rank, world, max_chunks=24)
     if world == 1 and a.chunks > 1:   # exercise the chunked two-stream launch path on one GPU (no collective)
         assert H % a.chunks == 0
         n_chunks, n_per = a.chunks, H // a.chunks
