@@ -119,3 +119,15 @@ def test_mask_descriptors_equal_oracle_parameters():
     wc = sparsity_to_width(0.25, 226, 13, 1350)
     assert cog_mm(226, 13, 1350, wc).as_tuple() == tuple(O.cog_band_params(17776, 226, 13, 1350, wc).values())
     assert hy_mm(256, 64, 33, 3600, w).band == 15616 and wan_mm(0, 0, 21, 3600, ww).band == 12417
+
+
+def test_tools_and_benches_compile():
+    """the measurement scripts (bench*.py, tools/*.py) are part of what the profiles/ numbers come from: keep them importable"""
+    import py_compile
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    files = sorted(root.glob("bench*.py")) + sorted((root / "tools").glob("*.py")) + [root / "__graft_entry__.py"]
+    assert len(files) >= 10
+    for f in files:
+        py_compile.compile(str(f), doraise=True)
