@@ -175,8 +175,20 @@ def main():
     # 5.7 ms per rank at N = 8 against 4.9 ms for the single launch: every launch ends with a partly idle round.)
     chunk_launches = bool(os.environ.get("SVG_BENCH_CHUNK_LAUNCHES"))
     side = [torch.cuda.Stream(device=dev) for _ in range(2)] if n_chunks > 1 else None
-    done = torch.zeros(Hl, device=dev, dtype=torch.int32) if n_chunks > 1 else None
-    target = nat.band_notify_target(S, mask)
+    # every head is cut into row segments with their own counters: what stays exposed at the end of a step is the gather of the
+    # last segment of the last head (a quarter of a head per rank)
+    nseg, row_bounds, seg_targets = nat.band_notify_layout(S, mask, 4)
+    done = torch.zeros(Hl * nseg, device=dev, dtype=torch.int32) if n_chunks > 1 else None
+
+    def gather_segment(c: int, sg: int):
+        """all-gather rows [row_bounds[sg], row_bounds[sg + 1]) of local chunk c (n_per heads per rank) into the natural layout"""
+        a0, a1 = row_bounds[sg], row_bounds[sg + 1]
+        src = o[0, c * n_per:(c + 1) * n_per, a0:a1]
+        if n_per == 1:   # one contiguous [rows, D] block per rank: receive straight into the views of `full`
+            outs = [full[c * world * n_per + r * n_per, a0:a1] for r in range(world)]
+            return dist.all_gather(outs, src[0], async_op=True)
+        outs = [full[c * world * n_per + r * n_per:c * world * n_per + (r + 1) * n_per, a0:a1] for r in range(world)]
+        return dist.all_gather(outs, src, async_op=True)
 
     def step(timed: bool):
         if not a.no_profiler:
@@ -203,15 +215,19 @@ def main():
             done.zero_()
             zeroed = torch.cuda.Event()
             zeroed.record()
-            nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, done=done, **kw)
+            nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, done=done, done_nseg=nseg, **kw)
+            cnt = done.view(Hl, nseg)
+            i = 0
             for c in range(n_chunks):
-                sl = slice(c * n_per, (c + 1) * n_per)
-                st = side[c % 2]
-                st.wait_event(zeroed)          # NOT the launch itself: the waiter runs beside it
-                with torch.cuda.stream(st):
-                    nat.wait_counters(done[sl], target)
-                    if world > 1:   # RCCL all-gather of this chunk as soon as its heads are complete
-                        works.append(gather_chunk(full, o[0, sl], c, n_per, world))
+                for sg in range(nseg):
+                    st = side[i % 2]
+                    i += 1
+                    st.wait_event(zeroed)          # NOT the launch itself: the waiter runs beside it
+                    with torch.cuda.stream(st):
+                        for h in range(c * n_per, (c + 1) * n_per):   # (views of the live counters, never copies)
+                            nat.wait_counters(cnt[h, sg:sg + 1], seg_targets[sg])
+                        if world > 1:   # RCCL all-gather of this row segment as soon as it is complete on every head of the chunk
+                            works.append(gather_segment(c, sg))
         if side:
             for st in side:
                 main.wait_stream(st)

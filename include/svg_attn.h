@@ -309,6 +309,13 @@ int svg_band_attention_notify(const void* q, const void* k, const void* v, void*
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                               int32_t* done_per_head, void* stream);
 int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream);
+/* The same with `nseg` counters per head (done: int32 [BH * nseg], zeroed by the caller): segment s of a head is a contiguous
+ * row range, q-tiles in row order.  svg_band_attention_notify_layout fills row_bounds[0 .. n] (segment s = rows
+ * [row_bounds[s], row_bounds[s + 1])) and targets[0 .. n) for this S / mask and returns n <= nseg, the number of segments used. */
+int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_mask_t* mask, int32_t nseg, int32_t* row_bounds, int32_t* targets);
+int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                  int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                  int32_t* done, int32_t nseg, void* stream);
 
 /* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
  * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised

@@ -48,9 +48,10 @@ struct BandPolicy {
         // 8 * (q-tiles of a head) means head h of O is complete and visible — a consumer on another stream (svg_wait_counters) can
         // start exchanging it while the launch is still working on the next heads (dispatch is head-major)
         int32_t* done;
+        int done_nseg, done_tps;   // counters per head: segment of q-tile qt (row order) = min(qt / done_tps, done_nseg - 1)
     };
     struct Ctx {
-        int head, q0, q_end, nT, perm;
+        int head, qt, q0, q_end, nT, perm;
         int seg_lo[3], seg_n[3];
         int fk_lo, fk_hi;  // per WAVE: tiles with first key in [fk_lo, fk_hi] are FULL for this wave's 32 rows (fast path)
     };
@@ -105,6 +106,7 @@ struct BandPolicy {
         const int rlo = r3 ? p.reg_lo[3] : r2 ? p.reg_lo[2] : r1 ? p.reg_lo[1] : p.reg_lo[0];
         const int rhi = r3 ? p.reg_hi[3] : r2 ? p.reg_hi[2] : r1 ? p.reg_hi[1] : p.reg_hi[0];
         const int rt0 = r3 ? p.reg_t0[3] : r2 ? p.reg_t0[2] : r1 ? p.reg_t0[1] : 0;
+        c.qt = qt;
         c.q0 = rlo + (qt - rt0) * BM;
         c.q_end = min(rhi, c.q0 + BM);
         c.perm = (p.head_flag != nullptr) && (p.head_flag[c.head] != 0);
@@ -269,7 +271,7 @@ struct BandPolicy {
         if (p.done) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __threadfence();
-            if ((threadIdx.x & 63) == 0) atomicAdd(p.done + c.head, 1);
+            if ((threadIdx.x & 63) == 0) atomicAdd(p.done + c.head * p.done_nseg + min(c.qt / p.done_tps, p.done_nseg - 1), 1);
         }
     }
 };
@@ -642,6 +644,7 @@ static thread_local bool g_band_pp = false;    // set per call from `variant` bi
 static thread_local bool g_band_pp_trace = false;  // `variant` bit 6: ping-pong schedule with the cycle trace (bf16, D = 128)
 static thread_local bool g_band_pp2 = false;       // `variant` bit 7: two-phase ping-pong schedule (attn_body_pp2)
 static thread_local int32_t* g_band_done = nullptr;     // svg_band_attention_notify: per-head completion counters of this call
+static thread_local int g_band_done_nseg = 1;           // ... split into this many row segments per head
 static thread_local bool g_vb_trace = false;            // svg_varblock_attention variant 5: variant 3 with the launch timeline (bf16, D = 128)
 static thread_local bool g_vb_block_row_order = false;  // svg_varblock_attention variant 4: two-phase kernel in block-row order (A/B)
 static thread_local int g_band_pp_abl = 0;         // `variant` bits 8..11 together with bit 6: ablation of the traced kernel
@@ -673,7 +676,7 @@ static typename Pol::Params make_band_params(const void* q, const void* k, const
     p.scale_log2 = sm_scale * 1.4426950408889634f;
     p.real_len = mask->real_len, p.band = mask->band;
     p.cf_lo = mask->colfull_lo, p.cf_hi = mask->colfull_hi, p.rf_lo = mask->rowfull_lo, p.rf_hi = mask->rowfull_hi;
-    p.done = g_band_done;
+    p.done = g_band_done, p.done_nseg = 1, p.done_tps = 1 << 30;   // (done_tps is set once nqt is known, below)
     p.head_flag = nullptr, p.vid0 = 0, p.F = 1, p.P = 1, p.V = 0;
     if (perm && perm->head_perm_flag) {
         p.head_flag = perm->head_perm_flag;
@@ -700,6 +703,8 @@ static typename Pol::Params make_band_params(const void* q, const void* k, const
             ++nreg;
         }
         p.nqt = t0;
+        p.done_nseg = std::max(1, std::min(g_band_done_nseg, t0));
+        p.done_tps = (t0 + p.done_nseg - 1) / p.done_nseg;
         for (int i = nreg; i < 4; ++i) p.reg_lo[i] = S, p.reg_hi[i] = S, p.reg_t0[i] = 1 << 30;
         p.heavy_lo = 0, p.n_heavy = 0;
         if (heavy_reg >= 0) {
@@ -794,13 +799,42 @@ extern "C" int32_t svg_band_attention_notify_target(int32_t S, const svg_band_ma
     return p.nqt * 8;   // every wave of every q-tile of a head reports once
 }
 
+extern "C" int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_mask_t* mask, int32_t nseg, int32_t* row_bounds,
+                                                    int32_t* targets) {
+    if (!mask || S <= 0 || nseg <= 0 || !row_bounds || !targets) return -1;
+    using Pol = svg::BandPolicy<__bf16, 128, 8, false>;
+    g_band_done_nseg = nseg;
+    const auto p = svg::make_band_params<Pol, __bf16>(nullptr, nullptr, nullptr, nullptr, 1, S, 1.f, mask, nullptr);
+    g_band_done_nseg = 1;
+    auto tile_row = [&](int t) {   // first row of q-tile t (row order), S behind the last tile
+        if (t >= p.nqt) return S;
+        int r = 0;
+        for (int i = 1; i < 4; ++i)
+            if (t >= p.reg_t0[i]) r = i;
+        return p.reg_lo[r] + (t - p.reg_t0[r]) * Pol::BM;
+    };
+    for (int sgm = 0; sgm < p.done_nseg; ++sgm) {
+        const int t_lo = sgm * p.done_tps, t_hi = (sgm == p.done_nseg - 1) ? p.nqt : std::min(p.nqt, (sgm + 1) * p.done_tps);
+        row_bounds[sgm] = tile_row(t_lo);
+        targets[sgm] = (t_hi - t_lo) * 8;
+    }
+    row_bounds[p.done_nseg] = S;
+    return p.done_nseg;   // segments actually used (<= nseg)
+}
+
 extern "C" int svg_band_attention_notify(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                          int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                                          int32_t* done_per_head, void* stream) {
-    if (!done_per_head) return SVG_ERR_BAD_ARG;
-    g_band_done = done_per_head;
+    return svg_band_attention_notify_seg(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, done_per_head, 1, stream);
+}
+
+extern "C" int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                             int32_t dtype, float sm_scale, const svg_band_mask_t* mask,
+                                             const svg_perm_desc_t* perm, int32_t* done, int32_t nseg, void* stream) {
+    if (!done || nseg <= 0) return SVG_ERR_BAD_ARG;
+    g_band_done = done, g_band_done_nseg = nseg;
     const int rc = svg_band_attention(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, 0, stream);
-    g_band_done = nullptr;
+    g_band_done = nullptr, g_band_done_nseg = 1;
     return rc;
 }
 

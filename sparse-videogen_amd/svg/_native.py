@@ -108,6 +108,9 @@ SIGNATURES = {
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _VP]),
     "svg_wait_counters": (C.c_int, [_VP, _I32, _I32, _VP]),
+    "svg_band_attention_notify_layout": (_I32, [_I32, C.POINTER(BandMask), _I32, _VP, _VP]),
+    "svg_band_attention_notify_seg": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                                C.POINTER(PermDesc), _VP, _I32, _VP]),
     "svg_band_attention_switch": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
     "svg_sample_mse_flagged": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
@@ -247,9 +250,10 @@ def argsort_labels(labels: torch.Tensor, K: int):
 def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
                    head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1,
                    frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None,
-                   done: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   done: Optional[torch.Tensor] = None, done_nseg: int = 1) -> torch.Tensor:
     """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape.
-    done: int32 [BH] zeroed completion counters (svg_band_attention_notify; see band_notify_target / wait_counters)."""
+    done: int32 [BH * done_nseg] zeroed completion counters (svg_band_attention_notify[_seg]; see band_notify_target /
+    band_notify_layout / wait_counters)."""
     lib = load()
     _dev(q, k, v, head_perm_flag)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
@@ -265,10 +269,11 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
     if done is not None:
         _dev(done)
-        assert done.dtype == torch.int32 and done.numel() == BH and variant == 0
-        rc = lib.svg_band_attention_notify(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
-                                           C.byref(mask), C.byref(perm) if perm is not None else None, done.data_ptr(), _stream())
-        _check(rc, "svg_band_attention_notify")
+        assert done.dtype == torch.int32 and done.numel() == BH * done_nseg and variant == 0
+        rc = lib.svg_band_attention_notify_seg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
+                                               scale, C.byref(mask), C.byref(perm) if perm is not None else None, done.data_ptr(),
+                                               int(done_nseg), _stream())
+        _check(rc, "svg_band_attention_notify_seg")
         return o
     rc = lib.svg_band_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
                                 C.byref(mask), C.byref(perm) if perm is not None else None, variant, _stream())
@@ -281,6 +286,16 @@ def band_notify_target(S: int, mask: BandMask) -> int:
     t = load().svg_band_attention_notify_target(int(S), C.byref(mask))
     assert t > 0
     return int(t)
+
+
+def band_notify_layout(S: int, mask: BandMask, nseg: int):
+    """(n, row_bounds [n + 1], targets [n]) of the per-segment completion counters (svg_band_attention_notify_layout):
+    segment s of a head = rows [row_bounds[s], row_bounds[s + 1]), complete when its counter reaches targets[s]; n <= nseg."""
+    rb = (C.c_int32 * (nseg + 1))()
+    tg = (C.c_int32 * nseg)()
+    n = load().svg_band_attention_notify_layout(int(S), C.byref(mask), int(nseg), C.cast(rb, C.c_void_p), C.cast(tg, C.c_void_p))
+    assert n > 0
+    return n, list(rb)[: n + 1], list(tg)[:n]
 
 
 def wait_counters(counters: torch.Tensor, target: int) -> None:
