@@ -213,6 +213,14 @@ def test_band_attention_notify_counters(nat, model):
     assert torch.equal(o, ref)
     assert (done.cpu() == target).all(), (done.cpu(), target)
     assert (seen.cpu()[1:4] == target).all()
+    # per-segment counters: rows [row_bounds[s], row_bounds[s + 1]) of every head, q-tiles in row order
+    n, bounds, targets = nat.band_notify_layout(S, mask, 3)
+    assert bounds[0] == 0 and bounds[-1] == S and sorted(bounds) == bounds and sum(targets) == target
+    done2 = torch.zeros(H * n, dtype=torch.int32, device=q.device)
+    o2 = nat.band_attention(q, k, v, mask, done=done2, done_nseg=n)
+    torch.cuda.synchronize()
+    assert torch.equal(o2, ref)
+    assert torch.equal(done2.cpu().view(H, n), torch.tensor(targets, dtype=torch.int32).expand(H, n))
 
 
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])
