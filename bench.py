@@ -181,14 +181,15 @@ def main():
     done = torch.zeros(Hl * nseg, device=dev, dtype=torch.int32) if n_chunks > 1 else None
 
     def gather_segment(c: int, sg: int):
-        """all-gather rows [row_bounds[sg], row_bounds[sg + 1]) of local chunk c (n_per heads per rank) into the natural layout"""
+        """all-gather rows [row_bounds[sg], row_bounds[sg + 1]) of local chunk c (n_per heads per rank) into the natural [H, S, D]
+        layout: one contiguous all_gather_into_tensor (the call the head-granular path uses) into a staging buffer, then `world`
+        strided copies on the same side stream (the received blocks of different ranks are S * D apart in `full`)."""
         a0, a1 = row_bounds[sg], row_bounds[sg + 1]
-        src = o[0, c * n_per:(c + 1) * n_per, a0:a1]
-        if n_per == 1:   # one contiguous [rows, D] block per rank: receive straight into the views of `full`
-            outs = [full[c * world * n_per + r * n_per, a0:a1] for r in range(world)]
-            return dist.all_gather(outs, src[0], async_op=True)
-        outs = [full[c * world * n_per + r * n_per:c * world * n_per + (r + 1) * n_per, a0:a1] for r in range(world)]
-        return dist.all_gather(outs, src, async_op=True)
+        src = o[0, c * n_per:(c + 1) * n_per, a0:a1].contiguous()
+        tmp = torch.empty((world,) + tuple(src.shape), device=dev, dtype=src.dtype)
+        dist.all_gather_into_tensor(tmp.view(world * n_per, a1 - a0, D), src, async_op=True).wait()   # the stream waits, not the host
+        h0 = c * world * n_per
+        full[h0:h0 + world * n_per, a0:a1].view(world, n_per, a1 - a0, D).copy_(tmp)
 
     def step(timed: bool):
         if not a.no_profiler:
@@ -227,7 +228,7 @@ def main():
                         for h in range(c * n_per, (c + 1) * n_per):   # (views of the live counters, never copies)
                             nat.wait_counters(cnt[h, sg:sg + 1], seg_targets[sg])
                         if world > 1:   # RCCL all-gather of this row segment as soon as it is complete on every head of the chunk
-                            works.append(gather_segment(c, sg))
+                            gather_segment(c, sg)
         if side:
             for st in side:
                 main.wait_stream(st)
