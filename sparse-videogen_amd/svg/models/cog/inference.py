@@ -11,6 +11,25 @@ from .utils import get_attention_mask, sparsity_to_width
 GEOMETRY = {"v1": (226, 13, 1350), "v1.5": (226, 11, 4080)}  # (context_length, num_frame, frame_size), ref :31-38
 
 
+def sample_image(pipe, prompt, image_path, output_path, seed, version, num_step=50):
+    """ref: svg/models/cog/inference.py:11-23 — one image-to-video sample with the pipeline's own sampler (diffusers
+    `load_image` / `export_to_video`; this function is the entry script's glue, not part of the attention path)."""
+    from diffusers.utils import export_to_video, load_image
+
+    print("\n" * 5)
+    print(f"Prompt: {prompt}")
+    image = load_image(image_path)
+    print(f"Image Is Ready. Seed is {seed}")
+    if version == "v1":
+        video = pipe(image=image, prompt=prompt, guidance_scale=6, use_dynamic_cfg=True, num_inference_steps=num_step).frames[0]
+    elif version == "v1.5":
+        video = pipe(image=image, prompt=prompt, num_videos_per_prompt=1, num_inference_steps=num_step, num_frames=81,
+                     guidance_scale=6, height=768, width=1360).frames[0]
+    else:
+        raise ValueError(f"Unsupported version: {version}")
+    export_to_video(video, output_path, fps=8)
+
+
 def replace_cog_attention(pipe, version, num_sampled_rows, sparsity, first_layers_fp, first_times_fp):
     if version not in GEOMETRY:
         raise ValueError(f"Unsupported version: {version}")

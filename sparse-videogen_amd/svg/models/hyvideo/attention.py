@@ -308,3 +308,11 @@ class Hunyuan_SAPAttn_Processor2_0(Hunyuan_SVGAttn_Processor2_0):
                                           self.kmeans_iter_step, prompt_length=int(self.prompt_length),
                                           logging_file=self.logging_file, timestep=timestep)
         return out.reshape(cfg, num_heads, seq_len, dim)
+
+
+def replace_hyvideo_flashattention(pipe):
+    """hyvideo_i2v_inference.py:14 imports this name from `svg.models.hyvideo.attention` (the reference defines it in
+    `.inference`, ref: svg/models/hyvideo/inference.py:16-30); both module paths work here."""
+    from .inference import replace_hyvideo_flashattention as _impl
+
+    return _impl(pipe)

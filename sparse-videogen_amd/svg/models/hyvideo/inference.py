@@ -2,6 +2,8 @@
 svg/models/hyvideo/inference.py (`replace_hyvideo_flashattention`, `replace_hyvideo_attention`)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ...logger import logger
@@ -39,16 +41,17 @@ def replace_hyvideo_attention(
     pattern="SVG",
     # SVG
     num_sampled_rows=64,
+    sample_mse_max_row=10000,
     sparsity=0.25,
     # SAP
-    num_q_centroids=50,
-    num_k_centroids=200,
-    top_p_kmeans=0.9,
-    min_kc_ratio=0.0,
+    num_q_centroids=None,
+    num_k_centroids=None,
+    top_p_kmeans=None,
+    min_kc_ratio=0,
+    logging_file=None,
     kmeans_iter_init=0,
     kmeans_iter_step=0,
     zero_step_kmeans_init=False,
-    logging_file=None,
 ):
     """ref: hyvideo/inference.py:33-166.  Sets the class-level configuration of the processor class and installs one
     processor per block."""
@@ -61,7 +64,7 @@ def replace_hyvideo_attention(
         AttnModule = Hunyuan_SVGAttn_Processor2_0
         multiplier = diag_width = sparsity_to_width(sparsity, context_length, num_frame, frame_size)
         AttnModule.num_sampled_rows = num_sampled_rows
-        AttnModule.sample_mse_max_row = 10000
+        AttnModule.sample_mse_max_row = sample_mse_max_row
         AttnModule.attention_masks = [
             get_attention_mask(name, AttnModule.sample_mse_max_row, context_length, num_frame, frame_size)
             for name in ("spatial", "temporal")
@@ -70,7 +73,13 @@ def replace_hyvideo_attention(
                                                       prompt_length, num_frame, frame_size, diag_width=diag_width,
                                                       multiplier=multiplier)
         logger.info(f"SVG: sparsity {sparsity} -> width {multiplier:.4f} frames -> band {AttnModule.block_mask.band} tokens")
-    elif pattern == "SAP":
+    elif pattern in ["SAP"]:
+        logger.info(f"Configuring KMEANS_BLOCK attention with QC: {num_q_centroids}, KC: {num_k_centroids}, P: {top_p_kmeans}, "
+                    f"min_kc_ratio: {min_kc_ratio}")
+        if logging_file is not None:   # ref :126-130: make the directory and clear the density log
+            os.makedirs(os.path.dirname(logging_file) or ".", exist_ok=True)
+            with open(logging_file, "w") as f:
+                f.write("")
         AttnModule = Hunyuan_SAPAttn_Processor2_0
         AttnModule.num_q_centroids = num_q_centroids
         AttnModule.num_k_centroids = num_k_centroids
@@ -82,7 +91,8 @@ def replace_hyvideo_attention(
         AttnModule.logging_file = logging_file
         AttnModule.reset_state()
     else:
-        raise ValueError(f"Unsupported pattern: {pattern}")
+        assert pattern == "dense", f"Invalid pattern: {pattern}"   # ref :165-166: "dense" leaves the pipeline's own processors in place
+        return None
 
     AttnModule.prompt_length = prompt_length
     AttnModule.context_length = context_length

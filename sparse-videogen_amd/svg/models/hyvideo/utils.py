@@ -12,6 +12,11 @@ from math import floor
 
 from ... import _native
 
+try:   # the reference takes the template from diffusers (ref: svg/models/hyvideo/utils.py:8); optional here
+    from diffusers.pipelines.hunyuan_video.pipeline_hunyuan_video import DEFAULT_PROMPT_TEMPLATE
+except Exception:  # noqa: BLE001 — diffusers absent: the caller passes prompt_template (or a template with crop_start)
+    DEFAULT_PROMPT_TEMPLATE = None
+
 
 def sparsity_to_width(sparsity, context_length, num_frame, frame_size):
     """ref: svg/models/hyvideo/utils.py:142-151 — density target -> band half-width in frames."""
@@ -55,3 +60,27 @@ def profile_desc(context_length, num_frame, frame_size, emulate_bf16=True) -> _n
     d.variant[0] = get_attention_mask("spatial", 0, context_length, num_frame, frame_size)
     d.variant[1] = get_attention_mask("temporal", 0, context_length, num_frame, frame_size)
     return d
+
+
+def get_prompt_length(pipe, prompt, prompt_template=DEFAULT_PROMPT_TEMPLATE, max_sequence_length=256, device="cuda"):
+    """ref: svg/models/hyvideo/utils.py:96-141 — number of real prompt tokens (prompt_length + pad = context_length = 256),
+    needed before the masks are built.  Tokenises the templated prompt with the pipeline's tokenizer, drops the template
+    prefix (`crop_start`) and sums the attention mask.  Host logic only (tokenizer call); returns a 0-dim tensor like the
+    reference."""
+    if prompt_template is None:
+        raise RuntimeError("get_prompt_length: diffusers is not installed, pass prompt_template explicitly")
+    prompt = [prompt] if isinstance(prompt, str) else prompt
+    prompt = [prompt_template["template"].format(p) for p in prompt]
+    crop_start = prompt_template.get("crop_start", None)
+    if crop_start is None:
+        tmpl = pipe.tokenizer(prompt_template["template"], padding="max_length", return_tensors="pt", return_length=False,
+                              return_overflowing_tokens=False, return_attention_mask=False)
+        crop_start = tmpl["input_ids"].shape[-1] - 2   # minus <|eot_id|> and the {} placeholder
+    max_sequence_length += crop_start
+    text_inputs = pipe.tokenizer(prompt, max_length=max_sequence_length, padding="max_length", truncation=True,
+                                 return_tensors="pt", return_length=False, return_overflowing_tokens=False,
+                                 return_attention_mask=True)
+    prompt_attention_mask = text_inputs.attention_mask.to(device=device)
+    if crop_start is not None and crop_start > 0:
+        prompt_attention_mask = prompt_attention_mask[:, crop_start:]
+    return prompt_attention_mask.sum()

@@ -1,5 +1,5 @@
 """Per-operator timing, ref: svg/timer.py.  Same knob (env TIME_BENCH = 0 off / 1 cumulative seconds / 2 per-print ms and
-clear), same label strings ("Level 2 - attention core logic", ...), same `operator_log_data` dict and forward-hook
+clear), same label strings ("Level 2 - attention core logic", ...), same `operator_log_data` dict (milliseconds) and forward-hook
 printer.  Timing uses HIP events on the current stream (torch.cuda.Event on ROCm) when tensors live on the GPU."""
 from __future__ import annotations
 
@@ -35,9 +35,9 @@ class TimeLoggingContext:
             if torch.cuda.is_available():
                 self._e.record()
                 torch.cuda.synchronize()
-                operator_log_data[self.operation_name] += self._s.elapsed_time(self._e) / 1000.0
+                operator_log_data[self.operation_name] += self._s.elapsed_time(self._e)
             else:
-                operator_log_data[self.operation_name] += time.perf_counter() - self._t0
+                operator_log_data[self.operation_name] += (time.perf_counter() - self._t0) * 1000.0
         return False
 
     def __call__(self, fn):
@@ -53,15 +53,23 @@ def time_logging_decorator(operation_name: str) -> TimeLoggingContext:
     return TimeLoggingContext(operation_name)
 
 
-def print_operator_log_data(module=None, inputs=None, outputs=None):
-    """Forward-hook compatible printer (ref: svg/timer.py:43-74)."""
-    if not ENABLE_LOGGING:
+def print_operator_log_data(module, input, output):
+    """Forward-hook printer, `register_forward_hook(print_operator_log_data)` (ref: svg/timer.py:43-74).  The dict holds
+    milliseconds like the reference's (HIP-event elapsed time); TIME_BENCH=1 prints cumulative seconds, TIME_BENCH=2 prints
+    milliseconds and clears."""
+    if not ENABLE_LOGGING or not operator_log_data:
         return
-    scale, unit = (1.0, "s") if ENABLE_LOGGING == 1 else (1000.0, "ms")
+    width = max(len(str(k)) for k in operator_log_data)
+    lines = []
     for name in sorted(operator_log_data):
-        print(f"{name:<60s} {operator_log_data[name] * scale:10.3f} {unit}")
+        if ENABLE_LOGGING == 2:
+            lines.append(f"{name:<{width}} : {operator_log_data[name]:10.3f} ms")
+        else:
+            lines.append(f"{name:<{width}} : {operator_log_data[name] / 1000.0:10.3f} s")
+    print("\n\n")
     if ENABLE_LOGGING == 2:
         operator_log_data.clear()
+    print("\n".join(lines))
 
 
 def clear_operator_log_data():
