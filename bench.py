@@ -178,7 +178,7 @@ def main():
     # every head is cut into row segments with their own counters: what stays exposed at the end of a step is the gather of the
     # last segment of the last head (a quarter of a head per rank)
     nseg, row_bounds, seg_targets = nat.band_notify_layout(S, mask, 4)
-    done = torch.zeros(Hl * nseg, device=dev, dtype=torch.int32) if n_chunks > 1 else None
+    done = nat.notify_counters(Hl, nseg, dev) if n_chunks > 1 else None   # + BH words of library scratch behind the counters
 
     def gather_segment(c: int, sg: int):
         """all-gather rows [row_bounds[sg], row_bounds[sg + 1]) of local chunk c (n_per heads per rank) into the natural [H, S, D]
@@ -217,7 +217,7 @@ def main():
             zeroed = torch.cuda.Event()
             zeroed.record()
             nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, done=done, done_nseg=nseg, **kw)
-            cnt = done.view(Hl, nseg)
+            cnt = done[:Hl * nseg].view(Hl, nseg)
             i = 0
             for c in range(n_chunks):
                 for sg in range(nseg):

@@ -105,14 +105,17 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = shipped schedule: two-phase ping-pong, 8 waves x 32 query rows — the two waves that share a SIMD alternate a
- * matrix phase (PV of tile t + QK^T of tile t+1, operands streamed from LDS) and a vector phase (softmax, LDS-DMA requests),
- * always in opposite phases.  Non-zero values select the alternative schedules kept for A/B measurements (all produce the same
- * result up to rounding): 1 = lock-step, 4 waves / 128-row q-tiles (2 workgroups per CU), 2 = skewed two-group schedule,
- * 4 = intra-wave software-pipelined body, 8 = 4 waves x 64 rows (one wave per SIMD), 16 = lock-step 8 waves, one tile per stage,
- * 32 = four-cluster ping-pong (register-operand MFMA clusters), 128 = same as 0, 4096 = lock-step 8 waves, two 64-key tiles per
- * stage (the default before the ping-pong schedule); 64 = with 32 / 128: cycle trace (svg_debug_pp_trace); bits 8..11 =
- * timing-only ablations (wrong results by construction, see profiles/). */
+/* variant: 0 = default (currently 3).  All schedules produce the same result up to rounding.
+ *   1 = lock-step, 4 waves x 32 query rows, 128-row q-tiles, two workgroups per CU (register-staged K/V) — the plain schedule
+ *       the test-suite uses as the in-library reference;
+ *   2 = two-phase ping-pong, 8 waves x 32 rows: the two waves that share a SIMD alternate a matrix phase (PV of tile t + QK^T
+ *       of tile t+1, operands streamed from LDS) and a vector phase (softmax, LDS-DMA requests), always in opposite phases;
+ *   3 = one wave per SIMD, 4 waves x 64 rows, O and Q in the AGPR half of the register file, softmax / LDS reads / LDS-DMA
+ *       requests software-pipelined into the gaps between the wave's own MFMAs, one barrier per tile (csrc/attn_w4.h).
+ * Any other value: SVG_ERR_BAD_ARG.  Builds with -DSVG_ABLATIONS (diagnostics, never the product library) additionally accept
+ * 32: variant 3 with the per-phase cycle trace (svg_debug_pp_trace), and
+ * 64 | (abl << 8): variant 2 with the per-phase cycle trace / launch timeline (svg_debug_pp_trace, svg_debug_wg_trace) and its
+ * timing-only ablations abl = 1..7 (wrong results by construction); the product library returns SVG_ERR_UNSUPPORTED for them. */
 int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                        int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                        int32_t variant, void* stream);
@@ -299,8 +302,9 @@ int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const in
                            void* workspace, size_t workspace_bytes, const int32_t* skip_flag, void* stream);
 
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
- * also counts completions: every wave adds 1 to done_per_head[h] (int32 [BH], zeroed by the caller) after its last store of head
- * h, so done_per_head[h] == svg_band_attention_notify_target(S, mask) means head h of `o` is complete and visible.  The launch is
+ * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is
+ * scratch of the library) after its last store of head h, so done_per_head[h] == svg_band_attention_notify_target(S, mask)
+ * means head h of `o` is complete and visible.  The launch is
  * head-major, so heads complete in order; svg_wait_counters enqueues a one-wave kernel on another stream that returns once
  * `n` counters have reached `target` — the all-gather of those heads goes behind it and runs while the launch is still working
  * on the next heads (no chunked launches: at N = 8 three launches of one head cost 5.7 ms, one launch of three heads 4.9 ms). */
@@ -309,23 +313,28 @@ int svg_band_attention_notify(const void* q, const void* k, const void* v, void*
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                               int32_t* done_per_head, void* stream);
 int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream);
-/* The same with `nseg` counters per head (done: int32 [BH * nseg], zeroed by the caller): segment s of a head is a contiguous
- * row range, q-tiles in row order.  svg_band_attention_notify_layout fills row_bounds[0 .. n] (segment s = rows
- * [row_bounds[s], row_bounds[s + 1])) and targets[0 .. n) for this S / mask and returns n <= nseg, the number of segments used. */
+/* The same with several counters per head.  svg_band_attention_notify_layout fills row_bounds[0 .. n] and targets[0 .. n) for this
+ * S / mask and returns n <= nseg, the number of segments used; pass that n as `nseg` of svg_band_attention_notify_seg together
+ * with done = int32 [BH * (n + 1)], zeroed by the caller (counter (h, s) at done[h * n + s]; the last BH words are scratch of
+ * the library).  Contract: done[h * n + s] >= targets[s]  =>  the PHYSICAL rows [row_bounds[s], row_bounds[s + 1]) of head h of
+ * `o` are complete and visible.  Segments are cut in q-tile (logical row) order; a head that runs with the fused layout
+ * permutation (perm->head_perm_flag[h] != 0) writes the rows of a logical segment to every frame, so its segments are all
+ * released together when the head is complete — the contract holds for both kinds of head without the host knowing which
+ * is which (best_mask_idx is device data). */
 int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_mask_t* mask, int32_t nseg, int32_t* row_bounds, int32_t* targets);
 int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                   int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                                   int32_t* done, int32_t nseg, void* stream);
 
-/* Diagnostics (not part of the reference's interface): cycle trace of the ping-pong attention schedules.
- * After a svg_band_attention call with variant bit 6 set together with bit 5 or bit 7 (bf16, D = 128) and a synchronised
+/* Diagnostics (not part of the reference's interface; -DSVG_ABLATIONS builds, otherwise SVG_ERR_UNSUPPORTED): cycle trace of
+ * the two-phase attention schedule.  After a svg_band_attention call with variant 64 (bf16, D = 128) and a synchronised
  * stream, copies 104 counters to the host: out[8 * wave + i] = s_memtime ticks wave `wave` of one workgroup spent in
- *   variant 32:  i = 0..7  [LK work, barrier, QK work, barrier, SV work, barrier, PV work, barrier]
- *   variant 128: i = 0..3  [matrix phase, barrier, vector phase, barrier]
+ *   variant 64: i = 0..3  [matrix phase, barrier, vector phase, barrier]
+ *   variant 32: i = 0..3  [phase A up to the barrier, wait + barrier, rest of A, phase B]   (waves 0..3)
  * out[64] = KV tiles of that workgroup, out[65] = ticks of its tile loop. */
 int svg_debug_pp_trace(uint64_t* out104);
 
-/* Launch timeline of the same traced kernel (variant 128 | 64): for each of the first n_workgroups (<= 16384) workgroups
+/* Launch timeline of the same traced kernel (variant 64): for each of the first n_workgroups (<= 16384) workgroups
  * out[6 * b + ..] = [s_memtime at entry, at the start of the tile loop, at its end, after the last store of O, HW_ID, XCC_ID]. */
 int svg_debug_wg_trace(uint64_t* out, int32_t n_workgroups);
 

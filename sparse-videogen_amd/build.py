@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build libsvgattn.so (the C-ABI HIP library) for gfx950, in-tree.
 
-    python sparse-videogen_amd/build.py [--force] [--asm]
+    python sparse-videogen_amd/build.py [--force] [--asm] [--ablations]
 
 Every csrc/*.hip is compiled with hipcc --offload-arch=gfx950 to an object (in parallel), then linked into
 sparse-videogen_amd/lib/libsvgattn.so.  hipcc cross-compiles, so this works on a machine without a GPU.
@@ -50,14 +50,16 @@ def _newest_header() -> float:
     return max(h.stat().st_mtime for h in hs)
 
 
-def _compile(src: Path, force: bool, asm: bool) -> tuple[Path, str]:
-    obj = OBJ / (src.stem + ".o")
+def _compile(src: Path, force: bool, asm: bool, ablations: bool = False) -> tuple[Path, str]:
+    obj = OBJ / (src.stem + (".abl.o" if ablations else ".o"))
     stamp = max(src.stat().st_mtime, _newest_header())
     if not force and obj.exists() and obj.stat().st_mtime >= stamp:
         return obj, ""
     flags = list(FLAGS)
     if src.name in STRICT_FP:
         flags = [f for f in flags if f not in ("-ffast-math", "-fno-finite-math-only")] + ["-fno-fast-math", "-ffp-contract=off"]
+    if ablations:
+        flags.append("-DSVG_ABLATIONS")
     cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
     if asm:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
@@ -91,36 +93,40 @@ def _summarise(logs: str) -> str:
     return "\n".join(out)
 
 
-def build(force: bool = False, asm: bool = False, verbose: bool = True) -> Path:
+def build(force: bool = False, asm: bool = False, verbose: bool = True, ablations: bool = False) -> Path:
+    """ablations=True builds lib/libsvgattn_abl.so with -DSVG_ABLATIONS: the traced / timing-ablation kernels of the diagnostics
+    tools (tools/pp_trace.py, tools/wg_timeline.py; select it with SVG_ATTN_LIB).  The product library never contains them."""
     OBJ.mkdir(exist_ok=True)
     LIB.parent.mkdir(exist_ok=True)
+    lib = LIB.with_name("libsvgattn_abl.so") if ablations else LIB
     srcs = sorted(CSRC.glob("*.hip"))
     if not srcs:
         raise RuntimeError("no HIP sources found")
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, asm), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, asm, ablations), srcs))
     objs = [o for o, _ in results]
     logs = "".join(l for _, l in results)
     if verbose and logs.strip():
         print(_summarise(logs))
     newest_obj = max(o.stat().st_mtime for o in objs)
-    if force or not LIB.exists() or LIB.stat().st_mtime < newest_obj:
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+    if force or not lib.exists() or lib.stat().st_mtime < newest_obj:
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"linked {LIB} ({LIB.stat().st_size / 1e6:.1f} MB)")
-    return LIB
+            print(f"linked {lib} ({lib.stat().st_size / 1e6:.1f} MB)")
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--asm", action="store_true", help="keep .s files and print register usage")
+    ap.add_argument("--ablations", action="store_true", help="diagnostics library lib/libsvgattn_abl.so (-DSVG_ABLATIONS)")
     a = ap.parse_args()
     try:
-        build(force=a.force, asm=a.asm)
+        build(force=a.force, asm=a.asm, ablations=a.ablations)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

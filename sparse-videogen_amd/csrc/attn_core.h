@@ -455,334 +455,18 @@ __device__ __forceinline__ void attn_body(const typename P::Params& prm, char* s
     }
 }
 
-// =====================================================================================================================
-// attn_body_pipe — software-pipelined schedule (8 waves, three LDS stages).
-//
-// attn_body runs QK^T -> softmax -> PV per tile; the ablation in profiles/r01_ablation.md shows those phases do not
-// overlap (the two waves of a SIMD sit in the same phase).  Here every wave overlaps them itself: while the matrix pipe
-// executes QK^T of tile t+1, the same wave issues the softmax VALU work of tile t in the shadow of its own MFMAs
-// (an MFMA occupies the pipe for 32 cycles but issues in ~4; independent VALU instructions issue behind it).
-//
-//   iteration t:   phase 1   S(t+1) = K(t+1) Q^T    interleaved, k-step by k-step, with  softmax(S(t)) -> P(t), alpha
-//                  (rare)    O *= alpha             only when a row maximum moved
-//                  phase 2   O^T += V(t)^T P(t)^T   interleaved with ds_write of tile t+2 and the global loads of t+3
-//                  barrier
-// LDS: tile t lives in stage t % 3; iteration t reads K(t+1), V(t) and writes tile t+2 over tile t-1 (dead since the
-// barrier of iteration t-1).  No SKIP class: a tile that a wave does not need is masked (p = 0), band-edge waste ~1 %.
-// =====================================================================================================================
-template <typename T, int D, int NW, typename P>
-__device__ __forceinline__ void attn_body_pipe(const typename P::Params& prm, char* smem, char* policy_lds) {
-    using E = Elt<T>;
-    using V8 = typename E::v8;
-    using L = LdsLayout<D>;
-    constexpr int NT = NW * 64;
-    constexpr int KS = D / 16;
-    constexpr int DB = D / 32;
-    constexpr int NCH = (kBN * L::kCPR) / NT;
-    constexpr int NS = 3;
-    static_assert(KS == 8 || KS == 4, "softmax interleave is written for 8 or 4 k-steps");
-
-    typename P::Ctx ctx;  // workgroup-uniform, except fields a policy documents as per-wave / per-lane
-    if (!P::init(prm, ctx, policy_lds)) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = wave_id();
-    const int g = lane >> 5;
-    const int ql = lane & 31;
-    const int row_in_wg = wave * 32 + ql;
-
-    const T* __restrict__ qb = P::q_base(prm, ctx);
-    const T* __restrict__ kb = P::k_base(prm, ctx);
-    const T* __restrict__ vb = P::v_base(prm, ctx);
-
-    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
-    const int q_log = P::q_logical(ctx, row_in_wg);
-    V8 qf[KS];
-    {
-        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
-    }
-
-    int srow[NCH], k_dst[NCH], v_dst[NCH], scol[NCH];
-    typename P::KvCursor cur[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int id = tid + i * NT;
-        srow[i] = id / L::kCPR;
-        scol[i] = id - srow[i] * L::kCPR;
-        k_dst[i] = L::k_off(srow[i], scol[i]);
-        v_dst[i] = L::kKBytes + L::v_off(srow[i], scol[i]);
-        P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
-    }
-    u32x4 kreg[NCH], vreg[NCH];
-    int nphys[NCH];
-    auto stage_resolve = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) nphys[i] = (t < ctx.nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
-    };
-    auto stage_issue = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const size_t off = (size_t)nphys[i] * D + scol[i] * 8;
-            kreg[i] = *(const u32x4*)(kb + off);
-            vreg[i] = *(const u32x4*)(vb + off);
-        }
-        stage_resolve(t + 1);
-    };
-    auto stage_write = [&](int buf) {
-        char* base = smem + buf * L::kStageBytes;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            *(u32x4*)(base + k_dst[i]) = kreg[i];
-            *(u32x4*)(base + v_dst[i]) = vreg[i];
-        }
-    };
-
-    const int ksw0 = (D == 128) ? (ql & 15) : ((ql >> 1) & 7);
-    const int vi = lane & 15;
-    const int v_lane_off = L::kKBytes + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
-
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 acc_o[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-    const float c_log2 = prm.scale_log2;
-    const int nT = ctx.nT;
-
-    // ---- prologue: tiles 0 and 1 into LDS, tile 2 into registers, S(0) ----
-    stage_resolve(0);
-    if (nT > 0) stage_issue(0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-    if (nT > 0) {
-        stage_write(0);
-        if (nT > 1) {
-            stage_issue(1);
-            stage_write(1);
-        }
-        if (nT > 2) stage_issue(2);
-    }
-    __syncthreads();
-
-    f32x16 sc[2], sn[2];  // scores of the current tile / of the next tile (being accumulated)
-    auto zero = [](f32x16 (&x)[2]) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[b][r] = 0.f;
-    };
-    auto kfrag = [&](const char* kbuf, int b, int ks) -> V8 {
-        return *(const V8*)(kbuf + (32 * b + ql) * L::kRowBytes + (((2 * ks + g) ^ ksw0) << 4));
-    };
-    zero(sc);
-    if (nT > 0) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) sc[b] = E::mfma(kfrag(smem, b, ks), qf[ks], sc[b]);
-    }
-
-    V8 pf[2][2];
-    int buf = 0;  // stage of tile t
-    // one iteration; HAS_NEXT is a compile-time flag so that phase 1 is a single basic block (a run-time test would put
-    // every k-step into its own block and the scheduler could not interleave the softmax with the MFMAs)
-    auto iteration = [&](int t, auto has_next_c) {
-        constexpr bool has_next = decltype(has_next_c)::value;
-        const int nbuf = (buf + 1 == NS) ? 0 : buf + 1;      // stage of tile t+1
-        const int wbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;    // stage of tile t+2 (= stage of dead tile t-1)
-        const char* kcur = smem + buf * L::kStageBytes;
-        const char* knxt = smem + nbuf * L::kStageBytes;
-
-        // ---- element mask on the current scores (band edges / text boundary / tile tail): rare ----
-        const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * 32);
-        if constexpr (P::kFixup) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[b][r] = P::score_fixup(prm, sc[b][r]);
-        }
-        if (cls != TILE_FULL) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    const bool ok = (cls == TILE_PARTIAL) && P::allowed(prm, ctx, q_log, tk0 + key);
-                    sc[b][r] = ok ? sc[b][r] : -INFINITY;
-                }
-        }
-
-        // ---- phase 1: S(t+1) = K(t+1) Q^T  ||  softmax(S(t)) ----
-        zero(sn);
-        float mx, m_new, m_use, alpha, psum = 0.f;
-        // K fragments are prefetched one k-step ahead INSIDE the pinned step (reads for step ks+1 are issued before the
-        // MFMAs and the softmax chunk of step ks), so the LDS latency hides behind that chunk instead of adding to it.
-        V8 kf[2][2];  // [parity][block]
-        if constexpr (has_next) {
-            kf[0][0] = kfrag(knxt, 0, 0);
-            kf[0][1] = kfrag(knxt, 1, 0);
-        }
-        auto qk_step = [&](int ks) {
-            if constexpr (has_next) {
-                if (ks + 1 < KS) {
-                    kf[(ks + 1) & 1][0] = kfrag(knxt, 0, ks + 1);
-                    kf[(ks + 1) & 1][1] = kfrag(knxt, 1, ks + 1);
-                }
-                sn[0] = E::mfma(kf[ks & 1][0], qf[ks], sn[0]);
-                sn[1] = E::mfma(kf[ks & 1][1], qf[ks], sn[1]);
-            }
-        };
-        auto sm_max = [&](int b) {  // row max of block b into mx
-            float a = sc[b][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) a = fmaxf(a, sc[b][r]);
-            mx = (b == 0) ? a : fmaxf(mx, a);
-        };
-        auto sm_stats = [&]() {
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            m_new = fmaxf(m_run, mx * c_log2);
-            m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
-            asm volatile("" : "+v"(m_use), "+v"(alpha));
-        };
-        auto sm_exp = [&](int b, int h) {  // 8 probabilities: registers 8h..8h+7 of block b
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][8 * h + j], c_log2, -m_use));
-                psum += p;
-                pf[b][h][j] = E::from_float(p);
-            }
-            // anchor: keeps the IR optimiser from sinking this chunk to its first use (the PV phase, another block)
-            asm volatile("" : "+v"(pf[b][h]), "+v"(psum));
-        };
-        if constexpr (KS == 8) {
-            qk_step(0); sm_max(0);              __builtin_amdgcn_sched_barrier(0);
-            qk_step(1); sm_max(1); sm_stats();  __builtin_amdgcn_sched_barrier(0);
-            qk_step(2); sm_exp(0, 0);           __builtin_amdgcn_sched_barrier(0);
-            qk_step(3); sm_exp(0, 1);           __builtin_amdgcn_sched_barrier(0);
-            qk_step(4); sm_exp(1, 0);           __builtin_amdgcn_sched_barrier(0);
-            qk_step(5); sm_exp(1, 1);           __builtin_amdgcn_sched_barrier(0);
-            qk_step(6);                         __builtin_amdgcn_sched_barrier(0);
-            qk_step(7);
-        } else {
-            qk_step(0); sm_max(0); sm_max(1); sm_stats();  __builtin_amdgcn_sched_barrier(0);
-            qk_step(1); sm_exp(0, 0); sm_exp(0, 1);        __builtin_amdgcn_sched_barrier(0);
-            qk_step(2); sm_exp(1, 0); sm_exp(1, 1);        __builtin_amdgcn_sched_barrier(0);
-            qk_step(3);
-        }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.f)) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
-        }
-
-        // ---- phase 2: O^T += V(t)^T P(t)^T  ||  staging of tiles t+2 (LDS write) and t+3 (global loads) ----
-        const char* vbase = kcur + v_lane_off;
-        auto vfrag = [&](int idx) -> V8 {  // idx = db * 4 + b * 2 + h
-            const int db = idx >> 2, kb0 = 32 * ((idx >> 1) & 1) + 16 * (idx & 1);
-            const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + kb0 * 64);
-            const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (kb0 + 8) * 64);
-            i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            return __builtin_bit_cast(V8, both);
-        };
-        constexpr int NPV = DB * 4;
-        constexpr int PFD = 2;  // prefetch distance in MFMAs
-        V8 vf[PFD + 1];
-#pragma unroll
-        for (int i = 0; i < PFD; ++i) vf[i] = vfrag(i);
-#pragma unroll
-        for (int idx = 0; idx < NPV; ++idx) {
-            if (idx + PFD < NPV) vf[(idx + PFD) % (PFD + 1)] = vfrag(idx + PFD);
-            acc_o[idx >> 2] = E::mfma(vf[idx % (PFD + 1)], pf[(idx >> 1) & 1][idx & 1], acc_o[idx >> 2]);
-            if (idx == 3) {
-                if (t + 2 < nT) stage_write(wbuf);
-            }
-            if (idx == 7 || (NPV <= 8 && idx == NPV - 1)) {
-                if (t + 3 < nT) stage_issue(t + 3);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) sc[b] = sn[b];
-        __syncthreads();
-        buf = nbuf;
-    };
-    for (int t = 0; t + 1 < nT; ++t) iteration(t, std::true_type{});
-    if (nT > 0) iteration(nT - 1, std::false_type{});
-
-    // ---------------- epilogue (same as attn_body) ----------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    if constexpr (P::kPartialOut) {
-        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
-        return;
-    } else {
-        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-        constexpr int kEpiStride = D * 2 + 8;
-        char* erow = smem + (size_t)(wave * 32) * kEpiStride;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                typename E::v4 o4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
-                const int d0 = 32 * db + 8 * rq + 4 * g;
-                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        T* __restrict__ ob = P::o_base(prm, ctx);
-        constexpr int kLanesPerRow = D * 2 / 8;
-        constexpr int kRowsPerPass = 64 / kLanesPerRow;
-        const int sub = lane / kLanesPerRow;
-        const int colb = (lane - sub * kLanesPerRow) * 8;
-        int ephys[32 / kRowsPerPass];
-#pragma unroll
-        for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
-#pragma unroll
-        for (int i = 0; i < 32 / kRowsPerPass; ++i) {
-            const int rr = i * kRowsPerPass + sub;
-            const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
-            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
-        }
-    }
-}
 
 // =====================================================================================================================
-// attn_body_pp — "ping-pong" schedule: 8 waves x 32 rows, the two waves that share a SIMD run complementary clusters,
-// K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).
-//
-// attn_body's ablations (profiles/r01_ablation.md) show that in lock-step the phases of a tile simply add up: the two
-// waves of a SIMD are in the matrix phase together (sharing the pipe, each stalling on its own LDS operand reads) and in the
-// softmax phase together.  Here every tile is cut into four clusters separated by workgroup barriers,
-//     LK   K(t) LDS -> 64 operand registers (ds_read_b128);  DMA issue for tile t+2
-//     QK   S^T = K Q^T          16 MFMAs, register operands only
-//     SV   V(t)^T LDS -> the SAME 64 operand registers (hardware transpose reads);  softmax(S) -> P;  DMA wait
-//     PV   O^T += V^T P^T       16 MFMAs, register operands only
-// and waves 4..7 run one cluster behind waves 0..3 (one extra barrier in front), so a SIMD always pairs a matrix cluster
-// of one wave (back-to-back MFMAs, nothing to wait for) with a memory / VALU cluster of its partner:
-//     slot       4t      4t+1   4t+2   4t+3
-//     waves 0-3  LK(t)   QK(t)  SV(t)  PV(t)
-//     waves 4-7  PV(t-1) LK(t)  QK(t)  SV(t)
-// LDS: three stages of [K image | V image]; tile u lives in stage u % 3 and is requested during LK(u-2) (its stage was last
-// read by SV(u-3) of the lagging group, one barrier earlier); every wave waits for its own DMA pieces of tile u at the end
-// of SV(u-1), i.e. before the barrier in front of slot 4u.  The DMAs are inline asm: hipcc's waitcnt pass would drain a
-// builtin LDS-DMA (vmcnt(0)) in front of the next ds_read; compiler-inserted vmcnt(N) waits stay safe (loads retire in
-// order, extra outstanding requests only make vmcnt(N) stricter).
+// Helpers of the LDS-DMA bodies (attn_body_pp2 below, attn_body_w4 in attn_w4.h).
+// K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write).  The DMAs are inline asm: hipcc's
+// waitcnt pass would drain a builtin LDS-DMA (vmcnt(0)) in front of the next ds_read; compiler-inserted vmcnt(N) waits stay
+// safe (loads retire in order, extra outstanding requests only make vmcnt(N) stricter).
 // Images (16-B slots): both are sub-tiled [D/32][64 keys][4 slots] so that one DMA piece = 16 keys x 64 B = 1 KiB lands
 // lane-linear; K stores chunk c at slot (c & 3) ^ ((key >> 2) & 3) (conflict-free ds_read_b128 for the 32x32x16 A operand),
 // V stores it at slot c & 3 (ds_read_b64_tr_b16 wants 4 keys x 32 columns contiguous).  The swizzle is applied to the
 // per-lane SOURCE address.
-// Online softmax uses a deferred maximum: while no row's tile maximum exceeds the running maximum by more than 2^kDefer
-// the old maximum is kept (p <= 2^kDefer, harmless in bf16 relative precision) and O is not rescaled.
+// (The earlier schedules of this core — intra-wave pipelining on 8 waves, the four-cluster ping-pong — are in the history of
+//  this file; profiles/r01_ablation.md has their measurements.)
 // =====================================================================================================================
 // v_max3_f32 / v_max_f32 without the input canonicalisation hipcc attaches to fmaxf()
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -807,376 +491,16 @@ __device__ __forceinline__ void lds_dma16(unsigned lds, unsigned voff, const voi
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_u), "v"(voff), "s"(base) : "memory");
 }
 
-template <int D>
-constexpr int attn_pp_lds_bytes() {
-    // 3 stages of K image + V image; the epilogue staging reuses them
-    constexpr int stages = 3 * 2 * kBN * D * 2;
-    constexpr int epi = 8 * 32 * (D * 2 + 8);
-    return stages > epi ? stages : epi;
-}
 
-// cycle trace of the ping-pong clusters (diagnostics, variant bit 6): per wave 8 sums of s_memtime ticks —
-// [LK work, barrier wait, QK work, wait, SV work, wait, PV work, wait] — of workgroup blockIdx.x == kPpTraceBlock
-__device__ unsigned long long g_pp_trace[8 * 8 + 8 + 8 * 4];
+// cycle trace of the two-phase body (diagnostics, -DSVG_ABLATIONS builds): per wave sums of s_memtime ticks per phase of
+// workgroup blockIdx.x == kPpTraceBlock (static: one copy per translation unit, read with hipMemcpyFromSymbol in attention.hip)
+static __device__ unsigned long long g_pp_trace[8 * 8 + 8 + 8 * 4];
 constexpr int kPpTraceBlock = 1000;
 // Launch timeline of the traced two-phase kernel: per workgroup [s_memtime at entry, at loop start, at loop end, at exit, HW_ID, XCC_ID]
 // (wave 0), read with svg_debug_wg_trace; tools/wg_timeline.py turns it into per-CU occupancy and launch gaps.
 constexpr int kWgTraceMax = 16384;
-__device__ unsigned long long g_wg_trace[kWgTraceMax * 6];
+static __device__ unsigned long long g_wg_trace[kWgTraceMax * 6];
 
-// ABL > 0 (trace kernels only, results wrong by construction): 1 no V^T reads, 2 no row maximum / decision, 3 no
-// probabilities of keys 0..31, 4 no probabilities of keys 32..63, 5 no K reads, 6 no DMA, 7 no mask evaluation
-template <typename T, int D, typename P, bool TRACE = false, int ABL = 0>
-__device__ __forceinline__ void attn_body_pp(const typename P::Params& prm, char* smem, char* policy_lds) {
-    using E = Elt<T>;
-    using V8 = typename E::v8;
-    constexpr int NW = 8;
-    constexpr int KS = D / 16;
-    constexpr int DB = D / 32;
-    constexpr int NS = 3;
-    constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
-    constexpr int kStage = 2 * kImg;
-    constexpr int NP = DB / 2;              // DMA pieces per wave per tensor per tile (DB * 4 pieces / 8 waves)
-    constexpr float kDefer = 8.f;
-    constexpr bool kParkQ = false;          // true: Q fragments live in LDS and are re-read per tile (frees 32 registers)
-    static_assert(D == 64 || D == 128, "head dim");
-    static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1, "ping-pong body: 32 rows per wave, one tile per stage");
-
-    typename P::Ctx ctx;
-    if (!P::init(prm, ctx, policy_lds)) return;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = wave_id();
-    const int g = lane >> 5;
-    const int ql = lane & 31;
-    const int row_in_wg = wave * 32 + ql;
-    const bool lagging = wave >= NW / 2;
-    const int nT = ctx.nT;
-
-    const T* __restrict__ qb = P::q_base(prm, ctx);
-    const T* __restrict__ kb = P::k_base(prm, ctx);
-    const T* __restrict__ vb = P::v_base(prm, ctx);
-    // The Q fragments (B operand of S^T, 32 registers at D = 128) are parked in LDS in fragment order and re-read in
-    // every LK cluster: with two waves per SIMD the budget is 256 registers, and O (64) + operand block (64) + scores (32)
-    // + Q (32) + addressing does not fit — hipcc spills Q to scratch otherwise.
-    constexpr int kQBytes = kParkQ ? NW * 32 * D * 2 : 0;
-    char* const stages = smem + kQBytes;
-    const unsigned lds0 = (unsigned)(size_t)stages;
-    char* const qpark = smem + wave * (32 * D * 2) + lane * 16;
-
-    // ---- DMA bookkeeping: this wave's pieces are (db = wave % DB, key group kg = (wave / DB) * NP + j) ----
-    const int dma_db = wave % DB;
-    const int dma_kg0 = (wave / DB) * NP;
-    int krow[NP];
-    typename P::KvCursor cur[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        krow[j] = 16 * (dma_kg0 + j) + (lane >> 2);
-        P::kv_cursor_init(prm, ctx, cur[j], krow[j]);
-    }
-    const unsigned col_v = (unsigned)(dma_db * 64 + (lane & 3) * 16);   // source byte column of this lane's V chunk
-    const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);           // K: slot = chunk ^ ((key >> 2) & 3)
-    const unsigned lds_piece = lds0 + (unsigned)(dma_db * (kBN * 64) + dma_kg0 * 1024);
-    auto dma_piece = [&](int t, int j) {  // request this wave's piece j of tile t (t < nT) into stage t % NS
-        const unsigned st = lds_piece + (unsigned)((t % NS) * kStage);
-        const int phys = P::kv_phys(prm, ctx, cur[j], t, krow[j]);
-        const unsigned vo = (unsigned)phys * (unsigned)(2 * D) + col_v;
-        lds_dma16(st + j * 1024, vo ^ k_xor, kb);
-        lds_dma16(st + j * 1024 + kImg, vo, vb);
-    };
-    auto dma_issue = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) dma_piece(t, j);
-    };
-    if (nT > 0) dma_issue(0);
-    if (nT > 1) dma_issue(1);
-
-    const int q_phys = P::q_phys(prm, ctx, row_in_wg);
-    const int q_log = P::q_logical(ctx, row_in_wg);
-    V8 qf[KS];
-    {
-        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
-        if constexpr (kParkQ) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) *(V8*)(qpark + ks * 1024) = qf[ks];
-        }
-    }
-
-    // ---- per-lane LDS read offsets ----
-    // K fragment (block b, k-step ks): key 32 b + ql, chunk c = 2 ks + g -> [c >> 2][key][(c & 3) ^ ((key >> 2) & 3)]
-    const int k_lane0 = ql * 64 + (((g) ^ ((ql >> 2) & 3)) << 4);   // even k-steps (c & 3 = g)
-    const int k_lane1 = k_lane0 ^ 32;                               // odd k-steps  (c & 3 = 2 + g)
-    const int vi = lane & 15;
-    const int v_lane_off = kImg + (4 * g + (vi >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (vi & 3)) * 2;
-
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 acc_o[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-    const float c_log2 = prm.scale_log2;
-
-    if constexpr (!kParkQ) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pp_barrier();
-    if (lagging) pp_barrier();  // waves 4..7 run one cluster behind
-
-    unsigned tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tr_last = 0, tr_first = 0;
-    if constexpr (TRACE) tr_first = tr_last = __builtin_amdgcn_s_memtime();
-    auto tick = [&](auto slot_c) {  // close interval `slot`: work intervals end after the wave's own LDS reads have landed
-        if constexpr (TRACE) {
-            constexpr int slot = decltype(slot_c)::value;
-            if constexpr ((slot & 1) == 0 && slot < 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            tr_acc[slot] += (unsigned)(now - tr_last);
-            tr_last = now;
-        }
-    };
-
-    constexpr int NOPR = (2 * KS > 4 * DB) ? 2 * KS : 4 * DB;
-    int stage = 0;  // t % NS
-    for (int t = 0; t < nT; ++t) {
-        const char* sbuf = stages + stage * kStage;
-        stage = (stage + 1 == NS) ? 0 : stage + 1;
-        const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * 32);
-        const bool more = t + 2 < nT;
-        // A tile this wave does not need (band edge of a neighbouring wave) is processed fully masked (p = 0): a separate
-        // skip path costs more than the ~1 % of wasted MFMAs — hipcc then keeps two register sets for O and copies all 64
-        // accumulators between them in every iteration.
-        // (declared per tile: nothing of these is carried around the loop)
-        V8 opr[NOPR];  // the operand block: K fragments (LK -> QK), then V^T fragments (SV -> PV)
-        f32x16 s[2];
-        V8 pf[2][2];
-
-        // ---------------- LK ----------------
-        if constexpr (ABL == 5) {
-#pragma unroll
-            for (int j = 0; j < NOPR; ++j) opr[j] = qf[j % KS];
-        } else {
-            const char* k0 = sbuf + k_lane0;
-            const char* k1 = sbuf + k_lane1;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    opr[ks * 2 + b] = *(const V8*)(((ks & 1) ? k1 : k0) + (ks >> 1) * (kBN * 64) + b * (32 * 64));
-        }
-        if constexpr (kParkQ) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qpark + ks * 1024);
-        }
-        tick(std::integral_constant<int, 0>{});
-        pp_barrier();
-        tick(std::integral_constant<int, 1>{});
-
-        // ---------------- QK ----------------
-        {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            s[0] = E::mfma(opr[0], qf[0], zero);
-            s[1] = E::mfma(opr[1], qf[0], zero);
-            // The two accumulator chains leave the issue port idle most of the time (a dependent MFMA waits for its
-            // predecessor): the DMA requests for tile t+2 (address arithmetic + ~60 cycles of issue each) go in between.
-            constexpr int kSeg = KS / (NP + 1);
-#pragma unroll
-            for (int ks = 1; ks < KS; ++ks) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) s[b] = E::mfma(opr[ks * 2 + b], qf[ks], s[b]);
-                if constexpr (ABL != 6) {
-                    if (ks % kSeg == kSeg - 1 && ks / kSeg < NP) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) dma_piece(t + 2, ks / kSeg);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            asm volatile("" : "+v"(s[0]), "+v"(s[1]));  // the scores are produced in this cluster
-        }
-        tick(std::integral_constant<int, 2>{});
-        pp_barrier();
-        tick(std::integral_constant<int, 3>{});
-
-        // ---------------- SV: V^T fragments, mask, row maximum, (rare) rescale, probabilities of keys 0..31 ----------------
-        float m_use, psum = 0.f;
-        {
-            const char* vbase = sbuf + v_lane_off;
-            if constexpr (ABL == 1) {
-#pragma unroll
-                for (int j = 0; j < NOPR; ++j) asm volatile("" : "+v"(opr[j]));
-            } else
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)          // 16-key step
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const i16x4 lo = lds_read_tr16(vbase + db * (kBN * 64) + (16 * kk) * 64);
-                    const i16x4 hi = lds_read_tr16(vbase + db * (kBN * 64) + (16 * kk + 8) * 64);
-                    i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    opr[kk * DB + db] = __builtin_bit_cast(V8, both);
-                }
-            if constexpr (P::kFixup) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[b][r] = P::score_fixup(prm, s[b][r]);
-            }
-            if (ABL != 7 && cls != TILE_FULL) {
-                // opaque copies: otherwise LICM hoists the 32 per-element row / key terms out of the tile loop and
-                // they occupy registers for the whole kernel (the budget is 256 with two waves per SIMD)
-                int qv = q_log, kv0 = tk0 + 4 * g;
-                asm volatile("" : "+v"(qv), "+v"(kv0));
-                const bool part = (cls == TILE_PARTIAL);  // SKIP: everything masked
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = 32 * b + (r & 3) + 8 * (r >> 2);
-                        s[b][r] = (part & P::allowed(prm, ctx, qv, kv0 + key)) ? s[b][r] : -INFINITY;
-                    }
-            }
-            float mx = s[0][0];
-            if constexpr (ABL != 2) {
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            }
-            if constexpr (ABL != 2) {   // the other half of the row lives in lane ^ 32: one v_permlane32_swap instead of an LDS bpermute
-                const unsigned u = __builtin_bit_cast(unsigned, mx);
-                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
-            }
-            m_use = (m_run == -INFINITY) ? 0.f : m_run;
-            if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
-                const float m_new = fmaxf(m_run, mx);
-                m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-                // v_exp_f32 -> consumer needs a wait state; hipcc inserts it for its own instructions, not for inline asm
-                asm volatile("s_nop 1" : "+v"(alpha));
-                m_run = m_new;
-                l_run *= alpha;
-                // in-place (tied operands): a plain `acc_o *= alpha` in this rare branch makes hipcc keep two register
-                // sets for O and copy all 64 accumulators between them on the common path of every tile
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float x = acc_o[db][r];
-                        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(alpha));
-                        acc_o[db][r] = x;
-                    }
-            }
-            if constexpr (ABL == 3) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) pf[0][0][r] = E::from_float(s[0][r]);
-            } else
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {   // keys 0..15 (the first PV step); the rest is computed in the shadow of the PV MFMAs
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][r], c_log2, -m_use));
-                psum += p;
-                pf[0][0][r] = E::from_float(p);
-            }
-            asm volatile("" : "+v"(pf[0][0]), "+v"(psum));  // keep this part of the softmax in this cluster
-            // this wave's DMA pieces of tile t+1 (requested in QK(t-1)); the pieces of tile t+2 (QK(t)) may stay in flight
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        tick(std::integral_constant<int, 4>{});
-        pp_barrier();
-        tick(std::integral_constant<int, 5>{});
-
-        // ---------------- PV: 16-key steps on the matrix pipe while the VALU computes the probabilities of the next step ----------------
-        {
-            auto probs = [&](int kk) {  // keys 16 kk .. 16 kk + 15: score registers 8 (kk & 1) .. + 7 of block kk >> 1
-                if constexpr (ABL == 4) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) pf[kk >> 1][kk & 1][r] = E::from_float(s[kk >> 1][8 * (kk & 1) + r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
-                        psum += p;
-                        pf[kk >> 1][kk & 1][r] = E::from_float(p);
-                    }
-                }
-            };
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk + 1 < 4) probs(kk + 1);
-#pragma unroll
-                for (int db = 0; db < DB; ++db) acc_o[db] = E::mfma(opr[kk * DB + db], pf[kk >> 1][kk & 1], acc_o[db]);
-            }
-            // one MFMA, then its share of the 3 x 28 VALU instructions (8 fma, 8 exp, 8 add, 4 cvt per step)
-#pragma unroll
-            for (int i = 0; i < 3 * DB; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (28 + DB - 1) / DB, 0);
-            }
-            l_run += psum;
-        }
-        if constexpr (TRACE) {
-#pragma unroll
-            for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(acc_o[db]));  // the MFMAs have to retire inside the interval
-        }
-        tick(std::integral_constant<int, 6>{});
-        pp_barrier();
-        tick(std::integral_constant<int, 7>{});
-    }
-    if constexpr (TRACE) {
-        if (blockIdx.x == kPpTraceBlock && lane == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g_pp_trace[wave * 8 + j] = tr_acc[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g_pp_trace[72 + wave * 4 + j] = tr_acc[8 + j];
-            if (wave == 0) g_pp_trace[64] = (unsigned long long)nT, g_pp_trace[65] = tr_last - tr_first;
-        }
-    }
-    if (!lagging) pp_barrier();  // matches the lagging group's last barrier; the stage buffers are free afterwards
-
-    // ---------------- epilogue (same as attn_body) ----------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    if constexpr (P::kPartialOut) {
-        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
-        return;
-    } else {
-        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-        constexpr int kEpiStride = D * 2 + 8;
-        char* erow = smem + (size_t)(wave * 32) * kEpiStride;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                typename E::v4 o4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
-                const int d0 = 32 * db + 8 * rq + 4 * g;
-                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        T* __restrict__ ob = P::o_base(prm, ctx);
-        constexpr int kLanesPerRow = D * 2 / 8;
-        constexpr int kRowsPerPass = 64 / kLanesPerRow;
-        const int sub = lane / kLanesPerRow;
-        const int colb = (lane - sub * kLanesPerRow) * 8;
-        int ephys[32 / kRowsPerPass];
-#pragma unroll
-        for (int i = 0; i < 32 / kRowsPerPass; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
-#pragma unroll
-        for (int i = 0; i < 32 / kRowsPerPass; ++i) {
-            const int rr = i * kRowsPerPass + sub;
-            const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
-            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
-        }
-    }
-}
 
 // =====================================================================================================================
 // attn_body_pp2 — two-phase ping-pong: per tile every wave runs ONE matrix phase and ONE vector phase, and the two waves

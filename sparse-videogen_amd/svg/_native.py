@@ -252,8 +252,9 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
                    frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None,
                    done: Optional[torch.Tensor] = None, done_nseg: int = 1) -> torch.Tensor:
     """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape.
-    done: int32 [BH * done_nseg] zeroed completion counters (svg_band_attention_notify[_seg]; see band_notify_target /
-    band_notify_layout / wait_counters)."""
+    done: int32 [BH * (done_nseg + 1)] zeroed completion counters (svg_band_attention_notify[_seg]; see band_notify_target /
+    band_notify_layout / wait_counters / notify_counters): counter (h, s) at done[h * done_nseg + s], the last BH words are scratch
+    of the library (hidden per-head counters of heads that run with the fused layout permutation)."""
     lib = load()
     _dev(q, k, v, head_perm_flag)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
@@ -269,7 +270,7 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
     if done is not None:
         _dev(done)
-        assert done.dtype == torch.int32 and done.numel() == BH * done_nseg and variant == 0
+        assert done.dtype == torch.int32 and done.numel() == BH * (done_nseg + 1) and variant == 0
         rc = lib.svg_band_attention_notify_seg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
                                                scale, C.byref(mask), C.byref(perm) if perm is not None else None, done.data_ptr(),
                                                int(done_nseg), _stream())
@@ -281,6 +282,11 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
     return o
 
 
+def notify_counters(BH: int, nseg: int, device) -> torch.Tensor:
+    """Zeroed counter buffer for band_attention(done=...): BH * nseg segment counters + BH words of library scratch."""
+    return torch.zeros(BH * (nseg + 1), device=device, dtype=torch.int32)
+
+
 def band_notify_target(S: int, mask: BandMask) -> int:
     """Value a head's completion counter reaches when the head is done (svg_band_attention_notify_target)."""
     t = load().svg_band_attention_notify_target(int(S), C.byref(mask))
@@ -290,7 +296,8 @@ def band_notify_target(S: int, mask: BandMask) -> int:
 
 def band_notify_layout(S: int, mask: BandMask, nseg: int):
     """(n, row_bounds [n + 1], targets [n]) of the per-segment completion counters (svg_band_attention_notify_layout):
-    segment s of a head = rows [row_bounds[s], row_bounds[s + 1]), complete when its counter reaches targets[s]; n <= nseg."""
+    counter (h, s) >= targets[s]  =>  the physical rows [row_bounds[s], row_bounds[s + 1]) of head h are complete and visible
+    (heads with the fused layout permutation release all their segments together, see include/svg_attn.h); n <= nseg."""
     rb = (C.c_int32 * (nseg + 1))()
     tg = (C.c_int32 * nseg)()
     n = load().svg_band_attention_notify_layout(int(S), C.byref(mask), int(nseg), C.cast(rb, C.c_void_p), C.cast(tg, C.c_void_p))

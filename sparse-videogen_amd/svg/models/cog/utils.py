@@ -15,7 +15,7 @@ def generate_temporal_head_mask_mod(prompt_length: int = 226, num_frames: int = 
     S = prompt_length + num_frames * token_per_frame
     band = floor(mul * token_per_frame / 128) * 128
     col_hi = prompt_length + (token_per_frame if attn_sink else 0)
-    return _native.BandMask(real_len=S, band=max(1, band), colfull_lo=0, colfull_hi=col_hi, rowfull_lo=0,
+    return _native.BandMask(real_len=S, band=band, colfull_lo=0, colfull_hi=col_hi, rowfull_lo=0,
                             rowfull_hi=prompt_length)
 
 

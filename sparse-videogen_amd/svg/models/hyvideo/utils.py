@@ -35,7 +35,7 @@ def generate_temporal_head_mask_mod(context_length: int = 226, prompt_length: in
     V = num_frames * token_per_frame
     real = V + prompt_length
     band = floor(mul * token_per_frame / 128) * 128
-    return _native.BandMask(real_len=real, band=max(1, band), colfull_lo=V, colfull_hi=real, rowfull_lo=V, rowfull_hi=real)
+    return _native.BandMask(real_len=real, band=band, colfull_lo=V, colfull_hi=real, rowfull_lo=V, rowfull_hi=real)
 
 
 def dense_mask(seq_len: int, valid_len: int | None = None) -> _native.BandMask:

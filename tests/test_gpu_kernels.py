@@ -113,12 +113,10 @@ def _band_case(model, F_, P_, ctx, L, mul):
 
 
 @pytest.mark.parametrize("model", ["hy", "wan", "cog", "dense", "dense2"])
-@pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 0), (128, torch.float16, 1), (64, torch.bfloat16, 1),
-                                             (64, torch.float16, 0), (128, torch.bfloat16, 4), (64, torch.float16, 4),
-                                             (128, torch.float16, 2), (128, torch.bfloat16, 8), (64, torch.float16, 8), (128, torch.bfloat16, 16),
-                                             (64, torch.float16, 16), (128, torch.bfloat16, 32), (64, torch.float16, 32),
-                                             (128, torch.float16, 32), (64, torch.bfloat16, 32), (128, torch.bfloat16, 128),
-                                             (64, torch.float16, 128), (128, torch.float16, 4096), (64, torch.bfloat16, 4096)])
+# every schedule of svg_band_attention (include/svg_attn.h: 0 default, 1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per
+# SIMD) x {bf16, fp16} x {D 128, 64}
+@pytest.mark.parametrize("D,dtype,variant", [(D, dt, var) for var in (0, 1, 2, 3) for D in (128, 64)
+                                             for dt in (torch.bfloat16, torch.float16)])
 def test_band_attention(nat, model, D, dtype, variant):
     torch.manual_seed(2)
     F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3
@@ -131,7 +129,8 @@ def test_band_attention(nat, model, D, dtype, variant):
 
 
 @pytest.mark.parametrize("seed", range(12))
-@pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 0), (64, torch.float16, 0), (128, torch.float16, 4096)])
+@pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 3), (64, torch.float16, 3), (128, torch.float16, 2), (64, torch.bfloat16, 2),
+                                             (128, torch.bfloat16, 1)])
 def test_band_attention_random_mask_family(nat, seed, D, dtype, variant):
     """Random members of the svg_band_mask_t family (include/svg_attn.h) against the dense restatement of the predicate:
     full rows / full columns anywhere (also empty, also overlapping real_len, also at q-tile boundaries), real_len <= S, bands
@@ -141,7 +140,7 @@ def test_band_attention_random_mask_family(nat, seed, D, dtype, variant):
     rng = random.Random(1000 + seed)
     S = rng.choice([300, 513, 777, 1024, 1301])
     real = rng.choice([S, S, rng.randint(1, S), max(1, S - rng.randint(0, 300))])
-    band = rng.choice([1, rng.randint(2, 200), rng.randint(100, S), S + 1])
+    band = rng.choice([0, 1, rng.randint(2, 200), rng.randint(100, S), S + 1])
     lo = min(S, rng.choice([0, 256, rng.randint(0, S - 1)]))
     cf = (lo, min(S, lo + rng.choice([0, 1, 64, rng.randint(1, 300)])))
     lo = min(S, rng.choice([0, 256, 512, rng.randint(0, S - 1)]))
@@ -199,7 +198,7 @@ def test_band_attention_notify_counters(nat, model):
     q, k, v = (dev(torch.randn(1, H, S, D).to(torch.bfloat16)) for _ in range(3))
     mask = nat.BandMask(**prm)
     ref = nat.band_attention(q, k, v, mask)
-    done = torch.zeros(H, dtype=torch.int32, device=q.device)
+    done = nat.notify_counters(H, 1, q.device)
     side = torch.cuda.Stream()
     ev = torch.cuda.Event()
     ev.record()
@@ -211,16 +210,58 @@ def test_band_attention_notify_counters(nat, model):
         seen = done.clone()          # runs behind the waiter: heads 1..3 are complete here
     torch.cuda.synchronize()
     assert torch.equal(o, ref)
-    assert (done.cpu() == target).all(), (done.cpu(), target)
+    assert (done.cpu()[:H] == target).all(), (done.cpu(), target)
     assert (seen.cpu()[1:4] == target).all()
     # per-segment counters: rows [row_bounds[s], row_bounds[s + 1]) of every head, q-tiles in row order
     n, bounds, targets = nat.band_notify_layout(S, mask, 3)
     assert bounds[0] == 0 and bounds[-1] == S and sorted(bounds) == bounds and sum(targets) == target
-    done2 = torch.zeros(H * n, dtype=torch.int32, device=q.device)
+    done2 = nat.notify_counters(H, n, q.device)
     o2 = nat.band_attention(q, k, v, mask, done=done2, done_nseg=n)
     torch.cuda.synchronize()
     assert torch.equal(o2, ref)
-    assert torch.equal(done2.cpu().view(H, n), torch.tensor(targets, dtype=torch.int32).expand(H, n))
+    assert torch.equal(done2.cpu()[:H * n].view(H, n), torch.tensor(targets, dtype=torch.int32).expand(H, n))
+
+
+def test_band_attention_notify_segments_with_fused_placement(nat):
+    """Contract of the per-segment counters (include/svg_attn.h): counter (h, s) >= targets[s] => the PHYSICAL rows
+    [row_bounds[s], row_bounds[s + 1]) of head h are final — also for heads that run with the fused layout permutation, whose
+    logical q-tiles write rows of every frame (they are released at head granularity).  A copy kernel enqueued behind
+    svg_wait_counters on another stream, while the attention launch is still running, must see the final rows; `o` is poisoned
+    first, so a premature release shows."""
+    torch.manual_seed(9)
+    F_, P_, ctx, L, mul, D, H = 7, 330, 64, 21, 1.6, 128, 6
+    S, prm, _, vid0 = _band_case("hy", F_, P_, ctx, L, mul)
+    q, k, v = (dev(torch.randn(1, H, S, D).to(torch.bfloat16)) for _ in range(3))
+    mask = nat.BandMask(**prm)
+    best = dev(torch.tensor([[0, 1, 1, 0, 1, 0]]))
+    kw = dict(head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_)
+    ref = nat.band_attention(q, k, v, mask, **kw)
+    n, bounds, targets = nat.band_notify_layout(S, mask, 4)
+    assert n >= 2
+    for _ in range(3):
+        o = torch.full_like(q, float("nan"))
+        done = nat.notify_counters(H, n, q.device)
+        torch.cuda.synchronize()
+        sides = [torch.cuda.Stream() for _ in range(2)]
+        ev = torch.cuda.Event()
+        ev.record()
+        nat.band_attention(q, k, v, mask, out=o, done=done, done_nseg=n, **kw)
+        cnt = done[:H * n].view(H, n)
+        seen = {}
+        i = 0
+        for h in range(H):
+            for sg in range(n):
+                st = sides[i % 2]
+                i += 1
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    nat.wait_counters(cnt[h, sg:sg + 1], targets[sg])
+                    seen[h, sg] = o[0, h, bounds[sg]:bounds[sg + 1]].clone()   # behind the waiter, beside the launch
+        torch.cuda.synchronize()
+        assert torch.equal(o, ref)
+        for (h, sg), rows in seen.items():
+            assert torch.equal(rows, ref[0, h, bounds[sg]:bounds[sg + 1]]), f"head {h} (perm={int(best[0, h])}) segment {sg} released early"
+        assert torch.equal(cnt.cpu(), torch.tensor(targets, dtype=torch.int32).expand(H, n))
 
 
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])

@@ -48,15 +48,15 @@ def band_schedule(q0, q_end, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
     return tiles
 
 
-def classify(w0, q_end, k0, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi):
-    # fast path (BandPolicy::init / classify): per-wave FULL range of first keys
-    w1f = min(w0 + 32, q_end)
+def classify(w0, q_end, k0, S, real, band, cf_lo, cf_hi, rf_lo, rf_hi, WR=32):
+    # fast path (BandPolicy::init / classify): per-wave FULL range of first keys; WR = rows per wave (32, or 64 in attn_body_w4)
+    w1f = min(w0 + WR, q_end)
     if w0 < q_end and w1f <= real:
         if max(w1f - band, 0) <= k0 <= min(w0 + band - BN, min(real, S) - BN):
             return 1
     if w0 >= q_end:
         return 0
-    w1 = min(w0 + 32, q_end)
+    w1 = min(w0 + WR, q_end)
     k1 = min(k0 + BN, S)
     all_ = False
     if k0 + BN <= S:
@@ -90,9 +90,9 @@ for (F_, P_, ctx, L, mul) in [(4, 140, 16, 9, 1.9), (5, 150, 40, 11, 2.3), (3, 1
     ]
 
 
-@pytest.mark.parametrize("BM", [128, 256])
+@pytest.mark.parametrize("BM,WR", [(128, 32), (256, 32), (256, 64)])
 @pytest.mark.parametrize("name,S,prm", CASES)
-def test_band_schedule_and_classify(name, S, prm, BM):
+def test_band_schedule_and_classify(name, S, prm, BM, WR):
     mask = O.band_mask(S, **prm)
     p = (prm["real_len"], prm["band"], prm["colfull_lo"], prm["colfull_hi"], prm["rowfull_lo"], prm["rowfull_hi"])
     for q0 in range(0, S, BM):
@@ -104,14 +104,14 @@ def test_band_schedule_and_classify(name, S, prm, BM):
             visited[t * BN: (t + 1) * BN] = True
         needed = mask[q0:q_end].any(dim=0)
         assert not (needed & ~visited).any(), f"{name}: q-tile {q0} misses allowed keys"
-        for w0 in range(q0, q0 + BM, 32):
+        for w0 in range(q0, q0 + BM, WR):
             for t in tiles:
                 k0 = t * BN
-                cls = classify(w0, q_end, k0, S, *p)
+                cls = classify(w0, q_end, k0, S, *p, WR=WR)
                 if w0 >= q_end:
                     assert cls == 0
                     continue
-                sub = mask[w0:min(w0 + 32, q_end), k0:min(k0 + BN, S)]
+                sub = mask[w0:min(w0 + WR, q_end), k0:min(k0 + BN, S)]
                 if cls == 1:
                     assert sub.all() and sub.shape[1] == BN, f"{name}: FULL tile has a masked element"
                 elif cls == 0:

@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Audit the kept gfx950 assembly (build.py --asm) for MFMA hazards hipcc cannot see: the MFMAs of csrc/attn_w4.h are inline
+asm, so the compiler's hazard recognizer pads nothing around them (cdna_hip_programming.md §5.7 item 2).  Checked per kernel:
+
+  W->M   a VALU / v_accvgpr write of a register that an MFMA reads as A, B or C operand fewer than 2 wait states earlier
+         (e.g. a compiler spill reload placed directly in front of an asm MFMA)
+  M->R   a non-MFMA instruction reading (or overwriting) the VGPR / AGPR destination of an MFMA fewer than `--mfma-states`
+         (default 18) wait states later, an MFMA that accumulates into the same tuple excepted
+
+  AGPR   a v_accvgpr_* or scratch_* instruction OUTSIDE an asm statement: the AGPRs of these kernels are owned by the asm
+         statements (csrc/attn_w4_agpr.inc); hipcc touching the accumulator file or spilling means it may have parked a value
+         in a register the asm statements use, or placed a reload inside a hazard window
+
+A wait state is one issued instruction; `s_nop N` counts N + 1.  Branches end a window (conservatively clean).
+    python tools/asm_hazards.py [kernel substring] [file.s]      exit code 1 if a hazard is found
+"""
+import re
+import sys
+from pathlib import Path
+
+BUILD = Path(__file__).resolve().parent.parent / "sparse-videogen_amd" / "build"
+REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
+
+
+def regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(2) is not None:
+            out.add((m.group(1), int(m.group(2))))
+        else:
+            out.update((m.group(1), r) for r in range(int(m.group(3)), int(m.group(4)) + 1))
+    return out
+
+
+def split_ops(line):
+    op, _, rest = line.partition(" ")
+    rest = rest.split(";")[0]
+    return op, [x.strip() for x in rest.split(",")]
+
+
+def states(line):
+    op, ops = split_ops(line)
+    if op == "s_nop":
+        return int(ops[0], 0) + 1
+    return 1
+
+
+def writes(line):
+    """registers a vector instruction writes (first operand; stores / compares / DMA write none)"""
+    op, ops = split_ops(line)
+    if not (op.startswith("v_") or op.startswith("ds_read") or op.startswith("global_load") or op.startswith("scratch_load")
+            or op.startswith("buffer_load")):
+        return set()
+    if op.startswith("v_cmp") or op.startswith("global_load_lds"):
+        return set()
+    w = regs(ops[0])
+    if op.startswith("v_permlane") or op.startswith("v_swap"):
+        w |= regs(ops[1])
+    return w
+
+
+def reads(line):
+    op, ops = split_ops(line)
+    if op.startswith(("v_", "ds_", "global_", "scratch_", "buffer_")):
+        src = ops[1:] if not (op.startswith("v_cmp") or "store" in op or op.startswith("global_load_lds") or op.startswith("ds_write")) else ops
+        return set().union(*[regs(x) for x in src]) if src else set()
+    return set()
+
+
+def audit(name, lines, mfma_states):
+    bad = []
+    n = len(lines)
+    for i, l in enumerate(lines):
+        if not l.startswith("v_mfma"):
+            continue
+        op, ops = split_ops(l)
+        dst, srcs = regs(ops[0]), set().union(*[regs(x) for x in ops[1:4]])
+        # W->M: look back 2 wait states
+        st, j = 0, i - 1
+        while j >= 0 and st < 2:
+            p = lines[j]
+            if p.startswith(("s_cbranch", "s_branch", "s_endpgm")) or p.endswith(":"):
+                break
+            if (p.startswith("v_") and not p.startswith("v_mfma")) and (writes(p) & srcs):
+                bad.append((i, "W->M", p, l))
+            st += states(p)
+            j -= 1
+        # M->R: look ahead
+        st, j = 0, i + 1
+        while j < n and st < mfma_states:
+            p = lines[j]
+            if p.startswith(("s_cbranch", "s_branch", "s_endpgm")) or p.endswith(":"):
+                break
+            if p.startswith("v_mfma"):
+                pop, pops = split_ops(p)
+                if regs(pops[0]) == dst and regs(pops[3]) == dst:   # accumulate chain on the same tuple: no wait needed
+                    st += 8   # an MFMA in between holds the pipe for 8 passes
+                    j += 1
+                    continue
+                if (regs(pops[1]) | regs(pops[2]) | regs(pops[3]) | regs(pops[0])) & dst:
+                    bad.append((i, "M->R", p, l))
+                st += 8
+                j += 1
+                continue
+            if (reads(p) | writes(p)) & dst:
+                bad.append((i, "M->R", p, l))
+            st += states(p)
+            j += 1
+    return bad
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    mfma_states = 18
+    for a in sys.argv[1:]:
+        if a.startswith("--mfma-states="):
+            mfma_states = int(a.split("=")[1])
+    pat = argv[0] if argv else "w4"
+    files = [Path(argv[1])] if len(argv) > 1 else sorted(BUILD.glob("*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    total = 0
+    for f in files:
+        s = f.read_text()
+        for m in re.finditer(r"^(_Z\w+):\s*; @", s, re.M):
+            name = m.group(1)
+            if pat not in name:
+                continue
+            end = s.index(".Lfunc_end", m.end())
+            lines, in_asm, foreign = [], False, []
+            for raw in s[m.end():end].split("\n"):
+                l = raw.strip()
+                if l.startswith(";;#ASMSTART"):
+                    in_asm = True
+                elif l.startswith(";;#ASMEND"):
+                    in_asm = False
+                if not l or l.startswith(";") or (l.startswith(".") and not l.startswith(".LBB")):
+                    continue
+                if not in_asm and l.startswith(("v_accvgpr", "scratch_")):
+                    foreign.append(l)
+                lines.append(l)
+            if not any(l.startswith("v_mfma") and "a[" in l.split(",")[0] for l in lines):
+                continue   # kernels whose MFMAs are compiler builtins: hipcc pads those itself
+            bad = audit(name, lines, mfma_states)
+            bad += [(-1, "AGPR", l, "outside an asm statement") for l in foreign]
+            print(f"{name[:100]}: {sum(l.startswith('v_mfma') for l in lines)} MFMAs, {len(bad)} hazards")
+            for i, kind, p, l in bad[:12]:
+                print(f"   {kind} line {i}: `{p}`  vs  `{l}`")
+            total += len(bad)
+    return 1 if total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -39,7 +39,7 @@ for N in (1, 2, 4, 8):
     def single():
         nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_, out=o)
 
-    done = torch.zeros(Hl, device=dev, dtype=torch.int32)
+    done = nat.notify_counters(Hl, 1, dev)
     target = nat.band_notify_target(S, mask)
 
     def notify():   # what bench.py --gpus N does: one launch + per-chunk waiters on the side streams (the gathers would follow them)

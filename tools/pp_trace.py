@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Print the per-cluster cycle trace of the ping-pong attention schedule on the HunyuanVideo 720p layer-call shape
-(variant bits 5 + 6 of svg_band_attention; see svg_debug_pp_trace in include/svg_attn.h)."""
+"""Print the per-phase cycle trace of the two-phase ping-pong attention schedule (svg_band_attention variant 2) on the
+HunyuanVideo 720p layer-call shape.  Needs the diagnostics library: `python sparse-videogen_amd/build.py --ablations`, then
+SVG_ATTN_LIB=sparse-videogen_amd/lib/libsvgattn_abl.so python tools/pp_trace.py [band] [abl,abl,...]
+(variant 64 | abl << 8 of svg_band_attention; svg_debug_pp_trace in include/svg_attn.h)."""
 import sys
 from pathlib import Path
 
@@ -17,14 +19,14 @@ q, k, v = (torch.randn(1, H, S, D, device=dev, dtype=torch.bfloat16) for _ in ra
 band = int(sys.argv[1]) if len(sys.argv) > 1 else 15616
 mask = nat.BandMask(real_len=V + 64, band=band, colfull_lo=V, colfull_hi=V + 64, rowfull_lo=V, rowfull_hi=V + 64)
 abls = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
-base = int(sys.argv[3]) if len(sys.argv) > 3 else 32   # 32: four-cluster schedule, 128: two-phase schedule
-for variant in [base | 64 | (a << 8) for a in abls]:
+mode = sys.argv[3] if len(sys.argv) > 3 else "pp2"   # pp2: two-phase ping-pong (variant 64 | abl << 8); w4: one wave per SIMD (variant 32)
+for variant in [(32 if mode == "w4" else 64) | (a << 8) for a in abls]:
     o = nat.band_attention(q, k, v, mask, variant=variant)
     tr = nat.debug_pp_trace()
     nT = max(tr["tiles"], 1)
-    print(f"--- variant {base} ablation {variant >> 8}")
+    print(f"--- {mode} schedule, ablation {variant >> 8}")
     print(f"tiles {tr['tiles']} loop ticks {tr['loop_ticks']} = {tr['loop_ticks'] / nT:.0f} per tile")
-    names = ["LK", "bar", "QK", "bar", "SV", "bar", "PV", "bar"] if base == 32 else ["M", "bar", "N", "bar"]
+    names = ["A<bar", "bar", "A>bar", "A->B", "B", "B->A"] if mode == "w4" else ["M", "bar", "N", "bar"]
     for w, acc in enumerate(tr["waves"]):
-        if w in (0, 4):
-            print(f"wave {w}: " + "  ".join(f"{n} {a / nT:7.1f}" for n, a in zip(names, acc)) + f"   sum {sum(acc) / nT:7.1f}")
+        if w in ((0, 1, 2, 3) if mode == "w4" else (0, 4)):
+            print(f"wave {w}: " + "  ".join(f"{n} {a / nT:7.1f}" for n, a in zip(names, acc)) + f"   sum {sum(acc[:6]) / nT:7.1f}")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a launch of the band-attention kernel spends its time outside the tile loops: per-workgroup s_memtime stamps
-(entry, loop start, loop end, exit) and hardware ids of the traced two-phase kernel (variant 128 | 64), folded into
+(entry, loop start, loop end, exit) and hardware ids of the traced two-phase kernel (variant 64, diagnostics library: build.py --ablations + SVG_ATTN_LIB), folded into
 per-CU occupancy, prologue / epilogue durations and the gap between consecutive workgroups on the same CU.
 python tools/wg_timeline.py [band] [heads: spatial|temporal|alt] [H]"""
 import sys
@@ -26,11 +26,11 @@ pat = {"alt": lambda h: h % 2, "spatial": lambda h: 0, "temporal": lambda h: 1}[
 best = torch.tensor([[pat(h) for h in range(H)]], device=dev, dtype=torch.int64)
 kw = dict(head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_)
 for _ in range(2):
-    nat.band_attention(q, k, v, mask, variant=128 | 64, **kw)
+    nat.band_attention(q, k, v, mask, variant=64, **kw)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-nat.band_attention(q, k, v, mask, variant=128 | 64, **kw)
+nat.band_attention(q, k, v, mask, variant=64, **kw)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
