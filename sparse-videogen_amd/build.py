@@ -43,6 +43,9 @@ FLAGS = [
 # Files whose arithmetic has to reproduce torch's rounding points bit for bit: IEEE semantics, no fma contraction, no
 # folding of double -> float -> half conversions.
 STRICT_FP = {"prologue.hip", "glue.hip"}
+# Files whose gfx950 assembly is always kept (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s): their MFMAs are inline asm, which
+# hipcc's hazard recognizer does not see — tools/asm_hazards.py audits the listing (tests/test_w4_asm_audit.py).
+KEEP_ASM = {"attention_w4.hip"}
 
 
 def _newest_header() -> float:
@@ -61,7 +64,7 @@ def _compile(src: Path, force: bool, asm: bool, ablations: bool = False) -> tupl
     if ablations:
         flags.append("-DSVG_ABLATIONS")
     cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
-    if asm:
+    if asm or src.name in KEEP_ASM:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(OBJ))
     if r.returncode != 0:

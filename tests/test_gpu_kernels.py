@@ -128,6 +128,30 @@ def test_band_attention(nat, model, D, dtype, variant):
     check_attn(o, ref, dtype)
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("spike", [30.0, 120.0, 400.0])
+def test_band_attention_score_spikes(nat, variant, spike):
+    """The rare softmax paths (cdna_hip_programming.md §5.4 rule 26): one key row is aligned with a few query rows so that their
+    score jumps by `spike` (natural-log units) over everything seen before, in a LATE key tile.  Variant 3 keeps the first tile's
+    row maximum as reference: +30 stays on the fast path with probabilities up to e^30, +120 passes the exponent range of fp32
+    inside one tile (row sum non-finite -> the q-tile is marked and the exact launch redoes it), +400 likewise; variant 2 takes
+    its rescale branch.  Full-tensor fp32 reference."""
+    torch.manual_seed(11)
+    S, D, H = 1500, 128, 2
+    q, k, v = (torch.randn(1, H, S, D) for _ in range(3))
+    scale = 1.0 / D ** 0.5
+    for (qi, ki) in [(5, 900), (300, 1340), (301, 70), (1400, 1499), (1401, 3)]:
+        for h in range(H):
+            qd = q[0, h, qi]
+            k[0, h, ki] = qd / qd.norm() ** 2 * (spike / scale)      # q . k * scale = spike
+    q, k, v = (x.to(torch.bfloat16) for x in (q, k, v))
+    prm = O.dense_band_params(S)
+    o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), variant=variant)
+    ref = O.masked_attention(q, k, v, None)
+    assert torch.isfinite(o.float()).all()
+    check_attn(o, ref, torch.bfloat16)
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 3), (64, torch.float16, 3), (128, torch.float16, 2), (64, torch.bfloat16, 2),
                                              (128, torch.bfloat16, 1)])

@@ -1,0 +1,57 @@
+"""Audit of the gfx950 assembly of the one-wave-per-SIMD attention kernels (csrc/attn_w4.h).  Their MFMAs are inline asm and their
+accumulators live in hand-assigned AGPRs, so three things hipcc normally guarantees have to be checked on the listing instead
+(tools/asm_hazards.py): no VALU write of an MFMA operand inside the MFMA's hazard window (a compiler spill reload in front of an
+asm MFMA), no early read of an MFMA result, no transcendental result consumed by an asm instruction without its wait state,
+and no compiler-generated access to the owned accumulator registers or to scratch (the kernels must compile without spills).
+Runs on the listing build.py keeps for attention_w4.hip; builds it when it is missing or stale (hipcc cross-compiles: no GPU)."""
+import importlib.util
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "sparse-videogen_amd"
+LISTING = PKG / "build" / "attention_w4-hip-amdgcn-amd-amdhsa-gfx950.s"
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def listing():
+    srcs = [PKG / "csrc" / n for n in ("attention_w4.hip", "attn_w4.h", "attn_w4_agpr.inc", "attn_core.h", "band_policy.h")]
+    if not LISTING.exists() or LISTING.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+        _load(PKG / "build.py", "svg_build").build(force=False, asm=False, verbose=False)
+    assert LISTING.exists(), "build.py keeps the assembly of attention_w4.hip"
+    return LISTING
+
+
+def test_generated_register_helpers_are_current():
+    """csrc/attn_w4_agpr.inc is generated (tools/gen_w4_agpr.py) and committed: the committed file must be what the generator writes."""
+    inc = PKG / "csrc" / "attn_w4_agpr.inc"
+    before = inc.read_text()
+    _load(ROOT / "tools" / "gen_w4_agpr.py", "gen_w4_agpr")
+    after = inc.read_text()
+    inc.write_text(before)
+    assert before == after, "re-run tools/gen_w4_agpr.py and commit csrc/attn_w4_agpr.inc"
+
+
+def test_no_mfma_hazards_no_spills(listing, capsys):
+    audit = _load(ROOT / "tools" / "asm_hazards.py", "asm_hazards")
+    argv = sys.argv
+    sys.argv = ["asm_hazards.py", "w4", str(listing)]
+    try:
+        rc = audit.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    kernels = [l for l in out.splitlines() if l.startswith("_Z")]
+    assert len(kernels) >= 8, out            # {plain, switch} x {bf16, f16} x {D 128, 64}
+    assert rc == 0, out
+    for l in kernels:
+        assert " 0 hazards, 0 spill moves" in l, l

@@ -7,9 +7,12 @@ asm, so the compiler's hazard recognizer pads nothing around them (cdna_hip_prog
   M->R   a non-MFMA instruction reading (or overwriting) the VGPR / AGPR destination of an MFMA fewer than `--mfma-states`
          (default 18) wait states later, an MFMA that accumulates into the same tuple excepted
 
-  AGPR   a v_accvgpr_* or scratch_* instruction OUTSIDE an asm statement: the AGPRs of these kernels are owned by the asm
-         statements (csrc/attn_w4_agpr.inc); hipcc touching the accumulator file or spilling means it may have parked a value
-         in a register the asm statements use, or placed a reload inside a hazard window
+  T->A   an instruction INSIDE an asm statement reading the result of a transcendental (v_exp_f32, v_rcp_f32 ...) issued fewer than
+         2 wait states earlier: the transcendental unit delivers some lane groups late and hipcc pads this hazard only for
+         instructions it knows (seen on gfx950: stale operands in every other quad of lanes)
+  AGPR   a scratch_* instruction, or a v_accvgpr_* instruction OUTSIDE an asm statement that touches a0 .. a223: those registers are
+         owned by the asm statements (csrc/attn_w4_agpr.inc).  hipcc parking values of its own in a224 .. a255 is reported as a
+         count ("spill moves": harmless for the owned registers; a reload directly in front of an asm MFMA shows up as W->M)
 
 A wait state is one issued instruction; `s_nop N` counts N + 1.  Branches end a window (conservatively clean).
     python tools/asm_hazards.py [kernel substring] [file.s]      exit code 1 if a hazard is found
@@ -19,6 +22,7 @@ import sys
 from pathlib import Path
 
 BUILD = Path(__file__).resolve().parent.parent / "sparse-videogen_amd" / "build"
+OWNED_AGPRS = 224   # a0 .. a223: O^T, Q, row sums (tools/gen_w4_agpr.py)
 REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 
 
@@ -125,7 +129,7 @@ def main():
             if pat not in name:
                 continue
             end = s.index(".Lfunc_end", m.end())
-            lines, in_asm, foreign = [], False, []
+            lines, in_asm, foreign, spill_moves, asm_lines = [], False, [], 0, set()
             for raw in s[m.end():end].split("\n"):
                 l = raw.strip()
                 if l.startswith(";;#ASMSTART"):
@@ -134,14 +138,32 @@ def main():
                     in_asm = False
                 if not l or l.startswith(";") or (l.startswith(".") and not l.startswith(".LBB")):
                     continue
-                if not in_asm and l.startswith(("v_accvgpr", "scratch_")):
+                asm_lines.add(len(lines)) if in_asm else None
+                if not in_asm and l.startswith("scratch_"):
                     foreign.append(l)
+                elif not in_asm and l.startswith("v_accvgpr"):
+                    if any(k == "a" and r < OWNED_AGPRS for k, r in regs(l)):
+                        foreign.append(l)
+                    else:
+                        spill_moves += 1
                 lines.append(l)
             if not any(l.startswith("v_mfma") and "a[" in l.split(",")[0] for l in lines):
                 continue   # kernels whose MFMAs are compiler builtins: hipcc pads those itself
             bad = audit(name, lines, mfma_states)
+            TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+            for i, l in enumerate(lines):
+                if l.startswith(TRANS):
+                    w, st, j = writes(l), 0, i + 1
+                    while j < len(lines) and st < 2:
+                        pl = lines[j]
+                        if pl.startswith(("s_cbranch", "s_branch")) or pl.endswith(":"):
+                            break
+                        if j in asm_lines and pl.startswith("v_") and (reads(pl) & w):
+                            bad.append((i, "T->A", pl, l))
+                        st += states(pl)
+                        j += 1
             bad += [(-1, "AGPR", l, "outside an asm statement") for l in foreign]
-            print(f"{name[:100]}: {sum(l.startswith('v_mfma') for l in lines)} MFMAs, {len(bad)} hazards")
+            print(f"{name[:100]}: {sum(l.startswith('v_mfma') for l in lines)} MFMAs, {len(bad)} hazards, {spill_moves} spill moves")
             for i, kind, p, l in bad[:12]:
                 print(f"   {kind} line {i}: `{p}`  vs  `{l}`")
             total += len(bad)

@@ -47,6 +47,8 @@ CASES = [
 
 
 def main():
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # schedule of svg_band_attention (include/svg_attn.h)
+    print(f"schedule variant {variant}")
     dev = torch.device("cuda", 0)
     print("| model geometry | S | density | sparse ms | PFLOP/s (algorithmic) | dense ms | dense PFLOP/s | speed-up |")
     print("|---|---|---|---|---|---|---|---|")
@@ -72,8 +74,8 @@ def main():
                 ts.append(e0.elapsed_time(e1))
             return min(ts)
 
-        ms = t(lambda: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o))
-        dms = t(lambda: nat.band_attention(q, k, v, dmask, out=o))
+        ms = t(lambda: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o, variant=variant))
+        dms = t(lambda: nat.band_attention(q, k, v, dmask, out=o, variant=variant))
         np_, dp = pairs(mask, S), pairs(dmask, S)
         fl, dfl = 4.0 * D * BH * np_, 4.0 * D * BH * dp
         print(f"| {name} | {S} | {np_ / S / S:.4f} | {ms:.3f} | {fl / ms / 1e12:.3f} | {dms:.3f} | {dfl / dms / 1e12:.3f} | {dms / ms:.2f}x |", flush=True)
