@@ -273,12 +273,27 @@ def weighted_softmax(scores: torch.Tensor, weights: torch.Tensor) -> torch.Tenso
     return (we / we.sum(dim=-1, keepdim=True).clamp(min=1e-12)).to(dt)
 
 
-def identify_dynamic_map(qc, kc, q_sizes, k_sizes, p, min_kc_ratio=0.0):
-    """ref: svg/kmeans_utils.py:864-896, with the sort made stable (ties -> lower cluster index; SURVEY hazard 2)."""
+def identify_dynamic_map(qc, kc, q_sizes, k_sizes, p, min_kc_ratio=0.0, exact=False):
+    """ref: svg/kmeans_utils.py:864-896, with the sort made stable (ties -> lower cluster index; SURVEY hazard 2).
+
+    exact=False: the reference's own arithmetic — torch's 16-bit matmul (fp32 accumulation in torch's order) and the fp32
+    softmax; this is what the golden vectors generated by the reference pin.
+    exact=True: the same rounding points with the rounded quantities computed exactly enough to be order-independent (dot
+    products and softmax in fp64, then the same conversions to the input dtype).  It differs from exact=False only where the
+    reference's fp32 accumulation ORDER decides a rounding (tests/test_oracle_golden.py shows every such entry is a <= 1 ulp
+    near-tie) and it is what the HIP kernel reproduces bit for bit (csrc/dynmap.hip)."""
     B, H, QC, D = qc.shape
     KC = kc.shape[2]
-    scores = torch.matmul(qc, kc.transpose(-2, -1)) / (D ** 0.5)
-    probs = weighted_softmax(scores, k_sizes.unsqueeze(-2).float())
+    if exact:
+        s0 = torch.matmul(qc.double(), kc.double().transpose(-2, -1)).to(qc.dtype)   # double -> float -> 16 bit, like Elt::from_double
+        scores = s0 / (D ** 0.5)
+        w = k_sizes.unsqueeze(-2).double()
+        e = torch.exp(scores.double() - scores.double().max(dim=-1, keepdim=True)[0])
+        we = w * e
+        probs = (we / we.sum(dim=-1, keepdim=True).clamp(min=1e-12)).to(qc.dtype)
+    else:
+        scores = torch.matmul(qc, kc.transpose(-2, -1)) / (D ** 0.5)
+        probs = weighted_softmax(scores, k_sizes.unsqueeze(-2).float())
     sp, si = torch.sort(probs, dim=-1, descending=True, stable=True)
     cum = torch.cumsum(sp, dim=-1)
     rm = cum > p

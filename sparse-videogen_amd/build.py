@@ -42,7 +42,7 @@ FLAGS = [
 
 # Files whose arithmetic has to reproduce torch's rounding points bit for bit: IEEE semantics, no fma contraction, no
 # folding of double -> float -> half conversions.
-STRICT_FP = {"prologue.hip", "glue.hip"}
+STRICT_FP = {"prologue.hip", "glue.hip", "dynmap.hip"}
 # Files whose gfx950 assembly is always kept (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s): their MFMAs are inline asm, which
 # hipcc's hazard recognizer does not see — tools/asm_hazards.py audits the listing (tests/test_w4_asm_audit.py).
 KEEP_ASM = {"attention_w4.hip"}

@@ -3,9 +3,15 @@
 // One workgroup per (head, query-cluster) row; KC <= 4096 probabilities live in LDS.  The reference does this with
 // ~8 torch launches and a full [B,H,QC,KC] sort; here it is one launch and no global temporaries.
 //
-// Arithmetic follows the reference's dtypes step by step so that the produced map is reproducible:
-//   scores  = bf16(bf16(qc . kc) / sqrt(D))            (matmul output and the division both round to the input dtype)
-//   probs   = fp32 weighted softmax (weights = k cluster sizes), clamp(sum, 1e-12), rounded to the input dtype
+// Arithmetic follows the reference's dtypes step by step, with every quantity the reference ROUNDS computed exactly enough
+// that the rounding is order-independent — so the map is bit-reproducible (tests: == the oracle's exact mode, bit for bit):
+//   scores  = bf16(bf16(qc . kc) / sqrt(D))            (matmul output and the division both round to the input dtype; the dot
+//                                                       product is accumulated in fp64: products of 16-bit values are exact and
+//                                                       128 fp64 additions stay 2^-45 away from a bf16 rounding boundary, whereas
+//                                                       an fp32 accumulation depends on its order — torch's, cuBLAS's and a plain
+//                                                       loop disagree on ~0.05 % of the scores)
+//   probs   = weighted softmax (weights = k cluster sizes) in fp64, clamp(sum, 1e-12), rounded to the input dtype (the reference
+//             computes it in fp32; the fp64 value rounds to the same 16-bit number except when fp32 error straddles a boundary)
 //   order   = descending by prob, ties -> lower cluster index (stable sort)
 //   cumsum  = sequential, fp32 accumulator, every prefix rounded to the input dtype (torch cumsum on bf16)
 //   keep[r] = r == 0 || !(cumsum[r-1] > p_dtype) || r < preserve_length
@@ -21,12 +27,12 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
                                                              int QC, int KC, float sqrt_d, float top_p,
                                                              int preserve) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: keys[N2] u64 (sort keys; N2 = KC rounded up to a power of two), prob[KC] f32
+    // LDS: keys[N2] u64 (sort keys; N2 = KC rounded up to a power of two), prob[KC] f64
     const int N2 = 1 << (32 - __builtin_clz(max(KC, 2) - 1));
     unsigned long long* keys = (unsigned long long*)smem;
-    float* prob = (float*)(keys + N2);
+    double* prob = (double*)(keys + N2);
     __shared__ float qrow[D];
-    __shared__ float red[4];
+    __shared__ double red[4];
     __shared__ int cut_s;
     const int row = blockIdx.x, bh = blockIdx.y, tid = threadIdx.x;
     const T* q = qc + ((size_t)bh * QC + row) * D;
@@ -39,41 +45,42 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
     float lmax = -INFINITY;
     for (int j = tid; j < KC; j += kDynThreads) {
         const T* kr = kb + (size_t)j * D;
-        float acc = 0.f;
+        double acc = 0.0;
 #pragma unroll 4
         for (int d0 = 0; d0 < D; d0 += 8) {
             const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(kr + d0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qrow[d0 + e], Elt<T>::to_float(v[e]), acc);
+            for (int e = 0; e < 8; ++e) acc = __builtin_fma((double)qrow[d0 + e], (double)Elt<T>::to_float(v[e]), acc);
         }
-        float s = Elt<T>::to_float(Elt<T>::from_float(acc));
+        float s = Elt<T>::to_float(Elt<T>::from_double(acc));
         s = Elt<T>::to_float(Elt<T>::from_float(s / sqrt_d));
-        prob[j] = s;
+        prob[j] = (double)s;
         lmax = fmaxf(lmax, s);
     }
     lmax = wave_max(lmax);
-    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    if ((tid & 63) == 0) red[tid >> 6] = (double)lmax;
     __syncthreads();
-    const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const double gmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     __syncthreads();
-    // 2. weighted exp, sum
-    float lsum = 0.f;
+    // 2. weighted exp, sum (fp64; the partial sums are combined in a fixed order)
+    double lsum = 0.0;
     for (int j = tid; j < KC; j += kDynThreads) {
-        const float we = (float)ks[j] * expf(prob[j] - gmax);
+        const double we = (double)ks[j] * exp(prob[j] - gmax);
         prob[j] = we;
         lsum += we;
     }
-    lsum = wave_sum(lsum);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
     if ((tid & 63) == 0) red[tid >> 6] = lsum;
     __syncthreads();
-    const float gsum = fmaxf(red[0] + red[1] + red[2] + red[3], 1e-12f);
+    const double gsum = fmax(red[0] + red[1] + red[2] + red[3], 1e-12);
     // 3. stable descending order: sort the unique keys (inverted probability bits, cluster index) ascending — probabilities
     //    are >= 0, so their bit patterns order like the values; ties fall back to the lower index like a stable sort.
     //    Bitonic network in LDS: O(N log^2 N) compare-exchanges instead of the N^2 rank counting this kernel started with.
     for (int j = tid; j < N2; j += kDynThreads) {
         unsigned long long key = ~0ull;
         if (j < KC) {
-            const float pj = Elt<T>::to_float(Elt<T>::from_float(prob[j] / gsum));
+            const float pj = Elt<T>::to_float(Elt<T>::from_double(prob[j] / gsum));
             key = ((unsigned long long)(0xffffffffu - __float_as_uint(pj)) << 32) | (unsigned)j;
         }
         keys[j] = key;
@@ -121,10 +128,10 @@ extern "C" int svg_identify_dynamic_map(const void* qc, const void* kc, const in
                                         int32_t preserve_length, void* stream) {
     if (!qc || !kc || !k_sizes || !out_map || BH <= 0 || QC <= 0 || KC <= 0) return SVG_ERR_BAD_ARG;
     if (KC > 4096) return SVG_ERR_UNSUPPORTED;
-    // LDS: keys[N2] u64 (N2 = KC rounded up to a power of two) + prob[KC] f32
+    // LDS: keys[N2] u64 (N2 = KC rounded up to a power of two) + prob[KC] f64
     int n2 = 2;
     while (n2 < KC) n2 <<= 1;
-    const size_t lds = (size_t)n2 * 8 + (size_t)KC * 4;
+    const size_t lds = (size_t)n2 * 8 + (size_t)KC * 8;
     const float inv = sqrtf((float)D);  // scores are divided by sqrt(D) like the reference
     dim3 grid(QC, BH);
     hipStream_t st = (hipStream_t)stream;

@@ -3,8 +3,9 @@ kernels of libsvgattn (flash-kmeans: csrc/kmeans.hip, top-p block selection: csr
 csrc/attention.hip).  No Triton, no flashinfer, no cuVS.
 
 Differences that are deliberate and documented:
-  * all iterations run on device without a host sync per iteration; convergence is checked every `check_every`
-    iterations (default: once, after the last) — the reference syncs every iteration (`center_shift < tol`, :723);
+  * batch_kmeans_Euclid(check_every=0) runs without any host synchronisation: the reference's stopping rule
+    (`center_shift < tol`, :723, a read-back per iteration) is evaluated on the device and freezes the result;
+    the default (check_every=1) reads the shift back after every iteration exactly like the reference;
   * centroid sums are reduced in a fixed order (bit-reproducible), the reference uses fp32 atomics;
   * `sorted_indices` is the *stable* argsort of the labels (the reference's order inside a cluster is unspecified);
   * the variable-block attention needs no planning pass, no 4 GiB index buffer and no 512 MB workspace per call.
@@ -50,15 +51,24 @@ _STATE_CACHE: dict = {}
 
 
 @time_logging_decorator("Level 4 - batch kmeans euclid")
-def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=None, verbose=False, check_every=0,
+def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=None, verbose=False, check_every=1,
                         return_sorted_indices=False):
     """ref: batch_kmeans_Euclid, svg/kmeans_utils.py:684-733.
 
     x: [B, N, D] bf16/fp16 GPU tensor.  Returns (cluster_ids int64 [B, N], centroids [B, K, D], cluster_sizes int32 [B, K],
     n_iters) — and the stable sorted indices int32 [B, N] when `return_sorted_indices` (they come for free from the
     centroid update and save the argsort of permute_tensor_by_labels_triton).
-    Like the reference, the returned centroids are one update ahead of the returned labels unless it converged.
-    check_every = n > 0 reads the convergence flag back every n iterations (reference behaviour: n = 1)."""
+
+    Semantics of the reference's loop (:716-733), in both modes: iteration `it` assigns with the current centroids and computes
+    new ones; if the largest centre shift (over all batches) is below `tol` the loop stops and returns the labels / sizes of
+    THAT iteration, the OLD centroids and n_iters = it + 1; otherwise the new centroids become current — so without
+    convergence the returned centroids are one update ahead of the returned labels.
+
+    check_every = 1 (default): like the reference, the shift is read back after every iteration (one host sync each; n > 1
+        reads it every n-th iteration only, i.e. may overshoot by up to n - 1 iterations).
+    check_every = 0: no host synchronisation at all — every iteration is launched, and a device-side flag freezes the result at
+        the iteration where the reference would have stopped (a few torch.where over the result tensors per iteration).  Same
+        labels, centroids and sizes as check_every = 1; n_iters is then a 0-dim int64 GPU tensor instead of an int."""
     assert x.is_cuda, "batch_kmeans_Euclid requires GPU tensors"
     assert max_iters >= 1, "max_iters must be >= 1 (the reference raises NameError for 0)"
     B, N, D = x.shape
@@ -74,21 +84,45 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
         c_in = torch.gather(x, dim=1, index=indices[..., None].expand(-1, -1, D)).contiguous()
     else:
         c_in = init_centroids.reshape(B, n_clusters, D).contiguous()
-    n_done = 0
     cur = c_in
+    if check_every:
+        n_done = 0
+        for it in range(max_iters):
+            c_out = st.c[it & 1]
+            _native.kmeans_iter(x, xsq, cur, c_out, st.buf)
+            n_done = it + 1
+            if verbose:
+                print(f"Iter {it}, center shift: {st.buf.shift.max().item():.6f}")
+            if (it + 1) % check_every == 0 and st.buf.shift.max().item() < tol:
+                break  # converged: like the reference, keep the OLD centroids (`cur`)
+            cur = c_out
+        out = (st.buf.labels.to(torch.int64), cur.clone(), st.buf.counts.clone(), n_done)
+        if return_sorted_indices:
+            return out + (st.buf.sorted_idx.clone(),)
+        return out
+    # ---- device-side convergence: nothing below reads a value back to the host ----
+    labels_r = cent_r = counts_r = sorted_r = None
+    stopped = torch.zeros((), dtype=torch.bool, device=x.device)   # the reference's loop has left at an earlier iteration
+    n_r = torch.zeros((), dtype=torch.int64, device=x.device)
     for it in range(max_iters):
         c_out = st.c[it & 1]
         _native.kmeans_iter(x, xsq, cur, c_out, st.buf)
-        n_done = it + 1
-        if verbose:
-            print(f"Iter {it}, center shift: {st.buf.shift.max().item():.6f}")
-        if check_every and (it + 1) % check_every == 0 and st.buf.shift.max().item() < tol:
-            break  # converged: like the reference, keep the OLD centroids (`cur`)
+        conv_now = st.buf.shift.max() < tol
+        if it == 0:
+            labels_r, counts_r, sorted_r = st.buf.labels.clone(), st.buf.counts.clone(), st.buf.sorted_idx.clone()
+            cent_r = torch.where(conv_now, c_in, c_out)
+        else:
+            run = ~stopped
+            labels_r = torch.where(run, st.buf.labels, labels_r)
+            counts_r = torch.where(run, st.buf.counts, counts_r)
+            sorted_r = torch.where(run, st.buf.sorted_idx, sorted_r)
+            cent_r = torch.where(run & ~conv_now, c_out, cent_r)
+        n_r = n_r + (~stopped).to(torch.int64)
+        stopped = stopped | conv_now
         cur = c_out
-    labels = st.buf.labels.to(torch.int64)
-    out = (labels, cur.clone(), st.buf.counts.clone(), n_done)
+    out = (labels_r.to(torch.int64), cent_r, counts_r, n_r)
     if return_sorted_indices:
-        return out + (st.buf.sorted_idx.clone(),)
+        return out + (sorted_r,)
     return out
 
 

@@ -165,10 +165,11 @@ def kmeans_clustering(store: CentroidStore, layer_idx: int, q_video, k_video, nu
     iters = iter_init if first else iter_step
     qi = None if first else store.q[layer_idx]
     ki = None if first else store.k[layer_idx]
+    # (check_every=0: the reference's stopping rule evaluated on the device — same result, no read-back per iteration)
     ql, qc, qs, qit, qidx = batch_kmeans_Euclid(q_video.reshape(cfg * H, N, D), num_q_centroids, max_iters=iters,
-                                                init_centroids=qi, return_sorted_indices=True)
+                                                init_centroids=qi, return_sorted_indices=True, check_every=0)
     kl, kc, ks, kit, kidx = batch_kmeans_Euclid(k_video.reshape(cfg * H, N, D), num_k_centroids, max_iters=iters,
-                                                init_centroids=ki, return_sorted_indices=True)
+                                                init_centroids=ki, return_sorted_indices=True, check_every=0)
     store.q[layer_idx] = qc
     store.k[layer_idx] = kc
     if first:

@@ -152,6 +152,39 @@ def test_band_attention_score_spikes(nat, variant, spike):
     check_attn(o, ref, torch.bfloat16)
 
 
+def _bf16_ordinal(t):
+    """bf16 values -> integers whose difference is the distance in units in the last place"""
+    i = t.contiguous().view(torch.int16).to(torch.int32)
+    return torch.where(i < 0, -(i & 0x7FFF), i)
+
+
+@pytest.mark.parametrize("model,variant", [("hy", 0), ("wan", 0), ("dense", 0), ("hy", 2), ("dense", 1)])
+def test_band_attention_bf16_ulp(nat, model, variant):
+    """How far the bf16 output is from the correctly rounded one, bf16(fp32 oracle), in units in the last place.  The kernel
+    rounds the probabilities to bf16 before P V (like every MFMA flash attention), so its error is absolute on the scale of a
+    row's typical output, not relative per element: elements that are themselves the result of cancellation (far below the
+    row's rms) carry the same absolute error in many more of THEIR ulps.  Hence two statements:
+      * elements with |ref| >= rms(row) / 4:   >= 99.9 % within 1 ulp, none beyond 2 ulp;
+      * every element:                          |o - bf16(ref)| <= 1 ulp of the row's rms magnitude."""
+    torch.manual_seed(31)
+    F_, P_, ctx, L, mul, D, H = 6, 170, 40, 11, 2.3, 128, 2
+    S, prm, mask, _ = _band_case(model, F_, P_, ctx, L, mul)
+    q, k, v = (torch.randn(1, H, S, D).to(torch.bfloat16) for _ in range(3))
+    o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), variant=variant).cpu()
+    ref32 = O.masked_attention(q, k, v, mask)
+    ref = ref32.to(torch.bfloat16)
+    dist = (_bf16_ordinal(o) - _bf16_ordinal(ref)).abs()
+    rms = ref32.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    big = ref32.abs() >= rms / 4
+    d_big = dist[big]
+    within1 = (d_big <= 1).float().mean().item()
+    print(f"[bf16 ulp {model} v{variant}] |ref|>=rms/4: {big.float().mean():.3f} of the elements, exact {(d_big == 0).float().mean():.4f}, "
+          f"<=1 ulp {within1:.5f}, max {int(d_big.max())} ulp")
+    assert within1 >= 0.999 and int(d_big.max()) <= 2
+    ulp_rms = torch.exp2(torch.floor(torch.log2(rms)) - 7)          # bf16: 8 significant bits
+    assert torch.all((o.float() - ref.float()).abs() <= ulp_rms)
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 3), (64, torch.float16, 3), (128, torch.float16, 2), (64, torch.bfloat16, 2),
                                              (128, torch.bfloat16, 1)])
@@ -516,22 +549,130 @@ def test_kmeans_iter(nat, N, K, D):
     torch.testing.assert_close(buf.shift.cpu(), shift_ref, rtol=2e-2, atol=1e-3)
 
 
+def _blobs(B, N, K, D, spread, seed, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    centers = torch.randn(B, K, D, generator=g) * 2
+    x = torch.gather(centers, 1, torch.randint(0, K, (B, N), generator=g)[..., None].expand(-1, -1, D))
+    return (x + spread * torch.randn(B, N, D, generator=g)).to(dtype), centers.to(dtype)
+
+
+def _labels_match(x, c_used, lab, ref_lab=None, frac=5e-3):
+    """label parity rule of test_kmeans_iter: equal to the oracle's argmin under `c_used`, or a rounding-level near-tie"""
+    dist = O.kmeans_distances(x, O.kmeans_xsq(x), c_used)
+    ref = dist.argmin(-1) if ref_lab is None else ref_lab
+    mism = lab != ref
+    d_got = torch.gather(dist, 2, lab[..., None])[..., 0]
+    d_ref = dist.min(-1).values
+    assert mism.float().mean() <= frac, f"{mism.float().mean():.4f} of the labels differ"
+    assert torch.all((d_got - d_ref)[mism] <= 1e-2 * d_ref[mism].clamp(min=1.0))
+    return int(mism.sum())
+
+
+@pytest.mark.parametrize("N,K,D,spread", [(4000, 24, 128, 0.7), (6001, 100, 64, 1.2)])
+def test_kmeans_loop_vs_oracle(nat, N, K, D, spread):
+    """The LOOP of batch_kmeans_Euclid (ref svg/kmeans_utils.py:716-733) against O.batch_kmeans_euclid for max_iters 1, 2, 5:
+    labels of the LAST executed iteration, centroids ONE UPDATE AHEAD of them (no convergence here), sizes, n_iters — in the
+    host-checked mode (check_every=1, the reference's) and in the device-side mode (check_every=0), which must agree bit for bit.
+    Besides the end-to-end comparison (near-tie labels may differ and then move later centroids by rounding), each step is
+    checked against the oracle's single-iteration functions applied to the HIP path's own previous state: run(m - 1)'s
+    centroids are exactly the ones iteration m assigns with."""
+    from svg.kmeans_utils import batch_kmeans_Euclid
+    B = 3
+    x, _ = _blobs(B, N, K, D, spread, seed=21)
+    c0 = x[:, 100:100 + K].clone()     # data points as initial centres: several iterations of real movement
+    xd, c0d = dev(x), dev(c0)
+    prev_c = c0
+    for m in (1, 2, 3, 5):
+        lab, cent, cnt, nit, sidx = batch_kmeans_Euclid(xd, K, max_iters=m, init_centroids=c0d, return_sorted_indices=True)
+        lab0, cent0, cnt0, nit0, sidx0 = batch_kmeans_Euclid(xd, K, max_iters=m, init_centroids=c0d, return_sorted_indices=True,
+                                                             check_every=0)
+        assert isinstance(nit, int) and nit == m and int(nit0) == m and nit0.is_cuda   # not converged: all m iterations count
+        assert torch.equal(lab, lab0) and torch.equal(cent, cent0) and torch.equal(cnt, cnt0) and torch.equal(sidx, sidx0)
+        assert lab.dtype == torch.int64 and cnt.dtype == torch.int32
+        lab, cent, cnt, sidx = lab.cpu(), cent.cpu(), cnt.cpu(), sidx.cpu()
+        # end to end vs the oracle's loop
+        rl, rc, rcnt, rit = O.batch_kmeans_euclid(x, K, max_iters=m, init_centroids=c0)
+        assert rit == m
+        frac = (lab != rl).float().mean().item()
+        assert frac < 2e-2, f"max_iters={m}: {frac:.4f} of the labels differ from the oracle's loop"
+        torch.testing.assert_close(cent.float(), rc.float(), rtol=0, atol=0.15)   # a moved near-tie point shifts a mean slightly
+        assert (cent.float() - rc.float()).abs().mean() < 2e-3
+        # step-exact: iteration m assigned with the centroids run(m - 1) returned ("one ahead"), and the returned centroids
+        # are the update computed from the returned labels
+        if m in (1, 2, 3):
+            _labels_match(x, prev_c, lab)
+            c_ref, cnt_ref = O.kmeans_update(x, lab, prev_c)
+            assert torch.equal(cnt, cnt_ref) and torch.equal(sidx, O.stable_argsort(lab).to(torch.int32))
+            torch.testing.assert_close(cent.float(), c_ref.float(), rtol=1e-2, atol=1e-2)
+            assert not torch.equal(cent, prev_c)          # one update ahead, not the centroids the labels were made with
+            prev_c = cent
+
+
+def test_kmeans_loop_early_exit(nat):
+    """Convergence (ref :723-725 `if center_shift < tol: break`): well-separated blobs stop moving after a few iterations
+    (identical labels -> identical centroids -> shift exactly 0).  n_iters is the oracle's, the centroids are the OLD ones
+    (= the ones the returned labels were assigned with) and later iterations do not change anything — host-checked and
+    device-side modes alike; check_every=3 may only overshoot to the next multiple of 3."""
+    from svg.kmeans_utils import batch_kmeans_Euclid
+    B, N, K, D = 4, 3000, 16, 128
+    x, centers = _blobs(B, N, K, D, 0.3, seed=5)
+    c0 = (centers.float() + 0.2 * torch.randn(B, K, D, generator=torch.Generator().manual_seed(6))).to(torch.bfloat16)
+    rl, rc, rcnt, rit = O.batch_kmeans_euclid(x, K, max_iters=20, init_centroids=c0)
+    assert 2 <= rit <= 6, rit
+    xd, c0d = dev(x), dev(c0)
+    lab, cent, cnt, nit, sidx = batch_kmeans_Euclid(xd, K, max_iters=20, init_centroids=c0d, return_sorted_indices=True)
+    assert nit == rit
+    assert torch.equal(lab.cpu(), rl) and torch.equal(cnt.cpu(), rcnt)       # separated blobs: no near-ties
+    torch.testing.assert_close(cent.cpu().float(), rc.float(), rtol=1e-2, atol=1e-2)
+    _labels_match(x, cent.cpu(), lab.cpu(), frac=0.0)                          # OLD centroids: the labels' own
+    c_next, _ = O.kmeans_update(x, lab.cpu(), cent.cpu())
+    torch.testing.assert_close(c_next.float(), cent.cpu().float(), rtol=1e-2, atol=1e-2)   # converged: the update is a fixed point
+    lab0, cent0, cnt0, nit0, sidx0 = batch_kmeans_Euclid(xd, K, max_iters=20, init_centroids=c0d, return_sorted_indices=True,
+                                                         check_every=0)
+    assert nit0.is_cuda and int(nit0) == rit
+    assert torch.equal(lab, lab0) and torch.equal(cent, cent0) and torch.equal(cnt, cnt0) and torch.equal(sidx, sidx0)
+    lab3, cent3, cnt3, nit3 = batch_kmeans_Euclid(xd, K, max_iters=20, init_centroids=c0d, check_every=3)
+    assert nit3 == -(-rit // 3) * 3 and torch.equal(lab3, lab) and torch.equal(cnt3, cnt)
+    # max_iters below the convergence point: all iterations run, centroids one ahead
+    lab1, cent1, cnt1, nit1 = batch_kmeans_Euclid(xd, K, max_iters=1, init_centroids=c0d)
+    assert nit1 == 1 and not torch.equal(cent1.cpu(), c0)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # top-p block selection
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("QC,KC,D,p,ratio", [(12, 40, 64, 0.9, 0.1), (50, 1000, 128, 0.9, 0.1), (7, 333, 128, 0.5, 0.0)])
-def test_identify_dynamic_map(nat, QC, KC, D, p, ratio):
-    torch.manual_seed(8)
-    BH = 3
-    qc = torch.randn(BH, QC, D).to(torch.bfloat16)
-    kc = torch.randn(BH, KC, D).to(torch.bfloat16)
-    ksz = torch.randint(0, 300, (BH, KC), dtype=torch.int32)
-    got = nat.identify_dynamic_map(dev(qc), dev(kc), dev(ksz), p, int(ratio * KC)).cpu()
-    ref = O.identify_dynamic_map(qc[None], kc[None], None, ksz[None], p, ratio)[0]
-    # identical tie rule; residual differences can only come from fp32 summation order inside a dot product that
-    # lands on a bf16 rounding boundary -> a handful of entries at most
-    assert (got != ref).float().mean() < 2e-3
-    assert (got.sum(-1) - ref.sum(-1)).abs().max() <= max(2, KC // 200)
+def _centroid_like(BH, QC, KC, D, dtype, seed):
+    """centroid-shaped inputs with structure (a few dominant directions per head), so that top-p keeps a non-trivial part of a row"""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(BH, 8, D, generator=g)
+    qc = (base[:, torch.randint(0, 8, (QC,), generator=g)] * 1.5 + torch.randn(BH, QC, D, generator=g)).to(dtype)
+    kc = (base[:, torch.randint(0, 8, (KC,), generator=g)] * 1.5 + torch.randn(BH, KC, D, generator=g)).to(dtype)
+    ksz = torch.randint(0, 300, (BH, KC), dtype=torch.int32, generator=g)
+    return qc, kc, ksz
+
+
+@pytest.mark.parametrize("BH,QC,KC,D,p,ratio,dtype", [
+    (3, 12, 40, 64, 0.9, 0.1, torch.bfloat16), (3, 50, 1000, 128, 0.9, 0.1, torch.bfloat16), (3, 7, 333, 128, 0.5, 0.0, torch.bfloat16),
+    (2, 33, 257, 64, 0.95, 0.05, torch.float16), (2, 64, 4096, 128, 0.9, 0.0, torch.bfloat16),
+    (24, 400, 1000, 128, 0.9, 0.1, torch.bfloat16),     # HunyuanVideo 720p SAP: scripts/hyvideo/hyvideo_t2v_720p_sap.sh
+    (40, 300, 1000, 128, 0.9, 0.1, torch.bfloat16),     # Wan 2.1 720p SAP: scripts/wan/wan_t2v_720p_sap.sh
+])
+def test_identify_dynamic_map(nat, BH, QC, KC, D, p, ratio, dtype):
+    """Block-map indices are BIT-EXACT (north_star): the kernel equals the oracle's exact mode entry for entry — random and
+    structured centroids, the test grid and the production shapes of both SAP models.  (The oracle's exact mode vs the
+    reference's own fp32-accumulation arithmetic: tests/test_oracle_golden.py::test_dynamic_map_exact_mode_vs_reference_arithmetic.)"""
+    for seed, structured in ((8, False), (9, True)):
+        if structured:
+            qc, kc, ksz = _centroid_like(BH, QC, KC, D, dtype, seed)
+        else:
+            torch.manual_seed(seed)
+            qc, kc = torch.randn(BH, QC, D).to(dtype), torch.randn(BH, KC, D).to(dtype)
+            ksz = torch.randint(0, 300, (BH, KC), dtype=torch.int32)
+        got = nat.identify_dynamic_map(dev(qc), dev(kc), dev(ksz), p, int(ratio * KC)).cpu()
+        ref = O.identify_dynamic_map(qc[None], kc[None], None, ksz[None], p, ratio, exact=True)[0]
+        assert torch.equal(got.bool(), ref), f"{int((got.bool() != ref).sum())} of {ref.numel()} map entries differ (structured={structured})"
+        if structured:
+            assert 0.02 < ref.float().mean() < 0.98   # the case is not degenerate
     d = nat.map_density(dev(ref), dev(torch.full((BH, QC), 5, dtype=torch.int32)), dev(ksz)).cpu()
     dref = O.density_calculation(ref[None], torch.full((1, BH, QC), 5), ksz[None].long())[0]
     torch.testing.assert_close(d, dref.float(), rtol=1e-5, atol=1e-6)
