@@ -10,12 +10,16 @@ exactly what Hunyuan_SVGAttn_Processor2_0.attention_core_logic does per layer in
 (ref: svg/models/hyvideo/attention.py:507-524).  Inputs are resident in HBM before the timed region.
 
 metric  = attention TFLOP/s, algorithmic: 4 * D * H * (#unmasked (q,k) pairs) per layer-call (42.78 TFLOP
-          at L=64) divided by wall time per step; `denoise_steps_per_s` (60 layer-calls per denoise step, attention only)
-          is reported beside it.
+          at L=64) divided by wall time per step; `attention_only_steps_per_s` (60 such layer-calls, nothing else of a
+          denoise step — no projections, norms, MLPs) is reported beside it.
 roofline: bound = MFMA (dense bf16 peak 2.5 PFLOP/s); `achieved` = algorithmic FLOPs of the dominant kernel
-          (band_attn_kernel) / its mean launch duration measured with HIP events on the launch stream.
-cpu_baseline: the reference's CPU-capable dense path torch SDPA (ref: svg/models/wan/attention.py:279-281) on the host
-          cores, bf16, on a bounded sample (one head, shortened sequence), scaled — see `sample`.
+          (band_attn_w4_kernel) / its mean launch duration measured with HIP events on the launch stream.
+cpu_baseline: BASELINE.md §3 — the reference's CPU-capable dense path torch SDPA (ref: svg/models/wan/attention.py:279-281,
+          svg/models/hyvideo_orig/modules/attenion.py:488-491) on all host cores, bf16, ONE head at the full sequence length
+          (median of 3), or the longest sequence that fits the time bound; plus flex_attention eager on the CPU with the
+          reference's mask_mod for the sparse semantics on a reduced geometry — see `sample`.
+svg2_wan720p: BASELINE.json configs[2] (SVG2 / SAP layer-call of Wan 2.1 720p) measured in the same process after the
+          headline workload (bench_svg2.measure); --no-svg2 skips it.
 N > 1   : heads are independent units; rank r owns heads r::N of the same layer-call (strong scaling), no data-path
           collective during attention, one all-gather of the attention output per step (the exchange the next op,
           `to_out`, needs) over RCCL.
@@ -35,7 +39,11 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+import warnings  # noqa: E402
+
 import torch  # noqa: E402
+
+warnings.filterwarnings("ignore", message="flex_attention called without torch.compile")
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -54,44 +62,107 @@ def allowed_pairs_hy(V: int, ctx: int, L: int, tf: int) -> int:
     return band + 2 * V * L + L * L + (ctx - L) ** 2
 
 
-def _pmc_traffic(workload: str):
+BAND_KERNELS = {0: "band_attn_w4_kernel<bf16,128>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
+                1: "band_attn_kernel<bf16,128,4>"}
+
+
+def _pmc_traffic(workload: str, kernel: str):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-    WRITE_SIZE, tools/gpu_pmc.sh).  PMC collection needs its own rocprofv3 runs, so bench.py reports the value of the
-    committed profile (profiles/r01_pmc_traffic.json) for the headline workload and null otherwise."""
-    p = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if workload != "hy720p" or not p.exists():
-        return None
-    try:
-        return float(json.loads(p.read_text())["traffic_bytes_per_launch"])
-    except Exception:  # noqa: BLE001
-        return None
+    WRITE_SIZE, tools/gpu_pmc.sh).  PMC collection needs its own rocprofv3 runs, so bench.py reports the value of the newest
+    committed profile of THIS kernel (profiles/r*_pmc_traffic.json) for the headline workload, with its file name as
+    `traffic_source`; (null, null) otherwise."""
+    if workload != "hy720p":
+        return None, None
+    for p in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+        try:
+            d = json.loads(p.read_text())
+            if d.get("kernel", "band_attn_pp2_kernel<bf16,128>").split("<")[0] == kernel.split("<")[0]:
+                return float(d["traffic_bytes_per_launch"]), f"profiles/{p.name} (committed rocprofv3 --pmc passes, not collected in this run)"
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
-def cpu_baseline(H: int, D: int, S: int, seconds_target: float = 15.0):
-    """torch SDPA (dense, bf16) on the host cores: one head, sequence shortened so that it runs ~10-30 s."""
+def cpu_baseline(H: int, D: int, S: int, budget_s: float = 24.0):
+    """BASELINE.md §3.  Dense leg: torch SDPA bf16 on all host cores, ONE head at the full sequence length S, median of 3 — if
+    a probe at S/8 predicts more than budget_s for that, the longest power-of-two fraction of S that fits is timed instead and
+    `sample` says so.  Sparse leg: flex_attention, eager, on the CPU with the reference's Hunyuan mask_mod (the reference's sparse
+    semantics on its only CPU-capable path) on a reduced geometry — eager flex materialises the [S, S] scores."""
+    import statistics
     import torch.nn.functional as F
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    s = 8192
-    q, k, v = (torch.randn(1, 1, s, D, dtype=torch.bfloat16) for _ in range(3))
-    F.scaled_dot_product_attention(q, k, v)  # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < seconds_target and reps < 64:
-        F.scaled_dot_product_attention(q, k, v)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    tflops = 4.0 * s * s * D / dt / 1e12
-    return {
+    g = torch.Generator().manual_seed(0)
+
+    def sdpa_s(s, reps):
+        q, k, v = (torch.randn(1, 1, s, D, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            F.scaled_dot_product_attention(q, k, v)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    probe_s = max(2048, S // 8)
+    sdpa_s(probe_s, 1)                       # page in / thread pool
+    t_probe = min(sdpa_s(probe_s, 2))
+    s_run, frac = S, 1
+    while t_probe * (s_run / probe_s) ** 2 * 3 > budget_s and s_run > probe_s:
+        s_run //= 2
+        frac *= 2
+    ts = sdpa_s(s_run, 3)
+    t_med = statistics.median(ts)
+    tflops = 4.0 * s_run * s_run * D / t_med / 1e12
+    full_head = 4.0 * S * S * D / 1e12
+    out = {
         "value": round(tflops, 4),
         "unit": "TFLOP/s",
         "cores": cores,
         "kind": "reference",
-        "sample": f"torch SDPA dense bf16, 1 head, S={s}, D={D}, {reps} reps (reference CPU path "
-                  f"svg/models/wan/attention.py:279-281); a full {H}-head S={S} layer-call is "
-                  f"{4.0 * S * S * D * H / 1e12:.1f} TFLOP dense = {4.0 * S * S * D * H / 1e12 / tflops:.0f} s at this rate",
+        "sample": f"torch SDPA dense bf16 (reference CPU path svg/models/wan/attention.py:279-281), 1 head of {H}, S={s_run}"
+                  f"{'' if frac == 1 else f' (= S/{frac}: the full S={S} would exceed the {budget_s:.0f} s bound)'}, D={D}, median of 3: "
+                  f"{t_med:.2f} s; one full head = {full_head:.2f} TFLOP, the {H}-head layer-call = {full_head * H:.1f} TFLOP dense "
+                  f"= {full_head * H / tflops:.0f} s at this rate",
+        "seconds": [round(t, 3) for t in ts],
     }
+    try:
+        from torch.nn.attention.flex_attention import create_block_mask, flex_attention
+
+        from svg.models.hyvideo.utils import sparsity_to_width
+
+        F_, P_, ctx, L, Hs = 9, 512, 256, 64, 2
+        Vs = F_ * P_
+        Ss = Vs + ctx
+        mul = sparsity_to_width(0.25, ctx, F_, P_)
+        two_frame = math.floor(mul * P_ / 128) * 128
+        real = Vs + L
+
+        def mask_mod(b, h, qi, ki):   # the predicate of generate_temporal_head_mask_mod, ref: svg/models/hyvideo/utils.py:20-44
+            both_real = (ki < real) & (qi < real)
+            both_pad = (ki >= real) & (qi >= real)
+            band = torch.abs(qi - ki) < two_frame
+            text = ((ki >= Vs) & (ki < real)) | ((qi >= Vs) & (qi < real))
+            return (both_real & (band | text)) | both_pad
+
+        q, k, v = (torch.randn(1, Hs, Ss, D, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        bm = create_block_mask(mask_mod, None, None, Ss, Ss, device="cpu", _compile=False)
+        flex_attention(q, k, v, block_mask=bm)
+        t0 = time.perf_counter()
+        flex_attention(q, k, v, block_mask=bm)
+        tf = time.perf_counter() - t0
+        tfw = two_frame
+        pairs = allowed_pairs_hy(Vs, ctx, L, tfw)
+        out["sparse_flex_cpu"] = {
+            "what": f"flex_attention eager on CPU, reference mask_mod (svg/models/hyvideo/utils.py:20-44), H={Hs} F={F_} "
+                    f"P={P_} ctx={ctx} prompt={L} S={Ss} band={tfw}",
+            "seconds": round(tf, 3),
+            "tflops_algorithmic": round(4.0 * D * Hs * pairs / tf / 1e12, 4),
+            "tflops_dense_equivalent": round(4.0 * D * Hs * Ss * Ss / tf / 1e12, 4),
+        }
+    except Exception as e:  # noqa: BLE001
+        out["sparse_flex_cpu"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return out
 
 
 def main():
@@ -100,10 +171,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="0: 8 waves/WG, 1: 4 waves/WG")
+    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 3), "
+                    "1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per SIMD")
     ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
+    ap.add_argument("--no-svg2", action="store_true", help="skip the SVG2 (BASELINE.json configs[2]) extras block")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
     ap.add_argument("--heads", default="alt", choices=["alt", "spatial", "temporal"], help="best_mask_idx pattern")
     a = ap.parse_args()
@@ -258,15 +331,27 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    if smoke and world > 1:   # the gathered output must hold this rank's heads as they are after the launch (an early gather would not)
-        mine_idx = torch.tensor(my_heads, device=dev)
-        assert torch.equal(full.index_select(0, mine_idx), o[0]), "all-gather ran ahead of the attention kernel"
+    if smoke and world > 1:
+        # One more step with o and `full` poisoned: a gather that runs ahead of the attention kernel, or a segment that lands in the
+        # wrong place, leaves NaNs / other heads' rows behind.  Checked against a plain all_gather of the finished outputs.
+        o.fill_(float("nan"))
+        full.fill_(float("nan"))
+        step(False)
+        torch.cuda.synchronize()
+        outs = [torch.empty_like(o[0]) for _ in range(world)]
+        dist.all_gather(outs, o[0].contiguous())
+        assert not torch.isnan(o.float()).any(), "attention output incomplete"
+        for r in range(world):
+            idx = torch.tensor(chunked_head_layout(H, r, world, max_chunks=24)[2], device=dev)
+            assert torch.equal(full.index_select(0, idx), outs[r]), f"exchange of rank {r}'s heads is wrong or ran ahead of the kernel"
     ms_step = dt / a.steps * 1e3
     attn_ms = sum(x.elapsed_time(y) for x, y in zip(ev_a0, ev_a1)) / len(ev_a0)
 
     out = None
     if rank == 0:
         value = flops_call / (ms_step * 1e-3) / 1e12
+        kernel_name = BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
+        traffic, traffic_src = _pmc_traffic(a.workload, kernel_name)
         kern_tf = (flops_call * Hl / H) / (attn_ms * 1e-3) / 1e12
         out = {
             "metric": "attn_tflops_svg1_block_sparse",
@@ -290,17 +375,19 @@ def main():
                 "heads": a.heads,
             },
             "algorithmic_tflop_per_step": round(flops_call / 1e12, 3),
-            "denoise_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
+            # 60 sparse attention layer-calls per second and NOTHING else of a denoise step (no projections / norms / MLPs / VAE)
+            "attention_only_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
             "roofline": {
                 "bound": "mfma",
-                "kernel": "band_attn_pp2_kernel<bf16,128>" if a.variant in (0, 128) else f"band_attn variant {a.variant}",
+                "kernel": kernel_name,
                 "achieved": round(kern_tf, 2),
                 "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(kern_tf / PEAK_BF16_TFLOPS, 4),
                 "kernel_ms": round(attn_ms, 3),
-                "traffic": _pmc_traffic(a.workload),          # HBM bytes per launch (PMC), profiles/r01_pmc_traffic.json
+                "traffic": traffic,                           # HBM bytes per launch (PMC)
                 "traffic_unit": "B/launch",
+                "traffic_source": traffic_src,
                 "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
             },
         }
@@ -343,6 +430,16 @@ def main():
             out["dense_same_gpu"]["speedup_sparse_vs_torch_sdpa"] = round(sms / ms_step, 3)
         except Exception as e:  # noqa: BLE001
             out["dense_same_gpu"]["torch_sdpa_error"] = str(e)[:200]
+    if world == 1 and not a.no_svg2 and a.workload == "hy720p":
+        # BASELINE.json configs[2]: one SVG2 / SAP layer-call of Wan 2.1 720p (k-means, block map, variable-block attention)
+        del q, k, v, o
+        torch.cuda.empty_cache()
+        try:
+            import bench_svg2
+
+            out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1)
+        except Exception as e:  # noqa: BLE001
+            out["svg2_wan720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(H, D, S)
     elif rank == 0:

@@ -33,15 +33,12 @@ def clustered(H, N, D, modes, dev, gen, spread=0.35):
     return x.to(torch.bfloat16)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="wan720p", choices=sorted(WORKLOADS))
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order)")
-    ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
-                    "(the reference's pipeline) instead of the fused row-index gather")
-    a = ap.parse_args()
+def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False):
+    """one SVG2 layer-call (2 warm-started k-means iterations on q and k, block map, variable-block attention), timed per stage
+    with HIP events on the current stream; returns the dict bench_svg2.py prints (bench.py embeds it as `svg2_wan720p`)."""
+    import types
+
+    a = types.SimpleNamespace(workload=workload, steps=steps, warmup=warmup, variant=variant, materialize=materialize)
     from svg import _native as nat
     from svg.kmeans_utils import density_calculation
     from svg.models import _core
@@ -119,7 +116,19 @@ def main():
         "speedup_vs_dense_at_1000tflops": round((dense_flops / 1e15 * 1e3) / ms["total"], 2),
         "data": "synthetic (64-mode Gaussian mixture per head)",
     }
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="wan720p", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order)")
+    ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
+                    "(the reference's pipeline) instead of the fused row-index gather")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.workload, a.steps, a.warmup, a.variant, a.materialize)))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turn the counter summary of tools/gpu_pmc.sh into profiles/<tag>_pmc_traffic.json (what bench.py reports as
+roofline.traffic): HBM-side bytes per launch of the dominant attention kernel = 2 x FETCH_SIZE (gfx950 correction of
+MI355X_MICROARCH.md: the counter counts 64-B units of 128-B requests) + WRITE_SIZE, both in KB.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_<tag>/summary.txt <tag>  >  profiles/<tag>_pmc_traffic.json
+"""
+import json
+import re
+import sys
+
+txt = open(sys.argv[1]).read()
+tag = sys.argv[2] if len(sys.argv) > 2 else "?"
+blocks = {}
+cur = None
+for line in txt.splitlines():
+    if line and not line.startswith(" "):
+        cur = blocks.setdefault(line.strip(), {})
+    else:
+        m = re.match(r"\s+(\S+)\s+n=(\d+)\s+mean=(\S+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = float(m.group(3))
+# dominant kernel: the band attention kernel with the most wave cycles (or the only one)
+name, c = max(((k, v) for k, v in blocks.items() if "band_attn" in k), key=lambda kv: kv[1].get("SQ_WAVE_CYCLES", 0.0))
+g = c.get
+out = {
+    "kernel": name.split("(")[0].replace("void svg::", "").strip(),
+    "source": f"tools/gpu_pmc.sh {tag}: separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-profiler`, one launch each",
+    "FETCH_SIZE_KB": g("FETCH_SIZE"),
+    "WRITE_SIZE_KB": g("WRITE_SIZE"),
+    "traffic_bytes_per_launch": (2.0 * g("FETCH_SIZE", 0.0) + g("WRITE_SIZE", 0.0)) * 1024.0,
+    "note": "FETCH_SIZE x2: gfx950 correction (MI355X_MICROARCH.md).  The counter sits between L2 and the fabric: reads served by the "
+            "256 MiB Infinity Cache are included, so this is an upper bound of the HBM bytes.",
+    "l2_hit_rate": (g("TCC_HIT_sum", 0.0) / max(1.0, g("TCC_HIT_sum", 0.0) + g("TCC_MISS_sum", 0.0))) if g("TCC_HIT_sum") else None,
+    "mfma_busy_frac": (g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, g("SQ_BUSY_CYCLES", 1.0))) if g("SQ_VALU_MFMA_BUSY_CYCLES") else None,
+    "counters": c,
+}
+print(json.dumps(out, indent=1))
