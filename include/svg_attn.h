@@ -313,6 +313,12 @@ int svg_band_attention_notify(const void* q, const void* k, const void* v, void*
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                               int32_t* done_per_head, void* stream);
 int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream);
+/* svg_wait_counters with a deadline: the one-wave kernel gives up `timeout_ms` after it started, stores 1 to timed_out[0] (int32
+ * in device or pinned host memory, zeroed by the caller) and returns — a waiter of this kind cannot hang its stream whatever
+ * happens to the launch it watches; what was queued behind it then runs on incomplete rows, so the caller must read the flag
+ * before trusting the exchange (bench.py does after warm-up and falls back to one launch per chunk of heads). */
+int svg_wait_counters_deadline(const int32_t* counters, int32_t n, int32_t target, int32_t timeout_ms, int32_t* timed_out,
+                               void* stream);
 /* The same with several counters per head.  svg_band_attention_notify_layout fills row_bounds[0 .. n] and targets[0 .. n) for this
  * S / mask and returns n <= nseg, the number of segments used; pass that n as `nseg` of svg_band_attention_notify_seg together
  * with done = int32 [BH * (n + 1)], zeroed by the caller (counter (h, s) at done[h * n + s]; the last BH words are scratch of

@@ -398,6 +398,23 @@ __global__ __launch_bounds__(64) void wait_counters_kernel(const int32_t* __rest
     }
 }
 
+// the same with a deadline (wall_clock64: the constant 100 MHz counter): a waiter can never hang a stream — when the deadline
+// passes it sets *timed_out and returns, and whatever was queued behind it runs on incomplete data, which the caller detects by
+// reading the flag (bench.py: after warm-up, then falls back to chunk launches)
+__global__ __launch_bounds__(64) void wait_counters_deadline_kernel(const int32_t* __restrict__ counters, int n, int target,
+                                                                    long long ticks, int32_t* __restrict__ timed_out) {
+    const long long t0 = wall_clock64();
+    for (int i = threadIdx.x; i < n; i += 64) {
+        while (__hip_atomic_load(counters + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (wall_clock64() - t0 > ticks) {
+                __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+
 static bool g_trace_is_w4 = false;   // diagnostics only: which translation unit holds the last cycle trace
 
 static int band_check_args(const void* q, const void* k, const void* v, const void* o, int32_t BH, int32_t S, int32_t D,
@@ -506,6 +523,14 @@ extern "C" int svg_band_attention_notify_seg(const void* q, const void* k, const
 extern "C" int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream) {
     if (!counters || n <= 0) return SVG_ERR_BAD_ARG;
     hipLaunchKernelGGL(wait_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, n, target);
+    return launch_status();
+}
+
+extern "C" int svg_wait_counters_deadline(const int32_t* counters, int32_t n, int32_t target, int32_t timeout_ms,
+                                          int32_t* timed_out, void* stream) {
+    if (!counters || n <= 0 || timeout_ms <= 0 || !timed_out) return SVG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(wait_counters_deadline_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, n, target,
+                       (long long)timeout_ms * 100000LL, timed_out);
     return launch_status();
 }
 

@@ -108,6 +108,7 @@ SIGNATURES = {
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _VP]),
     "svg_wait_counters": (C.c_int, [_VP, _I32, _I32, _VP]),
+    "svg_wait_counters_deadline": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "svg_band_attention_notify_layout": (_I32, [_I32, C.POINTER(BandMask), _I32, _VP, _VP]),
     "svg_band_attention_notify_seg": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                                 C.POINTER(PermDesc), _VP, _I32, _VP]),
@@ -305,10 +306,18 @@ def band_notify_layout(S: int, mask: BandMask, nseg: int):
     return n, list(rb)[: n + 1], list(tg)[:n]
 
 
-def wait_counters(counters: torch.Tensor, target: int) -> None:
-    """Enqueue, on the current stream, a one-wave kernel that returns once every element of `counters` (int32, GPU) >= target."""
+def wait_counters(counters: torch.Tensor, target: int, timeout_ms: int = 0, timed_out: Optional[torch.Tensor] = None) -> None:
+    """Enqueue, on the current stream, a one-wave kernel that returns once every element of `counters` (int32, GPU) >= target.
+    timeout_ms > 0: the kernel gives up after that time and stores 1 to `timed_out` (int32 [1], GPU) — it cannot hang the stream;
+    the caller reads the flag before trusting what was queued behind the waiter."""
     _dev(counters)
     assert counters.dtype == torch.int32 and counters.is_contiguous()
+    if timeout_ms > 0:
+        _dev(timed_out)
+        assert timed_out.dtype == torch.int32 and timed_out.numel() >= 1
+        _check(load().svg_wait_counters_deadline(counters.data_ptr(), counters.numel(), int(target), int(timeout_ms),
+                                                 timed_out.data_ptr(), _stream()), "svg_wait_counters_deadline")
+        return
     _check(load().svg_wait_counters(counters.data_ptr(), counters.numel(), int(target), _stream()), "svg_wait_counters")
 
 

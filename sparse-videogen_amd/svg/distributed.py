@@ -10,10 +10,63 @@ single-GPU result, which is bitwise because per-head arithmetic does not change.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+# ---------------------------------------------------------------------------------------------------------------
+# opt-in switch for the processors (svg/models/_core.py): svg.distributed.enable(group) makes every SVG1 / SVG2 layer-call run
+# this rank's heads only and all-gather the result; nothing changes for a process that never calls it.
+# ---------------------------------------------------------------------------------------------------------------
+_STATE: Dict[str, object] = {"enabled": False, "group": None}
+
+
+def enable(group=None) -> None:
+    """Shard every attention layer-call of the installed processors over the ranks of `group` (default: the world group).
+    The processors keep receiving full [cfg, H, S, D] tensors (replicated activations); each rank computes
+    `shard_heads(H, rank, world)` and the outputs are all-gathered, so the caller sees the same tensors as on one GPU —
+    bitwise, because nothing in the path mixes heads (the k-means stopping rule, a maximum over all heads, is all-reduced)."""
+    assert dist.is_available() and dist.is_initialized(), "svg.distributed.enable: call torch.distributed.init_process_group first"
+    _STATE["enabled"], _STATE["group"] = True, group
+
+
+def disable() -> None:
+    _STATE["enabled"], _STATE["group"] = False, None
+
+
+def active() -> bool:
+    return bool(_STATE["enabled"]) and dist.is_initialized() and dist.get_world_size(_STATE["group"]) > 1
+
+
+def current_group():
+    return _STATE["group"]
+
+
+def all_reduce_max_(t: torch.Tensor) -> torch.Tensor:
+    """in-place MAX over the ranks of the enabled group (identity when sharding is off) — the k-means stopping rule's
+    `center_shift` is a maximum over ALL heads (ref: svg/kmeans_utils.py:721-723)"""
+    if active():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_STATE["group"])
+    return t
+
+
+def run_sharded(fn: Callable[..., Tuple[torch.Tensor, ...]], head_tensors: Sequence[torch.Tensor], group=None):
+    """fn(*[t[:, my heads] for t in head_tensors]) -> tensor or tuple of tensors with the head dimension at dim 1; every result is
+    all-gathered back to all heads (global order).  Ragged splits (H % world != 0) are allowed."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    H = head_tensors[0].shape[1]
+    mine = shard_heads(H, rank, world)
+    sl = slice(mine[0], mine[-1] + 1) if mine else slice(0, 0)
+    res = fn(*[t[:, sl].contiguous() for t in head_tensors])
+    single = not isinstance(res, (tuple, list))
+    outs = []
+    for r in ([res] if single else res):
+        extra = r.shape[2:]
+        r4 = r.reshape(r.shape[0], r.shape[1], -1, 1) if r.dim() != 4 else r
+        g = all_gather_heads(r4, H, group)
+        outs.append(g.reshape(g.shape[0], H, *extra))
+    return outs[0] if single else tuple(outs)
 
 
 def shard_heads(num_heads: int, rank: int, world: int) -> List[int]:
@@ -58,11 +111,107 @@ def sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_fn
     return all_gather_heads(o_local, H, group)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# token shards <-> head shards (the two exchanges either side of the attention when activations live token-sharded)
+# ---------------------------------------------------------------------------------------------------------------
+def token_range(num_tokens: int, rank: int, world: int, unit: int = 1) -> Tuple[int, int]:
+    """Tokens [a, b) of the sequence that live on `rank` between attention calls: contiguous, in whole `unit`s (unit = tokens
+    per frame keeps frames together: 33 frames / 8 ranks -> 5, 4, 4, ... frames), a trailing partial unit (the text tokens) goes
+    to the last rank."""
+    n_units = num_tokens // unit
+    base, rem = divmod(n_units, world)
+    a = (rank * base + min(rank, rem)) * unit
+    b = a + (base + (1 if rank < rem else 0)) * unit
+    if rank == world - 1:
+        b = num_tokens
+    return a, b
+
+
+def _owner_lists(num_heads: int, world: int, head_lists) -> List[List[int]]:
+    return [list(h) for h in head_lists] if head_lists is not None else [shard_heads(num_heads, r, world) for r in range(world)]
+
+
+def tokens_to_heads(x_local: torch.Tensor, num_tokens: int, group=None, unit: int = 1, head_lists=None, presorted: bool = False,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inbound exchange of a layer-call.  x_local [H, S_r, ...]: ALL heads of this rank's tokens `token_range(num_tokens, rank,
+    world, unit)` (head-major, as the fused prologue writes it) -> [H_local, num_tokens, ...]: this rank's heads of ALL tokens.
+    One all_to_all_single (every peer sends to every peer directly: the 7 xGMI links of a rank run concurrently), then one
+    strided copy per source rank into the sequence dimension.  Received per rank: (world - 1) / world of H_local * S * E bytes.
+    head_lists: per-rank head ids when ownership is not `shard_heads` (bench.py: chunked_head_layout); presorted=True says
+    x_local's heads are already ordered owner by owner."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    H = x_local.shape[0]
+    rest = tuple(x_local.shape[2:])
+    E = 1
+    for r_ in rest:
+        E *= r_
+    owners = _owner_lists(H, world, head_lists)
+    tr = [token_range(num_tokens, r, world, unit) for r in range(world)]
+    S_me = tr[rank][1] - tr[rank][0]
+    assert x_local.shape[1] == S_me, f"rank {rank} holds {x_local.shape[1]} tokens, token_range says {S_me}"
+    Hl = len(owners[rank])
+    order = [h for o in owners for h in o]
+    if not presorted and order != list(range(H)):
+        x_local = x_local.index_select(0, torch.tensor(order, device=x_local.device))
+    send = x_local.contiguous().view(-1)
+    recv = torch.empty(Hl * num_tokens * E, dtype=x_local.dtype, device=x_local.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[Hl * (b - a) * E for a, b in tr],
+                           input_split_sizes=[len(o) * S_me * E for o in owners], group=group)
+    if out is None:
+        out = torch.empty((Hl, num_tokens) + rest, dtype=x_local.dtype, device=x_local.device)
+    off = 0
+    for a, b in tr:
+        n = Hl * (b - a) * E
+        out[:, a:b].copy_(recv[off:off + n].view((Hl, b - a) + rest))
+        off += n
+    return out
+
+
+def heads_to_tokens(o_local: torch.Tensor, num_heads: int, group=None, unit: int = 1, head_lists=None) -> torch.Tensor:
+    """Outbound exchange, the inverse of tokens_to_heads: o_local [H_local, S, ...] (this rank's heads, all tokens) ->
+    [H, S_r, ...] (all heads of this rank's tokens; heads in global order) — what a token-sharded `to_out` consumes, world
+    times fewer received bytes than all-gathering the heads."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    S = o_local.shape[1]
+    rest = tuple(o_local.shape[2:])
+    E = 1
+    for r_ in rest:
+        E *= r_
+    owners = _owner_lists(num_heads, world, head_lists)
+    tr = [token_range(S, r, world, unit) for r in range(world)]
+    Hl = len(owners[rank])
+    assert o_local.shape[0] == Hl
+    S_me = tr[rank][1] - tr[rank][0]
+    send = torch.cat([o_local[:, a:b].reshape(-1) for a, b in tr])
+    recv = torch.empty(num_heads * S_me * E, dtype=o_local.dtype, device=o_local.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[len(o) * S_me * E for o in owners],
+                           input_split_sizes=[Hl * (b - a) * E for a, b in tr], group=group)
+    out = recv.view((num_heads, S_me) + rest)
+    order = [h for o in owners for h in o]
+    if order != list(range(num_heads)):
+        inv = torch.empty(num_heads, dtype=torch.long)
+        inv[torch.tensor(order)] = torch.arange(num_heads)
+        out = out.index_select(0, inv.to(out.device))
+    return out
+
+
+_SIDE_STREAMS: Dict[object, list] = {}
+
+
+def side_streams(device) -> list:
+    """two side streams per device, created once (a torch.cuda.Stream per call would leak HIP streams over a long run)"""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(2)]
+    return _SIDE_STREAMS[key]
+
+
 def chunked_head_layout(num_heads: int, rank: int, world: int, max_chunks: int = 3):
     """Head ownership for overlapping the output all-gather with compute: heads are taken in super-groups of world * n
     consecutive heads, n per rank, so the all-gather of local chunk c (n heads per rank) is the contiguous, naturally ordered
     slice [c * world * n, (c + 1) * world * n) of the full [H, ...] output.  Returns (n_chunks, n_per_chunk, my_heads)."""
-    assert num_heads % world == 0, f"{num_heads} heads do not split over {world} ranks"
+    assert num_heads % world == 0, (f"chunked_head_layout: {num_heads} heads do not split evenly over {world} ranks — the "
+                                    "overlapped scheme needs equal chunks; use sharded_attention / run_sharded (ragged splits) instead")
     local = num_heads // world
     n_chunks = 1 if world == 1 else max(c for c in range(max_chunks, 0, -1) if local % c == 0)
     n_per = local // n_chunks
@@ -90,7 +239,7 @@ def overlapped_sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tens
     full = torch.empty((H, S, D), dtype=q.dtype, device=q.device)
     cuda = q.is_cuda
     main = torch.cuda.current_stream() if cuda else None
-    side = [torch.cuda.Stream(device=q.device) for _ in range(2)] if cuda and n_chunks > 1 else None
+    side = side_streams(q.device) if cuda and n_chunks > 1 else None
     works = []
     for c in range(n_chunks):
         h0 = c * world * n_per + rank * n_per

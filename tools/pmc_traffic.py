@@ -24,7 +24,8 @@ for line in txt.splitlines():
 name, c = max(((k, v) for k, v in blocks.items() if "band_attn" in k), key=lambda kv: kv[1].get("SQ_WAVE_CYCLES", 0.0))
 g = c.get
 out = {
-    "kernel": name.split("(")[0].replace("void svg::", "").strip(),
+    "kernel": next((f"{k}<bf16,128>" for k in ("band_attn_w4_kernel", "band_attn_pp2_kernel", "band_attn_kernel") if k in name), name),
+    "kernel_symbol": name,
     "source": f"tools/gpu_pmc.sh {tag}: separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-profiler`, one launch each",
     "FETCH_SIZE_KB": g("FETCH_SIZE"),
     "WRITE_SIZE_KB": g("WRITE_SIZE"),
@@ -32,7 +33,12 @@ out = {
     "note": "FETCH_SIZE x2: gfx950 correction (MI355X_MICROARCH.md).  The counter sits between L2 and the fabric: reads served by the "
             "256 MiB Infinity Cache are included, so this is an upper bound of the HBM bytes.",
     "l2_hit_rate": (g("TCC_HIT_sum", 0.0) / max(1.0, g("TCC_HIT_sum", 0.0) + g("TCC_MISS_sum", 0.0))) if g("TCC_HIT_sum") else None,
-    "mfma_busy_frac": (g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, g("SQ_BUSY_CYCLES", 1.0))) if g("SQ_VALU_MFMA_BUSY_CYCLES") else None,
+    # busy cycles summed over the 1024 SIMDs / elapsed cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    "mfma_busy_frac": (g("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / max(1.0, g("GRBM_GUI_ACTIVE", 8.0) / 8.0))
+                      if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE") else None,
+    "per_mfma": {k: round(g(c, 0.0) / max(1.0, g("SQ_INSTS_MFMA", 1.0)), 3) for k, c in
+                 (("valu_incl_mfma", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"), ("vmem_rd", "SQ_INSTS_VMEM_RD"))}
+                if g("SQ_INSTS_MFMA") else None,
     "counters": c,
 }
 print(json.dumps(out, indent=1))
