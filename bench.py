@@ -21,8 +21,12 @@ cpu_baseline: BASELINE.md §3 — the reference's CPU-capable dense path torch S
 svg2_wan720p: BASELINE.json configs[2] (SVG2 / SAP layer-call of Wan 2.1 720p) measured in the same process after the
           headline workload (bench_svg2.measure); --no-svg2 skips it.
 N > 1   : heads are independent units; rank r owns heads r::N of the same layer-call (strong scaling), no data-path
-          collective during attention, one all-gather of the attention output per step (the exchange the next op,
-          `to_out`, needs) over RCCL.
+          collective inside the attention.  A step = the exchanges either side of it + the attention: q, k, v start
+          TOKEN-sharded (whole frames per rank, all heads — how the token-wise layers before the attention leave them) and
+          are turned into head shards by three all_to_all_single (inbound, svg.distributed.tokens_to_heads); the output is
+          all-gathered (the exchange the next op, `to_out`, needs) in row segments overlapped with the launch.  RCCL.
+          The overlap uses one-wave waiter kernels with a deadline; if one times out during warm-up the bench falls back
+          to one launch per chunk of heads and says so in `exchange`.
 """
 from __future__ import annotations
 
@@ -219,7 +223,7 @@ def main():
     # world * n consecutive heads, n per rank, so that the all-gather of one local chunk of n heads lands as ONE contiguous,
     # naturally ordered slice of the full [H, S, D] output — no reordering copy — and the gather of chunk c overlaps the
     # attention of chunk c + 1 ("overlappable").
-    from svg.distributed import chunked_head_layout, gather_chunk
+    from svg.distributed import chunked_head_layout, gather_chunk, token_range, tokens_to_heads
 
     # (one head per chunk: with one launch + completion counters a chunk costs a waiter and an all-gather call, not a kernel
     #  launch, and the exposed gather at the end of the step is that of ONE head instead of a third of the rank's heads)
@@ -229,7 +233,17 @@ def main():
         n_chunks, n_per = a.chunks, H // a.chunks
     Hl = len(my_heads)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+    if world > 1:
+        # token-sharded inputs: ALL heads (ordered owner by owner, as the fused prologue would write them) of this rank's frames
+        head_lists = [chunked_head_layout(H, r, world, max_chunks=24)[2] for r in range(world)]
+        ta, tb = token_range(S, rank, world, unit=P_)
+        q_tok, k_tok, v_tok = (torch.randn(H, tb - ta, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        q, k, v = (torch.empty(1, Hl, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                      # every rank of the communicator answered
+        rccl_ranks_seen = int(seen.item())
+    else:
+        q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
     o = torch.empty_like(q)
     pat = {"alt": lambda h: h % 2, "spatial": lambda h: 0, "temporal": lambda h: 1}[a.heads]
     best = torch.tensor([[pat(h) for h in my_heads]], device=dev, dtype=torch.int64)  # default: alternate spatial / temporal
@@ -247,6 +261,10 @@ def main():
     # still working on chunks c + 1 ...  (Chunked launches instead — SVG_BENCH_CHUNK_LAUNCHES=1, kept for A/B — cost
     # 5.7 ms per rank at N = 8 against 4.9 ms for the single launch: every launch ends with a partly idle round.)
     chunk_launches = bool(os.environ.get("SVG_BENCH_CHUNK_LAUNCHES"))
+    mode = {"chunk_launches": chunk_launches, "fallback": False}
+    WAIT_MS = int(os.environ.get("SVG_BENCH_WAITER_TIMEOUT_MS", "5000"))   # a step is tens of ms; a waiter that sits this long is stuck
+    timed_out = torch.zeros(1, device=dev, dtype=torch.int32)
+    stuck = 1 if os.environ.get("SVG_BENCH_TEST_STUCK_WAITER") else 0   # test hook: waiters wait for a count that never comes
     side = [torch.cuda.Stream(device=dev) for _ in range(2)] if n_chunks > 1 else None
     # every head is cut into row segments with their own counters: what stays exposed at the end of a step is the gather of the
     # last segment of the last head (a quarter of a head per rank)
@@ -265,6 +283,12 @@ def main():
         full[h0:h0 + world * n_per, a0:a1].view(world, n_per, a1 - a0, D).copy_(tmp)
 
     def step(timed: bool):
+        if world > 1:   # inbound exchange: token shards -> this rank's heads over the full sequence
+            for x_tok, x in ((q_tok, q), (k_tok, k), (v_tok, v)):
+                if smoke:   # gloo: stage through host memory (the smoke run checks control flow and placement, not speed)
+                    x[0].copy_(tokens_to_heads(x_tok.cpu(), S, unit=P_, head_lists=head_lists, presorted=True))
+                else:
+                    tokens_to_heads(x_tok, S, unit=P_, head_lists=head_lists, presorted=True, out=x[0])
         if not a.no_profiler:
             mse = nat.sample_mse(q[0], k[0], v[0], rows, prof)
             _ = mse.argmin(0)  # best_mask_idx (kept on device; the bench uses the fixed alternating pattern)
@@ -276,7 +300,7 @@ def main():
         kw = dict(vid0=0, num_frame=F_, frame_size=P_, variant=a.variant)
         if side is None:
             nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, **kw)
-        elif chunk_launches:
+        elif mode["chunk_launches"]:
             for c in range(n_chunks):
                 sl = slice(c * n_per, (c + 1) * n_per)
                 st = side[c % 2]
@@ -299,7 +323,7 @@ def main():
                     st.wait_event(zeroed)          # NOT the launch itself: the waiter runs beside it
                     with torch.cuda.stream(st):
                         for h in range(c * n_per, (c + 1) * n_per):   # (views of the live counters, never copies)
-                            nat.wait_counters(cnt[h, sg:sg + 1], seg_targets[sg])
+                            nat.wait_counters(cnt[h, sg:sg + 1], seg_targets[sg] + stuck, timeout_ms=WAIT_MS, timed_out=timed_out)
                         if world > 1:   # RCCL all-gather of this row segment as soon as it is complete on every head of the chunk
                             gather_segment(c, sg)
         if side:
@@ -314,6 +338,19 @@ def main():
 
     for _ in range(a.warmup):
         step(False)
+    if side is not None and not mode["chunk_launches"]:
+        # watchdog: did any waiter of the warm-up give up?  (every rank must take the same path: MAX over ranks.)  With no warm-up
+        # steps one untimed step is run for this check.
+        if a.warmup == 0:
+            step(False)
+        torch.cuda.synchronize()
+        flag = timed_out.clone().float()
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            mode["chunk_launches"] = mode["fallback"] = True
+            timed_out.zero_()
+            step(False)          # warm the fallback path
 
     def barrier():
         torch.cuda.synchronize()
@@ -338,6 +375,13 @@ def main():
         full.fill_(float("nan"))
         step(False)
         torch.cuda.synchronize()
+        # inbound: this rank's q must be its heads' rows of every rank's token shard
+        shards = [None] * world
+        dist.all_gather_object(shards, (ta, tb, q_tok.cpu()))
+        order = [h for hl in head_lists for h in hl]
+        pos = torch.tensor([order.index(h) for h in my_heads])
+        for a_, b_, xt in shards:
+            assert torch.equal(q[0][:, a_:b_].cpu(), xt[pos]), "inbound exchange put a token shard in the wrong place"
         outs = [torch.empty_like(o[0]) for _ in range(world)]
         dist.all_gather(outs, o[0].contiguous())
         assert not torch.isnan(o.float()).any(), "attention output incomplete"
@@ -377,6 +421,17 @@ def main():
             "algorithmic_tflop_per_step": round(flops_call / 1e12, 3),
             # 60 sparse attention layer-calls per second and NOTHING else of a denoise step (no projections / norms / MLPs / VAE)
             "attention_only_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
+            "exchange": None if world == 1 else {
+                "rccl_ranks_seen": rccl_ranks_seen,
+                "inbound": "3 x all_to_all_single (token shards [H, S/N, D] -> head shards [H/N, S, D]), inside the timed step",
+                "inbound_bytes_received_per_rank": int(3 * Hl * (S - (tb - ta)) * D * 2),
+                "outbound": "all_gather_into_tensor per row segment of a head chunk, behind completion counters of the single launch"
+                            if not mode["chunk_launches"] else "one launch + all-gather per chunk of heads on two streams",
+                "outbound_bytes_received_per_rank": int((H - Hl) * S * D * 2),
+                "waiter_timeout_ms": WAIT_MS,
+                "fallback_to_chunk_launches": mode["fallback"],
+                "waiter_timeouts_in_timed_steps": int(timed_out.item()),
+            },
             "roofline": {
                 "bound": "mfma",
                 "kernel": kernel_name,

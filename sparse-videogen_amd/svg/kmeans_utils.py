@@ -52,7 +52,7 @@ _STATE_CACHE: dict = {}
 
 @time_logging_decorator("Level 4 - batch kmeans euclid")
 def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=None, verbose=False, check_every=1,
-                        return_sorted_indices=False):
+                        return_sorted_indices=False, shift_reduce=None):
     """ref: batch_kmeans_Euclid, svg/kmeans_utils.py:684-733.
 
     x: [B, N, D] bf16/fp16 GPU tensor.  Returns (cluster_ids int64 [B, N], centroids [B, K, D], cluster_sizes int32 [B, K],
@@ -68,7 +68,11 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
         reads it every n-th iteration only, i.e. may overshoot by up to n - 1 iterations).
     check_every = 0: no host synchronisation at all — every iteration is launched, and a device-side flag freezes the result at
         the iteration where the reference would have stopped (a few torch.where over the result tensors per iteration).  Same
-        labels, centroids and sizes as check_every = 1; n_iters is then a 0-dim int64 GPU tensor instead of an int."""
+        labels, centroids and sizes as check_every = 1; n_iters is then a 0-dim int64 GPU tensor instead of an int.
+    shift_reduce: optional callable applied in place to the 0-dim maximum centre shift before it is compared with `tol` — the
+        head-sharded layer-call (svg.distributed) passes an all-reduce(MAX) so that the stopping rule stays the reference's
+        maximum over ALL heads."""
+    _red = shift_reduce if shift_reduce is not None else (lambda t: t)
     assert x.is_cuda, "batch_kmeans_Euclid requires GPU tensors"
     assert max_iters >= 1, "max_iters must be >= 1 (the reference raises NameError for 0)"
     B, N, D = x.shape
@@ -93,7 +97,7 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
             n_done = it + 1
             if verbose:
                 print(f"Iter {it}, center shift: {st.buf.shift.max().item():.6f}")
-            if (it + 1) % check_every == 0 and st.buf.shift.max().item() < tol:
+            if (it + 1) % check_every == 0 and _red(st.buf.shift.max()).item() < tol:
                 break  # converged: like the reference, keep the OLD centroids (`cur`)
             cur = c_out
         out = (st.buf.labels.to(torch.int64), cur.clone(), st.buf.counts.clone(), n_done)
@@ -107,7 +111,7 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
     for it in range(max_iters):
         c_out = st.c[it & 1]
         _native.kmeans_iter(x, xsq, cur, c_out, st.buf)
-        conv_now = st.buf.shift.max() < tol
+        conv_now = _red(st.buf.shift.max()) < tol
         if it == 0:
             labels_r, counts_r, sorted_r = st.buf.labels.clone(), st.buf.counts.clone(), st.buf.sorted_idx.clone()
             cent_r = torch.where(conv_now, c_in, c_out)

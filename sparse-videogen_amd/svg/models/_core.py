@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _native
+from .. import distributed as _dist
 from ..kmeans_utils import batch_kmeans_Euclid, density_calculation, identify_dynamic_map
 from ..timer import time_logging_decorator
 
@@ -95,11 +96,16 @@ def dense_flag_on_device(timestep, first_times_fp):
 
 
 def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask", dense_mask: "_native.BandMask",
-                                 prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, dense_flag):
+                                 prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, dense_flag,
+                                 _local: bool = False):
     """Dense warm-up step or sparse step, decided on the device: the profiler and the attention kernel read
     `dense_flag`; on a dense step the profiler returns at once and the kernel runs `dense_mask` without the head placement.
     Same results as the host-side branch of attention_core_logic (ref: hyvideo/attention.py:491-524)."""
     _require_gpu(q, "SVG1 attention")
+    if _dist.active() and not _local:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
+        return _dist.run_sharded(lambda qh, kh, vh: svg1_attention_device_switch(
+            qh, kh, vh, geo, mask, dense_mask, prof, num_sampled_rows, sample_max_row, dense_flag, _local=True), (q, k, v),
+            _dist.current_group())
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag)
     best_mask_idx = torch.argmin(mses, dim=0)
@@ -109,12 +115,15 @@ def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask
 
 
 def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof: "_native.ProfileDesc",
-                          num_sampled_rows: int, sample_max_row: int, fused: bool = True):
+                          num_sampled_rows: int, sample_max_row: int, fused: bool = True, _local: bool = False):
     """The sparse branch of attention_core_logic (ref: hyvideo/attention.py:507-524):
     online profiling -> best_mask_idx -> placement -> block-sparse attention -> inverse placement.
     fused=True folds both placements into the attention kernel (bit-identical result, ~5.9 GB less HBM traffic at
     Hunyuan 720p); fused=False runs the three kernels of the reference pipeline."""
     _require_gpu(q, "SVG1 sparse attention")
+    if _dist.active() and not _local:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
+        return _dist.run_sharded(lambda qh, kh, vh: svg1_sparse_attention(
+            qh, kh, vh, geo, mask, prof, num_sampled_rows, sample_max_row, fused, _local=True), (q, k, v), _dist.current_group())
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row)
     best_mask_idx = torch.argmin(mses, dim=0)  # [cfg, H] int64; NaN wins like torch.argmin in the reference
@@ -157,19 +166,32 @@ class CentroidStore:
 
 @time_logging_decorator("Level 3.5 - kmeans clustering")
 def kmeans_clustering(store: CentroidStore, layer_idx: int, q_video, k_video, num_q_centroids, num_k_centroids, iter_init,
-                      iter_step):
+                      iter_step, head_shard=None):
     """ref: kmeans_init / kmeans_step / kmeans_clustering, hyvideo/attention.py:576-626: random init from the data on the
-    first call of a layer, warm start from the previous denoise step's centroids afterwards."""
+    first call of a layer, warm start from the previous denoise step's centroids afterwards.
+    head_shard = (h0, h1, H): q_video / k_video hold heads [h0, h1) of H (svg.distributed) — the random initial points are drawn
+    for all H heads, in the order of the unsharded call, and this rank keeps its rows; the stopping rule's maximum centre shift is
+    all-reduced — so that the result does not depend on the sharding."""
     cfg, H, N, D = q_video.shape
     first = not store.has(layer_idx)
     iters = iter_init if first else iter_step
     qi = None if first else store.q[layer_idx]
     ki = None if first else store.k[layer_idx]
+    red = _dist.all_reduce_max_ if head_shard is not None else None
+    if first and head_shard is not None:
+        h0, h1, H_all = head_shard
+        rows = (torch.arange(cfg, device=q_video.device)[:, None] * H_all + torch.arange(h0, h1, device=q_video.device)[None]).reshape(-1)
+
+        def draw(x, n_clusters):   # ref svg/kmeans_utils.py:706-709 for all cfg * H heads, then this rank's rows
+            idx = torch.randint(0, N, (cfg * H_all, n_clusters), device=x.device).index_select(0, rows)
+            return torch.gather(x.reshape(cfg * H, N, D), 1, idx[..., None].expand(-1, -1, D)).contiguous()
+
+        qi, ki = draw(q_video, num_q_centroids), draw(k_video, num_k_centroids)
     # (check_every=0: the reference's stopping rule evaluated on the device — same result, no read-back per iteration)
     ql, qc, qs, qit, qidx = batch_kmeans_Euclid(q_video.reshape(cfg * H, N, D), num_q_centroids, max_iters=iters,
-                                                init_centroids=qi, return_sorted_indices=True, check_every=0)
+                                                init_centroids=qi, return_sorted_indices=True, check_every=0, shift_reduce=red)
     kl, kc, ks, kit, kidx = batch_kmeans_Euclid(k_video.reshape(cfg * H, N, D), num_k_centroids, max_iters=iters,
-                                                init_centroids=ki, return_sorted_indices=True, check_every=0)
+                                                init_centroids=ki, return_sorted_indices=True, check_every=0, shift_reduce=red)
     store.q[layer_idx] = qc
     store.k[layer_idx] = kc
     if first:
@@ -179,11 +201,18 @@ def kmeans_clustering(store: CentroidStore, layer_idx: int, q_video, k_video, nu
 
 def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_idx: int, num_q_centroids: int,
                           num_k_centroids: int, top_p: float, min_kc_ratio: float, iter_init: int, iter_step: int,
-                          prompt_length: int = 0, logging_file: Optional[str] = None, timestep=None):
+                          prompt_length: int = 0, logging_file: Optional[str] = None, timestep=None, _head_shard=None):
     """The sparse branch of the SAP processors (ref: hyvideo/attention.py:747-804, wan/attention.py:529-559):
     k-means on the video tokens -> top-p block map -> (Hunyuan) two pseudo clusters for prompt / unused prompt ->
     variable-block attention with the token permutation fused in (the result is already in the original order)."""
     _require_gpu(q, "SVG2 sparse attention")
+    if _dist.active() and _head_shard is None:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
+        grp = _dist.current_group()
+        mine = _dist.shard_heads(q.shape[1], torch.distributed.get_rank(grp), torch.distributed.get_world_size(grp))
+        shard = (mine[0], mine[-1] + 1, q.shape[1]) if mine else (0, 0, q.shape[1])
+        return _dist.run_sharded(lambda qh, kh, vh: svg2_sparse_attention(
+            qh, kh, vh, geo, store, layer_idx, num_q_centroids, num_k_centroids, top_p, min_kc_ratio, iter_init, iter_step,
+            prompt_length, logging_file, timestep, _head_shard=shard), (q, k, v), grp)
     cfg, H, S, D = q.shape
     assert cfg == 1, "Batch size must be 1 for kmeans block sparse attention"
     assert not geo.text_first, "SVG2 is defined for text-last models (Hunyuan, Wan)"
@@ -193,7 +222,8 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
     kv = k[:, :, :V].contiguous() if ctx else k
     with time_logging_decorator("Level 3 - semantic aware permutation"):
         (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = kmeans_clustering(store, layer_idx, qv, kv, num_q_centroids,
-                                                                         num_k_centroids, iter_init, iter_step)
+                                                                         num_k_centroids, iter_init, iter_step,
+                                                                         head_shard=_head_shard)
         q_sizes = qs.view(cfg, H, num_q_centroids)
         k_sizes = ks.view(cfg, H, num_k_centroids)
         dyn_map = identify_dynamic_map(qc.view(cfg, H, num_q_centroids, D), kc.view(cfg, H, num_k_centroids, D), q_sizes,
@@ -210,8 +240,11 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
         from .context import timestep_value
 
         densities = density_calculation(dyn_map, q_sizes, k_sizes)
-        DENSITY_LOG.push(logging_file, {"timestep": timestep_value(timestep) if timestep is not None else None, "layer": layer_idx},
-                         densities)
+        if _head_shard is not None:   # one log line per layer-call with all heads, written by rank 0
+            densities = _dist.all_gather_heads(densities.reshape(cfg, H, 1, 1), _head_shard[2], _dist.current_group()).reshape(cfg, -1)
+        if _head_shard is None or torch.distributed.get_rank(_dist.current_group()) == 0:
+            DENSITY_LOG.push(logging_file, {"timestep": timestep_value(timestep) if timestep is not None else None,
+                                            "layer": layer_idx}, densities)
     return out.view(cfg, H, S, D)
 
 

@@ -128,3 +128,84 @@ def test_overlapped_sharded_attention_gloo(H):
     port = 33500 + (os.getpid() % 2000) + H
     mp.spawn(_worker_overlapped, args=(world, port, H, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def _worker_exchange(rank, world, port, H, S, unit, chunked, ret):
+    """inbound (token shards -> head shards) and outbound (head shards -> token shards) all-to-all of a layer-call"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.distributed import chunked_head_layout, heads_to_tokens, shard_heads, token_range, tokens_to_heads
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = 4
+    torch.manual_seed(0)
+    x_all = torch.randn(H, S, D)                                   # the same global tensor on every rank
+    a, b = token_range(S, rank, world, unit)
+    lists = [chunked_head_layout(H, r, world, max_chunks=24)[2] for r in range(world)] if chunked else None
+    mine = lists[rank] if chunked else shard_heads(H, rank, world)
+    ok = sorted(t for r in range(world) for t in range(*token_range(S, r, world, unit))) == list(range(S))
+    ok &= (a % unit == 0) and (b % unit == 0 or rank == world - 1)
+    got = tokens_to_heads(x_all[:, a:b].contiguous(), S, unit=unit, head_lists=lists)
+    ok &= torch.equal(got, x_all[mine])
+    if chunked:   # bench.py's form: heads already ordered owner by owner, result written into a preallocated buffer
+        order = [h for o in lists for h in o]
+        buf = torch.full((len(mine), S, D), float("nan"))
+        tokens_to_heads(x_all[order][:, a:b].contiguous(), S, unit=unit, head_lists=lists, presorted=True, out=buf)
+        ok &= torch.equal(buf, x_all[mine])
+    fn = lambda t: torch.tanh(t) * 3.0                             # noqa: E731  stand-in for the per-head attention
+    back = heads_to_tokens(fn(got), H, unit=unit, head_lists=lists)
+    ok &= torch.equal(back, fn(x_all)[:, a:b])
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,S,unit,chunked", [
+    (2, 6, 50, 1, False),        # even heads, even tokens
+    (2, 5, 37, 1, False),        # ragged heads (3 + 2), ragged tokens
+    (2, 24, 5 * 7 + 3, 7, True),  # frames kept whole (unit = tokens per frame), text tokens on the last rank; chunked ownership
+    (3, 40, 4 * 9 + 2, 9, False),  # 40 heads over 3 ranks (14, 13, 13), 4 frames over 3 ranks
+    (8, 40, 21 * 3, 3, True),     # Wan: 40 heads / 8 ranks (5 each), 21 frames / 8 ranks (3, 3, 3, 3, 3, 2, 2, 2)
+])
+def test_token_head_exchange_gloo(world, H, S, unit, chunked):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 35500 + (os.getpid() % 2000) + H + world
+    mp.spawn(_worker_exchange, args=(world, port, H, S, unit, chunked, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def _worker_enable(rank, world, port, H, ret):
+    """svg.distributed.enable(): run_sharded is what the processors' attention cores go through (svg/models/_core.py)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg import distributed as sd
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = not sd.active()
+    sd.enable()
+    ok &= sd.active()
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(2, H, 24, 8) for _ in range(3))
+
+    def core(qh, kh, vh):   # (output [cfg, h, S, D], per-head index [cfg, h]) like svg1_sparse_attention
+        o = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh)
+        return o, o.sum(dim=(2, 3)).argsort(dim=1)[:, : qh.shape[1]] * 0 + (qh[:, :, 0, 0] > 0).long()
+
+    o, idx = sd.run_sharded(core, (q, k, v), sd.current_group())
+    ro, ridx = core(q, k, v)
+    ok &= torch.equal(o, ro) and torch.equal(idx, ridx) and idx.dtype == torch.int64
+    t = torch.tensor(float(rank))
+    ok &= float(sd.all_reduce_max_(t)) == world - 1
+    sd.disable()
+    ok &= (not sd.active()) and float(sd.all_reduce_max_(torch.tensor(-1.0))) == -1.0
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 6), (3, 40)])
+def test_enable_run_sharded_gloo(world, H):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 37500 + (os.getpid() % 2000) + H
+    mp.spawn(_worker_enable, args=(world, port, H, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}

@@ -44,3 +44,19 @@ def test_bench_two_rank_control_flow_smoke():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "heads/2"
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    ex = d["exchange"]
+    assert ex["rccl_ranks_seen"] == 2 and ex["fallback_to_chunk_launches"] is False and ex["waiter_timeouts_in_timed_steps"] == 0
+    assert ex["inbound_bytes_received_per_rank"] > 0 and ex["outbound_bytes_received_per_rank"] > 0
+
+
+def test_bench_two_rank_watchdog_falls_back():
+    """Waiters that never see their count (test hook) give up at their deadline during warm-up; the bench then switches to one
+    launch per chunk of heads on every rank, says so, and still produces a checked result (the smoke run's poisoned-output test)."""
+    env = dict(os.environ, SVG_BENCH_SMOKE="1", SVG_BENCH_TEST_STUCK_WAITER="1", SVG_BENCH_WAITER_TIMEOUT_MS="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    ex = _last_json(r.stdout)["exchange"]
+    assert ex["fallback_to_chunk_launches"] is True and ex["waiter_timeouts_in_timed_steps"] == 0
+    assert "per chunk" in ex["outbound"]
