@@ -322,6 +322,23 @@ def test_band_attention_notify_segments_with_fused_placement(nat):
         assert torch.equal(cnt.cpu(), torch.tensor(targets, dtype=torch.int32).expand(H, n))
 
 
+def test_wait_counters_deadline(nat):
+    """svg_wait_counters_deadline: returns at once when the counters are there; gives up after the deadline and raises the flag when
+    they never come — a waiter of this kind cannot hang its stream."""
+    import time
+
+    cnt = torch.tensor([5, 7, 9], dtype=torch.int32).cuda()
+    flag = torch.zeros(1, dtype=torch.int32).cuda()
+    nat.wait_counters(cnt, 5, timeout_ms=2000, timed_out=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    t0 = time.perf_counter()
+    nat.wait_counters(cnt, 8, timeout_ms=60, timed_out=flag)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(flag.item()) == 1 and 0.04 < dt < 1.5, dt
+
+
 @pytest.mark.parametrize("model", ["hy", "wan", "cog"])
 def test_band_attention_fused_placement(nat, model):
     """head_perm_flag path == placement -> attention -> inverse placement of the reference (attention.py:514-520)."""
