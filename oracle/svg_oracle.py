@@ -41,9 +41,14 @@ def sparsity_to_width(sparsity: float, context_length: int, num_frame: int, fram
     return width / frame_size
 
 
-def hy_mask(S: int, context_length: int, prompt_length: int, num_frames: int, P: int, mul: float) -> torch.Tensor:
+def _q_index(S: int, rows) -> torch.Tensor:
+    """query indices as a column: all of them, or the selected `rows` (full-size spot checks: the whole [S, S] mask does not fit)"""
+    return torch.arange(S)[:, None] if rows is None else torch.as_tensor(rows, dtype=torch.long)[:, None]
+
+
+def hy_mask(S: int, context_length: int, prompt_length: int, num_frames: int, P: int, mul: float, rows=None) -> torch.Tensor:
     """Dense bool mask of generate_temporal_head_mask_mod, ref: svg/models/hyvideo/utils.py:20-44"""
-    q = torch.arange(S)[:, None]
+    q = _q_index(S, rows)
     k = torch.arange(S)[None, :]
     real_length = num_frames * P + prompt_length
     real = (k < real_length) & (q < real_length)
@@ -55,17 +60,17 @@ def hy_mask(S: int, context_length: int, prompt_length: int, num_frames: int, P:
     return (real & (band | text_col | text_row)) | fake
 
 
-def wan_mask(S: int, num_frames: int, P: int, mul: float) -> torch.Tensor:
+def wan_mask(S: int, num_frames: int, P: int, mul: float, rows=None) -> torch.Tensor:
     """ref: svg/models/wan/utils.py:25-41 (ceil, <=, first-frame sink columns)"""
-    q = torch.arange(S)[:, None]
+    q = _q_index(S, rows)
     k = torch.arange(S)[None, :]
     two_frame = math.ceil(mul * P / 128) * 128
     return ((q - k).abs() <= two_frame) | (k < P)
 
 
-def cog_mask(S: int, prompt_length: int, num_frames: int, P: int, mul: float, attn_sink: bool = False) -> torch.Tensor:
+def cog_mask(S: int, prompt_length: int, num_frames: int, P: int, mul: float, attn_sink: bool = False, rows=None) -> torch.Tensor:
     """ref: svg/models/cog/utils.py:30-46 (text first)"""
-    q = torch.arange(S)[:, None]
+    q = _q_index(S, rows)
     k = torch.arange(S)[None, :]
     first_row = q < prompt_length
     first_col = k < (prompt_length + P) if attn_sink else k < prompt_length

@@ -12,6 +12,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fullgrid: the reference's complete parameter products; skipped unless SVG_FULL_GRID=1 "
+                                       "(minutes of CPU oracle time; the log of a full run is committed under profiles/)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("SVG_FULL_GRID"):
+        return
+    skip = pytest.mark.skip(reason="full reference grid: set SVG_FULL_GRID=1 (see profiles/*_fullgrid.txt for the committed run)")
+    for it in items:
+        if "fullgrid" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -32,6 +32,10 @@ def main():
             bm = ns["ref_gen_spatial_mask"](F, P, mul)
             em = ns["gen_mask_block2element"](bm, (P, P), L)
             out[f"spatial_{F}_{L}_{mul}"] = np.packbits(em.numpy())
+    # the reference's own grid (test_sparse_attn.py:160-161, 205-206): F = 21, P = 3600 — block masks only (the element mask is
+    # 75616^2); tests/test_gpu_bsr.py expands the rows it checks
+    out["blk_spatial_21_3600_2"] = (ns["ref_gen_spatial_mask"](21, 3600, 2) >= 0)
+    out["blk_temporal_21_3600_1.8"] = (ns["ref_gen_temporal_mask"](21, 3600, 1.8) >= 0)
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT} ({OUT.stat().st_size / 1024:.0f} KB, {len(out)} masks)")
 

@@ -64,3 +64,34 @@ def test_init_sparse_attn_and_gqa(ops):
         kr, vr = k.repeat_interleave(Hq // Hkv, dim=1), v.repeat_interleave(Hq // Hkv, dim=1)
         ref = O.masked_attention(q.permute(1, 0, 2)[None], kr.permute(1, 0, 2)[None], vr.permute(1, 0, 2)[None], mask)[0]
         close(o, ref.permute(1, 0, 2).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind,mul,heads,D", [("spatial", 2, 24, 128), ("temporal", 1.8, 32, 64), ("temporal", 1.8, 24, 128),
+                                               ("spatial", 2, 32, 64)])
+def test_sparse_attn_forward_reference_grid_fullsize(ops, kind, mul, heads, D):
+    """The reference's own grid (svg/kernels/test/test_sparse_attn.py:160-161, 205-206): F = 21, P = 3600, 16 prompt tokens, 24 / 32
+    heads, D 64 / 128, fp16 — S = 75616.  The dense reference of the whole problem is out of reach on the CPU, so spot rows of three
+    heads are compared with the oracle under the element mask expanded from the REFERENCE generators' block masks (golden), text
+    first like gen_mask_block2element (:66-86)."""
+    F, P_, L = 21, 3600, 16
+    S = F * P_ + L
+    dt = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q, k, v = (torch.randn(S, heads, D, device="cuda", dtype=dt, generator=g) for _ in range(3))
+    gen = ops._gen_spatial_mask if kind == "spatial" else ops._gen_temporal_mask
+    md = gen(F, P_, mul)
+    meta = ops.FAMetadata(L, F, P_, md if kind == "temporal" else None, md if kind == "spatial" else None, None)
+    o = ops.sparse_attn_forward(q, k, v, meta, kind)
+    blk = torch.from_numpy(GOLD[f"blk_{kind}_{F}_{P_}_{mul}"])
+    bs = P_ if kind == "spatial" else P_ // 10
+    rows = [0, 1, L - 1, L, L + 1, L + bs - 1, L + bs, L + 3 * P_ - 1, L + 3 * P_, L + 10 * P_ + 1799, S - bs - 1, S - bs, S - 1]
+    rows += torch.randint(0, S, (20,), generator=torch.Generator().manual_seed(2)).tolist()
+    rt = torch.tensor(rows)
+    kk = torch.arange(S)
+    mask = torch.ones(len(rows), S, dtype=torch.bool)
+    vid = rt >= L
+    bi = ((rt[vid] - L) // bs)
+    mask[vid, L:] = blk[bi][:, (kk[L:] - L) // bs]
+    for h in (0, heads // 2, heads - 1):
+        ref = O.masked_attention(q[rows, h].float().cpu(), k[:, h].float().cpu(), v[:, h].float().cpu(), mask)
+        close(o[rows, h], ref.to(dt))

@@ -86,3 +86,68 @@ def test_fullsize_linearity_in_v(setup):
     o12 = nat.band_attention(q, k, (v.float() + v2.float()).to(torch.bfloat16), mask).float()
     err = ((o12 - (o1 + o2)).norm() / (o1 + o2).norm()).item()
     assert err < 6e-3, err
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the other two SVG1 models at their production geometry (the reference's install hooks: svg/models/wan/inference.py:41-44,
+# svg/models/cog/inference.py:31-34 with the v1.5 numbers F = 11, P = 4080)
+# ---------------------------------------------------------------------------------------------------------
+FULLSIZE = {
+    # name: (D, F, P, ctx, text_first, sparsity)
+    "wan720p": (128, 21, 3600, 0, False, 0.30),
+    "cog15_768p": (64, 11, 4080, 226, True, 0.25),
+}
+
+
+@pytest.mark.parametrize("model", sorted(FULLSIZE))
+def test_fullsize_spot_rows_wan_cog(model):
+    """Wan 2.1 720p (S = 75600: `<=` band of ceil'ed width + first-frame sink columns, no text) and CogVideoX-v1.5 (S = 45106,
+    D = 64, text FIRST) at full size: (1) the fused layout transformation equals placement -> attention -> inverse placement bit
+    for bit, (2) spot rows of a spatial and a temporal head — band edges, sink / text columns, sequence ends — against the oracle
+    under the REFERENCE's mask predicate (svg/models/wan/utils.py:25-41, svg/models/cog/utils.py:30-46) evaluated on those rows."""
+    from svg import _native as nat
+
+    nat.load()
+    D_, F2, P2, ctx, text_first, sparsity = FULLSIZE[model]
+    V2 = F2 * P2
+    S2 = V2 + ctx
+    vid0 = ctx if text_first else 0
+    mul = O.sparsity_to_width(sparsity, ctx, F2, P2)
+    if model == "wan720p":
+        prm = O.wan_band_params(S2, F2, P2, mul)
+        assert prm["band"] == 12416 + 1
+        ref_mask = lambda rows: O.wan_mask(S2, F2, P2, mul, rows=rows)        # noqa: E731
+        edge = 12416
+    else:
+        prm = O.cog_band_params(S2, ctx, F2, P2, mul)
+        ref_mask = lambda rows: O.cog_mask(S2, ctx, F2, P2, mul, rows=rows)   # noqa: E731
+        edge = prm["band"]
+    g = torch.Generator(device="cuda").manual_seed(17)
+    q, k, v = (torch.randn(1, 2, S2, D_, device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(3))
+    best = torch.tensor([[0, 1]], device="cuda")
+    mask = nat.BandMask(**prm)
+    o = nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F2, frame_size=P2)
+    qp, kp, vp = (torch.empty_like(x) for x in (q, k, v))
+    nat.head_placement([q, k, v], [qp, kp, vp], best, ctx, F2, P2, text_first, False)
+    om = nat.band_attention(qp, kp, vp, mask)
+    oi = torch.empty_like(om)
+    nat.head_placement([om], [oi], best, ctx, F2, P2, text_first, True)
+    assert torch.equal(oi, o)
+    rows = [0, 1, vid0, vid0 + 1, P2 - 1, P2, P2 + 1, vid0 + edge - 1, vid0 + edge, vid0 + edge + 1, S2 // 2, S2 // 2 + 1,
+            S2 - edge - 2, S2 - edge - 1, S2 - edge, S2 - 2, S2 - 1]
+    if ctx:
+        rows += [ctx - 1, ctx, ctx + 1]
+    rows += torch.randint(0, S2, (24,), generator=torch.Generator().manual_seed(3)).tolist()
+    m = ref_mask(rows)
+
+    def logical(x):   # token order the mask is applied in: temporal heads are token-major inside the video part
+        x = x.float().cpu()
+        vidp = x[vid0:vid0 + V2].reshape(F2, P2, D_).transpose(0, 1).reshape(V2, D_)
+        return torch.cat([x[:vid0], vidp, x[vid0 + V2:]])
+
+    for h, temporal in ((0, False), (1, True)):
+        qh, kh, vh = ((logical(x[0, h]) if temporal else x[0, h].float().cpu()) for x in (q, k, v))
+        ref = O.masked_attention(qh[rows], kh, vh, m)
+        got = om[0, h].float().cpu()[rows]     # om is in logical order for both heads
+        torch.testing.assert_close(got, ref, atol=1e-2, rtol=1e-2)
+        assert ((got - ref).norm() / ref.norm()).item() < 3e-3

@@ -432,6 +432,21 @@ def test_varblock_attention(nat, hq, hkv, D, S, MB, NB, density, dtype, variant)
         assert rel_l2(o[h * g:(h + 1) * g], ref) <= (3e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
+_VB_FULL = [(hq, hkv, D, S, MB, NB, dens, dt)
+            for hq in (1, 4, 16) for hkv in (1, 4, 16) if hq % hkv == 0
+            for D in (64, 128) for S in (256, 4096, 8192) for MB in (10, 20) for NB in (50, 100) for dens in (0.2, 0.7, 0.9)
+            for dt in (torch.bfloat16, torch.float16)]
+
+
+@pytest.mark.fullgrid
+@pytest.mark.parametrize("hq,hkv,D,S,MB,NB,density,dtype", _VB_FULL)
+def test_varblock_attention_full_reference_grid(nat, hq, hkv, D, S, MB, NB, density, dtype):
+    """The complete product of svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:74-81 (864 runnable cases: qo heads x kv heads with
+    qo % kv == 0, D, S in {256, 4096, 8192}, row / column block counts, density, dtype) on the default schedule, same tolerance as
+    the reference (:133) plus the rel-L2 bound.  SVG_FULL_GRID=1 python -m pytest tests -m gpu -k full_reference_grid -n 8."""
+    test_varblock_attention(nat, hq, hkv, D, S, MB, NB, density, dtype, -1)
+
+
 def test_varblock_golden_and_edge_cases(nat, golden):
     """Reference dynamic_block_sparse_fwd_torch output (empty q block, empty k block, q block with no active keys)."""
     q, k, v = (torch.from_numpy(golden[n])[0].to(torch.float16) for n in ("vb_q", "vb_k", "vb_v"))
