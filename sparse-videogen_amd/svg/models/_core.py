@@ -76,15 +76,32 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 
 
 @time_logging_decorator("Level 3 - sample_mse")
-def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, skip_flag=None):
+def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, skip_flag=None,
+               generator=None):
     """ref: sample_mse svg/models/hyvideo/attention.py:376-399.  Rows are drawn with the CPU generator exactly like the
-    reference (`torch.randint(low=0, high=sample_mse_max_row, size=(n,))` without device=).  -> float32 [2, cfg, H]"""
+    reference (`torch.randint(low=0, high=sample_mse_max_row, size=(n,))` without device=) unless `generator` is given.
+    -> [2, cfg, H] in q's dtype: the reference stores the MSEs in `query.dtype` (:388) before the argmin, so two candidates that
+    round to the same bf16 value tie and resolve to index 0 (spatial) there — the fp32 results of the kernel are rounded the same way."""
     cfg, H, S, D = q.shape
     n = min(num_sampled_rows, S)
-    rows = torch.randint(low=0, high=sample_max_row, size=(n,))
+    rows = torch.randint(low=0, high=sample_max_row, size=(n,), generator=generator)
     mses = _native.sample_mse(q.reshape(cfg * H, S, D), k.reshape(cfg * H, S, D), v.reshape(cfg * H, S, D),
                               rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag)
-    return mses.reshape(2, cfg, H)
+    return mses.reshape(2, cfg, H).to(q.dtype)
+
+
+_SWITCH_GEN = None
+
+
+def _switch_generator():
+    """CPU generator of the device-switched path.  The reference (and the host-side branch) draw the profiler's rows from the global
+    CPU generator on SPARSE steps only; the switched path does not know on the host whether the step is dense, so it must not
+    touch the global stream at all: it draws from this generator, seeded once from the global seed.  (Deviation: at equal seeds the
+    sampled rows differ from the reference's; every other consumer of the global CPU RNG sees the reference's stream.)"""
+    global _SWITCH_GEN
+    if _SWITCH_GEN is None:
+        _SWITCH_GEN = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 63))
+    return _SWITCH_GEN
 
 
 def dense_flag_on_device(timestep, first_times_fp):
@@ -100,18 +117,19 @@ def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask
                                  _local: bool = False):
     """Dense warm-up step or sparse step, decided on the device: the profiler and the attention kernel read
     `dense_flag`; on a dense step the profiler returns at once and the kernel runs `dense_mask` without the head placement.
-    Same results as the host-side branch of attention_core_logic (ref: hyvideo/attention.py:491-524)."""
+    Same attention results as the host-side branch of attention_core_logic (ref: hyvideo/attention.py:491-524) for the same sampled
+    rows; the rows come from a dedicated CPU generator (`_switch_generator`).  The returned best_mask_idx is -1 on a dense step."""
     _require_gpu(q, "SVG1 attention")
     if _dist.active() and not _local:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
         return _dist.run_sharded(lambda qh, kh, vh: svg1_attention_device_switch(
             qh, kh, vh, geo, mask, dense_mask, prof, num_sampled_rows, sample_max_row, dense_flag, _local=True), (q, k, v),
             _dist.current_group())
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag)
+    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag, generator=_switch_generator())
     best_mask_idx = torch.argmin(mses, dim=0)
     out = _native.band_attention_switch(q, k, v, mask, dense_mask, dense_flag, head_perm_flag=best_mask_idx, vid0=geo.vid0,
                                         num_frame=geo.num_frame, frame_size=geo.frame_size)
-    return out, best_mask_idx
+    return out, torch.where(dense_flag.reshape(()) != 0, torch.full_like(best_mask_idx, -1), best_mask_idx)
 
 
 def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof: "_native.ProfileDesc",

@@ -52,6 +52,7 @@ def hy_reference(attn, hidden, enc, rope, best, single, geo, prm):
 
 
 def test_hunyuan_svg_processor_end_to_end():
+    from svg.models import _core
     from svg.models.hyvideo.inference import replace_hyvideo_attention
 
     torch.manual_seed(0)
@@ -108,10 +109,16 @@ def test_hunyuan_svg_processor_end_to_end():
         for dev_switch, ts in ((False, torch.tensor([t])), (True, torch.tensor([t]).cuda())):
             cls.device_switch = dev_switch
             torch.manual_seed(11)
+            _core._SWITCH_GEN = torch.Generator().manual_seed(11)   # the switched path draws its rows from its own generator
+            state = torch.get_rng_state()
             with torch.no_grad():
                 hh, ee = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
                                         timestep=ts)
             outs.append((hh, ee))
+            if dev_switch:   # ... and leaves the global CPU stream alone, on dense and on sparse steps
+                assert torch.equal(state, torch.get_rng_state())
+                best = blocks[1].attn.processor.last_best_mask_idx
+                assert bool((best == -1).all()) == (t > 900.0)
         cls.device_switch = True
         torch.testing.assert_close(outs[0][0].float(), outs[1][0].float(), atol=1e-2, rtol=1e-2)
         torch.testing.assert_close(outs[0][1].float(), outs[1][1].float(), atol=1e-2, rtol=1e-2)
