@@ -18,6 +18,8 @@ cpu_baseline: BASELINE.md §3 — the reference's CPU-capable dense path torch S
           svg/models/hyvideo_orig/modules/attenion.py:488-491) on all host cores, bf16, ONE head at the full sequence length
           (median of 3), or the longest sequence that fits the time bound; plus flex_attention eager on the CPU with the
           reference's mask_mod for the sparse semantics on a reduced geometry — see `sample`.
+denoise_step_hy720p: BASELINE.json configs[3] at N = 1 — a MEASURED denoise step of a synthetic 60-block HunyuanVideo stack
+          (hipBLASLt GEMMs + this repo's glue / prologue / attention kernels), sparse and dense (bench_step.measure); --no-step skips it.
 svg2_wan720p: BASELINE.json configs[2] (SVG2 / SAP layer-call of Wan 2.1 720p) measured in the same process after the
           headline workload (bench_svg2.measure); --no-svg2 skips it.
 N > 1   : heads are independent units; rank r owns heads r::N of the same layer-call (strong scaling), no data-path
@@ -181,6 +183,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-svg2", action="store_true", help="skip the SVG2 (BASELINE.json configs[2]) extras block")
+    ap.add_argument("--no-step", action="store_true", help="skip the measured 60-layer denoise step (bench_step.measure)")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
     ap.add_argument("--heads", default="alt", choices=["alt", "spatial", "temporal"], help="best_mask_idx pattern")
     a = ap.parse_args()
@@ -495,6 +498,17 @@ def main():
             out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1)
         except Exception as e:  # noqa: BLE001
             out["svg2_wan720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+    if world == 1 and not a.no_step and a.workload == "hy720p":
+        # BASELINE.json configs[3] at N = 1: a measured denoise step of the synthetic 60-block HunyuanVideo stack (GEMMs + glue +
+        # attention), sparse and dense; `denoise_steps_per_s` here is measured, unlike attention_only_steps_per_s above
+        torch.cuda.empty_cache()
+        try:
+            import bench_step
+
+            out["denoise_step_hy720p"] = bench_step.measure(steps=1, warmup=1)
+        except Exception as e:  # noqa: BLE001
+            out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        torch.cuda.empty_cache()
     if world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(H, D, S)
     elif rank == 0:

@@ -8,10 +8,10 @@ O=gpurun_out/$tag
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/$O/kt -o $tag -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-dense --no-svg2 > $R/$O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $R/$O/kt -o $tag -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-dense --no-svg2 --no-step > $R/$O/bench_under_rocprof.json 2>/dev/null
 cd $R
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) $O/bench_kernel_trace.txt
-bash tools/gpu_pmc.sh $tag --no-svg2 > $O/pmc.log 2>&1
+bash tools/gpu_pmc.sh $tag --no-svg2 --no-step > $O/pmc.log 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 python tools/pmc_traffic.py gpurun_out/pmc_$tag/summary.txt $tag > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python tools/svg1_models.py > $O/svg1_models.md 2>&1
