@@ -301,6 +301,20 @@ int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const in
                            int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
                            void* workspace, size_t workspace_bytes, const int32_t* skip_flag, void* stream);
 
+/* fp8 (OCP e4m3) QK^T and PV for the same mask family (BASELINE.json configs[4]; the reference has NO fp8 attention —
+ * /root/reference/README.md:117 "[ ] Support FP8 attention" — so there is no interface to cite: this entry point is
+ * svg_band_attention with a workspace).  q, k, v, o are the 16-bit tensors of svg_band_attention (D = 128 only); the call runs
+ * (1) a per-head absolute-maximum pass, (2) a quantise pass that writes q, k (row-major) and V^T (per 64-key tile) as e4m3 in
+ * LOGICAL token order — the head placement of `perm` is applied there — scaled by 448 / amax of the head, and (3) the attention
+ * kernel on v_mfma_scale_f32_32x32x64_f8f6f4 with fp32 softmax; probabilities are e4m3 (x 2^8), the output is written in the
+ * input dtype at the physical rows (inverse placement fused).  Accuracy is a property of fp8, not of this kernel: see
+ * tests/test_gpu_fp8.py for the measured distance to the fp32 oracle and to the 16-bit path.
+ * workspace: svg_band_attention_fp8_workspace_bytes(BH, S, D) bytes of device memory (3 * BH * ceil64(S) * D + a few words). */
+size_t svg_band_attention_fp8_workspace_bytes(int32_t BH, int32_t S, int32_t D);
+int svg_band_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D, int32_t dtype,
+                           float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
  * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is
  * scratch of the library) after its last store of head h, so done_per_head[h] == svg_band_attention_notify_target(S, mask)

@@ -1,0 +1,191 @@
+// fp8 (e4m3) SVG1 band / dense attention: quantise + placement pre-pass, kernel on attn_body_f8, C entry points.
+// BASELINE.json configs[4]; no reference implementation exists (README.md:117), see attn_f8.h.
+#include "attn_f8.h"
+#include "band_policy.h"
+
+namespace svg {
+
+template <typename T>
+using BandF8 = BandPolicy<T, 128, 8, false>;   // 8 waves x 32 rows: 256-row q-tiles (the tiling of the two-phase 16-bit kernel)
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void band_attn_f8_kernel(typename BandF8<T>::Params prm, F8Args fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_f8<T, BandF8<T>>(prm, fa, smem);
+}
+
+// ---- pre-pass 1: per-head absolute maxima of q, k, v (float bits of non-negative values order like unsigned integers) ----
+template <typename T>
+__global__ __launch_bounds__(256) void f8_amax_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                      unsigned* __restrict__ amax, size_t per_head) {
+    const int head = blockIdx.y;
+    const size_t n8 = per_head / 8;
+    float mq = 0.f, mk = 0.f, mv = 0.f;
+    using V8 = typename Elt<T>::v8;
+    const V8* q8 = (const V8*)(q + head * per_head);
+    const V8* k8 = (const V8*)(k + head * per_head);
+    const V8* v8 = (const V8*)(v + head * per_head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const V8 a = q8[i], b = k8[i], c = v8[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mq = fmaxf(mq, fabsf((float)a[j]));
+            mk = fmaxf(mk, fabsf((float)b[j]));
+            mv = fmaxf(mv, fabsf((float)c[j]));
+        }
+    }
+    mq = wave_max(mq), mk = wave_max(mk), mv = wave_max(mv);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(amax + 3 * head + 0, __float_as_uint(mq));
+        atomicMax(amax + 3 * head + 1, __float_as_uint(mk));
+        atomicMax(amax + 3 * head + 2, __float_as_uint(mv));
+    }
+}
+
+// ---- pre-pass 2: quantise to e4m3 with the head's scales, in LOGICAL token order (the head placement of the 16-bit kernels'
+// address arithmetic, ref svg/models/hyvideo/placement.py:34-153, applied here once), V transposed per 64-key tile in the slot
+// order of attn_f8.h.  One workgroup = one 64-row tile of one head.
+constexpr float kF8Max = 448.f;
+
+__device__ __forceinline__ int f8_phys_row(int logical, bool perm, int vid0, int F, int P, int V) {
+    if (perm) {
+        const unsigned i = (unsigned)(logical - vid0);
+        if (i < (unsigned)V) {
+            const unsigned pp = i / (unsigned)F, f = i - pp * (unsigned)F;
+            return vid0 + (int)(f * (unsigned)P + pp);
+        }
+    }
+    return logical;
+}
+
+__device__ __forceinline__ unsigned f8_pack4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void f8_quantize_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                          uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ vt8,
+                                                          const unsigned* __restrict__ amax, float* __restrict__ scales, int S, int S_pad,
+                                                          const int64_t* __restrict__ head_flag, int vid0, int F, int P, int V) {
+    constexpr int D = 128;
+    __shared__ __attribute__((aligned(16))) T vs[kBN][D + 8];   // V tile, rows padded by 16 B (column reads hit different banks)
+    const int head = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const bool perm = head_flag != nullptr && head_flag[head] != 0;
+    const float aq = __uint_as_float(amax[3 * head]), ak = __uint_as_float(amax[3 * head + 1]), av = __uint_as_float(amax[3 * head + 2]);
+    const float sq = aq > 0.f ? kF8Max / aq : 1.f, sk = ak > 0.f ? kF8Max / ak : 1.f, sv = av > 0.f ? kF8Max / av : 1.f;
+    if (tile == 0 && tid == 0) {
+        scales[2 * head] = 1.f / (sq * sk);
+        scales[2 * head + 1] = 1.f / sv;
+    }
+    const size_t hb = (size_t)head * S * D;
+    const size_t ob = (size_t)head * S_pad * D;
+    using V8 = typename Elt<T>::v8;
+    // q, k: 64 rows x 128 columns = 1024 groups of 8 elements per tensor, 4 per thread; v rows go to LDS
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int id = tid + it * 256;
+        const int r = id >> 4, c8 = (id & 15) * 8;
+        const int l = tile * kBN + r;
+        unsigned w0 = 0, w1 = 0, x0 = 0, x1 = 0;
+        V8 vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = (T)0.f;
+        if (l < S) {
+            const size_t src = hb + (size_t)f8_phys_row(l, perm, vid0, F, P, V) * D + c8;
+            const V8 a = *(const V8*)(q + src), b = *(const V8*)(k + src);
+            vv = *(const V8*)(v + src);
+            w0 = f8_pack4((float)a[0] * sq, (float)a[1] * sq, (float)a[2] * sq, (float)a[3] * sq);
+            w1 = f8_pack4((float)a[4] * sq, (float)a[5] * sq, (float)a[6] * sq, (float)a[7] * sq);
+            x0 = f8_pack4((float)b[0] * sk, (float)b[1] * sk, (float)b[2] * sk, (float)b[3] * sk);
+            x1 = f8_pack4((float)b[4] * sk, (float)b[5] * sk, (float)b[6] * sk, (float)b[7] * sk);
+        }
+        const size_t dst = ob + (size_t)l * D + c8;
+        *(u32x2*)(q8 + dst) = u32x2{w0, w1};
+        *(u32x2*)(k8 + dst) = u32x2{x0, x1};
+        *(V8*)(&vs[r][c8]) = vv;
+    }
+    __syncthreads();
+    // V^T: 128 rows (d) x 64 byte positions; thread = (d, 16-byte chunk), 2 per thread.  Position 32 g + 16 b + 4 j + i <-> key
+    // 32 b + 8 j + 4 g + i (attn_f8.h)
+    uint8_t* vt = vt8 + ob + (size_t)tile * (kBN * D);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = tid + it * 256;
+        const int d = id >> 2, ch = id & 3;       // chunk ch holds positions 16 ch .. 16 ch + 15: g = ch >> 1, b = ch & 1
+        const int gg = ch >> 1, b = ch & 1;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key0 = 32 * b + 8 * j + 4 * gg;
+            w[j] = f8_pack4((float)vs[key0][d] * sv, (float)vs[key0 + 1][d] * sv, (float)vs[key0 + 2][d] * sv, (float)vs[key0 + 3][d] * sv);
+        }
+        *(u32x4*)(vt + d * 64 + ch * 16) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+static size_t f8_ws_bytes(int BH, int S) {
+    const size_t S_pad = (size_t)(S + kBN - 1) / kBN * kBN;
+    return 3 * (size_t)BH * S_pad * 128 + (size_t)BH * (3 * sizeof(unsigned) + 2 * sizeof(float)) + 256;
+}
+
+template <typename T>
+static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale, const svg_band_mask_t* mask,
+                  const svg_perm_desc_t* perm, void* ws, const BandOpts& opts, hipStream_t st) {
+    using Pol = BandF8<T>;
+    constexpr int D = 128;
+    const int S_pad = (S + kBN - 1) / kBN * kBN;
+    uint8_t* q8 = (uint8_t*)ws;
+    uint8_t* k8 = q8 + (size_t)BH * S_pad * D;
+    uint8_t* vt8 = k8 + (size_t)BH * S_pad * D;
+    unsigned* amax = (unsigned*)(((uintptr_t)(vt8 + (size_t)BH * S_pad * D) + 63) & ~(uintptr_t)63);
+    float* scales = (float*)(amax + 3 * BH);
+    if (hipMemsetAsync(amax, 0, (size_t)BH * 3 * sizeof(unsigned), st) != hipSuccess) return SVG_ERR_LAUNCH;
+    hipLaunchKernelGGL(f8_amax_kernel<T>, dim3(64, BH), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v, amax, (size_t)S * D);
+    const bool has_perm = perm && perm->head_perm_flag;
+    hipLaunchKernelGGL(f8_quantize_kernel<T>, dim3(S_pad / kBN, BH), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v, q8, k8, vt8,
+                       amax, scales, S, S_pad, has_perm ? perm->head_perm_flag : nullptr, has_perm ? perm->vid0 : 0,
+                       has_perm ? perm->num_frame : 1, has_perm ? perm->frame_size : 1,
+                       has_perm ? perm->num_frame * perm->frame_size : 0);
+    const typename Pol::Params p = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+    F8Args fa{q8, k8, vt8, scales, S_pad};
+    auto kern = band_attn_f8_kernel<T>;
+    static thread_local bool configured = false;   // (a cache of hipFuncSetAttribute, not per-call state)
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_f8_lds_bytes<D>());
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return SVG_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nqt * BH), dim3(512), attn_f8_lds_bytes<D>(), st, p, fa);
+    return launch_status();
+}
+
+}  // namespace svg
+
+using namespace svg;
+
+extern "C" size_t svg_band_attention_fp8_workspace_bytes(int32_t BH, int32_t S, int32_t D) {
+    if (BH <= 0 || S <= 0 || D != 128) return 0;
+    return f8_ws_bytes(BH, S);
+}
+
+extern "C" int svg_band_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                      int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!q || !k || !v || !o || !mask || !workspace || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
+    if (D != 128) return SVG_ERR_UNSUPPORTED;
+    if (mask->real_len < 0 || mask->real_len > S || mask->band < 0 || mask->band > S + 1) return SVG_ERR_BAD_ARG;
+    if (mask->colfull_lo > mask->colfull_hi || mask->rowfull_lo > mask->rowfull_hi) return SVG_ERR_BAD_ARG;
+    if (perm && perm->head_perm_flag) {
+        if (perm->num_frame <= 0 || perm->frame_size <= 0 || perm->vid0 < 0 ||
+            (int64_t)perm->vid0 + (int64_t)perm->num_frame * perm->frame_size > S)
+            return SVG_ERR_BAD_ARG;
+    }
+    if (workspace_bytes < f8_ws_bytes(BH, S)) return SVG_ERR_WORKSPACE;
+    if (dtype == SVG_DTYPE_BF16) return run_f8<__bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), (hipStream_t)stream);
+    if (dtype == SVG_DTYPE_F16) return run_f8<_Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), (hipStream_t)stream);
+    return SVG_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,240 @@
+// fp8 (OCP e4m3) flash-attention body for gfx950: S^T = K Q^T and O^T = V^T P^T on v_mfma_scale_f32_32x32x64_f8f6f4 (64-deep
+// contraction per instruction, twice the bf16 rate: 16 instead of 64 MFMA issues per 256 x 64 tile), fp32 softmax, bf16 / fp16
+// output.  BASELINE.json configs[4] ("fp8 QK^T / PV"); the reference has no fp8 path (README.md:117 "[ ] Support FP8 attention"),
+// so accuracy is stated against the 16-bit path and the fp32 oracle (tests/test_gpu_fp8.py).
+//
+// Inputs come from the quantise pre-pass (attention_f8.hip), which also applies the head placement, so this body sees every head
+// in LOGICAL token order and never gathers:
+//   q8, k8 : [BH, S_pad, D] e4m3, row-major, S_pad = 64-row multiple (rows >= S are zero), x * 448 / amax_head(x)
+//   vt8    : [BH, S_pad / 64, D, 64] e4m3 — V^T per 64-key tile; inside a tile the key of byte position 32 g + 16 b + 4 j + i of a
+//            row is 32 b + 8 j + 4 g + i, which is exactly the order in which the S^T accumulators of lane half g hold their
+//            probabilities (see below): the P operand needs no data movement at all.
+//   scales : [BH, 2] float: 1 / (sq * sk) (folded into the softmax scale) and 1 / sv (folded into the final 1 / l)
+//
+// Operand layouts.  For the 32x32x64 f8f6f4 MFMA a lane supplies row / column (lane & 31) and 32 of the 64 contraction slots
+// (lane >> 5 selects which half) as 32 bytes; which d (or key) sits in which slot is irrelevant as long as A and B agree:
+//   S^T[key][q]: A = K row (32 b + ql) bytes [64 ks + 32 g, +32), B = Q row bytes [64 ks + 32 g, +32)          (ks = 0, 1: D = 128)
+//   O^T[d][q]  : A = vt8 row (32 db + ql) bytes [32 g, +32), B = the lane's 32 probabilities in the order above
+// The f32x16 result holds column (lane & 31) and rows (r & 3) + 8 (r >> 2) + 4 g like every 32x32 MFMA, so the epilogue is the
+// 16-bit kernels'.  Probabilities are scaled by 2^8 before the conversion (e4m3 tops out at 448; the scale cancels in O / l): a
+// probability of 2^-14 relative to the row maximum is still a normal number.
+//
+// Schedule: 8 waves x 32 rows (256-row q-tiles), two waves per SIMD, lock-step over 64-key tiles with two register-staged LDS
+// stages and one barrier per tile (the structure of attn_body, attn_core.h).  With a quarter of the MFMA issues the matrix pipe is
+// no longer what a tile waits for; the softmax VALU and the LDS operand reads are.
+#pragma once
+#include "attn_core.h"
+
+namespace svg {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct F8Args {
+    const uint8_t* q8;
+    const uint8_t* k8;
+    const uint8_t* vt8;
+    const float* scales;   // [BH, 2]
+    int S_pad;             // rows of q8 / k8 per head (multiple of 64)
+};
+
+constexpr int kF8Scale127 = 0x7f7f7f7f;   // E8M0 block scales of the scaled MFMA: 2^0 for every block
+
+__device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, kF8Scale127, 0, kF8Scale127);
+}
+
+template <int D>
+constexpr int attn_f8_lds_bytes() {
+    constexpr int stages = 2 * (2 * kBN * D);            // two stages of [K image | V^T image], one byte per element
+    constexpr int epi = 8 * 32 * (D * 2 + 8);            // epilogue staging of 256 output rows (16-bit)
+    return stages > epi ? stages : epi;
+}
+
+// byte offset of 16-B chunk c of key row `row` inside the K image ([64][128] bytes): the XOR makes the b128 reads of 16
+// consecutive rows hit 16 different 16-byte bank groups
+__device__ __forceinline__ int f8_k_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// byte offset of 16-B chunk c of row d inside the V^T image ([128][64] bytes)
+__device__ __forceinline__ int f8_v_off(int d, int c) { return d * 64 + ((c ^ ((d >> 2) & 3)) << 4); }
+
+template <typename T, typename P>
+__device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, const F8Args& fa, char* smem) {
+    using E = Elt<T>;
+    constexpr int D = 128, DB = D / 32, KS = D / 64, NT = 512;
+    constexpr int kKBytes = kBN * D, kStage = 2 * kBN * D;
+    static_assert(P::kRowBlocks == 1 && P::BM == 256, "fp8 body: 8 waves x 32 rows");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, nullptr)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), g = lane >> 5, ql = lane & 31;
+    const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.head * fa.S_pad * D;
+    const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.head * fa.S_pad * D;
+    const uint8_t* __restrict__ vt8 = fa.vt8 + (size_t)ctx.head * fa.S_pad * D;   // (S_pad / 64) tiles of 64 * D bytes
+    const float inv_qk = fa.scales[2 * ctx.head], inv_v = fa.scales[2 * ctx.head + 1];
+
+    // ---- Q fragments (B operand of S^T): rows are in logical order in q8; a row that does not exist reads row 0 (never stored) ----
+    const int row_in_wg = wave * 32 + ql;
+    const int q_log = P::q_logical(ctx, row_in_wg);
+    const bool q_exists = P::q_phys(prm, ctx, row_in_wg) >= 0;
+    i32x8 qf[KS];
+    {
+        const uint8_t* qrow = q8 + (size_t)(q_exists ? q_log : 0) * D + g * 32;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x8*)(qrow + ks * 64);
+    }
+
+    // ---- staging: one 16-B chunk of the K tile and one of the V^T tile per thread ----
+    const int kr = tid >> 3, kc = tid & 7;          // K: row, chunk
+    const int vd = tid >> 2, vc = tid & 3;          // V^T: row (= d), chunk
+    const int k_dst = f8_k_off(kr, kc), v_dst = kKBytes + f8_v_off(vd, vc);
+    u32x4 kreg, vreg;
+    auto issue = [&](int k0) {   // k0: first key of the tile (a multiple of 64; rows behind S are zero in the padded images)
+        kreg = *(const u32x4*)(k8 + (size_t)(k0 + kr) * D + kc * 16);
+        vreg = *(const u32x4*)(vt8 + (size_t)(k0 >> 6) * (kBN * D) + tid * 16);
+    };
+    auto stage_write = [&](int buf) {
+        char* base = smem + buf * kStage;
+        *(u32x4*)(base + k_dst) = kreg;
+        *(u32x4*)(base + v_dst) = vreg;
+    };
+
+    // per-lane operand offsets: K fragment (block b, step ks) = chunks 4 ks + 2 g, +1 of row 32 b + ql (32 % 16 == 0: same swizzle
+    // for both blocks); V^T fragment (d block db) = chunks 2 g, 2 g + 1 of row 32 db + ql
+    const int ksw = (ql >> 1) & 7;
+    const int vsw = (ql >> 2) & 3;                  // (32 db + ql) >> 2 & 3 == ql >> 2 & 3
+    const int k_lane = ql * 128, v_lane = kKBytes + ql * 64;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+
+    const float c_log2 = prm.scale_log2 * inv_qk;
+    const int nT = ctx.nT;
+    if (nT > 0) issue(P::tile_key0(ctx, 0));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q has landed before the loop (see attn_body)
+    if (nT > 0) {
+        stage_write(0);
+        if (nT > 1) issue(P::tile_key0(ctx, 1));
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (int t = 0; t < nT; ++t) {
+        const char* kbuf = smem + buf * kStage;
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if (cls != TILE_SKIP) {
+            // ---------------- S^T = K Q^T: 4 MFMAs ----------------
+            f32x16 s[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const char* rowp = kbuf + k_lane + b * (32 * 128);
+                    const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
+                    const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
+                    const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                    s[b] = mfma_f8(kf, qf[ks], s[b]);
+                }
+            // ---------------- mask + online softmax (a lane owns one query row) ----------------
+            if (cls == TILE_PARTIAL) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
+                    }
+            }
+            float mx = s[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx * c_log2);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            m_run = m_new;
+            const float m_off = m_use - 8.f;       // probabilities scaled by 2^8 (cancels in O / l)
+            float psum = 0.f;
+            i32x8 pf;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float p[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][4 * j + i], c_log2, -m_off));
+                        psum += p[i];
+                    }
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
+                    pf[4 * b + j] = w;
+                }
+            l_run = l_run * alpha + psum;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+            }
+            // ---------------- O^T += V^T P^T: 4 MFMAs ----------------
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const char* rowp = kbuf + v_lane + db * (32 * 64);
+                const u32x4 lo = *(const u32x4*)(rowp + (((2 * g) ^ vsw) << 4));
+                const u32x4 hi = *(const u32x4*)(rowp + (((2 * g + 1) ^ vsw) << 4));
+                const i32x8 vf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                acc_o[db] = mfma_f8(vf, pf, acc_o[db]);
+            }
+        }
+        if (t + 1 < nT) stage_write(buf ^ 1);
+        if (t + 2 < nT) issue(P::tile_key0(ctx, t + 2));
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---------------- epilogue: O^T -> LDS -> whole rows (inverse placement through q_phys), as attn_body ----------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    constexpr int kEpiStride = D * 2 + 8;
+    char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+    {
+        const float inv = l_tot > 0.f ? inv_v / l_tot : 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    T* __restrict__ ob = P::o_base(prm, ctx);
+    constexpr int kLanesPerRow = D * 2 / 8, kRowsPerPass = 64 / kLanesPerRow, kPasses = 32 / kRowsPerPass;
+    const int sub = lane / kLanesPerRow, colb = (lane - sub * kLanesPerRow) * 8;
+    int ephys[kPasses];
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) {
+        const int rr = i * kRowsPerPass + sub;
+        const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+    }
+    P::notify(prm, ctx);
+}
+
+}  // namespace svg

@@ -107,6 +107,8 @@ SIGNATURES = {
     "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _VP]),
+    "svg_band_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "svg_band_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _VP]),
     "svg_wait_counters": (C.c_int, [_VP, _I32, _I32, _VP]),
     "svg_wait_counters_deadline": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "svg_band_attention_notify_layout": (_I32, [_I32, C.POINTER(BandMask), _I32, _VP, _VP]),
@@ -280,6 +282,45 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
     rc = lib.svg_band_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
                                 C.byref(mask), C.byref(perm) if perm is not None else None, variant, _stream())
     _check(rc, "svg_band_attention")
+    return o
+
+
+_F8_WS = {}
+
+
+def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
+                       head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1, frame_size: int = 1,
+                       out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """band_attention with e4m3 QK^T / PV (svg_band_attention_fp8; D = 128).  Same arguments and output as band_attention; the
+    quantise + placement pre-pass runs inside the call.  workspace: uint8 GPU tensor of band_attention_fp8_workspace_bytes(...)
+    bytes, cached per (BH, S, device) when omitted."""
+    lib = load()
+    _dev(q, k, v, head_perm_flag)
+    assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
+    S, D = q.shape[-2], q.shape[-1]
+    BH = q.numel() // (S * D)
+    o = torch.empty_like(q) if out is None else out
+    _dev(o)
+    scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    perm = None
+    if head_perm_flag is not None:
+        flag = head_perm_flag.to(torch.int64).contiguous()
+        assert flag.numel() == BH
+        perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    need = int(lib.svg_band_attention_fp8_workspace_bytes(BH, S, D))
+    if need == 0:
+        raise RuntimeError(f"svg_band_attention_fp8: unsupported shape (D = {D}; only 128)")
+    if workspace is None:
+        key = (BH, S, q.device)
+        workspace = _F8_WS.get(key)
+        if workspace is None or workspace.numel() < need:
+            workspace = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    _dev(workspace)
+    assert workspace.dtype == torch.uint8 and workspace.numel() >= need
+    rc = lib.svg_band_attention_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
+                                    C.byref(mask), C.byref(perm) if perm is not None else None, workspace.data_ptr(),
+                                    workspace.numel(), _stream())
+    _check(rc, "svg_band_attention_fp8")
     return o
 
 
