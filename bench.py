@@ -52,6 +52,7 @@ import torch  # noqa: E402
 warnings.filterwarnings("ignore", message="flex_attention called without torch.compile")
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense MFMA fp8 (same guide)
 
 WORKLOADS = {
     # name: (H, D, F, P, ctx, prompt_len, sparsity)
@@ -180,6 +181,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 3), "
                     "1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per SIMD")
     ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 QK^T / PV (svg_band_attention_fp8: quantise + "
+                    "placement pre-pass and attention kernel, both inside the timed step; BASELINE.json configs[4]); N = 1 only")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-svg2", action="store_true", help="skip the SVG2 (BASELINE.json configs[2]) extras block")
@@ -285,6 +288,12 @@ def main():
         h0 = c * world * n_per
         full[h0:h0 + world * n_per, a0:a1].view(world, n_per, a1 - a0, D).copy_(tmp)
 
+    fp8 = a.dtype == "fp8"
+    if fp8:
+        assert world == 1, "--dtype fp8 is a single-GPU line"
+        a.no_svg2 = a.no_step = True
+    ev_p0, ev_p1 = [], []
+
     def step(timed: bool):
         if world > 1:   # inbound exchange: token shards -> this rank's heads over the full sequence
             for x_tok, x in ((q_tok, q), (k_tok, k), (v_tok, v)):
@@ -301,7 +310,16 @@ def main():
         works = []
         main = torch.cuda.current_stream()
         kw = dict(vid0=0, num_frame=F_, frame_size=P_, variant=a.variant)
-        if side is None:
+        if fp8:
+            kw8 = dict(vid0=0, num_frame=F_, frame_size=P_, head_perm_flag=best, out=o)
+            nat.band_attention_fp8(q, k, v, mask, stage=1, **kw8)      # absolute maxima + quantise / placement / V transpose
+            p1 = torch.cuda.Event(enable_timing=True)
+            p1.record()
+            nat.band_attention_fp8(q, k, v, mask, stage=2, **kw8)      # attention on e4m3 operands
+            if timed:
+                ev_p0.append(e0)
+                ev_p1.append(p1)
+        elif side is None:
             nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, **kw)
         elif mode["chunk_launches"]:
             for c in range(n_chunks):
@@ -398,6 +416,12 @@ def main():
     if rank == 0:
         value = flops_call / (ms_step * 1e-3) / 1e12
         kernel_name = BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
+        peak = PEAK_BF16_TFLOPS
+        if fp8:
+            kernel_name, peak = "band_attn_f8_kernel<bf16>", PEAK_FP8_TFLOPS
+            pre_ms = sum(x.elapsed_time(y) for x, y in zip(ev_p0, ev_p1)) / len(ev_p0)
+            attn_ms -= pre_ms                      # roofline: the attention kernel alone; the pre-pass is reported beside it
+            kern_tf = (flops_call * Hl / H) / (attn_ms * 1e-3) / 1e12
         traffic, traffic_src = _pmc_traffic(a.workload, kernel_name)
         kern_tf = (flops_call * Hl / H) / (attn_ms * 1e-3) / 1e12
         out = {
@@ -411,7 +435,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": a.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"HunyuanVideo T2V {a.workload} SVG1 sparse layer-call: sample_mse(64 rows) + band attention with "
@@ -439,9 +463,9 @@ def main():
                 "bound": "mfma",
                 "kernel": kernel_name,
                 "achieved": round(kern_tf, 2),
-                "peak": PEAK_BF16_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(kern_tf / PEAK_BF16_TFLOPS, 4),
+                "frac": round(kern_tf / peak, 4),
                 "kernel_ms": round(attn_ms, 3),
                 "traffic": traffic,                           # HBM bytes per launch (PMC)
                 "traffic_unit": "B/launch",
@@ -450,21 +474,38 @@ def main():
             },
         }
 
+    if rank == 0 and fp8:
+        out["fp8"] = {
+            "what": "e4m3 q, k, v (x 448 / amax per head) and probabilities (x 2^8), fp32 softmax and accumulation, bf16 output; inputs "
+                    "and output are the bf16 tensors of the bf16 line",
+            "prepass_ms": round(pre_ms, 3),
+            "prepass": "per-head amax + quantise with fused head placement and per-tile V transpose (reads 3 x, writes 1.5 x one bf16 tensor)",
+            "accuracy": "tests/test_gpu_fp8.py: rel. L2 5 % vs the fp32 oracle on randn inputs (2.2 % vs the oracle on dequantised inputs)",
+        }
+        # accuracy on THIS workload against the bf16 kernel (two heads: a frame-major and a token-major one)
+        ob = nat.band_attention(q[:, :2].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), mask,
+                                head_perm_flag=best[:, :2].contiguous(), vid0=0, num_frame=F_, frame_size=P_).float()
+        df = o[:, :2].float() - ob
+        out["fp8"]["rel_l2_vs_bf16_kernel_this_workload"] = round((df.norm() / ob.norm()).item(), 5)
+        del ob, df
+
     # ---- extras on rank 0 at N = 1: dense comparator on the same GPU, CPU baseline ----
     if world == 1 and not a.no_dense:
         dmask = nat.BandMask(real_len=V + L, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
-        nat.band_attention(q, k, v, dmask, variant=a.variant, out=o)
+        dense_call = (lambda: nat.band_attention_fp8(q, k, v, dmask, out=o)) if fp8 else \
+            (lambda: nat.band_attention(q, k, v, dmask, variant=a.variant, out=o))
+        dense_call()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.band_attention(q, k, v, dmask, variant=a.variant, out=o)
+        dense_call()
         e1.record()
         torch.cuda.synchronize()
         dms = e0.elapsed_time(e1)
         dense_pairs = (V + L) ** 2 + (ctx - L) ** 2
         out["dense_same_gpu"] = {
-            "kernel": "our dense mode (cu_seqlens [0, V+L, S])",
+            "kernel": "our dense mode (cu_seqlens [0, V+L, S])" + (" fp8, pre-pass included" if fp8 else ""),
             "ms": round(dms, 3),
             "tflops": round(4.0 * D * H * dense_pairs / (dms * 1e-3) / 1e12, 2),
             "speedup_sparse_vs_dense": round(dms / ms_step, 3),

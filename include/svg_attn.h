@@ -314,6 +314,12 @@ size_t svg_band_attention_fp8_workspace_bytes(int32_t BH, int32_t S, int32_t D);
 int svg_band_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D, int32_t dtype,
                            float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The two halves of svg_band_attention_fp8 on their own (same arguments): stage 1 = passes (1) + (2) into the workspace, stage 2 =
+ * the attention kernel on a workspace that stage 1 has filled for the same BH, S and perm — for callers that time or overlap the
+ * pre-pass separately. */
+int svg_band_attention_fp8_stage(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D, int32_t dtype,
+                                 float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* workspace,
+                                 size_t workspace_bytes, int32_t stage, void* stream);
 
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
  * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is

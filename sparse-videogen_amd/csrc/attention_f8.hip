@@ -129,9 +129,10 @@ static size_t f8_ws_bytes(int BH, int S) {
     return 3 * (size_t)BH * S_pad * 128 + (size_t)BH * (3 * sizeof(unsigned) + 2 * sizeof(float)) + 256;
 }
 
+// what = 1: pre-pass only, 2: attention on a workspace the pre-pass has filled (same BH, S, perm), 3: both
 template <typename T>
 static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale, const svg_band_mask_t* mask,
-                  const svg_perm_desc_t* perm, void* ws, const BandOpts& opts, hipStream_t st) {
+                  const svg_perm_desc_t* perm, void* ws, const BandOpts& opts, int what, hipStream_t st) {
     using Pol = BandF8<T>;
     constexpr int D = 128;
     const int S_pad = (S + kBN - 1) / kBN * kBN;
@@ -140,6 +141,7 @@ static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, 
     uint8_t* vt8 = k8 + (size_t)BH * S_pad * D;
     unsigned* amax = (unsigned*)(((uintptr_t)(vt8 + (size_t)BH * S_pad * D) + 63) & ~(uintptr_t)63);
     float* scales = (float*)(amax + 3 * BH);
+    if (what & 1) {
     if (hipMemsetAsync(amax, 0, (size_t)BH * 3 * sizeof(unsigned), st) != hipSuccess) return SVG_ERR_LAUNCH;
     hipLaunchKernelGGL(f8_amax_kernel<T>, dim3(64, BH), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v, amax, (size_t)S * D);
     const bool has_perm = perm && perm->head_perm_flag;
@@ -147,6 +149,8 @@ static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, 
                        amax, scales, S, S_pad, has_perm ? perm->head_perm_flag : nullptr, has_perm ? perm->vid0 : 0,
                        has_perm ? perm->num_frame : 1, has_perm ? perm->frame_size : 1,
                        has_perm ? perm->num_frame * perm->frame_size : 0);
+    }
+    if (!(what & 2)) return launch_status();
     const typename Pol::Params p = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
     F8Args fa{q8, k8, vt8, scales, S_pad};
     auto kern = band_attn_f8_kernel<T>;
@@ -172,9 +176,9 @@ extern "C" size_t svg_band_attention_fp8_workspace_bytes(int32_t BH, int32_t S, 
     return f8_ws_bytes(BH, S);
 }
 
-extern "C" int svg_band_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
-                                      int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+static int f8_entry(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D, int32_t dtype, float sm_scale,
+                    const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* workspace, size_t workspace_bytes, int what,
+                    void* stream) {
     if (!q || !k || !v || !o || !mask || !workspace || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
     if (D != 128) return SVG_ERR_UNSUPPORTED;
     if (mask->real_len < 0 || mask->real_len > S || mask->band < 0 || mask->band > S + 1) return SVG_ERR_BAD_ARG;
@@ -185,7 +189,20 @@ extern "C" int svg_band_attention_fp8(const void* q, const void* k, const void* 
             return SVG_ERR_BAD_ARG;
     }
     if (workspace_bytes < f8_ws_bytes(BH, S)) return SVG_ERR_WORKSPACE;
-    if (dtype == SVG_DTYPE_BF16) return run_f8<__bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), (hipStream_t)stream);
-    if (dtype == SVG_DTYPE_F16) return run_f8<_Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), (hipStream_t)stream);
+    if (dtype == SVG_DTYPE_BF16) return run_f8<__bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), what, (hipStream_t)stream);
+    if (dtype == SVG_DTYPE_F16) return run_f8<_Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, workspace, BandOpts(), what, (hipStream_t)stream);
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_band_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                      int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    return f8_entry(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, workspace, workspace_bytes, 3, stream);
+}
+
+extern "C" int svg_band_attention_fp8_stage(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                            int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                            void* workspace, size_t workspace_bytes, int32_t stage, void* stream) {
+    if (stage != 1 && stage != 2) return SVG_ERR_BAD_ARG;
+    return f8_entry(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, workspace, workspace_bytes, stage, stream);
 }

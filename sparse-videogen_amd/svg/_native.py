@@ -109,6 +109,7 @@ SIGNATURES = {
                                             C.POINTER(PermDesc), _VP, _VP]),
     "svg_band_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
     "svg_band_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _VP]),
+    "svg_band_attention_fp8_stage": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _I32, _VP]),
     "svg_wait_counters": (C.c_int, [_VP, _I32, _I32, _VP]),
     "svg_wait_counters_deadline": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "svg_band_attention_notify_layout": (_I32, [_I32, C.POINTER(BandMask), _I32, _VP, _VP]),
@@ -290,10 +291,11 @@ _F8_WS = {}
 
 def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
                        head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1, frame_size: int = 1,
-                       out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, stage: int = 0) -> torch.Tensor:
     """band_attention with e4m3 QK^T / PV (svg_band_attention_fp8; D = 128).  Same arguments and output as band_attention; the
     quantise + placement pre-pass runs inside the call.  workspace: uint8 GPU tensor of band_attention_fp8_workspace_bytes(...)
-    bytes, cached per (BH, S, device) when omitted."""
+    bytes, cached per (BH, S, device) when omitted.  stage 1 / 2: only the pre-pass / only the attention kernel on the workspace
+    a stage-1 call has filled (svg_band_attention_fp8_stage)."""
     lib = load()
     _dev(q, k, v, head_perm_flag)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
@@ -317,10 +319,12 @@ def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: 
             workspace = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
     _dev(workspace)
     assert workspace.dtype == torch.uint8 and workspace.numel() >= need
-    rc = lib.svg_band_attention_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
-                                    C.byref(mask), C.byref(perm) if perm is not None else None, workspace.data_ptr(),
-                                    workspace.numel(), _stream())
-    _check(rc, "svg_band_attention_fp8")
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale, C.byref(mask),
+            C.byref(perm) if perm is not None else None, workspace.data_ptr(), workspace.numel())
+    if stage:
+        _check(lib.svg_band_attention_fp8_stage(*args, int(stage), _stream()), "svg_band_attention_fp8_stage")
+    else:
+        _check(lib.svg_band_attention_fp8(*args, _stream()), "svg_band_attention_fp8")
     return o
 
 
