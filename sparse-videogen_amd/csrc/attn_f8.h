@@ -20,7 +20,7 @@
 // probability of 2^-14 relative to the row maximum is still a normal number.
 //
 // Schedule: 8 waves x 32 rows (256-row q-tiles), two waves per SIMD, lock-step over 64-key tiles with two register-staged LDS
-// stages and one barrier per tile (the structure of attn_body, attn_core.h).  With a quarter of the MFMA issues the matrix pipe is
+// stages and one barrier per tile.  With a quarter of the MFMA issues the matrix pipe is
 // no longer what a tile waits for; the softmax VALU and the LDS operand reads are.
 #pragma once
 #include "attn_core.h"
@@ -112,81 +112,110 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
 
     const float c_log2 = prm.scale_log2 * inv_qk;
     const int nT = ctx.nT;
-    if (nT > 0) issue(P::tile_key0(ctx, 0));
+
+    // S^T of one tile: 4 MFMAs (2 key blocks x 2 contraction steps of 64)
+    auto qk = [&](const char* kbuf, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const char* rowp = kbuf + k_lane + b * (32 * 128);
+                const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
+                const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
+                const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                s[b] = mfma_f8(kf, qf[ks], s[b]);
+            }
+    };
+
+    // Two LDS stages, register-staged: iteration t computes tile t from stage t & 1, then writes tile t + 1 (registers loaded
+    // during t - 1) into the other stage and requests tile t + 2; one barrier per tile.
+    typename P::TileCur tc;          // walks two tiles ahead of the tile being processed
+    P::tile_cur_init(ctx, tc);
+    int f0 = tc.k0;                  // first key of tile t, t + 1 (f1 is what `issue` reads next)
+    P::tile_cur_next(ctx, tc);
+    int f1 = tc.k0;
+    P::tile_cur_next(ctx, tc);
+    if (nT > 0) {
+        issue(f0);
+        stage_write(0);
+        if (nT > 1) issue(f1);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // Q has landed before the loop (see attn_body)
-    if (nT > 0) {
-        stage_write(0);
-        if (nT > 1) issue(P::tile_key0(ctx, 1));
-    }
     __syncthreads();
 
+    // Softmax without a running maximum (the scheme of attn_body_w4): probabilities are taken relative to a per-row reference
+    // m_ref that only changes on the exact path, p = 2^(s c - m_ref + 4); as long as a lane's 32 probabilities of a tile sum to
+    // <= 448 every one of them fits e4m3 and nothing else has to be checked.  A violation (normally also the first tile, whose
+    // reference is the pseudo-reference 0) sends the WAVE through the exact path: row maximum, new reference, O and l rescaled, probabilities
+    // recomputed.  On random data that is the first tile of a q-tile and a handful of later ones.
+    constexpr float kPShift = 4.f, kPSumMax = 448.f;
+    float m_ref = -INFINITY, m_off = -kPShift;    // m_off = (m_ref finite ? m_ref : 0) - kPShift
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
-        const int tk0 = P::tile_key0(ctx, t);
-        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        const int tk0 = f0;
+        f0 = f1, f1 = tc.k0;
+        P::tile_cur_next(ctx, tc);
+        const int cls = P::fast_full(ctx, tk0) ? (int)TILE_FULL : P::classify(prm, ctx, tk0, wave * 32);
         if (cls != TILE_SKIP) {
-            // ---------------- S^T = K Q^T: 4 MFMAs ----------------
-            f32x16 s[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const char* rowp = kbuf + k_lane + b * (32 * 128);
-                    const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
-                    const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
-                    const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                    s[b] = mfma_f8(kf, qf[ks], s[b]);
-                }
-            // ---------------- mask + online softmax (a lane owns one query row) ----------------
+            f32x16 s_cur[2];
+            qk(kbuf, s_cur);
             if (cls == TILE_PARTIAL) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        s[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s[b][r] : -INFINITY;
+                        s_cur[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s_cur[b][r] : -INFINITY;
                     }
             }
-            float mx = s[0][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx * c_log2);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            m_run = m_new;
-            const float m_off = m_use - 8.f;       // probabilities scaled by 2^8 (cancels in O / l)
-            float psum = 0.f;
+            // probabilities of this lane's 32 keys at reference offset `off`: packed e4m3 operand + their fp32 sum
             i32x8 pf;
+            float psum;
+            auto probs = [&](float off) {
+                psum = 0.f;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float p[4];
+                for (int w8 = 0; w8 < 8; ++w8) {
+                    float p4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][4 * j + i], c_log2, -m_off));
-                        psum += p[i];
+                        const int e = 4 * w8 + i;
+                        p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e >> 4][e & 15], c_log2, -off));
+                        psum += p4[i];
                     }
-                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
-                    w = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
-                    pf[4 * b + j] = w;
+                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+                    pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
                 }
-            l_run = l_run * alpha + psum;
-            if (__any(alpha != 1.f)) {
+            };
+            probs(m_off);
+            if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+                float mx = s_cur[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                // (until a row has seen a finite score its reference is the pseudo-reference 0 that m_off starts with: whatever was
+                //  accumulated under it is rescaled like under any other reference; the clamp keeps alpha finite when nothing was)
+                const float m_prev = m_off + kPShift;
+                const float m_new = fmaxf(m_ref, mx * c_log2);
+                const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+                m_ref = m_new;
+                m_off = m_use - kPShift;
+                probs(m_off);
+                l_run *= alpha;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
             }
+            l_run += psum;
             // ---------------- O^T += V^T P^T: 4 MFMAs ----------------
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -198,7 +227,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
             }
         }
         if (t + 1 < nT) stage_write(buf ^ 1);
-        if (t + 2 < nT) issue(P::tile_key0(ctx, t + 2));
+        if (t + 2 < nT) issue(f1);
         __syncthreads();
         buf ^= 1;
     }
