@@ -321,6 +321,17 @@ int svg_band_attention_fp8_stage(const void* q, const void* k, const void* v, vo
                                  float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* workspace,
                                  size_t workspace_bytes, int32_t stage, void* stream);
 
+/* svg_varblock_attention with e4m3 QK^T / PV — BASELINE.json configs[4] as named (SVG2 with fp8 on the CDNA4 fp8 MFMA; no
+ * reference implementation, see svg_band_attention_fp8).  Same arguments as svg_varblock_attention (D = 128; the default schedule:
+ * 256-row q tiles in longest-first order); q, k, v are quantised per head (x 448 / amax) in their original row order inside the call
+ * and the kernel gathers rows through the block map's run list and q_row_idx / kv_row_idx exactly like the 16-bit kernel; V^T
+ * fragments come from ds_read_b64_tr_b8.  workspace: svg_varblock_attention_fp8_workspace_bytes(...) bytes. */
+size_t svg_varblock_attention_fp8_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv, int32_t D);
+int svg_varblock_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq, int32_t Skv,
+                               int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map, const int32_t* q_sizes,
+                               const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
  * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is
  * scratch of the library) after its last store of head h, so done_per_head[h] == svg_band_attention_notify_target(S, mask)

@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "attn_core.h"
+#include "attn_f8.h"
 #include "band_policy.h"
 
 namespace svg {
@@ -229,6 +230,13 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_pp2_trace_kernel(typenam
     attn_body_pp2<T, D, VarblockPolicy<T, D, 8>, true>(prm, smem, smem + attn_pp2_lds_bytes<D>());
 }
 #endif
+
+// fp8 (e4m3) form: gathering fp8 body of attn_f8.h, 256-row q tiles, two waves per SIMD
+template <typename T>
+__global__ __launch_bounds__(512, 2) void varblock_attn_f8_kernel(typename VarblockPolicy<T, 128, 8>::Params prm, F8GArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_f8g<T, VarblockPolicy<T, 128, 8>>(prm, fa, smem, smem + attn_f8_lds_bytes<128>());
+}
 
 static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
 
@@ -592,13 +600,13 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
     int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
     hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
-                       KB, (NW < 0 ? -NW : NW) * 32);
+                       KB, (NW < 0 ? 8 : NW) * 32);
     auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
         constexpr int W = decltype(nw_c)::value;
         using Pol = VarblockPolicy<T, D, W>;
@@ -612,7 +620,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
         p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
         p.order = nullptr;
-        if constexpr (NW == -8) {
+        if constexpr (NW == -8 || NW == -9) {
             const int group = Hq / Hkv;
             if (!block_row_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
                 int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);
@@ -626,6 +634,24 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, toff, work, hist, order, Hkv,
                                    QB, group);
                 p.order = order;
+                if constexpr (NW == -9) {
+                    if constexpr (D == 128) {
+                        auto kern = varblock_attn_f8_kernel<T>;
+                        const int lds = attn_f8_lds_bytes<128>() + vb_policy_lds(p.kb_cap);
+                        static thread_local int configured = 0;   // (a cache of hipFuncSetAttribute, not per-call state)
+                        if (configured < lds) {
+                            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                            if (e != hipSuccess) {
+                                g_last_hip_error = (int)e;
+                                return SVG_ERR_LAUNCH;
+                            }
+                            configured = lds;
+                        }
+                        hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(512), lds, st, p, *f8);
+                        return launch_status();
+                    }
+                    return SVG_ERR_UNSUPPORTED;
+                }
 #ifdef SVG_ABLATIONS
                 if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
                     if (trace)
@@ -637,6 +663,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
                                    attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
             }
+            if constexpr (NW == -9) return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
             return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
                                attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
         } else
@@ -648,7 +675,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
         if (rc != SVG_OK) return rc;
         return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
-    } else if constexpr (NW == -8) {   // two-phase ping-pong body, 256-row q tiles
+    } else if constexpr (NW == -8 || NW == -9) {   // two-phase ping-pong body / fp8 body, 256-row q tiles
         return launch(std::integral_constant<int, 8>{}, 0, tile_off, Sq / 256 + QB);
     } else {
         return launch(std::integral_constant<int, NW>{}, 0, tile_off, Sq / (NW * 32) + QB);
@@ -692,5 +719,37 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     }
 #undef SVG_VB_ARGS
 #undef SVG_VB_DISPATCH
+    return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t svg_varblock_attention_fp8_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv,
+                                                             int32_t D) {
+    if (D != 128) return 0;
+    const size_t plan = svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq);
+    if (plan == 0 || Skv <= 0) return 0;
+    return ((plan + 255) & ~(size_t)255) + f8g_ws_bytes(Hq, Hkv, Sq, Skv);
+}
+
+extern "C" int svg_varblock_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
+                                          int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
+                                          const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
+                                          const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
+    if (D != 128 || KB > kVbMaxKB || QB >= 32768 || Sq / 256 + 1 >= 65536) return SVG_ERR_UNSUPPORTED;
+    if ((int64_t)Skv * D >= (1ll << 31) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_varblock_attention_fp8_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plan = (svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq) + 255) & ~(size_t)255;
+    F8GArgs fa;
+    int rc = f8g_quantize(q, k, v, Hq, Hkv, Sq, Skv, dtype, (char*)workspace + plan, &fa, st);
+    if (rc != SVG_OK) return rc;
+    if (dtype == SVG_DTYPE_BF16)
+        return run_varblock<__bf16, 128, -9>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
+                                            kv_row_idx, workspace, false, false, st, &fa);
+    if (dtype == SVG_DTYPE_F16)
+        return run_varblock<_Float16, 128, -9>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
+                                              kv_row_idx, workspace, false, false, st, &fa);
     return SVG_ERR_UNSUPPORTED;
 }

@@ -124,6 +124,75 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const T* __restrict__ 
     }
 }
 
+// ---- plain quantiser of the gathering body (SVG2): one tensor [H, S, D] -> e4m3 row-major with the head's scale; inv[head * stride]
+// receives amax / 448 ----
+template <typename T>
+__global__ __launch_bounds__(256) void f8_amax1_kernel(const T* __restrict__ x, unsigned* __restrict__ amax, size_t per_head) {
+    const int head = blockIdx.y;
+    using V8 = typename Elt<T>::v8;
+    const V8* x8 = (const V8*)(x + head * per_head);
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_head / 8; i += (size_t)gridDim.x * 256) {
+        const V8 a = x8[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf((float)a[j]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax + head, __float_as_uint(m));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void f8_quantize1_kernel(const T* __restrict__ x, uint8_t* __restrict__ y, const unsigned* __restrict__ amax,
+                                                           float* __restrict__ inv, int inv_stride, size_t per_head) {
+    const int head = blockIdx.y;
+    const float a = __uint_as_float(amax[head]);
+    const float sc = a > 0.f ? kF8Max / a : 1.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv[(size_t)head * inv_stride] = 1.f / sc;
+    using V8 = typename Elt<T>::v8;
+    const V8* x8 = (const V8*)(x + head * per_head);
+    u32x2* y8 = (u32x2*)(y + head * per_head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_head / 8; i += (size_t)gridDim.x * 256) {
+        const V8 v = x8[i];
+        y8[i] = u32x2{f8_pack4((float)v[0] * sc, (float)v[1] * sc, (float)v[2] * sc, (float)v[3] * sc),
+                      f8_pack4((float)v[4] * sc, (float)v[5] * sc, (float)v[6] * sc, (float)v[7] * sc)};
+    }
+}
+
+size_t f8g_ws_bytes(int Hq, int Hkv, int Sq, int Skv) {
+    return (size_t)Hq * Sq * 128 + 2 * (size_t)Hkv * Skv * 128 + (size_t)(Hq + 2 * Hkv) * (sizeof(unsigned) + sizeof(float)) + 512;
+}
+
+// quantise q [Hq, Sq, 128], k, v [Hkv, Skv, 128] into `ws` and fill `fa` (declared in band_policy.h; the kernel that consumes it
+// lives in attention.hip next to the variable-block policy)
+template <typename T>
+static int f8g_quantize_t(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, void* ws, F8GArgs* fa,
+                          hipStream_t st) {
+    constexpr int D = 128;
+    uint8_t* q8 = (uint8_t*)ws;
+    uint8_t* k8 = q8 + (size_t)Hq * Sq * D;
+    uint8_t* v8 = k8 + (size_t)Hkv * Skv * D;
+    unsigned* amax = (unsigned*)(((uintptr_t)(v8 + (size_t)Hkv * Skv * D) + 63) & ~(uintptr_t)63);   // [Hq] q, [Hkv] k, [Hkv] v
+    float* q_inv = (float*)(amax + Hq + 2 * Hkv);
+    float* kv_inv = q_inv + Hq;
+    if (hipMemsetAsync(amax, 0, (size_t)(Hq + 2 * Hkv) * sizeof(unsigned), st) != hipSuccess) return SVG_ERR_LAUNCH;
+    const size_t phq = (size_t)Sq * D, phk = (size_t)Skv * D;
+    hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hq), dim3(256), 0, st, (const T*)q, amax, phq);
+    hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hkv), dim3(256), 0, st, (const T*)k, amax + Hq, phk);
+    hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hkv), dim3(256), 0, st, (const T*)v, amax + Hq + Hkv, phk);
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hq), dim3(256), 0, st, (const T*)q, q8, amax, q_inv, 1, phq);
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)k, k8, amax + Hq, kv_inv, 2, phk);
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)v, v8, amax + Hq + Hkv, kv_inv + 1, 2, phk);
+    fa->q8 = q8, fa->k8 = k8, fa->v8 = v8, fa->q_inv = q_inv, fa->kv_inv = kv_inv;
+    return launch_status();
+}
+
+int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, void* ws, F8GArgs* fa,
+                 hipStream_t st) {
+    if (dtype == SVG_DTYPE_BF16) return f8g_quantize_t<__bf16>(q, k, v, Hq, Hkv, Sq, Skv, ws, fa, st);
+    if (dtype == SVG_DTYPE_F16) return f8g_quantize_t<_Float16>(q, k, v, Hq, Hkv, Sq, Skv, ws, fa, st);
+    return SVG_ERR_UNSUPPORTED;
+}
+
 static size_t f8_ws_bytes(int BH, int S) {
     const size_t S_pad = (size_t)(S + kBN - 1) / kBN * kBN;
     return 3 * (size_t)BH * S_pad * 128 + (size_t)BH * (3 * sizeof(unsigned) + 2 * sizeof(float)) + 256;

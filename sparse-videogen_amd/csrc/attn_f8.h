@@ -28,6 +28,7 @@
 namespace svg {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int v2i32 __attribute__((ext_vector_type(2)));
 
 struct F8Args {
     const uint8_t* q8;
@@ -166,6 +167,8 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
             f32x16 s_cur[2];
             qk(kbuf, s_cur);
             if (cls == TILE_PARTIAL) {
+                asm volatile("; element-wise mask of a partial tile" ::: "memory");   // (keeps hipcc from if-converting the 32 predicates
+                                                                                      //  into code that every tile executes)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -264,6 +267,224 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
         if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
     }
     P::notify(prm, ctx);
+}
+
+
+// =====================================================================================================================
+// Gathering form of the fp8 body (SVG2 variable-block attention, BASELINE.json configs[4] as named): q, k, v stay in their
+// original row order as plain row-major e4m3 tensors [H, S, D] (per-head scales) and rows are gathered through the policy
+// (q_phys / kv_phys: the run list of the block-row and the sorted-index arrays), exactly like the 16-bit lock-step body.
+// V is therefore row-major in LDS and V^T fragments come from the hardware transpose read ds_read_b64_tr_b8: the 16 lanes of a
+// group pool their 16 x 8 bytes as an [8 rows][16 columns] byte matrix (row r = lanes 2r, 2r+1) and lane i receives column i
+// (tools/probe_tr8.hip).  Lane i of a group points at key row 16 m + 8 (i >> 3) + 4 g + ((i >> 1) & 3), so the 8 bytes a lane
+// gets in read m are its column's values at exactly the keys of its probability slots 8 m .. 8 m + 7.
+// =====================================================================================================================
+struct F8GArgs {
+    const uint8_t* q8;     // [Hq, Sq, D]
+    const uint8_t* k8;     // [Hkv, Skv, D]
+    const uint8_t* v8;     // [Hkv, Skv, D]
+    const float* q_inv;    // [Hq]   amax / 448
+    const float* kv_inv;   // [Hkv, 2]: k, v
+};
+
+// chunk c (16 B) of V row `row` inside the row-major V image ([64][128] bytes): the XOR keeps the transpose reads conflict-free
+__device__ __forceinline__ int f8_vrow_off(int row, int c) { return row * 128 + ((c ^ ((row & 2) | ((row >> 1) & 4))) << 4); }
+
+template <typename T, typename P>
+__device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, const F8GArgs& fa, char* smem, char* policy_lds) {
+    using E = Elt<T>;
+    constexpr int D = 128, DB = D / 32, KS = D / 64;
+    constexpr int kKBytes = kBN * D, kStage = 2 * kBN * D;
+    static_assert(P::kRowBlocks == 1 && P::BM == 256, "fp8 body: 8 waves x 32 rows");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, policy_lds)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), g = lane >> 5, ql = lane & 31;
+    const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.hq * prm.Sq * D;
+    const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.hkv * prm.Skv * D;
+    const uint8_t* __restrict__ v8 = fa.v8 + (size_t)ctx.hkv * prm.Skv * D;
+    const float inv_qk = fa.q_inv[ctx.hq] * fa.kv_inv[2 * ctx.hkv], inv_v = fa.kv_inv[2 * ctx.hkv + 1];
+
+    const int row_in_wg = wave * 32 + ql;
+    i32x8 qf[KS];
+    {
+        const int qp = P::q_phys(prm, ctx, row_in_wg);
+        const uint8_t* qrow = q8 + (size_t)(qp >= 0 ? qp : 0) * D + g * 32;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x8*)(qrow + ks * 64);
+    }
+    const int q_log = P::q_logical(ctx, row_in_wg);
+
+    // staging: thread = (row kr, chunk kc) of the tile, for K and V alike (the same gathered row)
+    const int kr = tid >> 3, kc = tid & 7;
+    const int k_dst = f8_k_off(kr, kc), v_dst = kKBytes + f8_vrow_off(kr, kc);
+    typename P::KvCursor cur;
+    P::kv_cursor_init(prm, ctx, cur, kr);
+    u32x4 kreg, vreg;
+    int nphys = 0;
+    const int nT = ctx.nT;
+    auto resolve = [&](int t) { nphys = (t < nT) ? P::kv_phys(prm, ctx, cur, t, kr) : 0; };   // a global index load: one tile ahead
+    auto issue = [&](int t) {
+        const size_t off = (size_t)nphys * D + kc * 16;
+        kreg = *(const u32x4*)(k8 + off);
+        vreg = *(const u32x4*)(v8 + off);
+        resolve(t + 1);
+    };
+    auto stage_write = [&](int buf) {
+        char* base = smem + buf * kStage;
+        *(u32x4*)(base + k_dst) = kreg;
+        *(u32x4*)(base + v_dst) = vreg;
+    };
+
+    const int ksw = (ql >> 1) & 7;
+    const int k_lane = ql * 128;
+    // transpose-read address of read m, d block db: row 16 m + vrow, byte column 32 db + vcol (+ the row's swizzle)
+    const int li = lane & 15;
+    const int vrow = 8 * (li >> 3) + 4 * g + ((li >> 1) & 3);
+    const int vcol = 16 * ((lane >> 4) & 1) + 8 * (li & 1);
+    const int vsw = (vrow & 2) | ((vrow >> 1) & 4);       // (16 m does not touch the swizzle bits)
+    const int v_lane = kKBytes + vrow * 128 + (vcol & 8);
+
+    float l_run = 0.f;
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    const float c_log2 = prm.scale_log2 * inv_qk;
+
+    resolve(0);
+    if (nT > 0) {
+        issue(0);
+        stage_write(0);
+        if (nT > 1) issue(1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    __syncthreads();
+
+    constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
+    float m_ref = -INFINITY, m_off = -kPShift;
+    int buf = 0;
+    for (int t = 0; t < nT; ++t) {
+        const char* kbuf = smem + buf * kStage;
+        const int tk0 = P::tile_key0(ctx, t);
+        const int cls = P::classify(prm, ctx, tk0, wave * 32);
+        if (cls != TILE_SKIP) {
+            f32x16 s_cur[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_cur[b][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const char* rowp = kbuf + k_lane + b * (32 * 128);
+                    const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
+                    const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
+                    const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                    s_cur[b] = mfma_f8(kf, qf[ks], s_cur[b]);
+                }
+            if (cls == TILE_PARTIAL) {
+                asm volatile("; element-wise mask of a partial tile" ::: "memory");
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        s_cur[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s_cur[b][r] : -INFINITY;
+                    }
+            }
+            i32x8 pf;
+            float psum;
+            auto probs = [&](float off) {
+                psum = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) {
+                    float p4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 4 * w8 + i;
+                        p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e >> 4][e & 15], c_log2, -off));
+                        psum += p4[i];
+                    }
+                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+                    pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
+                }
+            };
+            probs(m_off);
+            if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+                float mx = s_cur[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_prev = m_off + kPShift;
+                const float m_new = fmaxf(m_ref, mx * c_log2);
+                const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+                m_ref = m_new;
+                m_off = m_use - kPShift;
+                probs(m_off);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+            }
+            l_run += psum;
+            // ---------------- O^T += V^T P^T: 4 MFMAs, V^T through 4 transpose reads each ----------------
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                i32x8 vf;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c16 = 2 * db + ((lane >> 4) & 1);     // 16-byte chunk of the row that holds this group's columns
+                    const char* ap = kbuf + v_lane + m * (16 * 128) + ((c16 ^ vsw) << 4);
+                    const v2i32 t2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((__attribute__((address_space(3))) v2i32*)(ap));
+                    vf[2 * m] = t2[0], vf[2 * m + 1] = t2[1];
+                }
+                acc_o[db] = mfma_f8(vf, pf, acc_o[db]);
+            }
+        }
+        if (t + 1 < nT) stage_write(buf ^ 1);
+        if (t + 2 < nT) issue(t + 2);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    constexpr int kEpiStride = D * 2 + 8;
+    char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+    {
+        const float inv = l_tot > 0.f ? inv_v / l_tot : 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    T* __restrict__ ob = P::o_base(prm, ctx);
+    constexpr int kLanesPerRow = D * 2 / 8, kRowsPerPass = 64 / kLanesPerRow, kPasses = 32 / kRowsPerPass;
+    const int sub = lane / kLanesPerRow, colb = (lane - sub * kLanesPerRow) * 8;
+    int ephys[kPasses];
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) {
+        const int rr = i * kRowsPerPass + sub;
+        const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+    }
 }
 
 }  // namespace svg

@@ -107,6 +107,9 @@ SIGNATURES = {
     "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _VP]),
+    "svg_varblock_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "svg_varblock_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
+                                             _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
     "svg_band_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_stage": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _I32, _VP]),
@@ -395,8 +398,9 @@ def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mas
 
 def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
                        k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
-                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1) -> torch.Tensor:
-    """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB]."""
+                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1, fp8: bool = False) -> torch.Tensor:
+    """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB].
+    fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only)."""
     lib = load()
     _dev(q, k, v, block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
     Hq, Sq, D = q.shape
@@ -409,8 +413,21 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
     if kv_row_idx is not None:
         assert kv_row_idx.dtype == torch.int32 and kv_row_idx.shape == (Hkv, Skv)
     o = torch.zeros_like(q) if q_row_idx is None else torch.zeros_like(q)
-    ws = torch.empty(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq), dtype=torch.uint8, device=q.device)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    if fp8:
+        need = int(lib.svg_varblock_attention_fp8_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
+        if need == 0:
+            raise RuntimeError(f"svg_varblock_attention_fp8: unsupported shape (D = {D}; only 128)")
+        key = ("vb", Hq, Hkv, Sq, Skv, QB, KB, q.device)
+        ws = _F8_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+        rc = lib.svg_varblock_attention_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D, _dtype_code(q),
+                                            scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(), QB, KB,
+                                            _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "svg_varblock_attention_fp8")
+        return o
+    ws = torch.empty(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq), dtype=torch.uint8, device=q.device)
     rc = lib.svg_varblock_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D,
                                     _dtype_code(q), scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(),
                                     QB, KB, _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), variant,

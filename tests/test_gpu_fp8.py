@@ -107,3 +107,64 @@ def test_fp8_rejects_unsupported(nat):
     q = torch.randn(1, 2, 300, 64).to(torch.bfloat16).cuda()
     with pytest.raises(RuntimeError):
         nat.band_attention_fp8(q, q, q, nat.BandMask(**O.dense_band_params(300)))
+
+
+def _random_partition(seq_len, num_blocks, bsz, gen):
+    sizes = torch.empty((bsz, num_blocks), dtype=torch.int32)
+    for i in range(bsz):
+        cut = torch.sort(torch.randperm(seq_len - 1, generator=gen)[: num_blocks - 1] + 1).values
+        sizes[i] = torch.diff(torch.cat((torch.tensor([0]), cut, torch.tensor([seq_len]))))
+    return sizes
+
+
+@pytest.mark.parametrize("hq,hkv,S,MB,NB,density,dtype", [
+    (4, 4, 4096, 20, 100, 0.7, torch.bfloat16), (4, 1, 2048, 10, 50, 0.5, torch.float16), (2, 2, 256, 10, 50, 0.2, torch.bfloat16),
+    (16, 4, 4096, 10, 50, 0.9, torch.bfloat16), (1, 1, 8192, 20, 100, 0.7, torch.bfloat16),
+])
+def test_fp8_varblock_attention(nat, hq, hkv, S, MB, NB, density, dtype):
+    """svg_varblock_attention_fp8 (SVG2 with e4m3 QK^T / PV, gathered rows, ds_read_b64_tr_b8 V^T) on the parameter family of
+    svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:74-133: vs the fp32 oracle under the expanded block mask, vs the oracle on
+    dequantised inputs and vs the 16-bit kernel; ragged row / column blocks, GQA, empty blocks."""
+    D = 128
+    gen = torch.Generator().manual_seed(hq * 1000 + S + MB)
+    rsz = _random_partition(S, MB, hkv, gen)
+    csz = _random_partition(S, NB, hkv, gen)
+    bmap = torch.rand(hkv, MB, NB, generator=gen) > density
+    q = torch.randn(hq, S, D, generator=gen).to(dtype)
+    k = torch.randn(hkv, S, D, generator=gen).to(dtype)
+    v = torch.randn(hkv, S, D, generator=gen).to(dtype)
+    args = (q.cuda(), k.cuda(), v.cuda(), bmap.cuda(), rsz.cuda(), csz.cuda())
+    o = nat.varblock_attention(*args, fp8=True).float().cpu()
+    o16 = nat.varblock_attention(*args).float().cpu()
+    assert torch.isfinite(o).all()
+    gq = hq // hkv
+    worst = 0.0
+    for h in range(hkv):
+        em = O.block_mask_to_element_mask(bmap[h], rsz[h], csz[h])
+        sl = slice(h * gq, (h + 1) * gq)
+        ref = O.masked_attention(q[sl], k[h:h + 1], v[h:h + 1], em)
+        ref_dq = O.masked_attention(dequant(q[sl]), dequant(k[h:h + 1]), dequant(v[h:h + 1]), em)
+        e_ref, e_dq = rel_l2(o[sl], ref), rel_l2(o[sl], ref_dq)
+        worst = max(worst, e_ref)
+        assert e_dq < 4e-2 and e_ref < 8e-2, (h, e_dq, e_ref)
+        rows_without_keys = ~em.any(dim=1)
+        assert (o[sl][:, rows_without_keys] == 0).all()        # block-rows with no active key block give zeros like the 16-bit path
+    print(f"[fp8 varblock hq={hq} hkv={hkv} S={S}] worst rel L2 vs fp32 oracle {worst:.4f}, vs 16-bit kernel {rel_l2(o, o16):.4f}")
+
+
+def test_fp8_varblock_fused_permutation(nat):
+    """row-index gather / scatter (the fused token permutation of SVG2) through the fp8 kernel: same statement as the 16-bit test —
+    attention on un-permuted tensors with index arrays equals attention on permuted tensors followed by the inverse permutation."""
+    torch.manual_seed(12)
+    H, S, D, MB, NB = 3, 2048, 128, 12, 40
+    gen = torch.Generator().manual_seed(5)
+    rsz, csz = _random_partition(S, MB, H, gen), _random_partition(S, NB, H, gen)
+    bmap = torch.rand(H, MB, NB, generator=gen) > 0.5
+    q, k, v = (torch.randn(H, S, D, generator=gen).to(torch.bfloat16).cuda() for _ in range(3))
+    qi = torch.stack([torch.randperm(S, generator=gen) for _ in range(H)]).to(torch.int32).cuda()
+    ki = torch.stack([torch.randperm(S, generator=gen) for _ in range(H)]).to(torch.int32).cuda()
+    fused = nat.varblock_attention(q, k, v, bmap.cuda(), rsz.cuda(), csz.cuda(), q_row_idx=qi, kv_row_idx=ki, fp8=True)
+    qp, kp, vp = nat.permute_rows(q, qi), nat.permute_rows(k, ki), nat.permute_rows(v, ki)
+    op = nat.varblock_attention(qp, kp, vp, bmap.cuda(), rsz.cuda(), csz.cuda(), fp8=True)
+    mat = nat.permute_rows(op, qi, inverse=True)
+    assert torch.equal(fused, mat)        # per-head scales do not depend on the row order: bit-identical
