@@ -291,7 +291,7 @@ def main():
     fp8 = a.dtype == "fp8"
     if fp8:
         assert world == 1, "--dtype fp8 is a single-GPU line"
-        a.no_svg2 = a.no_step = True
+        a.no_step = True
     ev_p0, ev_p1 = [], []
 
     def step(timed: bool):
@@ -536,7 +536,7 @@ def main():
         try:
             import bench_svg2
 
-            out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1)
+            out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1, fp8=fp8)   # fp8: BASELINE.json configs[4] as named
         except Exception as e:  # noqa: BLE001
             out["svg2_wan720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if world == 1 and not a.no_step and a.workload == "hy720p":

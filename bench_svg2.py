@@ -33,12 +33,12 @@ def clustered(H, N, D, modes, dev, gen, spread=0.35):
     return x.to(torch.bfloat16)
 
 
-def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False):
+def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False, fp8=False):
     """one SVG2 layer-call (2 warm-started k-means iterations on q and k, block map, variable-block attention), timed per stage
     with HIP events on the current stream; returns the dict bench_svg2.py prints (bench.py embeds it as `svg2_wan720p`)."""
     import types
 
-    a = types.SimpleNamespace(workload=workload, steps=steps, warmup=warmup, variant=variant, materialize=materialize)
+    a = types.SimpleNamespace(workload=workload, steps=steps, warmup=warmup, variant=variant, materialize=materialize, fp8=fp8)
     from svg import _native as nat
     from svg.kmeans_utils import density_calculation
     from svg.models import _core
@@ -90,7 +90,7 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         else:
             o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
                                        q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant)
+                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8)
         t[3].record()
         torch.cuda.synchronize()
         if it >= a.warmup:
@@ -116,6 +116,15 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         "speedup_vs_dense_at_1000tflops": round((dense_flops / 1e15 * 1e3) / ms["total"], 2),
         "data": "synthetic (64-mode Gaussian mixture per head)",
     }
+    if a.fp8:
+        # e4m3 QK^T / PV (svg_varblock_attention_fp8: quantisation inside the call): distance to the 16-bit kernel on this workload
+        o16 = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
+                                     q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
+                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+        d = o.float() - o16.float()
+        out["attention_dtype"] = "fp8 e4m3 (q, k, v per-head scales; quantise pass inside `attention` time)"
+        out["attention_frac_of_5pflops_fp8"] = round(out["attention_tflops_algorithmic"] / 5000.0, 4)
+        out["rel_l2_vs_16bit_kernel"] = round((d.norm() / o16.float().norm()).item(), 5)
     return out
 
 
@@ -125,10 +134,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order)")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 QK^T / PV in the attention (BASELINE.json configs[4])")
     ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
                     "(the reference's pipeline) instead of the fused row-index gather")
     a = ap.parse_args()
-    print(json.dumps(measure(a.workload, a.steps, a.warmup, a.variant, a.materialize)))
+    print(json.dumps(measure(a.workload, a.steps, a.warmup, a.variant, a.materialize, a.fp8)))
 
 
 if __name__ == "__main__":

@@ -20,6 +20,27 @@ from ..kmeans_utils import batch_kmeans_Euclid, density_calculation, identify_dy
 from ..timer import time_logging_decorator
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# precision of the sparse attention kernels: "bf16" (the input dtype: bf16 / fp16 MFMA, default) or "fp8" (e4m3 QK^T / PV,
+# svg_band_attention_fp8 / svg_varblock_attention_fp8; head_dim 128 only — other head sizes stay on the 16-bit kernels).
+# No reference counterpart (the reference lists fp8 attention as future work, README.md:117): an opt-in of this package.
+# ---------------------------------------------------------------------------------------------------------------
+_ATTENTION_DTYPE = {"value": "bf16"}
+
+
+def set_attention_dtype(name: str) -> None:
+    assert name in ("bf16", "fp8"), name
+    _ATTENTION_DTYPE["value"] = name
+
+
+def attention_dtype() -> str:
+    return _ATTENTION_DTYPE["value"]
+
+
+def _use_fp8(q: torch.Tensor) -> bool:
+    return _ATTENTION_DTYPE["value"] == "fp8" and q.shape[-1] == 128
+
+
 @dataclass
 class Geometry:
     """Token layout of one model: [text?][video F*P][text?]"""
@@ -147,8 +168,8 @@ def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof
     best_mask_idx = torch.argmin(mses, dim=0)  # [cfg, H] int64; NaN wins like torch.argmin in the reference
     if fused:
         with time_logging_decorator("Level 3 - sparse_flex_attention"):
-            out = _native.band_attention(q, k, v, mask, head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame,
-                                         frame_size=geo.frame_size)
+            attn = _native.band_attention_fp8 if _use_fp8(q) else _native.band_attention
+            out = attn(q, k, v, mask, head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame, frame_size=geo.frame_size)
         return out, best_mask_idx
     qo, ko, vo = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     with time_logging_decorator("Level 3 - fast_sparse_head_placement"):
@@ -253,7 +274,7 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
     QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
     out = _native.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dyn_map.view(H, QB, KB).contiguous(),
                                      q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), fp8=_use_fp8(q))
     if logging_file is not None:
         from .context import timestep_value
 

@@ -168,3 +168,44 @@ def test_fp8_varblock_fused_permutation(nat):
     op = nat.varblock_attention(qp, kp, vp, bmap.cuda(), rsz.cuda(), csz.cuda(), fp8=True)
     mat = nat.permute_rows(op, qi, inverse=True)
     assert torch.equal(fused, mat)        # per-head scales do not depend on the row order: bit-identical
+
+
+def test_processor_core_fp8_switch(nat):
+    """svg.models._core.set_attention_dtype("fp8"): the SVG1 and SVG2 attention cores the processors call run the e4m3 kernels (head
+    dim 128) and stay within the fp8 distance of their 16-bit results; "bf16" restores the default bit for bit."""
+    from svg.models import _core
+
+    H, D, F_, P_, ctx, L = 3, 128, 4, 200, 40, 11
+    V = F_ * P_
+    S = V + ctx
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(1, H, S, D, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    geo = _core.Geometry(ctx, F_, P_)
+    mask = nat.BandMask(real_len=V + L, band=256, colfull_lo=V, colfull_hi=V + L, rowfull_lo=V, rowfull_hi=V + L)
+    prof = nat.ProfileDesc(0, F_, P_, 1)
+    prof.variant[0] = nat.ProfileVariant(0, 0, V, 2, 0, V, S)
+    prof.variant[1] = nat.ProfileVariant(1, 0, V, 2, 0, V, S)
+
+    def svg1():
+        torch.manual_seed(11)
+        return _core.svg1_sparse_attention(q, k, v, geo, mask, prof, 32, V)
+
+    def svg2():
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        return _core.svg2_sparse_attention(q[:, :, :V].contiguous(), k[:, :, :V].contiguous(), v[:, :, :V].contiguous(),
+                                           _core.Geometry(0, F_, P_), _core.CentroidStore(), 0, 10, 25, 0.9, 0.1, 4, 2)
+
+    assert _core.attention_dtype() == "bf16"
+    o1, b1 = svg1()
+    o2 = svg2()
+    try:
+        _core.set_attention_dtype("fp8")
+        o1f, b1f = svg1()
+        o2f = svg2()
+    finally:
+        _core.set_attention_dtype("bf16")
+    assert torch.equal(b1, b1f)                                  # the profiler stays 16-bit
+    assert 1e-3 < rel_l2(o1f, o1) < 8e-2 and 1e-3 < rel_l2(o2f, o2) < 8e-2
+    o1b, _ = svg1()
+    assert torch.equal(o1b, o1)
