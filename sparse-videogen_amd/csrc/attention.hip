@@ -231,11 +231,19 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_pp2_trace_kernel(typenam
 }
 #endif
 
-// fp8 (e4m3) form: gathering fp8 body of attn_f8.h, 256-row q tiles, two waves per SIMD
+// fp8 (e4m3) form: gathering fp8 body of attn_f8.h, NW x 32-row q tiles, two waves per SIMD (8 / NW workgroups per CU).  The waves
+// of this lock-step body are independent between barriers, so a tile's time follows its ACTIVE waves and smaller tiles only cost
+// more K / V staging per row: the ragged q-clusters of SVG2 (252 +- 160 rows) fill 69 % of 256-row tiles, 80 % of 128-row tiles,
+// 89 % of 64-row tiles (tools/vb_stats.py).
+#ifndef SVG_VB_F8_WAVES
+#define SVG_VB_F8_WAVES 4
+#endif
+constexpr int kVbF8Waves = SVG_VB_F8_WAVES;
 template <typename T>
-__global__ __launch_bounds__(512, 2) void varblock_attn_f8_kernel(typename VarblockPolicy<T, 128, 8>::Params prm, F8GArgs fa) {
+__global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8_kernel(typename VarblockPolicy<T, 128, kVbF8Waves>::Params prm,
+                                                                              F8GArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_f8g<T, VarblockPolicy<T, 128, 8>>(prm, fa, smem, smem + attn_f8_lds_bytes<128>());
+    attn_body_f8g<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8_lds_bytes<128, kVbF8Waves>());
 }
 
 static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
@@ -587,7 +595,7 @@ extern "C" size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t 
     if (Hq <= 0 || Hkv <= 0 || QB <= 0 || KB <= 0 || Sq <= 0) return 0;
     // plan (prefix sums) + longest-first order: per-block-row bucket, histogram / cursors, (count, pad, entries[2 * max workgroups])
     const size_t plan = (size_t)Hkv * (3 * (size_t)(QB + 1) + (size_t)(KB + 1));
-    const size_t order = (size_t)Hkv * QB + (size_t)Hkv * kVbBuckets + 2 + 2 * ((size_t)Sq / 256 + QB) * Hq;
+    const size_t order = (size_t)Hkv * QB + (size_t)Hkv * kVbBuckets + 2 + 2 * ((size_t)Sq / 64 + QB) * Hq;   // (q tiles of >= 64 rows)
     return (plan + order) * sizeof(int32_t);
 }
 
@@ -606,7 +614,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
     int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
     hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
-                       KB, (NW < 0 ? 8 : NW) * 32);
+                       KB, (NW == -9 ? kVbF8Waves : NW < 0 ? 8 : NW) * 32);
     auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
         constexpr int W = decltype(nw_c)::value;
         using Pol = VarblockPolicy<T, D, W>;
@@ -637,7 +645,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 if constexpr (NW == -9) {
                     if constexpr (D == 128) {
                         auto kern = varblock_attn_f8_kernel<T>;
-                        const int lds = attn_f8_lds_bytes<128>() + vb_policy_lds(p.kb_cap);
+                        const int lds = attn_f8_lds_bytes<128, kVbF8Waves>() + vb_policy_lds(p.kb_cap);
                         static thread_local int configured = 0;   // (a cache of hipFuncSetAttribute, not per-call state)
                         if (configured < lds) {
                             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -647,25 +655,28 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                             }
                             configured = lds;
                         }
-                        hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(512), lds, st, p, *f8);
+                        hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(kVbF8Waves * 64), lds, st, p, *f8);
                         return launch_status();
                     }
                     return SVG_ERR_UNSUPPORTED;
-                }
+                } else {
 #ifdef SVG_ABLATIONS
-                if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
-                    if (trace)
-                        return launch_attn(varblock_attn_pp2_trace_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
-                                           attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
-                }
+                    if constexpr (D == 128 && std::is_same<T, __bf16>::value) {
+                        if (trace)
+                            return launch_attn(varblock_attn_pp2_trace_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
+                                               attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+                    }
 #endif
-                if (trace) return SVG_ERR_UNSUPPORTED;   // diagnostics builds only (-DSVG_ABLATIONS)
-                return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
-                                   attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+                    if (trace) return SVG_ERR_UNSUPPORTED;   // diagnostics builds only (-DSVG_ABLATIONS)
+                    return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
+                                       attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+                }
             }
-            if constexpr (NW == -9) return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
-            return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
-                               attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+            if constexpr (NW == -9)
+                return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
+            else
+                return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
+                                   attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
         } else
             return launch_attn(varblock_attn_kernel<T, D, W>, p, dim3(p.max_tiles, Hq), W * 64,
                                attn_lds_bytes<D, W>() + vb_policy_lds(p.kb_cap), st);
@@ -675,7 +686,9 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
         if (rc != SVG_OK) return rc;
         return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
-    } else if constexpr (NW == -8 || NW == -9) {   // two-phase ping-pong body / fp8 body, 256-row q tiles
+    } else if constexpr (NW == -9) {   // fp8 body
+        return launch(std::integral_constant<int, kVbF8Waves>{}, 0, tile_off, Sq / (kVbF8Waves * 32) + QB);
+    } else if constexpr (NW == -8) {   // two-phase ping-pong body, 256-row q tiles
         return launch(std::integral_constant<int, 8>{}, 0, tile_off, Sq / 256 + QB);
     } else {
         return launch(std::integral_constant<int, NW>{}, 0, tile_off, Sq / (NW * 32) + QB);

@@ -44,10 +44,10 @@ __device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, kF8Scale127, 0, kF8Scale127);
 }
 
-template <int D>
+template <int D, int NW = 8>
 constexpr int attn_f8_lds_bytes() {
     constexpr int stages = 2 * (2 * kBN * D);            // two stages of [K image | V^T image], one byte per element
-    constexpr int epi = 8 * 32 * (D * 2 + 8);            // epilogue staging of 256 output rows (16-bit)
+    constexpr int epi = NW * 32 * (D * 2 + 8);           // epilogue staging of the output rows (16-bit)
     return stages > epi ? stages : epi;
 }
 
@@ -290,12 +290,13 @@ struct F8GArgs {
 // chunk c (16 B) of V row `row` inside the row-major V image ([64][128] bytes): the XOR keeps the transpose reads conflict-free
 __device__ __forceinline__ int f8_vrow_off(int row, int c) { return row * 128 + ((c ^ ((row & 2) | ((row >> 1) & 4))) << 4); }
 
-template <typename T, typename P>
+template <typename T, typename P, int NW = 8>
 __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, const F8GArgs& fa, char* smem, char* policy_lds) {
     using E = Elt<T>;
-    constexpr int D = 128, DB = D / 32, KS = D / 64;
+    constexpr int D = 128, DB = D / 32, KS = D / 64, NT = NW * 64;
     constexpr int kKBytes = kBN * D, kStage = 2 * kBN * D;
-    static_assert(P::kRowBlocks == 1 && P::BM == 256, "fp8 body: 8 waves x 32 rows");
+    constexpr int NCH = 512 / NT;      // (row, 16-B chunk) pairs per thread
+    static_assert(P::kRowBlocks == 1 && P::BM == NW * 32, "fp8 body: NW waves x 32 rows");
 
     typename P::Ctx ctx;
     if (!P::init(prm, ctx, policy_lds)) return;
@@ -316,24 +317,38 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
     const int q_log = P::q_logical(ctx, row_in_wg);
 
     // staging: thread = (row kr, chunk kc) of the tile, for K and V alike (the same gathered row)
-    const int kr = tid >> 3, kc = tid & 7;
-    const int k_dst = f8_k_off(kr, kc), v_dst = kKBytes + f8_vrow_off(kr, kc);
-    typename P::KvCursor cur;
-    P::kv_cursor_init(prm, ctx, cur, kr);
-    u32x4 kreg, vreg;
-    int nphys = 0;
+    int srow[NCH], scol[NCH], k_dst[NCH], v_dst[NCH], nphys[NCH];
+    typename P::KvCursor cur[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int id = tid + i * NT;
+        srow[i] = id >> 3, scol[i] = (id & 7) * 16;
+        k_dst[i] = f8_k_off(srow[i], id & 7), v_dst[i] = kKBytes + f8_vrow_off(srow[i], id & 7);
+        P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
+        nphys[i] = 0;
+    }
+    u32x4 kreg[NCH], vreg[NCH];
     const int nT = ctx.nT;
-    auto resolve = [&](int t) { nphys = (t < nT) ? P::kv_phys(prm, ctx, cur, t, kr) : 0; };   // a global index load: one tile ahead
+    auto resolve = [&](int t) {   // a global index load per row: one tile ahead of the data loads
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) nphys[i] = (t < nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
+    };
     auto issue = [&](int t) {
-        const size_t off = (size_t)nphys * D + kc * 16;
-        kreg = *(const u32x4*)(k8 + off);
-        vreg = *(const u32x4*)(v8 + off);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const size_t off = (size_t)nphys[i] * D + scol[i];
+            kreg[i] = *(const u32x4*)(k8 + off);
+            vreg[i] = *(const u32x4*)(v8 + off);
+        }
         resolve(t + 1);
     };
     auto stage_write = [&](int buf) {
         char* base = smem + buf * kStage;
-        *(u32x4*)(base + k_dst) = kreg;
-        *(u32x4*)(base + v_dst) = vreg;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *(u32x4*)(base + k_dst[i]) = kreg[i];
+            *(u32x4*)(base + v_dst[i]) = vreg[i];
+        }
     };
 
     const int ksw = (ql >> 1) & 7;
