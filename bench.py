@@ -489,6 +489,35 @@ def main():
         out["fp8"]["rel_l2_vs_bf16_kernel_this_workload"] = round((df.norm() / ob.norm()).item(), 5)
         del ob, df
 
+    if world == 1 and not fp8 and a.workload == "hy720p" and D == 128:
+        # BASELINE.json configs[4] beside the bf16 headline: the same layer-call with e4m3 QK^T / PV (python bench.py --dtype fp8 is
+        # the full line).  Attention only (pre-pass + kernel), HIP events, mean of 3 after one warm-up.
+        try:
+            kw8 = dict(vid0=0, num_frame=F_, frame_size=P_, head_perm_flag=best, out=o)
+            ref16 = o[:, :2].clone()
+            nat.band_attention_fp8(q, k, v, mask, **kw8)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+            for i in range(3):
+                evs[2 * i].record()
+                nat.band_attention_fp8(q, k, v, mask, stage=1, **kw8)
+                evs[2 * i + 1].record()
+                nat.band_attention_fp8(q, k, v, mask, stage=2, **kw8)
+            evs[6].record()
+            torch.cuda.synchronize()
+            pre = sum(evs[2 * i].elapsed_time(evs[2 * i + 1]) for i in range(3)) / 3
+            tot = evs[0].elapsed_time(evs[6]) / 3
+            out["fp8_hy720p"] = {
+                "what": "the headline layer-call's attention with e4m3 q, k, v, probabilities (svg_band_attention_fp8); bf16 in / out",
+                "prepass_ms": round(pre, 3), "kernel_ms": round(tot - pre, 3), "attention_ms": round(tot, 3),
+                "kernel_tflops": round(flops_call / ((tot - pre) * 1e-3) / 1e12, 1),
+                "kernel_frac_of_5pflops_fp8": round(flops_call / ((tot - pre) * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4),
+                "speedup_vs_bf16_kernel": round(attn_ms / tot, 3),
+                "rel_l2_vs_bf16_kernel": round(((o[:, :2].float() - ref16.float()).norm() / ref16.float().norm()).item(), 5),
+            }
+            del ref16
+        except Exception as e:  # noqa: BLE001
+            out["fp8_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
     # ---- extras on rank 0 at N = 1: dense comparator on the same GPU, CPU baseline ----
     if world == 1 and not a.no_dense:
         dmask = nat.BandMask(real_len=V + L, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
