@@ -566,6 +566,8 @@ def main():
             import bench_svg2
 
             out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1, fp8=fp8)   # fp8: BASELINE.json configs[4] as named
+            if not fp8:   # ... and configs[4] beside it in the default run
+                out["svg2_wan720p_fp8"] = bench_svg2.measure("wan720p", steps=3, warmup=1, fp8=True)
         except Exception as e:  # noqa: BLE001
             out["svg2_wan720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     if world == 1 and not a.no_step and a.workload == "hy720p":
