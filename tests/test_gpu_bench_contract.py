@@ -60,3 +60,26 @@ def test_bench_two_rank_watchdog_falls_back():
     ex = _last_json(r.stdout)["exchange"]
     assert ex["fallback_to_chunk_launches"] is True and ex["waiter_timeouts_in_timed_steps"] == 0
     assert "per chunk" in ex["outbound"]
+
+
+def test_bench_fp8_line():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu",
+                        "--dtype", "fp8"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert KEYS <= set(d) and d["dtype"] == "fp8" and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["peak"] == 5000.0 and rf["kernel"].startswith("band_attn_f8_kernel") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0 < d["fp8"]["prepass_ms"] < d["ms_per_step"] and 1e-3 < d["fp8"]["rel_l2_vs_bf16_kernel_this_workload"] < 0.1
+
+
+def test_bench_step_small_stack():
+    """bench_step.measure on a 1 + 1 block stack (the full 20 + 40 stack is what bench.py embeds): finite outputs, both kinds of
+    step, attention share in (0, 1)."""
+    sys.path.insert(0, str(ROOT))
+    import bench_step
+
+    d = bench_step.measure(steps=1, warmup=0, n_double=1, n_single=1)
+    for kind in ("sparse_step", "dense_step"):
+        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflop"] > 0
+    assert d["denoise_steps_per_s"] > 0 and d["speedup_sparse_vs_dense_step"] > 0
