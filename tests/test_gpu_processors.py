@@ -133,7 +133,8 @@ def _clustered(H, N, D, modes, gen):
 @pytest.mark.parametrize("model", ["hy", "wan"])
 def test_svg2_core_against_oracle_and_dense(model):
     """SVG2 sparse branch: (a) top_p = 1 keeps every block -> must equal dense attention (permutation invariance);
-    (b) top_p < 1: equals oracle attention under the element mask built from the kernels' own labels and block map."""
+    (b) top_p < 1: equals oracle attention under the element mask built from the kernels' labels and block map, which are themselves
+    checked against the oracle's k-means loop and exact-mode block map."""
     from svg import _native as nat
     from svg.kmeans_utils import batch_kmeans_Euclid, identify_dynamic_map
     from svg.models import _core
@@ -165,6 +166,17 @@ def test_svg2_core_against_oracle_and_dense(model):
     dmap = identify_dynamic_map(qc[None], kc[None], qs[None], ks[None], 0.6, 0.1)[0].cpu()
     assert 0.05 < dmap.float().mean() < 0.95
     ql, kl = ql.cpu(), kl.cpu()
+    # the clustering half against the ORACLE (not only against the kernels themselves): labels of the 2-iteration warm-started
+    # k-means equal the oracle's loop up to rounding-level near-ties, cluster sizes follow the labels, and the block map equals
+    # the oracle's exact mode bit for bit on the kernels' own centroids (tests/test_gpu_kernels.py holds the per-kernel forms)
+    for x, init, lab, cent, sizes, K in ((q, qc0, ql, qc, qs, QC), (k, kc0, kl, kc, ks, KC)):
+        xv = x[0, :, :V].cpu()
+        rl, rc, rcnt, rit = O.batch_kmeans_euclid(xv, K, max_iters=2, init_centroids=init.cpu())
+        assert rit == 2 and (lab != rl).float().mean() < 2e-2
+        assert torch.equal(sizes.cpu(), torch.stack([torch.bincount(lab[h], minlength=K) for h in range(H)]).to(torch.int32))
+        assert (cent.float().cpu() - rc.float()).abs().mean() < 5e-3
+    ref_map = O.identify_dynamic_map(qc[None].cpu(), kc[None].cpu(), qs[None].cpu(), ks[None].cpu(), 0.6, 0.1, exact=True)[0]
+    assert torch.equal(dmap.bool(), ref_map)
     for h in range(H):
         em = torch.zeros(S, S, dtype=torch.bool)
         em[:V, :V] = dmap[h][ql[h]][:, kl[h]]
