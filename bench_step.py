@@ -147,7 +147,8 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
     img = (torch.randn(V, HID, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     txt = (torch.randn(CTX, HID, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     res = {}
-    for kind, sparse_step in (("sparse", True), ("dense", False)):
+    for kind, sparse_step in (("sparse", True), ("dense", False), ("sparse_fp8", True)):
+        core.set_attention_dtype("fp8" if kind == "sparse_fp8" else "bf16")   # fp8: e4m3 QK^T / PV in the 59 sparse layers
         times, attn_ms = [], []
         for it in range(warmup + steps):
             ev = []
@@ -167,6 +168,7 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
         res[kind] = {"ms": round(t, 2), "attention_ms": round(a, 2), "attention_share": round(a / t, 4),
                      "gemm_and_glue_ms": round(t - a, 2), "gemm_tflop": round(st.gemm_flops / 1e12, 1),
                      "gemm_tflops_lower_bound": round(st.gemm_flops / ((t - a) * 1e-3) / 1e12, 1)}
+    core.set_attention_dtype("bf16")
     ts, td = res["sparse"]["ms"] * 1e-3, res["dense"]["ms"] * 1e-3
     video = (5 * td + 45 * ts) / 50
     return {
@@ -175,7 +177,8 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
                     f"{HEADS} x {HD} heads, MLP {MLP}, S = {S} ({V} video + {CTX} text tokens, prompt {L}), bf16, random weights; "
                     f"sparse step = {first_layers_fp} dense + {n_layers - first_layers_fp} SVG1 layers (sparsity 0.25, band {tf})",
         "steps": steps, "warmup": warmup,
-        "sparse_step": res["sparse"], "dense_step": res["dense"],
+        "sparse_step": res["sparse"], "dense_step": res["dense"], "sparse_step_fp8_attention": res["sparse_fp8"],
+        "denoise_steps_per_s_fp8_attention": round(1e3 / res["sparse_fp8"]["ms"], 4),
         "denoise_steps_per_s": round(1.0 / ts, 4),
         "denoise_steps_per_s_dense": round(1.0 / td, 4),
         "denoise_steps_per_s_video_average": round(1.0 / video, 4),
