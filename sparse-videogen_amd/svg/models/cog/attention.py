@@ -97,7 +97,7 @@ class CogVideoX_SparseAttn_Processor2_0:
         # ref :173-176 — Cog's warm-up thresholds are fractions of 42 layers / 1000 timesteps
         first_layers, first_times = 42 * self.first_layers_fp, 1000 * (1 - self.first_times_fp)
         dense_flag = None   # (device-side dense / sparse switch, see the Hunyuan processor)
-        if self.device_switch and self.fused_placement and self.layer_idx >= first_layers and self.block_mask is not None \
+        if self.device_switch and _core.attention_dtype() == "bf16" and self.fused_placement and self.layer_idx >= first_layers and self.block_mask is not None \
                 and query.is_cuda:
             dense_flag = _core.dense_flag_on_device(timestep, first_times)
         if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, first_layers, first_times):

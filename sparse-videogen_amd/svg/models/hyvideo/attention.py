@@ -239,7 +239,7 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
             geo.video_length + self.prompt_length)
         # the layer test is host data; the timestep test stays on the device when the timestep is a GPU tensor (device_switch)
         dense_flag = None
-        if self.device_switch and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
+        if self.device_switch and _core.attention_dtype() == "bf16" and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
                 and query.is_cuda:
             dense_flag = _core.dense_flag_on_device(timestep, self.first_times_fp)
         if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):

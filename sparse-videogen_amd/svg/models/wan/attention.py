@@ -144,7 +144,7 @@ class WanAttn_SVGAttn_Processor2_0:
         assert seq_len == geo.seq_len, (
             f"Query Shape: {seq_len} is not equivalent to {geo.context_length} + {geo.num_frame} * {geo.frame_size}")
         dense_flag = None   # (device-side dense / sparse switch, see the Hunyuan processor)
-        if self.device_switch and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
+        if self.device_switch and _core.attention_dtype() == "bf16" and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
                 and query.is_cuda:
             dense_flag = _core.dense_flag_on_device(timestep, self.first_times_fp)
         if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
