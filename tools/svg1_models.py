@@ -47,12 +47,15 @@ CASES = [
 
 
 def main():
-    variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # schedule of svg_band_attention (include/svg_attn.h)
-    print(f"schedule variant {variant}")
+    fp8 = len(sys.argv) > 1 and sys.argv[1] == "fp8"         # e4m3 kernels (head_dim 128 geometries only), pre-pass included
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 and not fp8 else 0   # schedule of svg_band_attention (include/svg_attn.h)
+    print("fp8 (e4m3) kernels, quantise pre-pass included" if fp8 else f"schedule variant {variant}")
     dev = torch.device("cuda", 0)
     print("| model geometry | S | density | sparse ms | PFLOP/s (algorithmic) | dense ms | dense PFLOP/s | speed-up |")
     print("|---|---|---|---|---|---|---|---|")
     for name, BH, D, F_, P_, ctx, text_first, mk in CASES:
+        if fp8 and D != 128:
+            continue
         S = F_ * P_ + ctx
         mask = mk(F_, P_, ctx)
         q, k, v = (torch.randn(1, BH, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
@@ -74,8 +77,12 @@ def main():
                 ts.append(e0.elapsed_time(e1))
             return min(ts)
 
-        ms = t(lambda: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o, variant=variant))
-        dms = t(lambda: nat.band_attention(q, k, v, dmask, out=o, variant=variant))
+        if fp8:
+            ms = t(lambda: nat.band_attention_fp8(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o))
+            dms = t(lambda: nat.band_attention_fp8(q, k, v, dmask, out=o))
+        else:
+            ms = t(lambda: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o, variant=variant))
+            dms = t(lambda: nat.band_attention(q, k, v, dmask, out=o, variant=variant))
         np_, dp = pairs(mask, S), pairs(dmask, S)
         fl, dfl = 4.0 * D * BH * np_, 4.0 * D * BH * dp
         print(f"| {name} | {S} | {np_ / S / S:.4f} | {ms:.3f} | {fl / ms / 1e12:.3f} | {dms:.3f} | {dfl / dms / 1e12:.3f} | {dms / ms:.2f}x |", flush=True)
