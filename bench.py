@@ -13,7 +13,7 @@ metric  = attention TFLOP/s, algorithmic: 4 * D * H * (#unmasked (q,k) pairs) pe
           at L=64) divided by wall time per step; `attention_only_steps_per_s` (60 such layer-calls, nothing else of a
           denoise step — no projections, norms, MLPs) is reported beside it.
 roofline: bound = MFMA (dense bf16 peak 2.5 PFLOP/s); `achieved` = algorithmic FLOPs of the dominant kernel
-          (band_attn_w4_kernel) / its mean launch duration measured with HIP events on the launch stream.
+          (band_attn_pp2_kernel) / its mean launch duration measured with HIP events on the launch stream.
 cpu_baseline: BASELINE.md §3 — the reference's CPU-capable dense path torch SDPA (ref: svg/models/wan/attention.py:279-281,
           svg/models/hyvideo_orig/modules/attenion.py:488-491) on all host cores, bf16, ONE head at the full sequence length
           (median of 3), or the longest sequence that fits the time bound; plus flex_attention eager on the CPU with the
@@ -69,7 +69,7 @@ def allowed_pairs_hy(V: int, ctx: int, L: int, tf: int) -> int:
     return band + 2 * V * L + L * L + (ctx - L) ** 2
 
 
-BAND_KERNELS = {0: "band_attn_w4_kernel<bf16,128>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
+BAND_KERNELS = {0: "band_attn_pp2_kernel<bf16,128>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
                 1: "band_attn_kernel<bf16,128,4>"}
 
 
@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 3), "
+    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 2 at D = 128), "
                     "1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per SIMD")
     ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 QK^T / PV (svg_band_attention_fp8: quantise + "

@@ -105,11 +105,13 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = default (currently 3).  All schedules produce the same result up to rounding.
+/* variant: 0 = default (2 for D = 128, 3 for D = 64; launches that count completions always 2).  All schedules produce the same
+ * result up to rounding.
  *   1 = lock-step, 4 waves x 32 query rows, 128-row q-tiles, two workgroups per CU (register-staged K/V) — the plain schedule
  *       the test-suite uses as the in-library reference;
  *   2 = two-phase ping-pong, 8 waves x 32 rows: the two waves that share a SIMD alternate a matrix phase (PV of tile t + QK^T
- *       of tile t+1, operands streamed from LDS) and a vector phase (softmax, LDS-DMA requests), always in opposite phases;
+ *       of tile t+1, operands streamed from LDS) and a vector phase (softmax without a running maximum, LDS-DMA requests), always
+ *       in opposite phases;
  *   3 = one wave per SIMD, 4 waves x 64 rows, O and Q in the AGPR half of the register file, softmax / LDS reads / LDS-DMA
  *       requests software-pipelined into the gaps between the wave's own MFMAs, one barrier per tile (csrc/attn_w4.h).
  * Any other value: SVG_ERR_BAD_ARG.  Builds with -DSVG_ABLATIONS (diagnostics, never the product library) additionally accept

@@ -366,10 +366,14 @@ thread_local int g_last_hip_error = 0;
 
 // Schedules of svg_band_attention (`variant`, include/svg_attn.h).
 enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3 };
-constexpr int kBandDefault = kBandW4;
+// default (variant 0): the two-phase ping-pong body with the max-free softmax for head_dim 128 (round 2, late: 33.7 vs 35.0 ms for the
+// one-wave-per-SIMD body on the same box), the one-wave-per-SIMD body for head_dim 64 (2.60 vs 2.67 ms, 13.6 vs 13.8 ms on the
+// CogVideoX geometries).  Launches that count completions (svg_band_attention_notify*) always run the two-phase body: their targets
+// (svg_band_attention_notify_target / _layout) do not know the head size.
+static inline int band_default(int D, bool counting) { return (D == 128 || counting) ? kBandPingPong : kBandW4; }
 
 int band_waves_per_tile(int variant) {
-    const int v = variant == kBandAuto ? kBandDefault : variant;
+    const int v = variant == kBandAuto ? kBandPingPong : variant;
     return v == kBandW4 ? 4 : (v == kBandPingPong ? 8 : -1);   // waves that report per 256-row q-tile; -1: no counters
 }
 
@@ -464,7 +468,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         variant = kBandPingPong;
         g_trace_is_w4 = false;
     }
-    if (variant == kBandAuto) variant = kBandDefault;
+    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \

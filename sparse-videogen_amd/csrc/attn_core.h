@@ -533,7 +533,16 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     constexpr int KS = D / 16;
     constexpr int DB = D / 32;
     constexpr bool kDma = true;             // true: LDS-DMA staging (4 stages); false: register staging (3 stages), measured 15 % slower
-    constexpr int kShadow = (D == 64) ? 2 : P::kShadow128;              // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
+#ifndef SVG_PP2_MAXFREE
+#define SVG_PP2_MAXFREE 1
+#endif
+    // Softmax without a running maximum (the scheme of attn_body_w4 / attn_body_f8): probabilities are taken relative to a per-row
+    // reference that only changes on the exact path; the common path checks that a lane's 32 probabilities of the tile sum to
+    // <= 2^11 (one compare instead of the 16-instruction maximum chain + lane exchange) and otherwise takes the exact path — row
+    // maximum, new reference, O and l rescaled, probabilities recomputed — BEFORE any PV MFMA has consumed them, which is why all
+    // four 16-key steps are computed in the vector phase then (kShadow = 0).
+    constexpr bool kMaxFree = SVG_PP2_MAXFREE != 0 && ABL == 0;
+    constexpr int kShadow = kMaxFree ? 0 : (D == 64) ? 2 : P::kShadow128;   // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
     constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;
@@ -792,40 +801,82 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                     }
             }
         }
-        float mx = sc[0][0];
-        if constexpr (ABL != 2) {
-            // (asm: fmaxf() makes hipcc canonicalise every input with a v_max_f32 x, x — 8 extra issue slots per tile)
+        if constexpr (kMaxFree) {
+            // (m_use persists: the reference the accumulators are scaled to; 0 until a row has seen a finite score)
+            if constexpr (kSpread && NP > 1) {
+                if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
+            }
+            psum = 0.f;
 #pragma unroll
-            for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
-            const unsigned u = __builtin_bit_cast(unsigned, vmax2(mx, sc[1][15]));
-            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
-            mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
-        }
-        m_use = (m_run == -INFINITY) ? 0.f : m_run;
-        if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
-            const float m_new = fmaxf(m_run, mx);
-            m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
-            m_run = m_new;
-            l_run *= alpha;
+            for (int kk = 0; kk < 4; ++kk) {
+                probs(kk, 0, 8);
+                asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
+            }
+            if (!__all(psum <= 2048.f)) {      // exact path (rare; also a non-finite sum)
+                float mx = sc[0][0];
 #pragma unroll
-            for (int db = 0; db < DB; ++db)
+                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+                const unsigned u = __builtin_bit_cast(unsigned, vmax2(mx, sc[1][15]));
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
+                mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
+                const float m_prev = m_use;
+                const float m_new = fmaxf(m_run, mx);
+                m_use = (m_new == -INFINITY) ? m_prev : m_new;
+                float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+                asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
+                m_run = m_new;
+                l_run *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {   // in place (tied operands), see attn_body_pp
-                    float x = acc_o[db][r];
-                    asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(alpha));
-                    acc_o[db][r] = x;
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {   // in place (tied operands)
+                        float x = acc_o[db][r];
+                        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(alpha));
+                        acc_o[db][r] = x;
+                    }
+                psum = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    probs(kk, 0, 8);
+                    asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));
                 }
-        }
-        if constexpr (kSpread && NP > 1) {
-            if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
-        }
-        psum = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 4 - kShadow; ++kk) {
-            probs(kk, 0, 8);
-            asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
+            }
+        } else {
+            float mx = sc[0][0];
+            if constexpr (ABL != 2) {
+                // (asm: fmaxf() makes hipcc canonicalise every input with a v_max_f32 x, x — 8 extra issue slots per tile)
+    #pragma unroll
+                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+                const unsigned u = __builtin_bit_cast(unsigned, vmax2(mx, sc[1][15]));
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
+                mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
+            }
+            m_use = (m_run == -INFINITY) ? 0.f : m_run;
+            if (ABL != 2 && !__all(mx <= m_run + kDefer)) {     // some row's maximum moved by more than 2^kDefer: exact update
+                const float m_new = fmaxf(m_run, mx);
+                m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
+                m_run = m_new;
+                l_run *= alpha;
+    #pragma unroll
+                for (int db = 0; db < DB; ++db)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {   // in place (tied operands), see attn_body_pp
+                        float x = acc_o[db][r];
+                        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(alpha));
+                        acc_o[db][r] = x;
+                    }
+            }
+            if constexpr (kSpread && NP > 1) {
+                if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
+            }
+            psum = 0.f;
+    #pragma unroll
+            for (int kk = 0; kk < 4 - kShadow; ++kk) {
+                probs(kk, 0, 8);
+                asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
+            }
         }
         if constexpr (kSpread) {
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
@@ -947,7 +998,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // ---------------- epilogue (same as attn_body) ----------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if constexpr (P::kPartialOut) {
-        P::store_partial(prm, ctx, row_in_wg, g, acc_o, m_run, l_tot);
+        // (max-free softmax: O and l are scaled to the reference m_use, not to the running maximum)
+        P::store_partial(prm, ctx, row_in_wg, g, acc_o, kMaxFree ? ((m_run == -INFINITY) ? -INFINITY : m_use) : m_run, l_tot);
         return;
     } else {
         const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
