@@ -8,10 +8,17 @@ namespace svg {
 template <typename T>
 using BandF8 = BandPolicy<T, 128, 8, false>;   // 8 waves x 32 rows: 256-row q-tiles (the tiling of the two-phase 16-bit kernel)
 
+#ifndef SVG_F8_PINGPONG
+#define SVG_F8_PINGPONG 1     // 1: two-phase ping-pong body (attn_body_f8pp), 0: lock-step body (attn_body_f8)
+#endif
 template <typename T>
 __global__ __launch_bounds__(512, 2) void band_attn_f8_kernel(typename BandF8<T>::Params prm, F8Args fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#if SVG_F8_PINGPONG
+    attn_body_f8pp<T, BandF8<T>>(prm, fa, smem);
+#else
     attn_body_f8<T, BandF8<T>>(prm, fa, smem);
+#endif
 }
 
 // ---- pre-pass 1: per-head absolute maxima of q, k, v (float bits of non-negative values order like unsigned integers) ----
@@ -225,14 +232,15 @@ static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, 
     auto kern = band_attn_f8_kernel<T>;
     static thread_local bool configured = false;   // (a cache of hipFuncSetAttribute, not per-call state)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_f8_lds_bytes<D>());
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_f8_lds_bytes<D, 8, 4>());
         if (e != hipSuccess) {
             g_last_hip_error = (int)e;
             return SVG_ERR_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nqt * BH), dim3(512), attn_f8_lds_bytes<D>(), st, p, fa);
+    constexpr int kLds = attn_f8_lds_bytes<D, 8, 4>();
+    hipLaunchKernelGGL(kern, dim3(p.nqt * BH), dim3(512), kLds, st, p, fa);
     return launch_status();
 }
 

@@ -44,9 +44,9 @@ __device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, kF8Scale127, 0, kF8Scale127);
 }
 
-template <int D, int NW = 8>
+template <int D, int NW = 8, int NS = 2>
 constexpr int attn_f8_lds_bytes() {
-    constexpr int stages = 2 * (2 * kBN * D);            // two stages of [K image | V^T image], one byte per element
+    constexpr int stages = NS * (2 * kBN * D);           // NS stages of [K image | V^T image], one byte per element
     constexpr int epi = NW * 32 * (D * 2 + 8);           // epilogue staging of the output rows (16-bit)
     return stages > epi ? stages : epi;
 }
@@ -269,6 +269,280 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
     P::notify(prm, ctx);
 }
 
+
+// =====================================================================================================================
+// Two-phase ping-pong form of the fp8 band body: the schedule of attn_body_pp2 (attn_core.h) on e4m3 operands.  Per tile every wave
+// runs ONE matrix phase — O^T += V(t)^T P(t)^T (4 MFMAs), S(t+1)^T = K(t+1) Q^T (4 MFMAs), operands streamed from LDS ahead of
+// their MFMA — and ONE vector phase — mask, softmax numerators without a running maximum, LDS-DMA request of a later tile, DMA
+// wait; waves 4..7 run one phase behind waves 0..3 (two barriers per tile), so a SIMD always pairs the matrix phase of one wave
+// with the vector phase of the other, and `s_setprio 1` lets the matrix phase win the issue arbitration.  In the lock-step body
+// (attn_body_f8) both waves of a SIMD are in the same part of the tile at the same time: they stall on their MFMAs together, then
+// share the VALU.
+//   slot         2t      2t+1    2t+2     2t+3
+//   waves 0-3    M(t)    N(t)    M(t+1)   N(t+1)          M(t) reads V(t-1) and K(t)
+//   waves 4-7    N(t-1)  M(t)    N(t)     M(t+1)
+// LDS: four stages of [K image 8 KiB | V^T image 8 KiB]; K / V^T arrive by LDS-DMA (one 1-KiB piece of each per wave and tile:
+// 8 key rows / 16 d rows, the XOR swizzle of the images applied to the per-lane SOURCE address); tile w is requested in N(w - 2)
+// (leading waves) / N(w - 3) (lagging waves), and every wave waits at the end of a vector phase for what it requested in the
+// previous one.  Inputs are those of attn_body_f8 (pre-pass images in logical token order: nothing is gathered).
+// =====================================================================================================================
+template <typename T, typename P>
+__device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, const F8Args& fa, char* smem) {
+    using E = Elt<T>;
+    constexpr int D = 128, DB = D / 32, KS = D / 64, NW = 8, NS = 4;
+    constexpr int kKBytes = kBN * D, kStage = 2 * kBN * D;
+    static_assert(P::kRowBlocks == 1 && P::BM == 256 && P::kIntervalMask, "fp8 two-phase body: 8 waves x 32 rows, interval masks");
+
+    typename P::Ctx ctx;
+    if (!P::init(prm, ctx, nullptr)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id(), g = lane >> 5, ql = lane & 31;
+    const bool lagging = wave >= NW / 2;
+    const int nT = ctx.nT;
+    const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.head * fa.S_pad * D;
+    const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.head * fa.S_pad * D;
+    const uint8_t* __restrict__ vt8 = fa.vt8 + (size_t)ctx.head * fa.S_pad * D;
+    const float inv_qk = fa.scales[2 * ctx.head], inv_v = fa.scales[2 * ctx.head + 1];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    // ---- DMA: wave w brings K rows 8 w .. 8 w + 7 and V^T rows 16 w .. 16 w + 15 of every tile ----
+    const int kr = 8 * wave + (lane >> 3);                                         // key row of this lane's K chunk
+    const unsigned k_src = (unsigned)(kr * D + (((lane & 7) ^ ((kr >> 1) & 7)) << 4));   // chunk that belongs at slot lane & 7
+    const int vd = 16 * wave + (lane >> 2);                                        // d row of this lane's V^T chunk
+    const unsigned v_src = (unsigned)(vd * 64 + (((lane & 3) ^ ((vd >> 2) & 3)) << 4));
+    const unsigned lds_k = lds0 + (unsigned)(wave * 1024), lds_v = lds0 + (unsigned)(kKBytes + wave * 1024);
+    typename P::TileCur rc;          // tile whose images are requested next
+    P::tile_cur_init(ctx, rc);
+    auto dma_issue = [&](int t) {    // request tile t (t < nT; its first key is in the cursor) into stage t % NS
+        const unsigned k0 = (unsigned)rc.k0;
+        const unsigned st = (unsigned)((t % NS) * kStage);
+        lds_dma16(lds_k + st, k0 * (unsigned)D + k_src, k8);
+        lds_dma16(lds_v + st, (k0 >> 6) * (unsigned)(kBN * D) + v_src, vt8);
+    };
+    const int dist = lagging ? 3 : 2;     // tile u + dist is requested in N(u)
+    for (int t = 0; t < dist; ++t) {
+        if (t < nT) dma_issue(t);
+        P::tile_cur_next(ctx, rc);
+    }
+
+    // ---- Q fragments, masks, accumulators ----
+    const int row_in_wg = wave * 32 + ql;
+    const int q_log = P::q_logical(ctx, row_in_wg);
+    const bool q_exists = P::q_phys(prm, ctx, row_in_wg) >= 0;
+    i32x8 qf[KS];
+    {
+        const uint8_t* qrow = q8 + (size_t)(q_exists ? q_log : 0) * D + g * 32;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x8*)(qrow + ks * 64);
+    }
+    int m_a0 = 0, m_b0 = 0;
+    unsigned m_alen = 0, m_blen = 0;
+    P::row_intervals(prm, ctx, q_log, m_a0, m_alen, m_b0, m_blen);
+    const int ksw = (ql >> 1) & 7, vsw = (ql >> 2) & 3;
+    const int k_lane = ql * 128, v_lane = kKBytes + ql * 64;
+    float l_run = 0.f;
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+    const float c_log2 = prm.scale_log2 * inv_qk;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_barrier();
+    if (lagging) pp_barrier();      // waves 4..7 run one phase behind
+
+    const bool idle = !P::wave_active(ctx, wave * 32);
+    // request half of a vector phase: tile t + dist, then wait for the pieces of the previous request
+    auto stage_request = [&](int t) {
+        const bool more = t + dist < nT;
+        if (more) dma_issue(t + dist);
+        P::tile_cur_next(ctx, rc);
+        if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (idle) {      // a wave without query rows keeps the barrier / staging protocol and computes nothing
+        for (int t = 0; t < nT; ++t) {
+            pp_barrier();
+            stage_request(t);
+            pp_barrier();
+        }
+        pp_barrier();
+        if (!lagging) pp_barrier();
+        P::notify(prm, ctx);
+        return;
+    }
+
+    f32x16 sc[2];          // S(t) until the vector phase has turned it into pf, then S(t + 1) accumulates here
+    i32x8 pf;              // probabilities of tile t (e4m3, slot order of the file header)
+    constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
+    float m_ref = -INFINITY, m_off = -kPShift, psum = 0.f;
+    typename P::TileCur vc;          // tile of the next vector phase
+    P::tile_cur_init(ctx, vc);
+
+    auto kfrag = [&](const char* st, int i) -> i32x8 {     // QK operand i: step i >> 1, key block i & 1
+        const char* rowp = st + k_lane + (i & 1) * (32 * 128);
+        const int c0 = 4 * (i >> 1) + 2 * g;
+        const u32x4 lo = *(const u32x4*)(rowp + ((c0 ^ ksw) << 4));
+        const u32x4 hi = *(const u32x4*)(rowp + (((c0 + 1) ^ ksw) << 4));
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    auto vfrag = [&](const char* st, int db) -> i32x8 {
+        const char* rowp = st + v_lane + db * (32 * 64);
+        const u32x4 lo = *(const u32x4*)(rowp + (((2 * g) ^ vsw) << 4));
+        const u32x4 hi = *(const u32x4*)(rowp + (((2 * g + 1) ^ vsw) << 4));
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    auto probs = [&](float off) {
+        psum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) {
+            float p4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * w8 + i;
+                p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e >> 4][e & 15], c_log2, -off));
+                psum += p4[i];
+            }
+            const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+            pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
+        }
+    };
+    // vector phase of tile t on sc
+    auto vector_phase = [&](int t) {
+        const int tk0 = vc.k0;
+        P::tile_cur_next(ctx, vc);
+        const int cls = P::fast_full(ctx, tk0) ? (int)TILE_FULL : P::classify(prm, ctx, tk0, wave * 32);
+        if (cls != TILE_FULL) {
+            const bool part = (cls == TILE_PARTIAL);      // a tile this wave does not need at all is processed fully masked
+            int ka = tk0 + 4 * g - m_a0, kb_ = tk0 + 4 * g - m_b0;
+            asm volatile("" : "+v"(ka), "+v"(kb_));       // opaque: keeps LICM from hoisting the per-element terms out of the loop
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * b + (r & 3) + 8 * (r >> 2);
+                    const bool ok = ((unsigned)(ka + key) < m_alen) | ((unsigned)(kb_ + key) < m_blen);
+                    sc[b][r] = (part & ok) ? sc[b][r] : -INFINITY;
+                }
+        }
+        probs(m_off);
+        if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+            float mx = sc[0][0];
+#pragma unroll
+            for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+            mx = vmax2(mx, sc[1][15]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_prev = m_off + kPShift;
+            const float m_new = fmaxf(m_ref, mx * c_log2);
+            const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+            m_ref = m_new;
+            m_off = m_use - kPShift;
+            probs(m_off);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+        }
+        l_run += psum;
+        asm volatile("" : "+v"(pf), "+v"(l_run));      // stays in this phase
+        stage_request(t);
+    };
+    // matrix phase of tile t: PV(t), then S(t + 1); operand i + 2 is read from LDS in front of MFMA i (sched_barrier pins the order)
+    auto matrix_phase = [&](int t, auto has_next_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
+        constexpr int NALL = has_next ? 8 : 4, kPF = 2;
+        const char* stv = smem + (t % NS) * kStage;
+        const char* stk = smem + ((t + 1) % NS) * kStage;
+        auto fetch = [&](int i) -> i32x8 { return i < 4 ? vfrag(stv, i) : kfrag(stk, i - 4); };
+        i32x8 ring[kPF + 1];
+#pragma unroll
+        for (int i = 0; i < kPF; ++i) ring[i] = fetch(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NALL; ++i) {
+            if (i + kPF < NALL) ring[(i + kPF) % (kPF + 1)] = fetch(i + kPF);
+            if (i < 4) {
+                acc_o[i] = mfma_f8(ring[i % (kPF + 1)], pf, acc_o[i]);
+            } else {
+                const int j = i - 4, ks = j >> 1, b = j & 1;
+                if (ks == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    sc[b] = mfma_f8(ring[i % (kPF + 1)], qf[0], z);
+                } else {
+                    sc[b] = mfma_f8(ring[i % (kPF + 1)], qf[ks], sc[b]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (has_next) asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    };
+
+    // ---- M(0): only S(0) ----
+    if (nT > 0) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i & 1] = mfma_f8(kfrag(smem, i), qf[i >> 1], sc[i & 1]);
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+    }
+    auto tile = [&](int t, auto has_next_c) {
+        pp_barrier();
+        vector_phase(t);
+        pp_barrier();
+        __builtin_amdgcn_s_setprio(1);     // the matrix phase wins the issue arbitration against the partner's vector phase
+        matrix_phase(t, has_next_c);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    {   // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc keep two register sets for O)
+        int t = 0;
+        for (; t + 1 < nT; ++t) tile(t, std::true_type{});
+        if (nT > 0) tile(nT - 1, std::false_type{});
+    }
+    // the leading waves wait until the lagging waves have read V of the last tile: the epilogue reuses the stages
+    pp_barrier();
+    if (!lagging) pp_barrier();
+
+    // ---------------- epilogue: as attn_body_f8 ----------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    constexpr int kEpiStride = D * 2 + 8;
+    char* erow = smem + (size_t)(wave * 32) * kEpiStride;
+    {
+        const float inv = l_tot > 0.f ? inv_v / l_tot : 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                typename E::v4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = E::from_float(acc_o[db][rq * 4 + j] * inv);
+                const int d0 = 32 * db + 8 * rq + 4 * g;
+                *(typename E::v4*)(erow + ql * kEpiStride + d0 * 2) = o4;
+            }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    T* __restrict__ ob = P::o_base(prm, ctx);
+    constexpr int kLanesPerRow = D * 2 / 8, kRowsPerPass = 64 / kLanesPerRow, kPasses = 32 / kRowsPerPass;
+    const int sub = lane / kLanesPerRow, colb = (lane - sub * kLanesPerRow) * 8;
+    int ephys[kPasses];
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) ephys[i] = P::q_phys(prm, ctx, wave * 32 + i * kRowsPerPass + sub);
+#pragma unroll
+    for (int i = 0; i < kPasses; ++i) {
+        const int rr = i * kRowsPerPass + sub;
+        const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
+        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+    }
+    P::notify(prm, ctx);
+}
 
 // =====================================================================================================================
 // Gathering form of the fp8 body (SVG2 variable-block attention, BASELINE.json configs[4] as named): q, k, v stay in their
