@@ -74,16 +74,26 @@ template <typename T>
 __global__ __launch_bounds__(256) void f8_quantize_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                           uint8_t* __restrict__ q8, uint8_t* __restrict__ k8, uint8_t* __restrict__ vt8,
                                                           const unsigned* __restrict__ amax, float* __restrict__ scales, int S, int S_pad,
-                                                          const int64_t* __restrict__ head_flag, int vid0, int F, int P, int V) {
+                                                          const int64_t* __restrict__ head_flag, int vid0, int F, int P, int V,
+                                                          float scale_log2) {
     constexpr int D = 128;
     __shared__ __attribute__((aligned(16))) T vs[kBN][D + 8];   // V tile, rows padded by 16 B (column reads hit different banks)
     const int head = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const bool perm = head_flag != nullptr && head_flag[head] != 0;
     const float aq = __uint_as_float(amax[3 * head]), ak = __uint_as_float(amax[3 * head + 1]), av = __uint_as_float(amax[3 * head + 2]);
-    const float sq = aq > 0.f ? kF8Max / aq : 1.f, sk = ak > 0.f ? kF8Max / ak : 1.f, sv = av > 0.f ? kF8Max / av : 1.f;
+    const float sk = ak > 0.f ? kF8Max / ak : 1.f, sv = av > 0.f ? kF8Max / av : 1.f;
+    // q carries the whole softmax scale: q8 = q * (scale_log2 / sk) * 2^-e, with the power of two e chosen so that the head's largest
+    // |q8| lands in (224, 448] — then sum(k8 q8) * 2^e IS the exponent argument scale_log2 * q.k, and 2^e is an E8M0 block scale of the
+    // MFMA (two-phase body) or one multiply (lock-step body): no per-element scale-and-shift on the VALU
+    const float mq_ideal = scale_log2 / sk;
+    int e = aq > 0.f ? (int)ceilf(log2f(aq * mq_ideal / kF8Max)) : 0;
+    e = max(-120, min(120, e));
+    const float sq = mq_ideal * exp2f((float)-e);
     if (tile == 0 && tid == 0) {
-        scales[2 * head] = 1.f / (sq * sk);
-        scales[2 * head + 1] = 1.f / sv;
+        scales[4 * head] = exp2f((float)e);
+        scales[4 * head + 1] = 1.f / sv;
+        scales[4 * head + 2] = __int_as_float((127 + e) * 0x01010101);
+        scales[4 * head + 3] = 0.f;
     }
     const size_t hb = (size_t)head * S * D;
     const size_t ob = (size_t)head * S_pad * D;
@@ -202,7 +212,7 @@ int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, i
 
 static size_t f8_ws_bytes(int BH, int S) {
     const size_t S_pad = (size_t)(S + kBN - 1) / kBN * kBN;
-    return 3 * (size_t)BH * S_pad * 128 + (size_t)BH * (3 * sizeof(unsigned) + 2 * sizeof(float)) + 256;
+    return 3 * (size_t)BH * S_pad * 128 + (size_t)BH * (3 * sizeof(unsigned) + 4 * sizeof(float)) + 256;
 }
 
 // what = 1: pre-pass only, 2: attention on a workspace the pre-pass has filled (same BH, S, perm), 3: both
@@ -224,7 +234,7 @@ static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, 
     hipLaunchKernelGGL(f8_quantize_kernel<T>, dim3(S_pad / kBN, BH), dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v, q8, k8, vt8,
                        amax, scales, S, S_pad, has_perm ? perm->head_perm_flag : nullptr, has_perm ? perm->vid0 : 0,
                        has_perm ? perm->num_frame : 1, has_perm ? perm->frame_size : 1,
-                       has_perm ? perm->num_frame * perm->frame_size : 0);
+                       has_perm ? perm->num_frame * perm->frame_size : 0, sm_scale * 1.4426950408889634f);
     }
     if (!(what & 2)) return launch_status();
     const typename Pol::Params p = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);

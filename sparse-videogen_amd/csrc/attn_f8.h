@@ -9,7 +9,8 @@
 //   vt8    : [BH, S_pad / 64, D, 64] e4m3 — V^T per 64-key tile; inside a tile the key of byte position 32 g + 16 b + 4 j + i of a
 //            row is 32 b + 8 j + 4 g + i, which is exactly the order in which the S^T accumulators of lane half g hold their
 //            probabilities (see below): the P operand needs no data movement at all.
-//   scales : [BH, 2] float: 1 / (sq * sk) (folded into the softmax scale) and 1 / sv (folded into the final 1 / l)
+//   scales : [BH, 4] float: 2^e, 1 / sv, the E8M0 scale word (127 + e) * 0x01010101, 0 — q8 carries the softmax scale:
+//            sum(k8 q8) * 2^e = scale_log2 * q.k, the exponent argument itself; 1 / sv is folded into the final 1 / l
 //
 // Operand layouts.  For the 32x32x64 f8f6f4 MFMA a lane supplies row / column (lane & 31) and 32 of the 64 contraction slots
 // (lane >> 5 selects which half) as 32 bytes; which d (or key) sits in which slot is irrelevant as long as A and B agree:
@@ -34,7 +35,7 @@ struct F8Args {
     const uint8_t* q8;
     const uint8_t* k8;
     const uint8_t* vt8;
-    const float* scales;   // [BH, 2]
+    const float* scales;   // [BH, 4]
     int S_pad;             // rows of q8 / k8 per head (multiple of 64)
 };
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
     const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.head * fa.S_pad * D;
     const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.head * fa.S_pad * D;
     const uint8_t* __restrict__ vt8 = fa.vt8 + (size_t)ctx.head * fa.S_pad * D;   // (S_pad / 64) tiles of 64 * D bytes
-    const float inv_qk = fa.scales[2 * ctx.head], inv_v = fa.scales[2 * ctx.head + 1];
+    const float two_e = fa.scales[4 * ctx.head], inv_v = fa.scales[4 * ctx.head + 1];
 
     // ---- Q fragments (B operand of S^T): rows are in logical order in q8; a row that does not exist reads row 0 (never stored) ----
     const int row_in_wg = wave * 32 + ql;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
 
-    const float c_log2 = prm.scale_log2 * inv_qk;
+    const float c_log2 = two_e;      // (q8 carries the softmax scale up to this power of two)
     const int nT = ctx.nT;
 
     // S^T of one tile: 4 MFMAs (2 key blocks x 2 contraction steps of 64)
@@ -301,7 +302,8 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.head * fa.S_pad * D;
     const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.head * fa.S_pad * D;
     const uint8_t* __restrict__ vt8 = fa.vt8 + (size_t)ctx.head * fa.S_pad * D;
-    const float inv_qk = fa.scales[2 * ctx.head], inv_v = fa.scales[2 * ctx.head + 1];
+    const float inv_v = fa.scales[4 * ctx.head + 1];
+    const int q_scale = __float_as_int(fa.scales[4 * ctx.head + 2]);     // E8M0 block scale of the Q operand: 2^e in every byte
     const unsigned lds0 = (unsigned)(size_t)smem;
 
     // ---- DMA: wave w brings K rows 8 w .. 8 w + 7 and V^T rows 16 w .. 16 w + 15 of every tile ----
@@ -345,7 +347,11 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-    const float c_log2 = prm.scale_log2 * inv_qk;
+    // S^T accumulators start at -m_off (16 registers, rewritten on the exact path only) and the Q operand's block scale is 2^e, so
+    // what the MFMAs deliver is the exponent argument itself: x = scale_log2 q.k - m_off.  No per-element scale-and-shift.
+    auto mfma_qk = [&](i32x8 a, i32x8 b, f32x16 c) -> f32x16 {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, kF8Scale127, 0, q_scale);
+    };
 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
@@ -378,6 +384,9 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     i32x8 pf;              // probabilities of tile t (e4m3, slot order of the file header)
     constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
     float m_ref = -INFINITY, m_off = -kPShift, psum = 0.f;
+    f32x16 cneg;           // -m_off in every register: the C operand of the first QK MFMA of a tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
     typename P::TileCur vc;          // tile of the next vector phase
     P::tile_cur_init(ctx, vc);
 
@@ -394,7 +403,8 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
         const u32x4 hi = *(const u32x4*)(rowp + (((2 * g + 1) ^ vsw) << 4));
         return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
-    auto probs = [&](float off) {
+    // probabilities from the exponent arguments in sc (+ delta on the exact path, where the reference has just moved)
+    auto probs = [&](auto shifted_c, float delta) {
         psum = 0.f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) {
@@ -402,7 +412,8 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = 4 * w8 + i;
-                p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e >> 4][e & 15], c_log2, -off));
+                if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15] + delta);
+                else p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
                 psum += p4[i];
             }
             const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
@@ -427,20 +438,24 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                     sc[b][r] = (part & ok) ? sc[b][r] : -INFINITY;
                 }
         }
-        probs(m_off);
+        probs(std::false_type{}, 0.f);
         if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
             float mx = sc[0][0];
 #pragma unroll
             for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
             mx = vmax2(mx, sc[1][15]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // (sc holds x = scaled score - m_off: the row maximum of the scaled scores is mx + m_off)
             const float m_prev = m_off + kPShift;
-            const float m_new = fmaxf(m_ref, mx * c_log2);
+            const float m_new = fmaxf(m_ref, mx + m_off);
             const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
             const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+            const float delta = m_prev - m_use;       // new exponent argument = x + (m_off_old - m_off_new)
             m_ref = m_new;
             m_off = m_use - kPShift;
-            probs(m_off);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -m_off;
+            probs(std::true_type{}, delta);
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
@@ -469,14 +484,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 acc_o[i] = mfma_f8(ring[i % (kPF + 1)], pf, acc_o[i]);
             } else {
                 const int j = i - 4, ks = j >> 1, b = j & 1;
-                if (ks == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    sc[b] = mfma_f8(ring[i % (kPF + 1)], qf[0], z);
-                } else {
-                    sc[b] = mfma_f8(ring[i % (kPF + 1)], qf[ks], sc[b]);
-                }
+                sc[b] = mfma_qk(ring[i % (kPF + 1)], qf[ks], ks == 0 ? cneg : sc[b]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -486,11 +494,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     // ---- M(0): only S(0) ----
     if (nT > 0) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[b][r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sc[i & 1] = mfma_f8(kfrag(smem, i), qf[i >> 1], sc[i & 1]);
+        for (int i = 0; i < 4; ++i) sc[i & 1] = mfma_qk(kfrag(smem, i), qf[i >> 1], i < 2 ? cneg : sc[i & 1]);
         asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
     }
     auto tile = [&](int t, auto has_next_c) {

@@ -32,6 +32,21 @@ def dequant(x):
     return (x.float() * s).to(torch.float8_e4m3fn).float() / s
 
 
+def dequant_q(q, k):
+    """q as the SVG1 pre-pass quantises it: it carries the softmax scale, q8 = q * (scale_log2 / sk) * 2^-e with the power of two e
+    that puts the head's largest |q8| into (224, 448] (csrc/attention_f8.hip: f8_quantize_kernel)"""
+    import math
+
+    D = q.shape[-1]
+    scale_log2 = (1.0 / math.sqrt(D)) * 1.4426950408889634
+    aq = q.float().abs().amax(dim=(-2, -1), keepdim=True).clamp(min=1e-30)
+    sk = 448.0 / k.float().abs().amax(dim=(-2, -1), keepdim=True).clamp(min=1e-30)
+    ideal = scale_log2 / sk
+    e = torch.ceil(torch.log2(aq * ideal / 448.0))
+    mq = ideal * torch.exp2(-e)
+    return (q.float() * mq).to(torch.float8_e4m3fn).float() / mq
+
+
 def _case(model, F_, P_, ctx, L, mul):
     V = F_ * P_
     if model == "hy":
@@ -55,7 +70,7 @@ def test_fp8_band_attention_vs_oracle(nat, model, dtype):
     o = nat.band_attention_fp8(q.cuda(), k.cuda(), v.cuda(), nat.BandMask(**prm)).float().cpu()
     o16 = nat.band_attention(q.cuda(), k.cuda(), v.cuda(), nat.BandMask(**prm)).float().cpu()
     ref = O.masked_attention(q, k, v, mask)
-    ref_dq = O.masked_attention(dequant(q), dequant(k), dequant(v), mask)
+    ref_dq = O.masked_attention(dequant_q(q, k), dequant(k), dequant(v), mask)
     e_ref, e_dq, e_16 = rel_l2(o, ref), rel_l2(o, ref_dq), rel_l2(o, o16)
     print(f"[fp8 {model} {dtype}] rel L2 vs fp32 oracle {e_ref:.4f}, vs oracle on dequantised inputs {e_dq:.4f}, vs 16-bit kernel {e_16:.4f}; "
           f"max abs {float((o - ref).abs().max()):.4f} (output rms {float(ref.pow(2).mean().sqrt()):.4f})")
