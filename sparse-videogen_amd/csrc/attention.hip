@@ -760,7 +760,7 @@ extern "C" int svg_varblock_attention_fp8(const void* q, const void* k, const vo
     hipStream_t st = (hipStream_t)stream;
     const size_t plan = (svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq) + 255) & ~(size_t)255;
     F8GArgs fa;
-    int rc = f8g_quantize(q, k, v, Hq, Hkv, Sq, Skv, dtype, (char*)workspace + plan, &fa, st);
+    int rc = f8g_quantize(q, k, v, Hq, Hkv, Sq, Skv, dtype, sm_scale, (char*)workspace + plan, &fa, st);
     if (rc != SVG_OK) return rc;
     if (dtype == SVG_DTYPE_BF16)
         return run_varblock<__bf16, 128, -9>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,

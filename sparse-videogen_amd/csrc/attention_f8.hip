@@ -158,13 +158,27 @@ __global__ __launch_bounds__(256) void f8_amax1_kernel(const T* __restrict__ x, 
     if ((threadIdx.x & 63) == 0) atomicMax(amax + head, __float_as_uint(m));
 }
 
+// mode 0: x * 448 / amax(head), inv = amax / 448.  mode 1 (q of the gathering body): q carries the softmax scale like in the SVG1
+// pre-pass — q8 = q * (scale_log2 / sk) * 2^-e with sk the scale of the kv head this q head reads and e the power of two that puts
+// the head's largest |q8| into (224, 448]; inv receives the E8M0 scale word (127 + e) * 0x01010101 as float bits.
 template <typename T>
 __global__ __launch_bounds__(256) void f8_quantize1_kernel(const T* __restrict__ x, uint8_t* __restrict__ y, const unsigned* __restrict__ amax,
-                                                           float* __restrict__ inv, int inv_stride, size_t per_head) {
+                                                           float* __restrict__ inv, int inv_stride, size_t per_head, int mode,
+                                                           const unsigned* __restrict__ amax_k, int group, float scale_log2) {
     const int head = blockIdx.y;
     const float a = __uint_as_float(amax[head]);
-    const float sc = a > 0.f ? kF8Max / a : 1.f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) inv[(size_t)head * inv_stride] = 1.f / sc;
+    float sc = a > 0.f ? kF8Max / a : 1.f;
+    float inv_val = 1.f / sc;
+    if (mode == 1) {
+        const float ak = __uint_as_float(amax_k[head / group]);
+        const float sk = ak > 0.f ? kF8Max / ak : 1.f;
+        const float ideal = scale_log2 / sk;
+        int e = a > 0.f ? (int)ceilf(log2f(a * ideal / kF8Max)) : 0;
+        e = max(-120, min(120, e));
+        sc = ideal * exp2f((float)-e);
+        inv_val = __int_as_float((127 + e) * 0x01010101);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv[(size_t)head * inv_stride] = inv_val;
     using V8 = typename Elt<T>::v8;
     const V8* x8 = (const V8*)(x + head * per_head);
     u32x2* y8 = (u32x2*)(y + head * per_head);
@@ -182,8 +196,8 @@ size_t f8g_ws_bytes(int Hq, int Hkv, int Sq, int Skv) {
 // quantise q [Hq, Sq, 128], k, v [Hkv, Skv, 128] into `ws` and fill `fa` (declared in band_policy.h; the kernel that consumes it
 // lives in attention.hip next to the variable-block policy)
 template <typename T>
-static int f8g_quantize_t(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, void* ws, F8GArgs* fa,
-                          hipStream_t st) {
+static int f8g_quantize_t(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, float sm_scale, void* ws,
+                          F8GArgs* fa, hipStream_t st) {
     constexpr int D = 128;
     uint8_t* q8 = (uint8_t*)ws;
     uint8_t* k8 = q8 + (size_t)Hq * Sq * D;
@@ -196,17 +210,20 @@ static int f8g_quantize_t(const void* q, const void* k, const void* v, int Hq, i
     hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hq), dim3(256), 0, st, (const T*)q, amax, phq);
     hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hkv), dim3(256), 0, st, (const T*)k, amax + Hq, phk);
     hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hkv), dim3(256), 0, st, (const T*)v, amax + Hq + Hkv, phk);
-    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hq), dim3(256), 0, st, (const T*)q, q8, amax, q_inv, 1, phq);
-    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)k, k8, amax + Hq, kv_inv, 2, phk);
-    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)v, v8, amax + Hq + Hkv, kv_inv + 1, 2, phk);
+    const unsigned* no_k = nullptr;
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hq), dim3(256), 0, st, (const T*)q, q8, amax, q_inv, 1, phq, 1,
+                       (const unsigned*)(amax + Hq), Hq / Hkv, sm_scale * 1.4426950408889634f);
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)k, k8, amax + Hq, kv_inv, 2, phk, 0, no_k, 1, 0.f);
+    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)v, v8, amax + Hq + Hkv, kv_inv + 1, 2, phk, 0, no_k,
+                       1, 0.f);
     fa->q8 = q8, fa->k8 = k8, fa->v8 = v8, fa->q_inv = q_inv, fa->kv_inv = kv_inv;
     return launch_status();
 }
 
-int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, void* ws, F8GArgs* fa,
-                 hipStream_t st) {
-    if (dtype == SVG_DTYPE_BF16) return f8g_quantize_t<__bf16>(q, k, v, Hq, Hkv, Sq, Skv, ws, fa, st);
-    if (dtype == SVG_DTYPE_F16) return f8g_quantize_t<_Float16>(q, k, v, Hq, Hkv, Sq, Skv, ws, fa, st);
+int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws,
+                 F8GArgs* fa, hipStream_t st) {
+    if (dtype == SVG_DTYPE_BF16) return f8g_quantize_t<__bf16>(q, k, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
+    if (dtype == SVG_DTYPE_F16) return f8g_quantize_t<_Float16>(q, k, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
     return SVG_ERR_UNSUPPORTED;
 }
 

@@ -561,8 +561,8 @@ struct F8GArgs {
     const uint8_t* q8;     // [Hq, Sq, D]
     const uint8_t* k8;     // [Hkv, Skv, D]
     const uint8_t* v8;     // [Hkv, Skv, D]
-    const float* q_inv;    // [Hq]   amax / 448
-    const float* kv_inv;   // [Hkv, 2]: k, v
+    const float* q_inv;    // [Hq]   E8M0 scale word of the q head, (127 + e) * 0x01010101, as float bits (q carries the softmax scale)
+    const float* kv_inv;   // [Hkv, 2]: amax / 448 of k, v
 };
 
 // chunk c (16 B) of V row `row` inside the row-major V image ([64][128] bytes): the XOR keeps the transpose reads conflict-free
@@ -582,7 +582,8 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
     const uint8_t* __restrict__ q8 = fa.q8 + (size_t)ctx.hq * prm.Sq * D;
     const uint8_t* __restrict__ k8 = fa.k8 + (size_t)ctx.hkv * prm.Skv * D;
     const uint8_t* __restrict__ v8 = fa.v8 + (size_t)ctx.hkv * prm.Skv * D;
-    const float inv_qk = fa.q_inv[ctx.hq] * fa.kv_inv[2 * ctx.hkv], inv_v = fa.kv_inv[2 * ctx.hkv + 1];
+    const float inv_v = fa.kv_inv[2 * ctx.hkv + 1];
+    const int q_scale = __float_as_int(fa.q_inv[ctx.hq]);     // E8M0 block scale of the Q operand (q carries the softmax scale)
 
     const int row_in_wg = wave * 32 + ql;
     i32x8 qf[KS];
@@ -644,7 +645,11 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
-    const float c_log2 = prm.scale_log2 * inv_qk;
+    // (as in attn_body_f8pp: the S^T accumulators start at -m_off and the Q operand's block scale is 2^e, so the MFMAs deliver the
+    //  exponent argument x = scale_log2 q.k - m_off itself)
+    auto mfma_qk = [&](i32x8 a, i32x8 b, f32x16 c) -> f32x16 {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, kF8Scale127, 0, q_scale);
+    };
 
     resolve(0);
     if (nT > 0) {
@@ -658,6 +663,9 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
 
     constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
     float m_ref = -INFINITY, m_off = -kPShift;
+    f32x16 cneg;           // -m_off in every register
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -666,10 +674,6 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
         if (cls != TILE_SKIP) {
             f32x16 s_cur[2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_cur[b][r] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -677,7 +681,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                     const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
                     const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
                     const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                    s_cur[b] = mfma_f8(kf, qf[ks], s_cur[b]);
+                    s_cur[b] = mfma_qk(kf, qf[ks], ks == 0 ? cneg : s_cur[b]);
                 }
             if (cls == TILE_PARTIAL) {
                 asm volatile("; element-wise mask of a partial tile" ::: "memory");
@@ -691,7 +695,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
             }
             i32x8 pf;
             float psum;
-            auto probs = [&](float off) {
+            auto probs = [&](auto shifted_c, float delta) {
                 psum = 0.f;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) {
@@ -699,14 +703,15 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int e = 4 * w8 + i;
-                        p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e >> 4][e & 15], c_log2, -off));
+                        if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15] + delta);
+                        else p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]);
                         psum += p4[i];
                     }
                     const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
                     pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
                 }
             };
-            probs(m_off);
+            probs(std::false_type{}, 0.f);
             if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
                 float mx = s_cur[0][0];
 #pragma unroll
@@ -715,12 +720,15 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_prev = m_off + kPShift;
-                const float m_new = fmaxf(m_ref, mx * c_log2);
+                const float m_new = fmaxf(m_ref, mx + m_off);      // (s_cur holds x = scaled score - m_off)
                 const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
+                const float delta = m_prev - m_use;
                 m_ref = m_new;
                 m_off = m_use - kPShift;
-                probs(m_off);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cneg[r] = -m_off;
+                probs(std::true_type{}, delta);
                 l_run *= alpha;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)

@@ -438,8 +438,8 @@ inline typename Pol::Params make_band_params(const void* q, const void* k, const
 // fp8 gathering body (attn_f8.h): quantiser in attention_f8.hip, kernel next to the variable-block policy in attention.hip
 struct F8GArgs;
 size_t f8g_ws_bytes(int Hq, int Hkv, int Sq, int Skv);
-int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, void* ws, F8GArgs* fa,
-                 hipStream_t st);
+int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws,
+                 F8GArgs* fa, hipStream_t st);
 
 // 4 waves x 64 rows, one wave per SIMD (attn_body_w4, attention_w4.hip)
 int run_band_w4(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,
