@@ -276,7 +276,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
 // runs ONE matrix phase — O^T += V(t)^T P(t)^T (4 MFMAs), S(t+1)^T = K(t+1) Q^T (4 MFMAs), operands streamed from LDS ahead of
 // their MFMA — and ONE vector phase — mask, softmax numerators without a running maximum, LDS-DMA request of a later tile, DMA
 // wait; waves 4..7 run one phase behind waves 0..3 (two barriers per tile), so a SIMD always pairs the matrix phase of one wave
-// with the vector phase of the other, and `s_setprio 1` lets the matrix phase win the issue arbitration.  In the lock-step body
+// with the vector phase of the other.  In the lock-step body
 // (attn_body_f8) both waves of a SIMD are in the same part of the tile at the same time: they stall on their MFMAs together, then
 // share the VALU.
 //   slot         2t      2t+1    2t+2     2t+3
@@ -469,7 +469,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     // matrix phase of tile t: PV(t), then S(t + 1); operand i + 2 is read from LDS in front of MFMA i (sched_barrier pins the order)
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
-        constexpr int NALL = has_next ? 8 : 4, kPF = 2;
+        constexpr int NALL = has_next ? 8 : 4, kPF = 1;     // (operands one MFMA ahead: 22.6 ms; two: 23.0; three: 23.5 — same box)
         const char* stv = smem + (t % NS) * kStage;
         const char* stk = smem + ((t + 1) % NS) * kStage;
         auto fetch = [&](int i) -> i32x8 { return i < 4 ? vfrag(stv, i) : kfrag(stk, i - 4); };
@@ -501,9 +501,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
         pp_barrier();
         vector_phase(t);
         pp_barrier();
-        __builtin_amdgcn_s_setprio(1);     // the matrix phase wins the issue arbitration against the partner's vector phase
-        matrix_phase(t, has_next_c);
-        __builtin_amdgcn_s_setprio(0);
+        matrix_phase(t, has_next_c);       // (no s_setprio around it, unlike attn_body_pp2: with 8 MFMAs per phase it costs 1.5 %)
     };
     {   // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc keep two register sets for O)
         int t = 0;
