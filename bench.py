@@ -80,7 +80,7 @@ def _pmc_traffic(workload: str, kernel: str):
     `traffic_source`; (null, null) otherwise."""
     if workload != "hy720p":
         return None, None
-    for p in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+    for p in sorted((ROOT / "profiles").glob("r*_pmc_traffic*.json"), reverse=True):
         try:
             d = json.loads(p.read_text())
             if d.get("kernel", "band_attn_pp2_kernel<bf16,128>").split("<")[0] == kernel.split("<")[0]:
