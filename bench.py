@@ -90,7 +90,7 @@ def _pmc_traffic(workload: str, kernel: str):
     return None, None
 
 
-def cpu_baseline(H: int, D: int, S: int, budget_s: float = 24.0):
+def cpu_baseline(H: int, D: int, S: int, budget_s: float = 36.0):
     """BASELINE.md §3.  Dense leg: torch SDPA bf16 on all host cores, ONE head at the full sequence length S, median of 3 — if
     a probe at S/8 predicts more than budget_s for that, the longest power-of-two fraction of S that fits is timed instead and
     `sample` says so.  Sparse leg: flex_attention, eager, on the CPU with the reference's Hunyuan mask_mod (the reference's sparse
