@@ -594,26 +594,26 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
     const int q_log = P::q_logical(ctx, row_in_wg);
 
     // staging: thread = (row kr, chunk kc) of the tile, for K and V alike (the same gathered row)
-    int srow[NCH], scol[NCH], k_dst[NCH], v_dst[NCH], nphys[NCH];
-    typename P::KvCursor cur[NCH];
+    // a thread stages NCH chunks of ONE key row (chunks c0, c0 + 8 / NCH, ...): one cursor, one index load per thread and tile
+    constexpr int kTPR = 8 / NCH;                  // threads per row
+    const int srow = tid / kTPR, c0 = tid % kTPR;
+    int scol[NCH], k_dst[NCH], v_dst[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int id = tid + i * NT;
-        srow[i] = id >> 3, scol[i] = (id & 7) * 16;
-        k_dst[i] = f8_k_off(srow[i], id & 7), v_dst[i] = kKBytes + f8_vrow_off(srow[i], id & 7);
-        P::kv_cursor_init(prm, ctx, cur[i], srow[i]);
-        nphys[i] = 0;
+        const int c = c0 + i * kTPR;
+        scol[i] = c * 16;
+        k_dst[i] = f8_k_off(srow, c), v_dst[i] = kKBytes + f8_vrow_off(srow, c);
     }
+    typename P::KvCursor cur;
+    P::kv_cursor_init(prm, ctx, cur, srow);
+    int nphys = 0;
     u32x4 kreg[NCH], vreg[NCH];
     const int nT = ctx.nT;
-    auto resolve = [&](int t) {   // a global index load per row: one tile ahead of the data loads
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) nphys[i] = (t < nT) ? P::kv_phys(prm, ctx, cur[i], t, srow[i]) : 0;
-    };
+    auto resolve = [&](int t) { nphys = (t < nT) ? P::kv_phys(prm, ctx, cur, t, srow) : 0; };   // a global index load: one tile ahead
     auto issue = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const size_t off = (size_t)nphys[i] * D + scol[i];
+            const size_t off = (size_t)nphys * D + scol[i];
             kreg[i] = *(const u32x4*)(k8 + off);
             vreg[i] = *(const u32x4*)(v8 + off);
         }
