@@ -487,6 +487,7 @@ def main():
                                 head_perm_flag=best[:, :2].contiguous(), vid0=0, num_frame=F_, frame_size=P_).float()
         df = o[:, :2].float() - ob
         out["fp8"]["rel_l2_vs_bf16_kernel_this_workload"] = round((df.norm() / ob.norm()).item(), 5)
+        out["fp8"]["psnr_db_vs_bf16_kernel_this_workload"] = round((20.0 * torch.log10(ob.abs().max() / df.pow(2).mean().sqrt())).item(), 2)
         del ob, df
 
     if world == 1 and not fp8 and a.workload == "hy720p" and D == 128:
@@ -513,6 +514,8 @@ def main():
                 "kernel_frac_of_5pflops_fp8": round(flops_call / ((tot - pre) * 1e-3) / 1e12 / PEAK_FP8_TFLOPS, 4),
                 "speedup_vs_bf16_kernel": round(attn_ms / tot, 3),
                 "rel_l2_vs_bf16_kernel": round(((o[:, :2].float() - ref16.float()).norm() / ref16.float().norm()).item(), 5),
+                "psnr_db_vs_bf16_kernel": round((20.0 * torch.log10(ref16.float().abs().max()
+                                                                     / (o[:, :2].float() - ref16.float()).pow(2).mean().sqrt())).item(), 2),
             }
             del ref16
         except Exception as e:  # noqa: BLE001

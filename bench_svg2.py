@@ -125,6 +125,7 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         out["attention_dtype"] = "fp8 e4m3 (q, k, v per-head scales; quantise pass inside `attention` time)"
         out["attention_frac_of_5pflops_fp8"] = round(out["attention_tflops_algorithmic"] / 5000.0, 4)
         out["rel_l2_vs_16bit_kernel"] = round((d.norm() / o16.float().norm()).item(), 5)
+        out["psnr_db_vs_16bit_kernel"] = round((20.0 * torch.log10(o16.float().abs().max() / d.pow(2).mean().sqrt())).item(), 2)
     return out
 
 
