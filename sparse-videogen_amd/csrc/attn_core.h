@@ -715,6 +715,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     f32x16 sc[2];          // scores: S(t) until the PV steps of the matrix phase have consumed it, then S(t+1) accumulates here
     V8 pf[2][2];           // probabilities: [32-key block][16-key half]
     float m_use = 0.f, psum = 0.f;
+    float psum_thr = -1.f;        // (wave-uniform) max-free softmax: 2048 once every row of the wave has a finite reference; until
+                                  // then no sum passes the check and every tile takes the exact path
 
     auto kfrag = [&](const char* st, int b, int ks) -> V8 {
         return *(const V8*)(st + ((ks & 1) ? k_lane1 : k_lane0) + (ks >> 1) * (kBN * 64) + b * (32 * 64));
@@ -812,7 +814,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 probs(kk, 0, 8);
                 asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));   // stays in this phase
             }
-            if (!__all(psum <= 2048.f)) {      // exact path (rare; also a non-finite sum)
+            // (a wave takes the exact path until every one of its rows has a reference taken from a finite score — a row maximum
+            //  instead of the pseudo-reference 0, under which scores below -126 in log2 units would underflow to nothing)
+            if (!__all(psum <= psum_thr)) {      // exact path (rare; also a non-finite sum)
                 float mx = sc[0][0];
 #pragma unroll
                 for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
@@ -825,6 +829,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
                 asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
                 m_run = m_new;
+                psum_thr = __all(m_new != -INFINITY) ? 2048.f : -1.f;
                 l_run *= alpha;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)

@@ -157,6 +157,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
     // recomputed.  On random data that is the first tile of a q-tile and a handful of later ones.
     constexpr float kPShift = 4.f, kPSumMax = 448.f;
     float m_ref = -INFINITY, m_off = -kPShift;    // m_off = (m_ref finite ? m_ref : 0) - kPShift
+    float psum_thr = -1.f;   // kPSumMax once every row of the wave has a finite reference (see attn_body_pp2)
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -197,7 +198,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
                 }
             };
             probs(m_off);
-            if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+            if (__any(!(psum <= psum_thr))) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
                 float mx = s_cur[0][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
@@ -211,6 +212,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
                 const float m_use = (m_new == -INFINITY) ? m_prev : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
                 m_ref = m_new;
+                psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
                 m_off = m_use - kPShift;
                 probs(m_off);
                 l_run *= alpha;
@@ -384,6 +386,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     i32x8 pf;              // probabilities of tile t (e4m3, slot order of the file header)
     constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
     float m_ref = -INFINITY, m_off = -kPShift, psum = 0.f;
+    float psum_thr = -1.f;   // kPSumMax once every row of the wave has a finite reference (see attn_body_pp2)
     f32x16 cneg;           // -m_off in every register: the C operand of the first QK MFMA of a tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
@@ -439,7 +442,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 }
         }
         probs(std::false_type{}, 0.f);
-        if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+        if (__any(!(psum <= psum_thr))) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
             float mx = sc[0][0];
 #pragma unroll
             for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
@@ -452,6 +455,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
             const float delta = m_prev - m_use;       // new exponent argument = x + (m_off_old - m_off_new)
             m_ref = m_new;
+            psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
             m_off = m_use - kPShift;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cneg[r] = -m_off;
@@ -661,6 +665,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
 
     constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
     float m_ref = -INFINITY, m_off = -kPShift;
+    float psum_thr = -1.f;   // kPSumMax once every row of the wave has a finite reference (see attn_body_pp2)
     f32x16 cneg;           // -m_off in every register
 #pragma unroll
     for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
@@ -710,7 +715,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 }
             };
             probs(std::false_type{}, 0.f);
-            if (__any(!(psum <= kPSumMax))) {      // exact path (rare)
+            if (__any(!(psum <= psum_thr))) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
                 float mx = s_cur[0][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
@@ -723,6 +728,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 const float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
                 const float delta = m_prev - m_use;
                 m_ref = m_new;
+                psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
                 m_off = m_use - kPShift;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cneg[r] = -m_off;

@@ -186,6 +186,28 @@ def test_band_attention_bf16_ulp(nat, model, variant):
     assert w1 >= 0.998 and err.max() <= 2.5
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_band_attention_all_scores_very_negative(nat, variant):
+    """Every score of every row far below zero (q . k / sqrt(D) ~ -150: 2^-216 against a reference of 0 underflows fp32): the
+    schedules that keep no running maximum must anchor their reference on the first tile's row maximum, not on the pseudo-reference
+    they start with.  Dense and banded."""
+    torch.manual_seed(13)
+    S, D, H = 1200, 128, 2
+    u = torch.randn(D)
+    u = u / u.norm()
+    a = (150.0 * D ** 0.5) ** 0.5
+    q = (-a * u + 0.5 * torch.randn(1, H, S, D)).to(torch.bfloat16)
+    k = (a * u + 0.5 * torch.randn(1, H, S, D)).to(torch.bfloat16)
+    v = torch.randn(1, H, S, D).to(torch.bfloat16)
+    assert (q.float() @ k.float().transpose(-1, -2)).max() / D ** 0.5 < -100
+    for prm in (O.dense_band_params(S), dict(real_len=S, band=200, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)):
+        o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), variant=variant)
+        ref = O.masked_attention(q, k, v, O.band_mask(S, **prm))
+        assert torch.isfinite(o.float()).all() and o.float().abs().max() > 0
+        # (scores of magnitude 150 carry the bf16 rounding of q and k times 150: the probabilities are only as good as that)
+        torch.testing.assert_close(o.float().cpu(), ref, atol=6e-2, rtol=6e-2)
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("D,dtype,variant", [(128, torch.bfloat16, 3), (64, torch.float16, 3), (128, torch.float16, 2), (64, torch.bfloat16, 2),
                                              (128, torch.bfloat16, 1)])
