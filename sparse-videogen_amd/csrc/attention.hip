@@ -75,15 +75,17 @@ struct VarblockPolicy {
     };
     struct Ctx {
         int hq, hkv, q0, q_end, nT, total;  // q rows [q0, q_end) in permuted coordinates; total = active keys
-        const int32_t* run_start;           // LDS: permuted start position of run j
-        const int32_t* run_pref;            // LDS: inclusive prefix of run lengths (run_pref[j] = end of run j in compact coords)
+        // LDS run list: .x = inclusive prefix of the run lengths (the end of run j in compact coordinates), .y = permuted start
+        // position of run j minus the compact position it starts at — one 8-byte read resolves a key: perm = pos + .y
+        const int2* run;
         const int32_t* qidx;
         const int32_t* kidx;
         int nruns;
     };
     struct KvCursor {
         int j;
-    };
+        int2 r, rn;   // run[j] and run[j + 1], kept across tiles: a lane crosses into the next run every other tile (mean run: 119
+    };            // keys) and then finds the entry in a register; the read that refills rn has until the next crossing to land
 
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char* plds) {
         int i, sub;
@@ -117,9 +119,8 @@ struct VarblockPolicy {
         c.kidx = p.kv_row_idx ? p.kv_row_idx + (size_t)c.hkv * p.Skv : nullptr;
 
         // ---- compact the active non-empty column blocks of row i into the LDS run list ----
-        int32_t* run_start = (int32_t*)plds;
-        int32_t* run_pref = run_start + p.kb_cap;
-        int32_t* wave_cnt = run_pref + p.kb_cap;      // [NW] counts, [NW] lengths
+        int2* run = (int2*)plds;
+        int32_t* wave_cnt = (int32_t*)(run + p.kb_cap + 2);  // [NW] counts, [NW] lengths
         const uint8_t* mrow = p.block_map + ((size_t)c.hkv * p.QB + i) * p.KB;
         const int32_t* koff = p.k_off + (size_t)c.hkv * (p.KB + 1);
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -145,16 +146,16 @@ struct VarblockPolicy {
             int wc = base_cnt, wl = base_len;
             for (int x = 0; x < wv; ++x) wc += wave_cnt[x], wl += wave_cnt[NW + x];
             if (flag) {
-                run_start[wc + icnt - 1] = st;
-                run_pref[wc + icnt - 1] = wl + ilen;
+                run[wc + icnt - 1] = make_int2(wl + ilen, st - (wl + ilen - len));
             }
             for (int x = 0; x < NW; ++x) base_cnt += wave_cnt[x], base_len += wave_cnt[NW + x];
         }
+        // two sentinels behind the last run: the cursor (kv_phys_at) reads one entry ahead and stops at them
+        if (tid < 2) run[base_cnt + tid] = make_int2(0x7fffffff, 0);
         __syncthreads();
         c.nruns = base_cnt;
         c.total = base_len;
-        c.run_start = run_start;
-        c.run_pref = run_pref;
+        c.run = run;
         c.nT = (c.total + kBN - 1) / kBN;
         return true;
     }
@@ -182,18 +183,25 @@ struct VarblockPolicy {
     static __device__ __forceinline__ void tile_cur_fix(const Ctx&, TileCur&) {}
     static constexpr bool kRowStep = false;   // rows come from the run list (kv_phys_at), resolved between the phases
     static __device__ __forceinline__ bool fast_full(const Ctx& c, int k0) { return k0 + kBN <= c.total; }
-    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx&, KvCursor& cu, int) { cu.j = 0; }
+    static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx& c, KvCursor& cu, int) {
+        cu.j = 0;
+        cu.r = c.run[0], cu.rn = c.run[1];   // (entries behind the last run are never used: a key behind the last run is clamped)
+    }
     static __device__ __forceinline__ int kv_phys(const Params& p, const Ctx& c, KvCursor& cu, int t, int row) {
         return kv_phys_at(p, c, cu, t * kBN, row);
     }
     static __device__ __forceinline__ int kv_phys_at(const Params&, const Ctx& c, KvCursor& cu, int k0, int row) {
-        const int pos = k0 + row;  // compact coordinate
-        if (pos >= c.total) return 0;   // masked by allowed(): reads row 0
+        // compact coordinate; keys behind the last one (ragged last tile; masked by allowed()) read the last key: no branch
+        const int pos = min(k0 + row, c.total - 1);
         int j = cu.j;
-        while (c.run_pref[j] <= pos) ++j;  // tiles advance monotonically: amortised O(1)
-        cu.j = j;
-        const int len_before = j > 0 ? c.run_pref[j - 1] : 0;
-        const int perm = c.run_start[j] + (pos - len_before);
+        int2 r = cu.r, rn = cu.rn;
+        while (r.x <= pos) {   // tiles advance monotonically: amortised O(1)
+            r = rn;
+            ++j;
+            rn = c.run[j + 1];
+        }
+        cu.j = j, cu.r = r, cu.rn = rn;
+        const int perm = pos + r.y;
         return c.kidx ? c.kidx[perm] : perm;
     }
     static __device__ __forceinline__ int classify(const Params&, const Ctx& c, int k0, int wrow0) {
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8_kernel(ty
     attn_body_f8g<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8_lds_bytes<128, kVbF8Waves>());
 }
 
-static inline int vb_policy_lds(int kb_cap) { return (2 * kb_cap + 32) * (int)sizeof(int32_t); }
+static inline int vb_policy_lds(int kb_cap) { return (2 * (kb_cap + 2) + 32) * (int)sizeof(int32_t); }
 
 // plan: exclusive prefix sums of q_sizes, k_sizes and of the per-block-row tile counts.  grid = (Hkv), block = 256
 __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __restrict__ q_sizes,
