@@ -58,7 +58,7 @@ def _compile(src: Path, force: bool, asm: bool, ablations: bool = False) -> tupl
     stamp = max(src.stat().st_mtime, _newest_header())
     if not force and obj.exists() and obj.stat().st_mtime >= stamp:
         return obj, ""
-    flags = list(FLAGS)
+    flags = list(FLAGS) + os.environ.get("SVG_EXTRA_HIPCC_FLAGS", "").split()   # (experiments: -DSVG_... switches of the kernels)
     if src.name in STRICT_FP:
         flags = [f for f in flags if f not in ("-ffast-math", "-fno-finite-math-only")] + ["-fno-fast-math", "-ffp-contract=off"]
     if ablations:
