@@ -199,11 +199,28 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict_
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int r = slot; r < cnt; r += SLOTS) {
-        const int row = sidx[r];
-        const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(xb + (size_t)row * D + li * 8);
+    // four rows of a slot in flight (index loads, then row loads); summed in the order a one-row loop sums them
+    int r = slot;
+    {
+#pragma clang fp reassociate(off)
+        using V8 = typename Elt<T>::v8;
+        for (; r + 3 * SLOTS < cnt; r += 4 * SLOTS) {
+            int row[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[j]);
+            for (int u = 0; u < 4; ++u) row[u] = sidx[r + u * SLOTS];
+            V8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const V8*)(xb + (size_t)row[u] * D + li * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[u][j]);
+        }
+        for (; r < cnt; r += SLOTS) {
+            const V8 v = *(const V8*)(xb + (size_t)sidx[r] * D + li * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[slot][li * 8 + j] = acc[j];
