@@ -164,3 +164,55 @@ def test_profile_predicates_equal_reference_masks(model, ctx, F_, P_):
         for q in rows:
             got = torch.tensor([prof_allowed(q, k, S, vid0, F_, P_, var) for k in range(S)])
             assert torch.equal(got, m[q] != 0), f"{model} variant coord={var[0]} row {q}"
+
+
+# ---- variable-block policy: run list and row cursor (csrc/attention.hip VarblockPolicy::init / kv_phys_at) ----
+def vb_run_list(map_row, k_off):
+    """host model of the LDS run list of one block-row: the active non-empty key blocks in ascending order as
+    (end in compact coordinates, permuted start - compact start) pairs, two sentinels behind the last run"""
+    runs, total = [], 0
+    for j, on in enumerate(map_row):
+        ln = k_off[j + 1] - k_off[j]
+        if on and ln > 0:
+            runs.append((total + ln, k_off[j] - total))
+            total += ln
+    return runs + [(0x7FFFFFFF, 0)] * 2, total
+
+
+def vb_walk(runs, total, row, n_tiles, BN=64):
+    """the cursor of one staging lane (key row `row` of every tile): current and next run in registers, the list is read only
+    when the lane crosses into the next run; keys behind the last one are clamped to it (they are masked in the softmax)"""
+    j, r, rn, reads, out = 0, runs[0], runs[1], 2, []
+    for t in range(n_tiles):
+        pos = min(t * BN + row, total - 1)
+        while r[0] <= pos:
+            r = rn
+            j += 1
+            rn = runs[j + 1]
+            reads += 1
+        out.append(pos + r[1])
+    return out, reads
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_varblock_run_cursor_model(seed):
+    """the cursor yields, for every tile and key row, the permuted position a brute-force expansion of the active blocks gives
+    (ragged clusters, empty clusters, single-key clusters, the ragged last tile), and never reads behind the sentinels"""
+    g = torch.Generator().manual_seed(seed)
+    KB = int(torch.randint(1, 40, (1,), generator=g))
+    sizes = torch.randint(0, 200, (KB,), generator=g)
+    sizes[torch.rand(KB, generator=g) < 0.2] = 0          # empty clusters
+    sizes[torch.rand(KB, generator=g) < 0.2] = 1          # single keys: several run crossings inside one tile
+    k_off = [0] + torch.cumsum(sizes, 0).tolist()
+    map_row = (torch.rand(KB, generator=g) < 0.5).tolist()
+    runs, total = vb_run_list(map_row, k_off)
+    flat = [p for j in range(KB) if map_row[j] for p in range(k_off[j], k_off[j + 1])]   # brute force: permuted position of every active key
+    assert total == len(flat) and len(runs) <= KB + 2
+    if total == 0:
+        return   # no tiles: the kernel never calls the cursor (nT == 0)
+    n_tiles = (total + 63) // 64
+    for row in (0, 1, 17, 63):
+        got, reads = vb_walk(runs, total, row, n_tiles)
+        want = [flat[min(t * 64 + row, total - 1)] for t in range(n_tiles)]
+        assert got == want
+        assert reads <= len(runs)   # every list entry is read at most once per lane
