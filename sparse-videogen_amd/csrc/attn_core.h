@@ -505,9 +505,12 @@ static __device__ unsigned long long g_wg_trace[kWgTraceMax * 6];
 // =====================================================================================================================
 // attn_body_pp2 — two-phase ping-pong: per tile every wave runs ONE matrix phase and ONE vector phase, and the two waves
 // of a SIMD are always in opposite phases (waves 4..7 run one phase behind waves 0..3; two barriers per tile).
-//     M(t+1)  O^T += V(t)^T P(t)^T  (16 MFMAs; the probabilities of keys 16..63 are computed in their shadow)
-//             S(t+1)^T = K(t+1) Q^T (16 MFMAs); operands stream from LDS just ahead of the MFMAs that consume them
-//     N(t+1)  mask, row maximum, (rare) rescale of O, probabilities of keys 0..15 of tile t+1; LDS-DMA requests; DMA wait
+//     M(t+1)  O^T += V(t)^T P(t)^T  (16 MFMAs), S(t+1)^T = K(t+1) Q^T (16 MFMAs); operands stream from LDS just ahead of the
+//             MFMAs that consume them
+//     N(t+1)  mask, all 64 probabilities of tile t+1 against the row's reference, the check of their sum and — rarely — the exact
+//             path (row maximum, new reference, rescale of O and l, probabilities again): kMaxFree, the shipped softmax;
+//             LDS-DMA requests; DMA wait.  (The earlier softmax — row maximum of every tile with a deferred rescale, probabilities
+//             of keys 16..63 in the shadow of the PV MFMAs — is kept behind SVG_PP2_MAXFREE=0 and for the timing ablations.)
 // In M the wave has the matrix pipe to itself (its partner is in N and issues no MFMA), in N it has the VALU to itself.
 // profiles/r01_ablation.md: in the lock-step body both waves of a SIMD sit in the same phase and the phases add up; the
 // four-cluster attn_body_pp separates them but pays four barriers per tile and serialises the LDS operand reads.
