@@ -130,7 +130,8 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
  *      block_map[h, i, j]; blocks are consecutive ranges of sizes q_sizes[h, :], k_sizes[h, :]; rows with no
  *      active key (and rows of empty blocks) give zeros.
  * q/o: [Hq, Sq, D], k/v: [Hkv, Skv, D] (Hq % Hkv == 0: GQA group shares map/sizes of its kv head).
- * block_map: device uint8/bool [Hkv, QB, KB]; q_sizes int32 [Hkv, QB]; k_sizes int32 [Hkv, KB].
+ * block_map: device uint8/bool [Hkv, QB, KB]; q_sizes int32 [Hkv, QB]; k_sizes int32 [Hkv, KB].  KB <= 4032 (the compacted key-block list of a
+ * block-row lives in LDS beside the K / V stages; more returns SVG_ERR_UNSUPPORTED).
  * Fused token permutation: q_row_idx (int32 [Hq, Sq]) / kv_row_idx (int32 [Hkv, Skv]) map a *permuted* position
  * to the physical row of q,o / k,v (the `sorted_indices` of permute_tensor_by_labels); NULL = tensors are
  * already permuted.  With both given the call equals permute(q,k,v) -> attention -> inverse_permute(o)

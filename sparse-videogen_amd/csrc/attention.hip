@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename Ba
 // (start, inclusive prefix of lengths); KV tiles are cut from the *concatenation* of the runs, so tiles are
 // always full except the last one — no per-cluster padding waste on the key side.
 // =====================================================================================================
-constexpr int kVbMaxKB = 4096;
+constexpr int kVbMaxKB = 4032;   // the run list of a block-row ((KB rounded up to 64) + 2 pairs of ints) has to fit beside the four 32 KB stages in 160 KB of LDS
 constexpr int kVbFull = 256;   // mixed tiling: full 256-row tiles go to the 8-wave kernel, the rest of a block-row to 128-row tiles
 
 template <typename T, int D, int NW>
