@@ -26,11 +26,50 @@ WORKLOADS = {  # H, D, F, P, ctx, prompt, QC, KC
 }
 
 
+def _pmc_traffic(workload, fp8):
+    """L2 <-> fabric bytes per launch of the attention kernel from the newest COMMITTED rocprofv3 PMC passes of this workload
+    (profiles/r*_pmc_traffic_svg2*.json, tools/gpu_pmc.sh + tools/pmc_traffic.py): collected in their own runs, labelled as such."""
+    if workload != "wan720p":
+        return None
+    tag = "svg2_fp8" if fp8 else "svg2"
+    for p in sorted((ROOT / "profiles").glob(f"r*_pmc_traffic_{tag}.json"), reverse=True):
+        try:
+            d = json.loads(p.read_text())
+            return {"traffic": float(d.get("traffic_bytes_per_launch", d.get("fetch_bytes_per_launch_x2_gfx950"))), "l2_hit_rate": d.get("l2_hit_rate"),
+                    "traffic_source": f"profiles/{p.name} (committed rocprofv3 --pmc passes, not collected in this run)"}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
 def clustered(H, N, D, modes, dev, gen, spread=0.35):
     centers = torch.randn(H, modes, D, device=dev, generator=gen) * 1.5
     lab = torch.randint(0, modes, (H, N), device=dev, generator=gen)
     x = torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + spread * torch.randn(H, N, D, device=dev, generator=gen)
     return x.to(torch.bfloat16)
+
+
+def spot_check(q, k, v, o, q_labels, k_labels, dmap, rows_per_head=8, tol=None):
+    """A perf number must not come from a wrong kernel: a handful of output rows per head recomputed in plain torch fp32 on the GPU
+    (softmax(q_r K^T / sqrt(D)) V over the keys j with map[label(r), label(j)] — the semantics of the reference's
+    dynamic_block_sparse_fwd_*, svg/kmeans_utils.py:902-995,1319-1392) and compared with what the kernel wrote.  Returns the worst
+    relative L2 distance over the heads; raises when it exceeds `tol`."""
+    H, S, D = q.shape
+    g = torch.Generator(device=q.device).manual_seed(5)
+    worst = 0.0
+    for h in range(H):
+        rows = torch.randint(0, S, (rows_per_head,), device=q.device, generator=g)
+        em = dmap[h][q_labels[h, rows]][:, k_labels[h]]                      # [rows, S]
+        s = (q[h, rows].float() @ k[h].float().T) * D ** -0.5
+        s = s.masked_fill(~em, float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        p = torch.where(em.any(dim=-1, keepdim=True), p, torch.zeros_like(p))
+        ref = p @ v[h].float()
+        e = ((o[h, rows].float() - ref).norm() / ref.norm().clamp(min=1e-20)).item()
+        worst = max(worst, e)
+    if tol is not None and not worst <= tol:
+        raise AssertionError(f"SVG2 attention spot rows differ from the torch fp32 statement: rel L2 {worst:.3e} > {tol}")
+    return worst
 
 
 def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False, fp8=False):
@@ -99,6 +138,14 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
             times["attention"].append(t[2].elapsed_time(t[3]))
             times["total"].append(t[0].elapsed_time(t[3]))
         dens = density_calculation(dmap, q_sizes, k_sizes)
+    # spot rows of the last timed output against a torch fp32 statement of the op (text rows: the two pseudo clusters)
+    qlab, klab = ql.view(H, V), kl.view(H, V)
+    if ctx:
+        tail_q = torch.cat([torch.full((L,), QC), torch.full((ctx - L,), QC + 1)]).to(qlab).expand(H, -1)
+        tail_k = torch.cat([torch.full((L,), KC), torch.full((ctx - L,), KC + 1)]).to(klab).expand(H, -1)
+        qlab, klab = torch.cat([qlab, tail_q], 1), torch.cat([klab, tail_k], 1)
+    spot = spot_check(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), o.view(H, S, D), qlab, klab, dmap.view(H, QB, KB),
+                      tol=0.15 if a.fp8 else 4e-3)
     ms = {k_: sum(v_) / len(v_) for k_, v_ in times.items()}
     pairs = (dmap.view(H, QB, KB).float() * q_sizes.view(H, QB, 1).float() * k_sizes.view(H, 1, KB).float()).sum().item()
     attn_flops = 4.0 * D * pairs
@@ -115,7 +162,13 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         "dense_equiv_tflop": round(dense_flops / 1e12, 2),
         "speedup_vs_dense_at_1000tflops": round((dense_flops / 1e15 * 1e3) / ms["total"], 2),
         "data": "synthetic (64-mode Gaussian mixture per head)",
+        "spot_rows_rel_l2_vs_torch_fp32": round(spot, 6),
+        "attention_frac_of_2500tflops_bf16": round(attn_flops / (ms["attention"] * 1e-3) / 1e12 / 2500.0, 4),
+        "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
     }
+    traffic = _pmc_traffic(a.workload, a.fp8)
+    if traffic:
+        out.update(traffic)
     if a.fp8:
         # e4m3 QK^T / PV (svg_varblock_attention_fp8: quantisation inside the call): distance to the 16-bit kernel on this workload
         o16 = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),

@@ -17,6 +17,13 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    import torch
+
+    if not torch.cuda.is_available():   # a plain `pytest tests` on a box without a GPU: the gpu-marked tests skip instead of failing
+        no_gpu = pytest.mark.skip(reason="needs a real MI355X (no GPU visible)")
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(no_gpu)
     if os.environ.get("SVG_FULL_GRID"):
         return
     skip = pytest.mark.skip(reason="full reference grid: set SVG_FULL_GRID=1 (see profiles/*_fullgrid.txt for the committed run)")
