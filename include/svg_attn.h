@@ -139,8 +139,12 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
  * variant: -1 = auto (what the Python layer passes), 0 = 128-row q tiles (4 waves, two workgroups per CU), 1 = 256-row q tiles
  * (8 waves, lock-step), 2 = mixed (full 256-row tiles on 8 waves, the rest of each block-row on 128-row tiles; two launches),
  * 3 = 256-row q tiles with the two-phase ping-pong body of svg_band_attention (waves without query rows idle), workgroups
- * launched longest-first inside every kv head (device-side counting sort on the active keys of the block-rows);
- * 4 = the same kernel in block-row order (A/B measurements); 5 = variant 3 recording the launch timeline (svg_debug_wg_trace).
+ * launched in similarity order inside every kv head: block-rows with (nearly) the same active key blocks are neighbours of a
+ * device-built nearest-neighbour chain, and consecutive workgroups go to the same XCD so that they meet in its L2
+ * (maps whose bitmap does not fit the chain kernel's 64 KiB of LDS — QB * (KB / 32 + 4) words — fall back to 6);
+ * 4 = the same kernel in block-row order, 6 = longest-first inside every kv head (device-side counting sort on the active keys of
+ * the block-rows; the default of round 2) — both for A/B measurements; 5 = variant 3 recording the launch timeline
+ * (svg_debug_wg_trace).
  * ---------------------------------------------------------------------------------------------- */
 size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq);
 int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
@@ -343,9 +347,12 @@ int svg_varblock_attention_fp8(const void* q, const void* k, const void* v, void
  * `n` counters have reached `target` — the all-gather of those heads goes behind it and runs while the launch is still working
  * on the next heads (no chunked launches: at N = 8 three launches of one head cost 5.7 ms, one launch of three heads 4.9 ms). */
 int32_t svg_band_attention_notify_target(int32_t S, const svg_band_mask_t* mask);
+/* done_words: the number of int32 words the caller allocated at `done_per_head` / `done` — the entry points cannot see the size
+ * of a device buffer, and the hidden per-head counters behind the segment counters made the requirement grow once (round 2): a
+ * buffer smaller than BH * (nseg + 1) words returns SVG_ERR_WORKSPACE instead of being written out of bounds. */
 int svg_band_attention_notify(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
-                              int32_t* done_per_head, void* stream);
+                              int32_t* done_per_head, int32_t done_words, void* stream);
 int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream);
 /* svg_wait_counters with a deadline: the one-wave kernel gives up `timeout_ms` after it started, stores 1 to timed_out[0] (int32
  * in device or pinned host memory, zeroed by the caller) and returns — a waiter of this kind cannot hang its stream whatever
@@ -364,7 +371,7 @@ int svg_wait_counters_deadline(const int32_t* counters, int32_t n, int32_t targe
 int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_mask_t* mask, int32_t nseg, int32_t* row_bounds, int32_t* targets);
 int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                   int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
-                                  int32_t* done, int32_t nseg, void* stream);
+                                  int32_t* done, int32_t done_words, int32_t nseg, void* stream);
 
 /* Diagnostics (not part of the reference's interface; -DSVG_ABLATIONS builds, otherwise SVG_ERR_UNSUPPORTED): cycle trace of
  * the two-phase attention schedule.  After a svg_band_attention call with variant 64 (bf16, D = 128) and a synchronised

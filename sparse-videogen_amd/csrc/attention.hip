@@ -370,6 +370,145 @@ __global__ __launch_bounds__(256) void varblock_scatter_kernel(const int32_t* __
         }
 }
 
+// Similarity order of the 256-row variable-block kernel (default since round 3).  The longest-first order above hands an XCD 32
+// unrelated block-rows of a head at a time: every workgroup streams its own quarter of the head's K / V through that XCD's 4 MiB
+// L2 (PMC, Wan 720p: hit rate 31 %, 117 GB per launch between L2 and the fabric for 3.1 GB of tensors).  Block-rows whose key
+// lists are (nearly) the same — q-clusters of the same neighbourhood of the data select the same k-clusters — read the same K / V
+// rows in the same order, so this kernel puts them next to each other and hands CONSECUTIVE workgroups to the SAME XCD:
+//   * one workgroup per kv head builds a nearest-neighbour chain over the block-rows (bitmap rows of the map in LDS, Jaccard
+//     similarity of the active key-block sets, start at the block-row with the most active key blocks; QB steps of one block-wide
+//     arg-max each);
+//   * the sub-tiles of a block-row and the q heads of a GQA group (same key list by construction) stay adjacent;
+//   * position p of the head-major chain order is mapped to dispatch id b so that, inside every window of 256 consecutive
+//     positions, XCD x (= b % 8, the hardware's round-robin) receives positions [32 x, 32 x + 32) — the remap of the band kernel.
+constexpr int kVbChainThreads = 512;
+static inline size_t vb_chain_lds(int QB, int KB) {
+    const int W = (KB + 31) / 32;
+    return ((size_t)QB * (W + 1) + 3 * (size_t)QB + 64) * sizeof(int32_t);
+}
+__global__ __launch_bounds__(kVbChainThreads) void varblock_chain_kernel(const uint8_t* __restrict__ block_map,
+                                                                         const int32_t* __restrict__ k_sizes,
+                                                                         const int32_t* __restrict__ tile_off, int32_t* __restrict__ order,
+                                                                         int Hkv, int QB, int KB, int group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = (KB + 31) / 32, WS = W + 1;   // (row stride W + 1 words: thread c reads word w of row c — conflict-free)
+    uint32_t* bits = (uint32_t*)smem;            // [QB][WS]
+    int32_t* pc = (int32_t*)(bits + (size_t)QB * WS);   // [QB] active key blocks of a block-row; -1 once it is in the chain
+    int32_t* chain = pc + QB;                    // [QB] block-row at chain position
+    int32_t* cnt = chain + QB;                   // [QB] workgroups of the block-row at chain position (then their exclusive prefix)
+    unsigned long long* red = (unsigned long long*)(cnt + QB);   // [8] per-wave arg-max
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t* toff = tile_off + (size_t)h * (QB + 1);
+    const int32_t* ks = k_sizes + (size_t)h * KB;
+    // ---- bitmap rows: bit j of row i = block (i, j) active and key block j not empty ----
+    for (int idx = tid; idx < QB * W; idx += kVbChainThreads) {
+        const int i = idx / W, w = idx - i * W;
+        const uint8_t* m = block_map + ((size_t)h * QB + i) * KB + w * 32;
+        uint32_t b = 0;
+        const int n = min(32, KB - w * 32);
+        for (int j = 0; j < n; ++j) b |= (m[j] && ks[w * 32 + j] > 0) ? (1u << j) : 0u;
+        bits[(size_t)i * WS + w] = b;
+    }
+    __syncthreads();
+    int n_live = 0;
+    for (int i = tid; i < QB; i += kVbChainThreads) {
+        int c = 0;
+        for (int w = 0; w < W; ++w) c += __popc(bits[(size_t)i * WS + w]);
+        const bool live = toff[i + 1] > toff[i];   // block-rows without query rows launch nothing
+        pc[i] = live ? c : -1;
+        n_live += live;
+    }
+    __syncthreads();
+    // ---- nearest-neighbour chain ----
+    auto block_argmax = [&](unsigned long long key) -> unsigned long long {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long t = __shfl_xor(key, o);
+            key = t > key ? t : key;
+        }
+        __syncthreads();   // (readers of the previous round are done)
+        if (lane == 0) red[wv] = key;
+        __syncthreads();
+        unsigned long long best = red[0];
+#pragma unroll
+        for (int x = 1; x < kVbChainThreads / 64; ++x) best = red[x] > best ? red[x] : best;
+        return best;
+    };
+    // start: the live block-row with the most active key blocks (ties: lowest index)
+    unsigned long long key = 0;
+    for (int i = tid; i < QB; i += kVbChainThreads)
+        if (pc[i] >= 0) {
+            const unsigned long long k2 = ((unsigned long long)(unsigned)(pc[i] + 1) << 32) | (unsigned)(0x7fffffff - i);
+            key = k2 > key ? k2 : key;
+        }
+    unsigned long long best = block_argmax(key);
+    int npos = 0;
+    while (best != 0) {
+        const int cur = 0x7fffffff - (int)(unsigned)(best & 0xffffffffu);
+        const int pcur = pc[cur];
+        __syncthreads();
+        if (tid == 0) {
+            chain[npos] = cur;
+            pc[cur] = -1;
+        }
+        ++npos;
+        __syncthreads();
+        key = 0;
+        for (int i = tid; i < QB; i += kVbChainThreads) {
+            const int pi = pc[i];
+            if (pi < 0) continue;
+            int inter = 0;
+            for (int w = 0; w < W; ++w) inter += __popc(bits[(size_t)i * WS + w] & bits[(size_t)cur * WS + w]);
+            const int uni = pcur + pi - inter;
+            const float jac = uni > 0 ? (float)inter / (float)uni : 1.f;
+            // (similarity in the high word — a non-negative float orders like its bits; +1 keeps 0 for "nothing left")
+            const unsigned long long k2 = ((unsigned long long)(__float_as_uint(jac) + 1u) << 32) | (unsigned)(0x7fffffff - i);
+            key = k2 > key ? k2 : key;
+        }
+        best = block_argmax(key);
+    }
+    // ---- workgroups per chain position, exclusive prefix, scatter with the XCD remap ----
+    for (int p = tid; p < npos; p += kVbChainThreads) {
+        const int i = chain[p];
+        cnt[p] = (toff[i + 1] - toff[i]) * group;
+    }
+    __syncthreads();
+    __shared__ int32_t s_base, s_total, s_head_total;
+    if (tid == 0) {
+        int run = 0;
+        for (int p = 0; p < npos; ++p) {   // (npos <= QB <= a few hundred: a serial scan is ~1 us)
+            const int t = cnt[p];
+            cnt[p] = run;
+            run += t;
+        }
+        int base = 0, total = 0;
+        for (int hh = 0; hh < Hkv; ++hh) {
+            const int t = tile_off[(size_t)hh * (QB + 1) + QB] * group;
+            if (hh < h) base += t;
+            total += t;
+        }
+        s_base = base, s_total = total, s_head_total = run;
+        if (h == 0) order[0] = total;
+    }
+    __syncthreads();
+    const int base = s_base, full = (s_total / (kNumXCD * 32)) * (kNumXCD * 32);
+    for (int p = tid; p < npos; p += kVbChainThreads) {
+        const int i = chain[p];
+        const int nsub = toff[i + 1] - toff[i];
+        int pos = base + cnt[p];
+        for (int g = 0; g < group; ++g)
+            for (int sub = 0; sub < nsub; ++sub, ++pos) {
+                int b = pos;
+                if (pos < full) {
+                    const int win = pos / (kNumXCD * 32), r = pos - win * (kNumXCD * 32);
+                    b = win * (kNumXCD * 32) + (r % 32) * kNumXCD + r / 32;
+                }
+                order[2 + 2 * b] = h * group + g;
+                order[3 + 2 * b] = (i << 16) | sub;
+            }
+    }
+}
+
 thread_local int g_last_hip_error = 0;
 
 // Schedules of svg_band_attention (`variant`, include/svg_attn.h).
@@ -533,16 +672,18 @@ extern "C" int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_ma
 
 extern "C" int svg_band_attention_notify(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                          int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
-                                         int32_t* done_per_head, void* stream) {
-    return svg_band_attention_notify_seg(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, done_per_head, 1, stream);
+                                         int32_t* done_per_head, int32_t done_words, void* stream) {
+    return svg_band_attention_notify_seg(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, done_per_head, done_words, 1, stream);
 }
 
 extern "C" int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                              int32_t dtype, float sm_scale, const svg_band_mask_t* mask,
-                                             const svg_perm_desc_t* perm, int32_t* done, int32_t nseg, void* stream) {
+                                             const svg_perm_desc_t* perm, int32_t* done, int32_t done_words, int32_t nseg,
+                                             void* stream) {
     if (!done || nseg <= 0) return SVG_ERR_BAD_ARG;
     const int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
     if (rc != SVG_OK) return rc;
+    if ((int64_t)done_words < (int64_t)BH * (nseg + 1)) return SVG_ERR_WORKSPACE;   // segment counters + one hidden counter per head
     BandOpts opts;
     opts.done = done, opts.done_nseg = nseg;
     return band_dispatch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, kBandAuto, opts, (hipStream_t)stream);
@@ -620,7 +761,7 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, bool longest_first = false) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
@@ -647,26 +788,24 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 int32_t* hist = work + (size_t)Hkv * QB;
                 const int nb = Hkv * kVbBuckets;
                 int32_t* order = hist + nb;
-                if (hipMemsetAsync(hist, 0, (size_t)nb * sizeof(int32_t), st) != hipSuccess) return SVG_ERR_LAUNCH;
-                hipLaunchKernelGGL(varblock_work_kernel, dim3((Hkv * QB + 3) / 4), dim3(256), 0, st, block_map, k_sizes, toff, work, hist,
-                                   Hkv, QB, KB, group);
-                hipLaunchKernelGGL(varblock_scan_kernel, dim3(1), dim3(256), 0, st, hist, order, nb);
-                hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, toff, work, hist, order, Hkv,
-                                   QB, group);
+                const size_t chain_lds = vb_chain_lds(QB, KB);
+                if (!longest_first && chain_lds <= 64 * 1024) {   // similarity order, consecutive workgroups on one XCD
+                    hipLaunchKernelGGL(varblock_chain_kernel, dim3(Hkv), dim3(kVbChainThreads), chain_lds, st, block_map, k_sizes, toff,
+                                       order, Hkv, QB, KB, group);
+                } else {   // longest-first inside every kv head (variant 6; also maps whose bitmap does not fit the chain kernel's LDS)
+                    if (hipMemsetAsync(hist, 0, (size_t)nb * sizeof(int32_t), st) != hipSuccess) return SVG_ERR_LAUNCH;
+                    hipLaunchKernelGGL(varblock_work_kernel, dim3((Hkv * QB + 3) / 4), dim3(256), 0, st, block_map, k_sizes, toff, work,
+                                       hist, Hkv, QB, KB, group);
+                    hipLaunchKernelGGL(varblock_scan_kernel, dim3(1), dim3(256), 0, st, hist, order, nb);
+                    hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, toff, work, hist, order,
+                                       Hkv, QB, group);
+                }
                 p.order = order;
                 if constexpr (NW == -9) {
                     if constexpr (D == 128) {
                         auto kern = varblock_attn_f8_kernel<T>;
                         const int lds = attn_f8_lds_bytes<128, kVbF8Waves>() + vb_policy_lds(p.kb_cap);
-                        static thread_local int configured = 0;   // (a cache of hipFuncSetAttribute, not per-call state)
-                        if (configured < lds) {
-                            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                            if (e != hipSuccess) {
-                                g_last_hip_error = (int)e;
-                                return SVG_ERR_LAUNCH;
-                            }
-                            configured = lds;
-                        }
+                        if (const int rc = configure_lds((const void*)kern, lds); rc != SVG_OK) return rc;
                         hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(kVbF8Waves * 64), lds, st, p, *f8);
                         return launch_status();
                     }
@@ -720,8 +859,8 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
-    const bool block_row_order = (variant == 4), trace = (variant == 5);
-#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st
+    const bool block_row_order = (variant == 4), trace = (variant == 5), longest_first = (variant == 6);
+#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, longest_first
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
@@ -733,7 +872,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
         if (variant >= 3) return run_varblock<T, 64, -8>(SVG_VB_ARGS);                           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
-    if (variant < -1 || variant > 5) return SVG_ERR_BAD_ARG;
+    if (variant < -1 || variant > 6) return SVG_ERR_BAD_ARG;
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;

@@ -257,15 +257,7 @@ static int run_f8(const void* q, const void* k, const void* v, void* o, int BH, 
     const typename Pol::Params p = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
     F8Args fa{q8, k8, vt8, scales, S_pad};
     auto kern = band_attn_f8_kernel<T>;
-    static thread_local bool configured = false;   // (a cache of hipFuncSetAttribute, not per-call state)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_f8_lds_bytes<D, 8, 4>());
-        if (e != hipSuccess) {
-            g_last_hip_error = (int)e;
-            return SVG_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    if (const int rc = configure_lds((const void*)kern, attn_f8_lds_bytes<D, 8, 4>()); rc != SVG_OK) return rc;
     constexpr int kLds = attn_f8_lds_bytes<D, 8, 4>();
     hipLaunchKernelGGL(kern, dim3(p.nqt * BH), dim3(512), kLds, st, p, fa);
     return launch_status();

@@ -65,15 +65,7 @@ static int run_w4_switch(const void* q, const void* k, const void* v, void* o, i
     const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
     const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
     auto kern = band_attn_w4_switch_kernel<T, D>;
-    static thread_local bool configured = false;   // (a cache of hipFuncSetAttribute, not per-call state)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, attn_w4_lds_bytes<D>());
-        if (e != hipSuccess) {
-            g_last_hip_error = (int)e;
-            return SVG_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    if (const int rc = configure_lds((const void*)kern, attn_w4_lds_bytes<D>()); rc != SVG_OK) return rc;
     hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(256), attn_w4_lds_bytes<D>(), st, a, b, flag);
     return launch_status();
 }

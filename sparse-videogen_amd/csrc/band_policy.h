@@ -368,20 +368,36 @@ struct BandPolicy {
     }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of `kernel` on the CURRENT device raised to at least `lds` bytes.  A cache of the
+// driver call, keyed by (device, kernel) and remembering the largest size configured so far: the variable-block kernels ask for
+// more LDS when KB grows, and a second GPU driven from the same thread needs its own attribute.
+inline int configure_lds(const void* kernel, int lds) {
+    struct Entry {
+        const void* kernel;
+        int device, lds;
+    };
+    static thread_local Entry table[64];
+    static thread_local int n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    Entry* e = nullptr;
+    for (int i = 0; i < n; ++i)
+        if (table[i].kernel == kernel && table[i].device == dev) e = &table[i];
+    if (e && e->lds >= lds) return SVG_OK;
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) {
+        g_last_hip_error = (int)err;
+        return SVG_ERR_LAUNCH;
+    }
+    if (e) e->lds = lds;
+    else if (n < 64) table[n++] = Entry{kernel, dev, lds};   // (a full table only costs the driver call again)
+    return SVG_OK;
+}
+
 template <typename K, typename Prm>
 inline int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds, hipStream_t st) {
-    static thread_local const void* configured[16];
-    static thread_local int nconf = 0;
-    bool seen = false;
-    for (int i = 0; i < nconf; ++i) seen |= (configured[i] == (const void*)kernel);
-    if (!seen) {
-        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            g_last_hip_error = (int)e;
-            return SVG_ERR_LAUNCH;
-        }
-        if (nconf < 16) configured[nconf++] = (const void*)kernel;
-    }
+    const int rc = configure_lds((const void*)kernel, lds);
+    if (rc != SVG_OK) return rc;
     hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, st, prm);
     return launch_status();
 }

@@ -106,7 +106,7 @@ SIGNATURES = {
                                      C.POINTER(PermDesc), _I32, _VP]),
     "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
-                                            C.POINTER(PermDesc), _VP, _VP]),
+                                            C.POINTER(PermDesc), _VP, _I32, _VP]),
     "svg_varblock_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "svg_varblock_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
                                              _VP, _VP, _VP, _SZ, _VP]),
@@ -117,7 +117,7 @@ SIGNATURES = {
     "svg_wait_counters_deadline": (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP]),
     "svg_band_attention_notify_layout": (_I32, [_I32, C.POINTER(BandMask), _I32, _VP, _VP]),
     "svg_band_attention_notify_seg": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
-                                                C.POINTER(PermDesc), _VP, _I32, _VP]),
+                                                C.POINTER(PermDesc), _VP, _I32, _I32, _VP]),
     "svg_band_attention_switch": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
     "svg_sample_mse_flagged": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
@@ -277,10 +277,10 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
     if done is not None:
         _dev(done)
-        assert done.dtype == torch.int32 and done.numel() == BH * (done_nseg + 1) and variant == 0
+        assert done.dtype == torch.int32 and done.is_contiguous() and variant == 0
         rc = lib.svg_band_attention_notify_seg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
                                                scale, C.byref(mask), C.byref(perm) if perm is not None else None, done.data_ptr(),
-                                               int(done_nseg), _stream())
+                                               int(done.numel()), int(done_nseg), _stream())   # too small: SVG_ERR_WORKSPACE
         _check(rc, "svg_band_attention_notify_seg")
         return o
     rc = lib.svg_band_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
@@ -316,7 +316,7 @@ def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: 
     if need == 0:
         raise RuntimeError(f"svg_band_attention_fp8: unsupported shape (D = {D}; only 128)")
     if workspace is None:
-        key = (BH, S, q.device)
+        key = (BH, S, q.device, _stream())   # (per stream: two calls of one shape on different streams must not share the buffer)
         workspace = _F8_WS.get(key)
         if workspace is None or workspace.numel() < need:
             workspace = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -361,6 +361,7 @@ def wait_counters(counters: torch.Tensor, target: int, timeout_ms: int = 0, time
     _dev(counters)
     assert counters.dtype == torch.int32 and counters.is_contiguous()
     if timeout_ms > 0:
+        assert timed_out is not None, "wait_counters(timeout_ms > 0) needs a `timed_out` flag tensor (int32 [1] on the GPU)"
         _dev(timed_out)
         assert timed_out.dtype == torch.int32 and timed_out.numel() >= 1
         _check(load().svg_wait_counters_deadline(counters.data_ptr(), counters.numel(), int(target), int(timeout_ms),
@@ -398,9 +399,12 @@ def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mas
 
 def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
                        k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
-                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1, fp8: bool = False) -> torch.Tensor:
+                       kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1, fp8: bool = False,
+                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB].
-    fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only)."""
+    fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only).
+    workspace: optional uint8 GPU tensor of svg_varblock_workspace_bytes(...) bytes for the 16-bit call (tests read the launch
+    order back from it; see varblock_launch_order)."""
     lib = load()
     _dev(q, k, v, block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
     Hq, Sq, D = q.shape
@@ -418,7 +422,7 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
         need = int(lib.svg_varblock_attention_fp8_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
         if need == 0:
             raise RuntimeError(f"svg_varblock_attention_fp8: unsupported shape (D = {D}; only 128)")
-        key = ("vb", Hq, Hkv, Sq, Skv, QB, KB, q.device)
+        key = ("vb", Hq, Hkv, Sq, Skv, QB, KB, q.device, _stream())
         ws = _F8_WS.get(key)
         if ws is None or ws.numel() < need:
             ws = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -427,13 +431,35 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
                                             _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), _stream())
         _check(rc, "svg_varblock_attention_fp8")
         return o
-    ws = torch.empty(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq), dtype=torch.uint8, device=q.device)
+    need = int(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq))
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device) if workspace is None else workspace
+    _dev(ws)
+    assert ws.dtype == torch.uint8 and ws.numel() >= need
     rc = lib.svg_varblock_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D,
                                     _dtype_code(q), scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(),
                                     QB, KB, _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), variant,
                                     _stream())
     _check(rc, "svg_varblock_attention")
     return o
+
+
+def varblock_workspace(Hq: int, Hkv: int, QB: int, KB: int, Sq: int, device) -> torch.Tensor:
+    return torch.zeros(int(load().svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)), dtype=torch.uint8, device=device)
+
+
+def varblock_launch_order(workspace: torch.Tensor, Hkv: int, QB: int, KB: int):
+    """The launch order a 256-row variable-block call (variants 3 / 6) left in its workspace: int32 [n, 2] rows of
+    (q head, block-row << 16 | sub-tile) in dispatch order (layout: csrc/attention.hip run_varblock — plan prefix sums, per-row
+    buckets, histogram, then [count, pad, entries])."""
+    w = workspace.view(torch.int32)
+    off = Hkv * (3 * (QB + 1) + (KB + 1)) + Hkv * QB + Hkv * 64
+    n = int(w[off].item())
+    return w[off + 2: off + 2 + 2 * n].view(n, 2).clone()
+
+
+def clear_workspace_cache() -> None:
+    """Drop the cached fp8 workspaces (band_attention_fp8 / varblock_attention(fp8=True) keep one per shape, device and stream)."""
+    _F8_WS.clear()
 
 
 def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,

@@ -57,7 +57,10 @@ def run_sharded(fn: Callable[..., Tuple[torch.Tensor, ...]], head_tensors: Seque
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     H = head_tensors[0].shape[1]
     mine = shard_heads(H, rank, world)
-    sl = slice(mine[0], mine[-1] + 1) if mine else slice(0, 0)
+    if not mine:
+        raise ValueError(f"svg.distributed: rank {rank} of {world} owns no head of {H} — head sharding needs num_heads >= world size "
+                         f"(use a smaller process group for this model)")
+    sl = slice(mine[0], mine[-1] + 1)
     res = fn(*[t[:, sl].contiguous() for t in head_tensors])
     single = not isinstance(res, (tuple, list))
     outs = []

@@ -112,16 +112,36 @@ def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_
 
 
 _SWITCH_GEN = None
+_SWITCH_SEED = None
+
+
+def reseed_switch_generator(seed: Optional[int] = None) -> None:
+    """(Re)build the CPU generator of the device-switched path from `seed` (default: the global seed, torch.initial_seed()).
+    Called by svg.utils.seed.seed_everything and by the replace_*_attention install hooks, so that seeding a second video in the
+    same process resets the sampled profiler rows exactly like a fresh process.  Under svg.distributed.enable() the seed of rank
+    0 is broadcast: every rank draws the same rows, whatever it was seeded with (the sharded result equals the single-GPU one)."""
+    global _SWITCH_GEN, _SWITCH_SEED
+    base = torch.initial_seed() if seed is None else int(seed)
+    use = base
+    if _dist.active():
+        grp = _dist.current_group()
+        on_gpu = torch.distributed.get_backend(grp) == "nccl"
+        t = torch.tensor([base % (2 ** 63)], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        torch.distributed.broadcast(t, src=torch.distributed.get_global_rank(grp, 0) if grp is not None else 0, group=grp)
+        use = int(t.item())
+    _SWITCH_GEN = torch.Generator().manual_seed(use % (2 ** 63))
+    _SWITCH_SEED = (base, _dist.active())
 
 
 def _switch_generator():
     """CPU generator of the device-switched path.  The reference (and the host-side branch) draw the profiler's rows from the global
     CPU generator on SPARSE steps only; the switched path does not know on the host whether the step is dense, so it must not
-    touch the global stream at all: it draws from this generator, seeded once from the global seed.  (Deviation: at equal seeds the
-    sampled rows differ from the reference's; every other consumer of the global CPU RNG sees the reference's stream.)"""
-    global _SWITCH_GEN
-    if _SWITCH_GEN is None:
-        _SWITCH_GEN = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 63))
+    touch the global stream at all: it draws from this generator, derived from the global seed — re-derived whenever
+    torch.initial_seed() changes (a later torch.manual_seed) or sharding is switched on, and by `reseed_switch_generator()`, which
+    the seeding / install hooks call (re-seeding with the SAME seed cannot be seen from the seed alone).  (Deviation: at equal seeds
+    the sampled rows differ from the reference's; every other consumer of the global CPU RNG sees the reference's stream.)"""
+    if _SWITCH_GEN is None or _SWITCH_SEED != (torch.initial_seed(), _dist.active()):
+        reseed_switch_generator()
     return _SWITCH_GEN
 
 

@@ -31,6 +31,9 @@ def sample_image(pipe, prompt, image_path, output_path, seed, version, num_step=
 
 
 def replace_cog_attention(pipe, version, num_sampled_rows, sparsity, first_layers_fp, first_times_fp):
+    from .._core import reseed_switch_generator
+
+    reseed_switch_generator()   # installing the processors (a new video) resets the switched path's profiler-row generator
     if version not in GEOMETRY:
         raise ValueError(f"Unsupported version: {version}")
     context_length, num_frame, frame_size = GEOMETRY[version]

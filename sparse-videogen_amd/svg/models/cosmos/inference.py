@@ -33,6 +33,9 @@ def replace_cosmos_attention(
     kmeans_iter_step=0,
     zero_step_kmeans_init=False,
 ):
+    from .._core import reseed_switch_generator
+
+    reseed_switch_generator()   # installing the processors (a new video) resets the switched path's profiler-row generator
     context_length = 0
     num_frame_patches = 1 + num_frames // (pipe.vae_scale_factor_temporal * pipe.transformer.config.patch_size[0])
     mod_value = pipe.vae_scale_factor_spatial * pipe.transformer.config.patch_size[1]

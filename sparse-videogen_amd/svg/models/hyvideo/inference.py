@@ -55,6 +55,9 @@ def replace_hyvideo_attention(
 ):
     """ref: hyvideo/inference.py:33-166.  Sets the class-level configuration of the processor class and installs one
     processor per block."""
+    from .._core import reseed_switch_generator
+
+    reseed_switch_generator()   # installing the processors (a new video) resets the switched path's profiler-row generator
     # geometry exactly as the reference derives it (:57-59)
     cfg_size, num_head, head_dim, dtype = 1, 24, 128, torch.bfloat16
     context_length, num_frame, frame_size = 256, 1 + num_frames // 4, height * width // 256

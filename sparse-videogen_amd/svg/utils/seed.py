@@ -13,3 +13,7 @@ def seed_everything(seed: int) -> None:
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+    # the device-switched SVG1 path draws its profiler rows from a private generator derived from this seed
+    from ..models._core import reseed_switch_generator
+
+    reseed_switch_generator(seed)

@@ -303,6 +303,20 @@ def test_band_attention_notify_counters(nat, model):
     assert torch.equal(done2.cpu()[:H * n].view(H, n), torch.tensor(targets, dtype=torch.int32).expand(H, n))
 
 
+def test_band_attention_notify_rejects_short_counter_buffer(nat):
+    """The C entry point is told how many words the caller allocated: the previous contract's BH * nseg words (without the hidden
+    per-head counters) are refused with SVG_ERR_WORKSPACE instead of being written out of bounds."""
+    S, D, H = 700, 128, 2
+    q = torch.randn(1, H, S, D, device="cuda", dtype=torch.bfloat16)
+    mask = nat.BandMask(**O.dense_band_params(S))
+    n, _, _ = nat.band_notify_layout(S, mask, 2)
+    short = torch.zeros(H * n, device="cuda", dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="workspace"):
+        nat.band_attention(q, q, q, mask, done=short, done_nseg=n)
+    nat.band_attention(q, q, q, mask, done=nat.notify_counters(H, n, "cuda"), done_nseg=n)
+    torch.cuda.synchronize()
+
+
 def test_band_attention_notify_segments_with_fused_placement(nat):
     """Contract of the per-segment counters (include/svg_attn.h): counter (h, s) >= targets[s] => the PHYSICAL rows
     [row_bounds[s], row_bounds[s + 1]) of head h are final — also for heads that run with the fused layout permutation, whose
@@ -480,6 +494,33 @@ assert len(_VB_SAMPLE) == 72 and len({c[:5] for c in _VB_SAMPLE}) == 72
 @pytest.mark.parametrize("hq,hkv,D,S,MB,NB,density,dtype", _VB_SAMPLE)
 def test_varblock_attention_reference_grid_sample(nat, hq, hkv, D, S, MB, NB, density, dtype):
     test_varblock_attention(nat, hq, hkv, D, S, MB, NB, density, dtype, -1)
+
+
+@pytest.mark.parametrize("variant", [3, 6])
+@pytest.mark.parametrize("hq,hkv,S,MB,NB", [(4, 2, 5000, 37, 90), (3, 3, 9000, 64, 200), (2, 1, 700, 5, 33)])
+def test_varblock_launch_order_is_a_permutation(nat, variant, hq, hkv, S, MB, NB):
+    """The device-built launch order (variant 3: similarity chain + XCD remap, variant 6: longest-first) lists every (q head,
+    block-row, 256-row sub-tile) exactly once — index work, checked for equality with the host's enumeration as a set — and the
+    attention result does not depend on the order (bit-identical between the two orders and the plain block-row order)."""
+    gen = torch.Generator().manual_seed(S + MB)
+    rsz = random_partition_batch(S, MB, hkv, gen)
+    rsz[0, 3] += rsz[0, 4]          # an empty block-row and an empty key block
+    rsz[0, 4] = 0
+    csz = random_partition_batch(S, NB, hkv, gen)
+    csz[-1, 7] += csz[-1, 8]
+    csz[-1, 8] = 0
+    bmap = torch.rand(hkv, MB, NB, generator=gen) > 0.6
+    bmap[:, 1::3] = bmap[:, 0:-1:3][:, : bmap[:, 1::3].shape[1]]      # groups of block-rows with identical key lists
+    q, k, v = (torch.randn(n, S, 128, generator=gen).to(torch.bfloat16) for n in (hq, hkv, hkv))
+    ws = nat.varblock_workspace(hq, hkv, MB, NB, S, "cuda")
+    o = nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=variant, workspace=ws)
+    order = nat.varblock_launch_order(ws, hkv, MB, NB).cpu().tolist()
+    g = hq // hkv
+    want = {(h * g + gg, (i << 16) | sub) for h in range(hkv) for i in range(MB) for sub in range((int(rsz[h, i]) + 255) // 256)
+            for gg in range(g)}
+    assert len(order) == len(want) and {tuple(e) for e in order} == want
+    o4 = nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=4)
+    assert torch.equal(o, o4)
 
 
 def test_varblock_golden_and_edge_cases(nat, golden):

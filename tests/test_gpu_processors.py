@@ -109,7 +109,7 @@ def test_hunyuan_svg_processor_end_to_end():
         for dev_switch, ts in ((False, torch.tensor([t])), (True, torch.tensor([t]).cuda())):
             cls.device_switch = dev_switch
             torch.manual_seed(11)
-            _core._SWITCH_GEN = torch.Generator().manual_seed(11)   # the switched path draws its rows from its own generator
+            _core.reseed_switch_generator(11)   # the switched path draws its rows from its own generator
             state = torch.get_rng_state()
             with torch.no_grad():
                 hh, ee = blocks[1].attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,

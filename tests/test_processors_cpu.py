@@ -129,3 +129,28 @@ def test_density_log_is_deferred_and_flushable(tmp_path):
     assert list(lines[0]) == ["timestep", "layer", "avg_density", "density"]
     assert lines[0]["avg_density"] == pytest.approx(0.5) and lines[1]["density"] == [[1.0, 0.0, 0.5]]
     assert not _core.DENSITY_LOG.pending
+
+
+def test_switch_generator_follows_seeding():
+    """The device-switched SVG1 path draws its profiler rows from a private CPU generator: it must restart whenever the process is
+    re-seeded — seed_everything (also with the SAME seed: a second video), a changed torch.manual_seed, the install hooks — and must
+    never consume the global CPU stream."""
+    from svg.models import _core
+    from svg.utils.seed import seed_everything
+
+    def draw():
+        return torch.randint(0, 10000, (16,), generator=_core._switch_generator())
+
+    seed_everything(7)
+    state = torch.get_rng_state()
+    a = draw()
+    assert torch.equal(state, torch.get_rng_state())
+    b = draw()
+    assert not torch.equal(a, b)
+    seed_everything(7)                       # same seed again: same rows as the first video
+    assert torch.equal(draw(), a) and torch.equal(draw(), b)
+    torch.manual_seed(8)                     # a different global seed is picked up without any hook
+    c = draw()
+    assert not torch.equal(c, a)
+    _core.reseed_switch_generator()          # what replace_*_attention calls
+    assert torch.equal(draw(), c)
