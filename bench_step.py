@@ -163,9 +163,10 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
             if it >= warmup:
                 times.append(e0.elapsed_time(e1))
                 attn_ms.append(sum(a.elapsed_time(b) for a, b in ev))
-        t = sum(times) / len(times)
-        a = sum(attn_ms) / len(attn_ms)
-        res[kind] = {"ms": round(t, 2), "attention_ms": round(a, 2), "attention_share": round(a / t, 4),
+        order = sorted(range(len(times)), key=lambda i: times[i])
+        mid = order[len(order) // 2]            # the median step (and ITS attention share)
+        t, a = times[mid], attn_ms[mid]
+        res[kind] = {"ms": round(t, 2), "ms_all_steps": [round(x, 1) for x in times], "attention_ms": round(a, 2), "attention_share": round(a / t, 4),
                      "gemm_and_glue_ms": round(t - a, 2), "gemm_tflop": round(st.gemm_flops / 1e12, 1),
                      "gemm_tflops_lower_bound": round(st.gemm_flops / ((t - a) * 1e-3) / 1e12, 1)}
     core.set_attention_dtype("bf16")

@@ -114,6 +114,8 @@ typedef struct svg_perm_desc {
  *       in opposite phases;
  *   3 = one wave per SIMD, 4 waves x 64 rows, O and Q in the AGPR half of the register file, softmax / LDS reads / LDS-DMA
  *       requests software-pipelined into the gaps between the wave's own MFMAs, one barrier per tile (csrc/attn_w4.h).
+ *   6 = frozen reference schedule (bf16, D = 128 only): the two-phase body with the round-1 softmax (running maximum, deferred
+ *       rescale) and operand fetch, kept so that a bench run can time it beside the default on the same box.
  * Any other value: SVG_ERR_BAD_ARG.  Builds with -DSVG_ABLATIONS (diagnostics, never the product library) additionally accept
  * 32: variant 3 with the per-phase cycle trace (svg_debug_pp_trace), and
  * 64 | (abl << 8): variant 2 with the per-phase cycle trace / launch timeline (svg_debug_pp_trace, svg_debug_wg_trace) and its
@@ -121,6 +123,15 @@ typedef struct svg_perm_desc {
 int svg_band_attention(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                        int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                        int32_t variant, void* stream);
+
+/* svg_band_attention for a q that already carries the softmax scale: q_scaled = q * sm_scale * log2(e), rounded ONCE to the 16-bit
+ * type by whoever produced q (svg_qk_norm_rope* with q_scale — the processors' prologue — so no second rounding happens on that
+ * path).  The kernel then starts its score accumulators at minus the row's softmax reference and the MFMAs deliver the exponent
+ * argument directly: one FMA per score less on the vector pipe (two-phase ping-pong schedule, the default of svg_band_attention at
+ * D = 128).  Same mask / perm semantics and the same result as svg_band_attention(q, ..., sm_scale) up to the rounding of
+ * q_scaled.  No reference counterpart: flex_attention takes `scale` as an argument (svg/models/hyvideo/attention.py:401-403). */
+int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                 int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SVG2 variable-block sparse attention.

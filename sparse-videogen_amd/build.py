@@ -53,8 +53,8 @@ def _newest_header() -> float:
     return max(h.stat().st_mtime for h in hs)
 
 
-def _compile(src: Path, force: bool, asm: bool, ablations: bool = False) -> tuple[Path, str]:
-    obj = OBJ / (src.stem + (".abl.o" if ablations else ".o"))
+def _compile(src: Path, force: bool, asm: bool, ablations: bool = False, tag: str = "") -> tuple[Path, str]:
+    obj = OBJ / (src.stem + (f".{tag}" if tag else "") + (".abl.o" if ablations else ".o"))
     stamp = max(src.stat().st_mtime, _newest_header())
     if not force and obj.exists() and obj.stat().st_mtime >= stamp:
         return obj, ""
@@ -96,17 +96,19 @@ def _summarise(logs: str) -> str:
     return "\n".join(out)
 
 
-def build(force: bool = False, asm: bool = False, verbose: bool = True, ablations: bool = False) -> Path:
+def build(force: bool = False, asm: bool = False, verbose: bool = True, ablations: bool = False, tag: str = "") -> Path:
     """ablations=True builds lib/libsvgattn_abl.so with -DSVG_ABLATIONS: the traced / timing-ablation kernels of the diagnostics
     tools (tools/pp_trace.py, tools/wg_timeline.py; select it with SVG_ATTN_LIB).  The product library never contains them."""
     OBJ.mkdir(exist_ok=True)
     LIB.parent.mkdir(exist_ok=True)
     lib = LIB.with_name("libsvgattn_abl.so") if ablations else LIB
+    if tag:   # comparison build for same-box A/B runs (tools/ab_*.sh; SVG_EXTRA_HIPCC_FLAGS carries its -DSVG_... switches)
+        lib = LIB.with_name(f"libsvgattn_{tag}.so")
     srcs = sorted(CSRC.glob("*.hip"))
     if not srcs:
         raise RuntimeError("no HIP sources found")
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, asm, ablations), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, asm, ablations, tag), srcs))
     objs = [o for o, _ in results]
     logs = "".join(l for _, l in results)
     if verbose and logs.strip():
@@ -127,9 +129,10 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--asm", action="store_true", help="keep .s files and print register usage")
     ap.add_argument("--ablations", action="store_true", help="diagnostics library lib/libsvgattn_abl.so (-DSVG_ABLATIONS)")
+    ap.add_argument("--tag", default="", help="comparison build lib/libsvgattn_<tag>.so (flags from SVG_EXTRA_HIPCC_FLAGS)")
     a = ap.parse_args()
     try:
-        build(force=a.force, asm=a.asm, ablations=a.ablations)
+        build(force=a.force, asm=a.asm, ablations=a.ablations, tag=a.tag)
     except RuntimeError as e:
         print(e, file=sys.stderr)
         sys.exit(1)

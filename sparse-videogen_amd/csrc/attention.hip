@@ -23,6 +23,20 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPoli
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
+// Frozen reference schedule (variant 6; bf16 / D = 128 only): the two-phase body as it stood at the end of round 1 — running row
+// maximum with a deferred rescale, one probability step in the shadow of the PV MFMAs, operands fetched at the start of the matrix
+// phase.  Kept so that ONE bench run can time it beside the default on the same box (bench.py `same_box_ab`): box-to-box clock
+// spread (+-4 %) is as large as a typical schedule gain.
+__global__ __launch_bounds__(512, 2) void band_attn_pp2_frozen_kernel(typename BandPolicy<__bf16, 128, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<__bf16, 128, BandPolicy<__bf16, 128, 8, false>, false, 8>(prm, smem, nullptr);
+}
+// the same for q that carries sm_scale * log2(e) (svg_band_attention_prescaled): no scale-and-shift per score
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2q_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, false, 0, true>(prm, smem, nullptr);
+}
 #ifdef SVG_ABLATIONS
 // Diagnostics build only (python sparse-videogen_amd/build.py --ablations): the two-phase kernel with the per-phase cycle trace
 // and the launch timeline, and its timing ablations (ABL > 0: results are wrong by construction).  Not in the product library.
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(kVbChainThreads) void varblock_chain_kernel(const u
 thread_local int g_last_hip_error = 0;
 
 // Schedules of svg_band_attention (`variant`, include/svg_attn.h).
-enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3 };
+enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3, kBandFrozen = 6 };
 // default (variant 0): the two-phase ping-pong body with the max-free softmax for head_dim 128 (round 2, late: 33.7 vs 35.0 ms for the
 // one-wave-per-SIMD body on the same box), the one-wave-per-SIMD body for head_dim 64 (2.60 vs 2.67 ms, 13.6 vs 13.8 ms on the
 // CogVideoX geometries).  Launches that count completions (svg_band_attention_notify*) always run the two-phase body: their targets
@@ -551,6 +565,7 @@ static int run_band_pp2(const void* q, const void* k, const void* v, void* o, in
     }
 #endif
     if (trace_abl >= 0) return SVG_ERR_UNSUPPORTED;   // the trace / ablation kernels exist in -DSVG_ABLATIONS builds only
+    if (opts.prescaled) return launch_attn(band_attn_pp2q_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
     return launch_attn(band_attn_pp2_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
 }
 
@@ -627,6 +642,12 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         case kBandW4: return run_band_w4(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, opts, st);
         case kBandPingPong: { SVG_BAND_TD(run_band_pp2, q, k, v, o, BH, S, sm_scale, mask, perm, opts, trace_abl, st) }
         case kBandLockstep4: { SVG_BAND_TD(run_band_lockstep4, q, k, v, o, BH, S, sm_scale, mask, perm, st) }
+        case kBandFrozen: {
+            if (dtype != SVG_DTYPE_BF16 || D != 128 || opts.done || opts.prescaled) return SVG_ERR_UNSUPPORTED;
+            using Pol = BandPolicy<__bf16, 128, 8, false>;
+            const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+            return launch_attn(band_attn_pp2_frozen_kernel, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<128>(), st);
+        }
         default: return SVG_ERR_BAD_ARG;
     }
 #undef SVG_BAND_TD
@@ -638,6 +659,16 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     const int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
     if (rc != SVG_OK) return rc;
     return band_dispatch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, variant, BandOpts(), (hipStream_t)stream);
+}
+
+extern "C" int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,
+                                            int32_t D, int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                            void* stream) {
+    const int rc = band_check_args(q_scaled, k, v, o, BH, S, D, mask, perm);
+    if (rc != SVG_OK) return rc;
+    BandOpts opts;
+    opts.prescaled = true;
+    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandPingPong, opts, (hipStream_t)stream);
 }
 
 extern "C" int32_t svg_band_attention_notify_target(int32_t S, const svg_band_mask_t* mask) {

@@ -528,7 +528,7 @@ constexpr int attn_pp2_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <typename T, int D, typename P, bool TRACE = false, int ABL = 0>
+template <typename T, int D, typename P, bool TRACE = false, int ABL = 0, bool PRE = false>
 __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
     using V8 = typename E::v8;
@@ -544,7 +544,20 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // <= 2^11 (one compare instead of the 16-instruction maximum chain + lane exchange) and otherwise takes the exact path — row
     // maximum, new reference, O and l rescaled, probabilities recomputed — BEFORE any PV MFMA has consumed them, which is why all
     // four 16-key steps are computed in the vector phase then (kShadow = 0).
-    constexpr bool kMaxFree = SVG_PP2_MAXFREE != 0 && ABL == 0;
+    // (ABL == 8 is not an ablation: the frozen reference schedule of svg_band_attention variant 6 — correct results)
+    constexpr bool kMaxFree = (SVG_PP2_MAXFREE != 0 && ABL == 0) || PRE;
+    // PRE: q arrives multiplied by sm_scale * log2(e) (svg_band_attention_prescaled; the prologue folds the factor into its single
+    // rounding of q), and the S^T accumulators start at minus the row's reference instead of zero — a 16-register tuple that only
+    // the exact path rewrites — so what the MFMAs deliver IS the exponent argument: no scale-and-shift FMA per score (the scheme
+    // of the fp8 bodies, attn_f8.h).
+    static_assert(!PRE || (SVG_PP2_MAXFREE != 0 && ABL == 0), "pre-scaled q: max-free softmax only");
+#ifndef SVG_PP2_CARRY
+#define SVG_PP2_CARRY 4
+#endif
+    // V operands of the first kCarry MFMAs of a matrix phase are read in the tail of the PREVIOUS matrix phase (tile t + 1 has been
+    // in LDS since the barrier in front of M(t)) and carried through the vector phase in registers: the phase opens with MFMAs
+    // instead of with an LDS round trip.
+    constexpr int kCarry = (ABL == 0) ? SVG_PP2_CARRY : 0;
     constexpr int kShadow = kMaxFree ? 0 : (D == 64) ? 2 : P::kShadow128;   // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
     constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
@@ -720,6 +733,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         }
     };
 
+    f32x16 neg_ref = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // PRE: minus the row's reference
     f32x16 sc[2];          // scores: S(t) until the PV steps of the matrix phase have consumed it, then S(t+1) accumulates here
     V8 pf[2][2];           // probabilities: [32-key block][16-key half]
     float m_use = 0.f, psum = 0.f;
@@ -738,18 +752,24 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     };
     // probabilities of keys 16 kk + [lo, hi) of the tile in sc
     // (scalar f32 on purpose: the packed forms v_pk_fma_f32 / v_pk_add_f32 measured 48.2 ms vs 42.3 ms here)
-    auto probs = [&](int kk, int lo, int hi) {
+    float pre_shift = 0.f;   // PRE, exact path only: old reference minus new reference (the scores in sc are relative to the old one)
+    auto probs_impl = [&](int kk, int lo, int hi, auto shifted_c) {
+        constexpr bool shifted = decltype(shifted_c)::value;
 #pragma unroll
         for (int r = lo; r < hi; ++r) {
             if constexpr (ABL == 4) {
                 pf[kk >> 1][kk & 1][r] = E::from_float(sc[kk >> 1][8 * (kk & 1) + r]);
             } else {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
+                float p;
+                if constexpr (PRE && shifted) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r] + pre_shift);
+                else if constexpr (PRE) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r]);   // the MFMAs delivered the exponent argument
+                else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
                 psum += p;
                 pf[kk >> 1][kk & 1][r] = E::from_float(p);
             }
         }
     };
+    auto probs = [&](int kk, int lo, int hi) { probs_impl(kk, lo, hi, std::false_type{}); };
     // staging half of a vector phase: resolve the rows of tile t+dist+1 (index loads first: they are older than the DMA
     // requests below, so the counted wait at the end retires them too), request tile t+dist, wait for tile t+dist-1
     auto stage_resolve_next = [&](int t, auto guard_c) {
@@ -830,8 +850,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
                 const unsigned u = __builtin_bit_cast(unsigned, vmax2(mx, sc[1][15]));
                 const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
-                mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1])) * c_log2;
+                mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
                 const float m_prev = m_use;
+                if constexpr (PRE) mx += m_prev;   // scores are relative to the reference they were accumulated under
+                else mx *= c_log2;
                 const float m_new = fmaxf(m_run, mx);
                 m_use = (m_new == -INFINITY) ? m_prev : m_new;
                 float alpha = __builtin_amdgcn_exp2f(fminf(m_prev - m_use, 126.f));
@@ -839,6 +861,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 m_run = m_new;
                 psum_thr = __all(m_new != -INFINITY) ? 2048.f : -1.f;
                 l_run *= alpha;
+                if constexpr (PRE) {
+                    pre_shift = m_prev - m_use;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) neg_ref[r] = -m_use;   // what the next S^T accumulators start from
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -850,7 +877,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 psum = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    probs(kk, 0, 8);
+                    probs_impl(kk, 0, 8, std::true_type{});
                     asm volatile("" : "+v"(pf[kk >> 1][kk & 1]), "+v"(psum));
                 }
             }
@@ -908,14 +935,19 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     //  reads but those — s_waitcnt lgkmcnt(4 / 8) — measured 0.8 % / 1.5 % slower, same box.)
     constexpr int kPF = 8;
     constexpr int NPV = 4 * DB;
+    static_assert(kCarry <= kPF && kCarry <= NPV, "carried operands are V operands of the first MFMAs");
     V8 ring[kPF + 1];
+    V8 carry[kCarry > 0 ? kCarry : 1];
     auto matrix_prefetch = [&](int t) {
         const char* stv = smem + (t % NS) * kStage;
 #pragma unroll
-        for (int i = 0; i < kPF; ++i) {
+        for (int i = kCarry; i < kPF; ++i) {
             if constexpr (ABL == 1) ring[i % (kPF + 1)] = qf[i % KS];
             else ring[i % (kPF + 1)] = vfrag(stv, i / DB, i % DB);
         }
+    };
+    auto carry_load = [&](int t, int i) {   // V operand i of tile t (its stage holds the tile by now, see kCarry)
+        if constexpr (kCarry > 0) carry[i] = vfrag(smem + (t % NS) * kStage, i / DB, i % DB);
     };
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
@@ -939,15 +971,18 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
 #pragma unroll
         for (int i = 0; i < NALL; ++i) {
             fetch(i + kPF);
+            if constexpr (has_next && kCarry > 0) {   // the last kPF steps have no operand of this phase left to fetch: the next tile's first
+                if (i + kPF >= NALL && i + kPF - NALL < kCarry) carry_load(t + 1, i + kPF - NALL);
+            }
             if (i < NPV) {
                 const int kk = i / DB, db = i % DB;
-                acc_o[db] = E::mfma(ring[i % (kPF + 1)], pf[kk >> 1][kk & 1], acc_o[db]);
+                acc_o[db] = E::mfma(i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)], pf[kk >> 1][kk & 1], acc_o[db]);
                 // probabilities of a later 16-key step in the shadow of this MFMA (one slice per d-block)
                 if (kk + 1 < 4 && kk + 1 >= 4 - kShadow) probs(kk + 1, db * (8 / DB), (db + 1) * (8 / DB));
                 if (i == NPV - 1) l_run += psum;
             } else {
                 const int j = i - NPV, ks = j >> 1, b = j & 1;
-                sc[b] = E::mfma(ring[i % (kPF + 1)], qf[ks], ks == 0 ? zero : sc[b]);
+                sc[b] = E::mfma(ring[i % (kPF + 1)], qf[ks], ks == 0 ? (PRE ? neg_ref : zero) : sc[b]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -973,8 +1008,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) sc[b] = E::mfma(kfrag(smem, b, ks), qf[ks], ks == 0 ? zero : sc[b]);
+            for (int b = 0; b < 2; ++b) sc[b] = E::mfma(kfrag(smem, b, ks), qf[ks], ks == 0 ? zero : sc[b]);   // (reference 0 so far)
         asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+#pragma unroll
+        for (int i = 0; i < kCarry; ++i) carry_load(0, i);
     }
     // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc hoist the common VALU work above
     //  the branch and keep two register sets for O with 32 copies per tile)

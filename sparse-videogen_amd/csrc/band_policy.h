@@ -12,6 +12,7 @@ namespace svg {
 struct BandOpts {
     int32_t* done = nullptr;   // completion counters (svg_band_attention_notify*), or nullptr
     int done_nseg = 1;         // counters per head
+    bool prescaled = false;    // q carries sm_scale * log2(e) (svg_band_attention_prescaled; two-phase body only)
     bool trace = false;        // diagnostics builds: the traced kernel (svg_debug_pp_trace)
     int trace_abl = 0;         // ... and its timing ablation
 };

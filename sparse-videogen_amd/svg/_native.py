@@ -104,6 +104,7 @@ SIGNATURES = {
     "svg_argsort_labels": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                      C.POINTER(PermDesc), _I32, _VP]),
+    "svg_band_attention_prescaled": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask), C.POINTER(PermDesc), _VP]),
     "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _I32, _VP]),
@@ -257,8 +258,10 @@ def argsort_labels(labels: torch.Tensor, K: int):
 def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
                    head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1,
                    frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None,
-                   done: Optional[torch.Tensor] = None, done_nseg: int = 1) -> torch.Tensor:
+                   done: Optional[torch.Tensor] = None, done_nseg: int = 1, q_prescaled: bool = False) -> torch.Tensor:
     """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape.
+    q_prescaled: q already carries sm_scale * log2(e) (SOFTMAX_Q_SCALE(D) for the default scale; what qk_norm_rope*(q_scale=...)
+    writes): svg_band_attention_prescaled, default schedule only.
     done: int32 [BH * (done_nseg + 1)] zeroed completion counters (svg_band_attention_notify[_seg]; see band_notify_target /
     band_notify_layout / wait_counters / notify_counters): counter (h, s) at done[h * done_nseg + s], the last BH words are scratch
     of the library (hidden per-head counters of heads that run with the fused layout permutation)."""
@@ -275,6 +278,12 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    if q_prescaled:
+        assert done is None and variant == 0 and sm_scale is None, "q_prescaled: plain default-schedule call, the scale lives in q"
+        rc = lib.svg_band_attention_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
+                                              C.byref(mask), C.byref(perm) if perm is not None else None, _stream())
+        _check(rc, "svg_band_attention_prescaled")
+        return o
     if done is not None:
         _dev(done)
         assert done.dtype == torch.int32 and done.is_contiguous() and variant == 0
@@ -287,6 +296,11 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
                                 C.byref(mask), C.byref(perm) if perm is not None else None, variant, _stream())
     _check(rc, "svg_band_attention")
     return o
+
+
+def softmax_q_scale(D: int, sm_scale: Optional[float] = None) -> float:
+    """The factor a pre-scaled q carries: sm_scale * log2(e) (default sm_scale = 1 / sqrt(D))."""
+    return (float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)) * 1.4426950408889634
 
 
 _F8_WS = {}
