@@ -45,6 +45,11 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename Ba
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, true, ABL>(prm, smem, nullptr);
 }
+template <typename T, int D>   // trace code 3: the pre-scaled-q body (svg_band_attention_prescaled) with the cycle trace
+__global__ __launch_bounds__(512, 2) void band_attn_pp2q_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, true, 0, true>(prm, smem, nullptr);
+}
 #endif
 
 // =====================================================================================================
@@ -557,7 +562,8 @@ static int run_band_pp2(const void* q, const void* k, const void* v, void* o, in
         if (trace_abl >= 0) {
 #define SVG_PP_TRACE(A) case A: return launch_attn(band_attn_pp2_trace_kernel<T, D, A>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
             switch (trace_abl) {
-                SVG_PP_TRACE(0) SVG_PP_TRACE(1) SVG_PP_TRACE(2) SVG_PP_TRACE(4) SVG_PP_TRACE(5) SVG_PP_TRACE(6) SVG_PP_TRACE(7)
+                SVG_PP_TRACE(0) SVG_PP_TRACE(1) SVG_PP_TRACE(2) SVG_PP_TRACE(4) SVG_PP_TRACE(5) SVG_PP_TRACE(6) SVG_PP_TRACE(7) SVG_PP_TRACE(8)
+                case 3: return launch_attn(band_attn_pp2q_trace_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
                 default: return SVG_ERR_UNSUPPORTED;
             }
 #undef SVG_PP_TRACE

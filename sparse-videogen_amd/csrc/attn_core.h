@@ -552,7 +552,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // of the fp8 bodies, attn_f8.h).
     static_assert(!PRE || (SVG_PP2_MAXFREE != 0 && ABL == 0), "pre-scaled q: max-free softmax only");
 #ifndef SVG_PP2_CARRY
-#define SVG_PP2_CARRY 4
+#define SVG_PP2_CARRY 8
 #endif
     // V operands of the first kCarry MFMAs of a matrix phase are read in the tail of the PREVIOUS matrix phase (tile t + 1 has been
     // in LDS since the barrier in front of M(t)) and carried through the vector phase in registers: the phase opens with MFMAs

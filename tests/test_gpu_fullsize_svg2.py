@@ -6,7 +6,7 @@ Everything upstream of the attention comes from the HIP path itself — labels a
 kernels, the block map from `svg_identify_dynamic_map` — and `svg_varblock_attention` runs with the permutation fused in
 (q_row_idx / kv_row_idx), i.e. exactly what the SAP processors call.  A dense CPU oracle of the whole problem would be tens of
 TFLOP, so the output is checked on spot rows — >= 256 per head: first / last row of the largest and of the smallest q-cluster, the
-neighbours of EMPTY clusters (forced: three initial centroids sit at the origin, far from every data point, and an empty cluster
+neighbours of EMPTY clusters (forced: three initial centroids sit far outside the data, and an empty cluster
 keeps its centroid, `svg/kmeans_utils.py:416-421`), rows of the block-rows with the longest and the shortest run lists, the text
 rows (Hunyuan), random rows — against `O.masked_attention` under the element mask rebuilt from labels + map, the semantics of
 `dynamic_block_sparse_fwd_flashinfer` (`svg/kmeans_utils.py:1319-1392`: q rows of block-row i attend the kv rows of the active
@@ -51,12 +51,13 @@ def build_case(name):
     k = clustered(H, S, D, 64, gen)
     v = torch.randn(H, S, D, device="cuda", dtype=torch.bfloat16, generator=gen)
     qv, kv = q[None, :, :V].contiguous(), k[None, :, :V].contiguous()
-    # warm start from the first QC / KC video rows (deterministic init) with three centroids moved to the
-    # origin: no data point is nearer to the origin than to its own mode, so these clusters are, and stay, EMPTY
+    # warm start from the first QC / KC video rows (deterministic init) with three centroids pushed out to three
+    # times their data point: every point of the mixture (|x| ~ 17, modes ~ 24 apart) is nearer to any other centroid than to a
+    # point at |x| ~ 51, so these clusters are, and stay, EMPTY
     store = _core.CentroidStore()
     qi, ki = qv[0, :, :QC].clone(), kv[0, :, :KC].clone()
     for c_, n_ in ((qi, QC), (ki, KC)):
-        c_[:, [5, n_ // 2, n_ - 1]] = 0
+        c_[:, [5, n_ // 2, n_ - 1]] *= 3
     store.q[0], store.k[0] = qi, ki
     (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = _core.kmeans_clustering(store, 0, qv, kv, QC, KC, 50, 2)
     q_sizes, k_sizes = qs.view(1, H, QC), ks.view(1, H, KC)
