@@ -439,52 +439,61 @@ __global__ __launch_bounds__(kVbChainThreads) void varblock_chain_kernel(const u
     }
     __syncthreads();
     // ---- nearest-neighbour chain ----
-    auto block_argmax = [&](unsigned long long key) -> unsigned long long {
+    // One step = one block-wide arg-max of the Jaccard similarity to the current block-row.  A thread keeps ITS candidate's bitmap
+    // row in registers for the whole chain (QB <= 512: one candidate per thread; larger maps loop over LDS), the current row is
+    // read from LDS with broadcast 16-byte loads, and the arg-max is one LDS atomic per thread on a 32-bit key (similarity in 20
+    // bits, inverted index in 12: ties go to the lowest index) — one barrier per step.
+    constexpr int kRegW = 32;   // bitmap words a thread can hold (KB <= 1024)
+    const bool in_regs = (W <= kRegW) && (QB <= kVbChainThreads);
+    uint32_t mine[kRegW];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long t = __shfl_xor(key, o);
-            key = t > key ? t : key;
-        }
-        __syncthreads();   // (readers of the previous round are done)
-        if (lane == 0) red[wv] = key;
-        __syncthreads();
-        unsigned long long best = red[0];
-#pragma unroll
-        for (int x = 1; x < kVbChainThreads / 64; ++x) best = red[x] > best ? red[x] : best;
-        return best;
-    };
+    for (int w = 0; w < kRegW; ++w) mine[w] = (in_regs && tid < QB && w < W) ? bits[(size_t)tid * WS + w] : 0u;
+    uint32_t* slot = (uint32_t*)red;   // [3] arg-max slots, used round-robin so that the reset needs no barrier of its own
+    if (tid < 3) slot[tid] = 0u;
     // start: the live block-row with the most active key blocks (ties: lowest index)
-    unsigned long long key = 0;
+    __syncthreads();
     for (int i = tid; i < QB; i += kVbChainThreads)
-        if (pc[i] >= 0) {
-            const unsigned long long k2 = ((unsigned long long)(unsigned)(pc[i] + 1) << 32) | (unsigned)(0x7fffffff - i);
-            key = k2 > key ? k2 : key;
-        }
-    unsigned long long best = block_argmax(key);
-    int npos = 0;
-    while (best != 0) {
-        const int cur = 0x7fffffff - (int)(unsigned)(best & 0xffffffffu);
+        if (pc[i] >= 0) atomicMax(&slot[0], ((uint32_t)min(pc[i] + 1, 0xFFFFF) << 12) | (uint32_t)(0xFFF - (i & 0xFFF)));
+    __syncthreads();
+    uint32_t best = slot[0];
+    int npos = 0, step = 0;
+    const bool wide_idx = QB > 4096;   // (never: KB and QB are limited by the LDS budget of this kernel; kept as a guard)
+    while (best != 0u && !wide_idx) {
+        const int cur = 0xFFF - (int)(best & 0xFFFu);
         const int pcur = pc[cur];
-        __syncthreads();
+        ++step;
+        __syncthreads();   // everybody has read slot[(step - 1) % 3] and pc[cur]
         if (tid == 0) {
             chain[npos] = cur;
             pc[cur] = -1;
+            slot[(step + 1) % 3] = 0u;   // the slot of the NEXT step (last read two steps ago)
         }
         ++npos;
-        __syncthreads();
-        key = 0;
-        for (int i = tid; i < QB; i += kVbChainThreads) {
-            const int pi = pc[i];
-            if (pi < 0) continue;
-            int inter = 0;
-            for (int w = 0; w < W; ++w) inter += __popc(bits[(size_t)i * WS + w] & bits[(size_t)cur * WS + w]);
-            const int uni = pcur + pi - inter;
-            const float jac = uni > 0 ? (float)inter / (float)uni : 1.f;
-            // (similarity in the high word — a non-negative float orders like its bits; +1 keeps 0 for "nothing left")
-            const unsigned long long k2 = ((unsigned long long)(__float_as_uint(jac) + 1u) << 32) | (unsigned)(0x7fffffff - i);
-            key = k2 > key ? k2 : key;
+        const uint32_t* crow = bits + (size_t)cur * WS;
+        uint32_t key = 0u;
+        if (in_regs) {
+            if (tid < QB && tid != cur && pc[tid] >= 0) {   // (pc[cur] is being cleared by thread 0: tid != cur covers the race)
+                int inter = 0;
+#pragma unroll
+                for (int w = 0; w < kRegW; ++w)
+                    if (w < W) inter += __popc(mine[w] & crow[w]);
+                const int uni = pcur + pc[tid] - inter;
+                const float jac = uni > 0 ? (float)inter / (float)uni : 1.f;
+                key = ((uint32_t)(jac * 1048574.f + 1.f) << 12) | (uint32_t)(0xFFF - tid);
+            }
+            if (key) atomicMax(&slot[step % 3], key);
+        } else {
+            for (int i = tid; i < QB; i += kVbChainThreads) {
+                if (i == cur || pc[i] < 0) continue;
+                int inter = 0;
+                for (int w = 0; w < W; ++w) inter += __popc(bits[(size_t)i * WS + w] & crow[w]);
+                const int uni = pcur + pc[i] - inter;
+                const float jac = uni > 0 ? (float)inter / (float)uni : 1.f;
+                atomicMax(&slot[step % 3], ((uint32_t)(jac * 1048574.f + 1.f) << 12) | (uint32_t)(0xFFF - i));
+            }
         }
-        best = block_argmax(key);
+        __syncthreads();
+        best = slot[step % 3];
     }
     // ---- workgroups per chain position, exclusive prefix, scatter with the XCD remap ----
     for (int p = tid; p < npos; p += kVbChainThreads) {
@@ -826,7 +835,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 const int nb = Hkv * kVbBuckets;
                 int32_t* order = hist + nb;
                 const size_t chain_lds = vb_chain_lds(QB, KB);
-                if (!longest_first && chain_lds <= 64 * 1024) {   // similarity order, consecutive workgroups on one XCD
+                if (!longest_first && chain_lds <= 64 * 1024 && QB <= 4096) {   // similarity order, consecutive workgroups on one XCD
                     hipLaunchKernelGGL(varblock_chain_kernel, dim3(Hkv), dim3(kVbChainThreads), chain_lds, st, block_map, k_sizes, toff,
                                        order, Hkv, QB, KB, group);
                 } else {   // longest-first inside every kv head (variant 6; also maps whose bitmap does not fit the chain kernel's LDS)

@@ -558,6 +558,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // in LDS since the barrier in front of M(t)) and carried through the vector phase in registers: the phase opens with MFMAs
     // instead of with an LDS round trip.
     constexpr int kCarry = (ABL == 0) ? SVG_PP2_CARRY : 0;
+#ifndef SVG_PP2_DOTSUM
+#define SVG_PP2_DOTSUM 1
+#endif
+    constexpr bool kDotSum = SVG_PP2_DOTSUM != 0 && kMaxFree;   // (the max-free softmax computes whole 8-key steps: always pairs)
     constexpr int kShadow = kMaxFree ? 0 : (D == 64) ? 2 : P::kShadow128;   // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
     constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
@@ -764,9 +768,15 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 if constexpr (PRE && shifted) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r] + pre_shift);
                 else if constexpr (PRE) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r]);   // the MFMAs delivered the exponent argument
                 else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
-                psum += p;
+                if constexpr (!kDotSum) psum += p;
                 pf[kk >> 1][kk & 1][r] = E::from_float(p);
             }
+        }
+        if constexpr (kDotSum && ABL != 4) {
+            // row sum from the ROUNDED probabilities, two per instruction (v_dot2c_f32_{bf16,f16} against (1, 1)): half the adds of the
+            // fp32 sum, and the normaliser is the sum of exactly what the PV MFMAs multiply
+#pragma unroll
+            for (int r = lo; r < hi; r += 2) psum = E::add_pair(pf[kk >> 1][kk & 1][r], pf[kk >> 1][kk & 1][r + 1], psum);
         }
     };
     auto probs = [&](int kk, int lo, int hi) { probs_impl(kk, lo, hi, std::false_type{}); };

@@ -45,6 +45,12 @@ struct Elt<__bf16> {
     static __device__ __forceinline__ float to_float(__bf16 x) { return (float)x; }
     static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
     static __device__ __forceinline__ __bf16 from_double(double x) { return (__bf16)(float)x; }  // torch: double -> float -> bf16
+    // acc + a + b in fp32 for a packed pair of 16-bit values: one v_dot2c_f32_bf16 against (1, 1)
+    static __device__ __forceinline__ float add_pair(__bf16 a, __bf16 b, float acc) {
+        using v2 = __bf16 __attribute__((ext_vector_type(2)));
+        const v2 x = {a, b}, one = {(__bf16)1.f, (__bf16)1.f};
+        return __builtin_amdgcn_fdot2_f32_bf16(x, one, acc, false);
+    }
 };
 
 template <>
@@ -56,6 +62,11 @@ struct Elt<_Float16> {
     }
     static __device__ __forceinline__ float to_float(_Float16 x) { return (float)x; }
     static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }
+    static __device__ __forceinline__ float add_pair(_Float16 a, _Float16 b, float acc) {   // v_dot2c_f32_f16 against (1, 1)
+        using v2 = _Float16 __attribute__((ext_vector_type(2)));
+        const v2 x = {a, b}, one = {(_Float16)1.f, (_Float16)1.f};
+        return __builtin_amdgcn_fdot2(x, one, acc, false);
+    }
     static __device__ __forceinline__ _Float16 from_double(double x) { return (_Float16)(float)x; }  // torch: double -> float -> half
 };
 

@@ -21,7 +21,9 @@ mask = nat.BandMask(real_len=V + 64, band=band, colfull_lo=V, colfull_hi=V + 64,
 abls = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0]
 mode = sys.argv[3] if len(sys.argv) > 3 else "pp2"   # pp2: two-phase ping-pong (variant 64 | abl << 8); w4: one wave per SIMD (variant 32)
 for variant in [(32 if mode == "w4" else 64) | (a << 8) for a in abls]:
-    o = nat.band_attention(q, k, v, mask, variant=variant)
+    # (trace code 3 = the pre-scaled-q body: hand it a q that carries the softmax scale, as svg_band_attention_prescaled gets it)
+    qq = (q.float() * nat.softmax_q_scale(D)).to(q.dtype) if (mode == "pp2" and (variant >> 8) == 3) else q
+    o = nat.band_attention(qq, k, v, mask, variant=variant)
     tr = nat.debug_pp_trace()
     nT = max(tr["tiles"], 1)
     print(f"--- {mode} schedule, ablation {variant >> 8}")
