@@ -90,67 +90,6 @@ def _pmc_traffic(workload: str, kernel: str):
     return None, None
 
 
-class ClockSampler:
-    """Sustained shader clock while the timed steps run (in-run calibration: the same library lands on boxes whose chips settle at
-    different clocks under this kernel, +-4 %).  A host thread polls the amdgpu sysfs files of the device every few milliseconds —
-    hwmon `freq1_input` (Hz, current gfx clock) when the driver has it, else the starred line of `pp_dpm_sclk` — between start()
-    and stop(); nothing is launched on the GPU.  Returns None fields when neither file exists."""
-
-    def __init__(self, index: int = 0):
-        import glob
-        import threading
-
-        self.samples, self.src, self._stop, self._thr = [], None, threading.Event(), None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
-        if not cards:
-            return
-        dev = cards[min(index, len(cards) - 1)]
-        hw = sorted(glob.glob(os.path.join(dev, "hwmon/hwmon*/freq1_input")))
-        self.src = hw[0] if hw else os.path.join(dev, "pp_dpm_sclk")
-
-    def _read_mhz(self):
-        try:
-            txt = open(self.src).read()
-        except OSError:
-            return None
-        if self.src.endswith("freq1_input"):
-            return float(txt) / 1e6
-        for line in txt.splitlines():
-            if "*" in line:
-                return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        return None
-
-    def start(self):
-        import threading
-
-        if self.src is None:
-            return
-        self.samples.clear()
-        self._stop.clear()
-
-        def run():
-            while not self._stop.is_set():
-                v = self._read_mhz()
-                if v is not None:
-                    self.samples.append(v)
-                time.sleep(0.004)
-
-        self._thr = threading.Thread(target=run, daemon=True)
-        self._thr.start()
-
-    def stop(self):
-        if self._thr is not None:
-            self._stop.set()
-            self._thr.join()
-            self._thr = None
-        xs = sorted(self.samples)
-        if not xs:
-            return {"sclk_mhz_median": None, "source": self.src}
-        return {"sclk_mhz_median": round(xs[len(xs) // 2], 1), "sclk_mhz_min": round(xs[0], 1), "sclk_mhz_max": round(xs[-1], 1),
-                "samples": len(xs), "source": self.src}
-
-
 def cpu_baseline(H: int, D: int, S: int, budget_s: float = 36.0):
     """BASELINE.md §3.  Dense leg: torch SDPA bf16 on all host cores, ONE head at the full sequence length S, median of 3 — if
     a probe at S/8 predicts more than budget_s for that, the longest power-of-two fraction of S that fits is timed instead and
@@ -250,8 +189,10 @@ def main():
     ap.add_argument("--no-step", action="store_true", help="skip the measured 60-layer denoise step (bench_step.measure)")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
     ap.add_argument("--no-ab", action="store_true", help="skip the same-box A/B block (frozen reference schedule and the other schedules timed beside the default)")
-    ap.add_argument("--prescaled", action="store_true", help="N = 1: q carries sm_scale * log2(e) (multiplied and rounded before the timed "
-                    "region, as the fused prologue delivers it) and the attention runs svg_band_attention_prescaled")
+    ap.add_argument("--no-prescaled", action="store_true", help="plain q and svg_band_attention (scale applied per score inside the kernel). "
+                    "Default at N = 1, bf16, default schedule: q carries sm_scale * log2(e) — what the fused prologue of "
+                    "Hunyuan_SVGAttn_Processor2_0 hands its attention core (svg_qk_norm_rope_transpose_qscale; here multiplied and "
+                    "rounded once before the timed region) — and the step runs svg_sample_mse / svg_band_attention_prescaled on it")
     ap.add_argument("--heads", default="alt", choices=["alt", "spatial", "temporal"], help="best_mask_idx pattern")
     a = ap.parse_args()
 
@@ -357,9 +298,12 @@ def main():
         assert world == 1, "--dtype fp8 is a single-GPU line"
         a.no_step = True
     q_att = q
-    if a.prescaled:
-        assert world == 1 and not fp8 and a.variant == 0, "--prescaled: single-GPU bf16 line on the default schedule"
+    a.prescaled = not fp8 and a.variant == 0 and D == 128 and not a.no_prescaled
+    if a.prescaled and world == 1:
         q_att = (q.float() * nat.softmax_q_scale(D)).to(q.dtype)   # outside the timed region: the prologue's job (svg_qk_norm_rope* q_scale)
+    if a.prescaled and world > 1:   # token shards as the token-sharded prologue would write them: pre-scaled q
+        q_tok = (q_tok.float() * nat.softmax_q_scale(D)).to(q_tok.dtype)
+    LN2 = math.log(2.0)
     ev_p0, ev_p1 = [], []
 
     def step(timed: bool):
@@ -370,14 +314,14 @@ def main():
                 else:
                     tokens_to_heads(x_tok, S, unit=P_, head_lists=head_lists, presorted=True, out=x[0])
         if not a.no_profiler:
-            mse = nat.sample_mse(q[0], k[0], v[0], rows, prof)
+            mse = nat.sample_mse(q_att[0], k[0], v[0], rows, prof, sm_scale=LN2 if a.prescaled else None)
             _ = mse.argmin(0)  # best_mask_idx (kept on device; the bench uses the fixed alternating pattern)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         works = []
         main = torch.cuda.current_stream()
-        kw = dict(vid0=0, num_frame=F_, frame_size=P_, variant=a.variant)
+        kw = dict(vid0=0, num_frame=F_, frame_size=P_, variant=a.variant, q_prescaled=a.prescaled)
         if fp8:
             kw8 = dict(vid0=0, num_frame=F_, frame_size=P_, head_perm_flag=best, out=o)
             nat.band_attention_fp8(q, k, v, mask, stage=1, **kw8)      # absolute maxima + quantise / placement / V transpose
@@ -387,17 +331,15 @@ def main():
             if timed:
                 ev_p0.append(e0)
                 ev_p1.append(p1)
-        elif side is None and a.prescaled:
-            nat.band_attention(q_att, k, v, mask, head_perm_flag=best, out=o, q_prescaled=True, vid0=0, num_frame=F_, frame_size=P_)
         elif side is None:
-            nat.band_attention(q, k, v, mask, head_perm_flag=best, out=o, **kw)
+            nat.band_attention(q_att, k, v, mask, head_perm_flag=best, out=o, **kw)
         elif mode["chunk_launches"]:
             for c in range(n_chunks):
                 sl = slice(c * n_per, (c + 1) * n_per)
                 st = side[c % 2]
                 st.wait_stream(main)   # inputs and the profiler's result are produced on the main stream
                 with torch.cuda.stream(st):
-                    nat.band_attention(q[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), out=o[:, sl], **kw)
+                    nat.band_attention(q_att[:, sl], k[:, sl], v[:, sl], mask, head_perm_flag=best[:, sl].contiguous(), out=o[:, sl], **kw)
                     if world > 1:
                         works.append(gather_chunk(full, o[0, sl], c, n_per, world))
         else:
@@ -449,7 +391,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    clock = ClockSampler(local_rank) if rank == 0 else None
+    # sustained shader clock of the timed steps: a one-wave probe kernel beside them (s_memtime against the 100 MHz counter)
+    clock = None
+    if rank == 0:
+        try:
+            clock = nat.ClockProbe(dev)
+        except Exception:  # noqa: BLE001
+            clock = None
     barrier()
     if clock:
         clock.start()
@@ -458,7 +406,11 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    clock_info = clock.stop() if clock else None
+    clock_info = None
+    if clock:
+        mhz = clock.stop()
+        clock_info = {"sclk_mhz_timed_steps": mhz, "frac_of_2400": round(mhz / 2400.0, 4) if mhz else None,
+                      "how": "svg_debug_clock_probe: shader-clock ticks / 100 MHz ticks of one sleeping wave while the timed steps ran"}
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -489,7 +441,7 @@ def main():
     out = None
     if rank == 0:
         value = flops_call / (ms_step * 1e-3) / 1e12
-        kernel_name = BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
+        kernel_name = "band_attn_pp2q_kernel<bf16,128>" if a.prescaled else BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
         peak = PEAK_BF16_TFLOPS
         if fp8:
             kernel_name, peak = "band_attn_f8_kernel<bf16>", PEAK_FP8_TFLOPS
@@ -546,17 +498,16 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
             },
-            "clock": clock_info,   # shader clock sampled by a host thread during the timed steps (sysfs), or nulls
+            "clock": clock_info,   # sustained shader clock during the timed steps (the 2.5 PFLOP/s peak is quoted at 2.4 GHz)
         }
         if a.prescaled:
-            kernel_name = out["roofline"]["kernel"] = "band_attn_pp2q_kernel<bf16,128>"
-            out["config"]["q_prescaled"] = True
+            out["config"]["q_prescaled"] = "q carries sm_scale * log2(e), as the fused prologue of the SVG1 processor writes it (--no-prescaled: plain q)"
             ob = nat.band_attention(q[:, :2].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), mask,
                                     head_perm_flag=best[:, :2].contiguous(), vid0=0, num_frame=F_, frame_size=P_).float()
             out["prescaled_rel_l2_vs_default_kernel"] = round(((o[:, :2].float() - ob).norm() / ob.norm()).item(), 6)
             del ob
 
-    if rank == 0 and world == 1 and not fp8 and not a.no_ab and a.workload == "hy720p" and a.variant == 0:
+    if rank == 0 and world == 1 and not fp8 and not a.no_ab and a.workload == "hy720p" and a.variant == 0 and a.chunks == 1:
         # In-run calibration: the other schedules of the library — among them the FROZEN reference schedule (variant 6: the two-phase
         # body with the round-1 softmax and operand fetch) — timed beside the default in this process, on this box, same inputs:
         # `default_ms / frozen_ms` shows a schedule gain whatever clock the box settles at.  Attention kernel only, HIP events,
@@ -575,17 +526,18 @@ def main():
         ab = {}
         try:
             qs = q_att if a.prescaled else (q.float() * nat.softmax_q_scale(D)).to(q.dtype)
-            ab["default_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, **pk)), 3)
+            ab["default_ms"] = round(time_attn(lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)), 3)
             ab["frozen_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=6, **pk)), 3)
-            ab["prescaled_ms"] = round(time_attn(lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)), 3)
+            ab["plain_q_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, **pk)), 3)
             ab["variant_3_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=3, **pk)), 3)
             ab["variant_1_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=1, **pk), n=2), 3)
-            ab["default_ms_again"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, **pk)), 3)   # (drift over the block)
+            ab["default_ms_again"] = round(time_attn(lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)), 3)   # (drift over the block)
             ab["default_over_frozen"] = round(ab["default_ms"] / ab["frozen_ms"], 4)
-            ab["prescaled_over_frozen"] = round(ab["prescaled_ms"] / ab["frozen_ms"], 4)
-            ab["what"] = ("attention kernel ms, same process / box / inputs: default = variant 0 (two-phase, max-free softmax, carried "
-                          "operands), frozen = variant 6 (two-phase body with the round-1 softmax and operand fetch), prescaled = "
-                          "svg_band_attention_prescaled, 3 = one wave per SIMD, 1 = lock-step 4 waves")
+            ab["plain_q_over_frozen"] = round(ab["plain_q_ms"] / ab["frozen_ms"], 4)
+            ab["what"] = ("attention kernel ms, same process / box / inputs: default = svg_band_attention_prescaled (two-phase body, "
+                          "max-free softmax, carried operands, score accumulators started at minus the reference; q pre-scaled by the "
+                          "prologue), frozen = variant 6 (two-phase body with the round-1 softmax and operand fetch, plain q), plain_q = "
+                          "svg_band_attention variant 0 on the plain q, 3 = one wave per SIMD, 1 = lock-step 4 waves")
             del qs
         except Exception as e:  # noqa: BLE001
             ab["error"] = f"{type(e).__name__}: {str(e)[:300]}"

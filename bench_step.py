@@ -82,12 +82,14 @@ def run_step(st: Stack, img, txt, sparse_step: bool, first_layers_fp: int, attn_
         nonlocal layer
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        q, k = nat.qk_norm_rope_transpose(q_buf, k_buf, HEADS, HEADS, 1, st.qn, None, st.kn, None, 1e-6, 1, st.cos, st.sin, 0, V)
+        # (like Hunyuan_SVGAttn_Processor2_0: the fused prologue hands the attention core a q that carries the softmax scale)
+        q, k = nat.qk_norm_rope_transpose(q_buf, k_buf, HEADS, HEADS, 1, st.qn, None, st.kn, None, 1e-6, 1, st.cos, st.sin, 0, V,
+                                          q_scale=nat.softmax_q_scale(HD))
         v, _ = nat.qk_norm_rope_transpose(v_buf, None, HEADS, 0)
         if sparse_step and layer >= first_layers_fp:
-            o, _ = core.svg1_sparse_attention(q, k, v, geo, mask, prof, 64, min(10000, V))
+            o, _ = core.svg1_sparse_attention(q, k, v, geo, mask, prof, 64, min(10000, V), q_prescaled=True)
         else:
-            o = core.dense_attention(q, k, v, valid_len=V + L)
+            o = core.dense_attention(q, k, v, valid_len=V + L, q_prescaled=True)
         o = o.transpose(1, 2).reshape(S, HID)      # head-major -> token-major for the output projection (one copy)
         e1.record()
         attn_events.append((e0, e1))

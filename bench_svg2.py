@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--workload", default="wan720p", choices=sorted(WORKLOADS))
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order)")
+    ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order, 7: two-phase similarity order)")
     ap.add_argument("--fp8", action="store_true", help="e4m3 QK^T / PV in the attention (BASELINE.json configs[4])")
     ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
                     "(the reference's pipeline) instead of the fused row-index gather")

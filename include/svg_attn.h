@@ -133,6 +133,12 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
 int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                  int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* stream);
 
+/* svg_band_attention_switch (device-side dense / sparse switch, below) for a pre-scaled q; D = 128 (other head sizes:
+ * SVG_ERR_UNSUPPORTED — take the decision on the host and call svg_band_attention_prescaled). */
+int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                        int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                        const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SVG2 variable-block sparse attention.
  * ref: dynamic_block_sparse_fwd_flashinfer, svg/kmeans_utils.py:1319-1392 (VariableBlockSparseAttentionWrapper
@@ -150,12 +156,13 @@ int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void
  * variant: -1 = auto (what the Python layer passes), 0 = 128-row q tiles (4 waves, two workgroups per CU), 1 = 256-row q tiles
  * (8 waves, lock-step), 2 = mixed (full 256-row tiles on 8 waves, the rest of each block-row on 128-row tiles; two launches),
  * 3 = 256-row q tiles with the two-phase ping-pong body of svg_band_attention (waves without query rows idle), workgroups
- * launched in similarity order inside every kv head: block-rows with (nearly) the same active key blocks are neighbours of a
- * device-built nearest-neighbour chain, and consecutive workgroups go to the same XCD so that they meet in its L2
- * (maps whose bitmap does not fit the chain kernel's 64 KiB of LDS — QB * (KB / 32 + 4) words — fall back to 6);
- * 4 = the same kernel in block-row order, 6 = longest-first inside every kv head (device-side counting sort on the active keys of
- * the block-rows; the default of round 2) — both for A/B measurements; 5 = variant 3 recording the launch timeline
- * (svg_debug_wg_trace).
+ * launched longest-first inside every kv head (device-side counting sort on the active keys of the block-rows); 6 = the same;
+ * 4 = the same kernel in block-row order (A/B measurements); 5 = variant 3 recording the launch timeline (svg_debug_wg_trace);
+ * 7 = similarity order: block-rows with (nearly) the same active key blocks are neighbours of a device-built nearest-neighbour
+ * chain and consecutive workgroups go to the same XCD so that they meet in its L2 (maps whose bitmap does not fit the chain
+ * kernel's 64 KiB of LDS — QB * (KB / 32 + 4) words — fall back to 3).  Measured at Wan 2.1 720p (profiles/r03b_pmc_svg2_*):
+ * L2 hit rate 48 % instead of 31 %, 90 GB instead of 119 GB between L2 and the fabric, kernel time unchanged, chain kernel
+ * 0.7 - 1.0 ms — kept for the traffic it saves when the fabric is shared (multi-GPU exchange), not the default.
  * ---------------------------------------------------------------------------------------------- */
 size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq);
 int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
@@ -284,6 +291,20 @@ int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, 
                                const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi,
                                void* stream);
 
+/* The two fused passes with a factor folded into the LAST rounding of q: q_out = round(q_scale * (norm + RoPE result in fp32)); k is
+ * not touched by it.  q_scale = sm_scale * log2(e) produces the q that svg_band_attention_prescaled expects without a second
+ * rounding of the rotated positions (positions outside [rope_lo, rope_hi) — the 256 text tokens of Hunyuan — were rounded by the
+ * norm already and are rounded again).  q_scale = 1 is bit-identical to the plain entry points; q_scale <= 0: SVG_ERR_BAD_ARG. */
+int svg_qk_norm_rope_qscale(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                            int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias,
+                            float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo,
+                            int32_t rope_hi, float q_scale, void* stream);
+int svg_qk_norm_rope_transpose_qscale(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz, int32_t Hq,
+                                      int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind, const void* q_weight,
+                                      const void* q_bias, const void* k_weight, const void* k_bias, float eps, int32_t rope_kind,
+                                      const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi,
+                                      float q_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Transformer-block glue of the Wan blocks, rows of [M, N], N % 8 == 0, N <= 8192; dtypes per tensor
  * (SVG_DTYPE_BF16 / F16 / F32); scale, shift, gate are fp32 [M / rows_per_batch, N] (one row per batch element).
@@ -383,6 +404,10 @@ int32_t svg_band_attention_notify_layout(int32_t S, const svg_band_mask_t* mask,
 int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                   int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                                   int32_t* done, int32_t done_words, int32_t nseg, void* stream);
+/* svg_band_attention_notify_seg for a pre-scaled q (see svg_band_attention_prescaled): same counters, layout and targets. */
+int svg_band_attention_prescaled_notify_seg(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,
+                                            int32_t D, int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                            int32_t* done, int32_t done_words, int32_t nseg, void* stream);
 
 /* Diagnostics (not part of the reference's interface; -DSVG_ABLATIONS builds, otherwise SVG_ERR_UNSUPPORTED): cycle trace of
  * the two-phase attention schedule.  After a svg_band_attention call with variant 64 (bf16, D = 128) and a synchronised
@@ -391,6 +416,12 @@ int svg_band_attention_notify_seg(const void* q, const void* k, const void* v, v
  *   variant 32: i = 0..3  [phase A up to the barrier, wait + barrier, rest of A, phase B]   (waves 0..3)
  * out[64] = KV tiles of that workgroup, out[65] = ticks of its tile loop. */
 int svg_debug_pp_trace(uint64_t* out104);
+
+/* Shader-clock probe (measurement aid of bench.py, product library): a one-wave kernel on `stream` that sleeps until
+ * stop_flag[0] != 0 (int32 in device or pinned host memory, written by a later memset / copy on ANOTHER stream) or max_ms have
+ * passed, then stores { shader-clock ticks (s_memtime), 100 MHz ticks } elapsed to out2[0..1]: the sustained shader clock of
+ * the span is 100 MHz * out2[0] / out2[1]. */
+int svg_debug_clock_probe(const int32_t* stop_flag, uint64_t* out2, int32_t max_ms, void* stream);
 
 /* Launch timeline of the same traced kernel (variant 64): for each of the first n_workgroups (<= 16384) workgroups
  * out[6 * b + ..] = [s_memtime at entry, at the start of the tile loop, at its end, after the last store of O, HW_ID, XCC_ID]. */

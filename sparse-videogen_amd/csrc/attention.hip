@@ -23,6 +23,17 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPoli
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
+// Device-side switch between two masks on the pre-scaled two-phase body (svg_band_attention_switch_prescaled, D = 128): `flag[0] != 0`
+// selects prm_alt — the dense warm-up mask without the layout transformation — otherwise prm (see band_attn_w4_switch_kernel)
+template <typename T>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2q_switch_kernel(typename BandPolicy<T, 128, 8, false>::Params prm,
+                                                                       typename BandPolicy<T, 128, 8, false>::Params prm_alt,
+                                                                       const int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (flag[0] != 0) attn_body_pp2<T, 128, BandPolicy<T, 128, 8, false>, false, 0, true>(prm_alt, smem, nullptr);
+    else attn_body_pp2<T, 128, BandPolicy<T, 128, 8, false>, false, 0, true>(prm, smem, nullptr);
+}
+
 // Frozen reference schedule (variant 6; bf16 / D = 128 only): the two-phase body as it stood at the end of round 1 — running row
 // maximum with a deferred rescale, one probability step in the shadow of the PV MFMAs, operands fetched at the start of the matrix
 // phase.  Kept so that ONE bench run can time it beside the default on the same box (bench.py `same_box_ab`): box-to-box clock
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void varblock_scatter_kernel(const int32_t* __
         }
 }
 
-// Similarity order of the 256-row variable-block kernel (default since round 3).  The longest-first order above hands an XCD 32
+// Similarity order of the 256-row variable-block kernel (variant 7; measured in round 3, NOT the default: see svg_varblock_attention).  The longest-first order above hands an XCD 32
 // unrelated block-rows of a head at a time: every workgroup streams its own quarter of the head's K / V through that XCD's 4 MiB
 // L2 (PMC, Wan 720p: hit rate 31 %, 117 GB per launch between L2 and the fabric for 3.1 GB of tensors).  Block-rows whose key
 // lists are (nearly) the same — q-clusters of the same neighbourhood of the data select the same k-clusters — read the same K / V
@@ -735,6 +746,19 @@ extern "C" int svg_band_attention_notify_seg(const void* q, const void* k, const
     return band_dispatch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, kBandAuto, opts, (hipStream_t)stream);
 }
 
+extern "C" int svg_band_attention_prescaled_notify_seg(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH,
+                                                       int32_t S, int32_t D, int32_t dtype, const svg_band_mask_t* mask,
+                                                       const svg_perm_desc_t* perm, int32_t* done, int32_t done_words, int32_t nseg,
+                                                       void* stream) {
+    if (!done || nseg <= 0) return SVG_ERR_BAD_ARG;
+    const int rc = band_check_args(q_scaled, k, v, o, BH, S, D, mask, perm);
+    if (rc != SVG_OK) return rc;
+    if ((int64_t)done_words < (int64_t)BH * (nseg + 1)) return SVG_ERR_WORKSPACE;
+    BandOpts opts;
+    opts.done = done, opts.done_nseg = nseg, opts.prescaled = true;
+    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandPingPong, opts, (hipStream_t)stream);
+}
+
 extern "C" int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream) {
     if (!counters || n <= 0) return SVG_ERR_BAD_ARG;
     hipLaunchKernelGGL(wait_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, n, target);
@@ -757,6 +781,30 @@ extern "C" int svg_band_attention_switch(const void* q, const void* k, const voi
     if (rc == SVG_OK) rc = band_check_args(q, k, v, o, BH, S, D, alt_mask, nullptr);
     if (rc != SVG_OK) return rc;
     return run_band_w4_switch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, alt_mask, use_alt_flag, (hipStream_t)stream);
+}
+
+extern "C" int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,
+                                                   int32_t D, int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                                   const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream) {
+    if (!alt_mask || !use_alt_flag) return SVG_ERR_BAD_ARG;
+    int rc = band_check_args(q_scaled, k, v, o, BH, S, D, mask, perm);
+    if (rc == SVG_OK) rc = band_check_args(q_scaled, k, v, o, BH, S, D, alt_mask, nullptr);
+    if (rc != SVG_OK) return rc;
+    if (D != 128) return SVG_ERR_UNSUPPORTED;
+    auto go = [&](auto t_c) -> int {
+        using T = decltype(t_c);
+        using Pol = BandPolicy<T, 128, 8, false>;
+        const typename Pol::Params a = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, mask, perm);
+        const typename Pol::Params b = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, alt_mask, nullptr);
+        auto kern = band_attn_pp2q_switch_kernel<T>;
+        if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<128>()); r2 != SVG_OK) return r2;
+        hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<128>(), (hipStream_t)stream, a, b,
+                           use_alt_flag);
+        return launch_status();
+    };
+    if (dtype == SVG_DTYPE_BF16) return go(__bf16{});
+    if (dtype == SVG_DTYPE_F16) return go(_Float16{});
+    return SVG_ERR_UNSUPPORTED;
 }
 
 extern "C" int svg_debug_wg_trace(uint64_t* out, int n_workgroups) {
@@ -807,7 +855,7 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, bool longest_first = false) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, bool longest_first = true) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
@@ -905,7 +953,9 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
-    const bool block_row_order = (variant == 4), trace = (variant == 5), longest_first = (variant == 6);
+    // (6 = 3: the longest-first order is the default again — the similarity order, variant 7, raised the L2 hit rate from 31 % to 48 %
+    //  and cut the L2 <-> fabric traffic by a quarter but not the kernel time, and its chain kernel costs 0.7 - 1.0 ms per call)
+    const bool block_row_order = (variant == 4), trace = (variant == 5), longest_first = (variant != 7);
 #define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, longest_first
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
@@ -918,7 +968,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
         if (variant >= 3) return run_varblock<T, 64, -8>(SVG_VB_ARGS);                           \
         return variant == 1 ? run_varblock<T, 64, 8>(SVG_VB_ARGS) : run_varblock<T, 64, 4>(SVG_VB_ARGS);   \
     }
-    if (variant < -1 || variant > 6) return SVG_ERR_BAD_ARG;
+    if (variant < -1 || variant > 7) return SVG_ERR_BAD_ARG;
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;

@@ -559,7 +559,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // instead of with an LDS round trip.
     constexpr int kCarry = (ABL == 0) ? SVG_PP2_CARRY : 0;
 #ifndef SVG_PP2_DOTSUM
-#define SVG_PP2_DOTSUM 1
+#define SVG_PP2_DOTSUM 0
 #endif
     constexpr bool kDotSum = SVG_PP2_DOTSUM != 0 && kMaxFree;   // (the max-free softmax computes whole 8-key steps: always pairs)
     constexpr int kShadow = kMaxFree ? 0 : (D == 64) ? 2 : P::kShadow128;   // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase

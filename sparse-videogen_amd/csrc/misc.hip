@@ -60,7 +60,29 @@ __global__ __launch_bounds__(256) void bsr_to_map_kernel(const int32_t* __restri
     }
 }
 
+// Shader-clock probe: one wave sleeps until `stop[0]` becomes non-zero (or `max_ticks` of the constant 100 MHz counter have
+// passed — it can never hang a queue) and reports how far the shader-clock counter (s_memtime) and the 100 MHz counter
+// (wall_clock64) advanced meanwhile: sclk = 100 MHz * d_shader / d_wall, the clock the chip actually sustained while whatever ran
+// beside this wave was running (bench.py: the timed steps).  The wave issues one s_sleep per ~64 clocks: no measurable load.
+__global__ __launch_bounds__(64) void clock_probe_kernel(const int32_t* __restrict__ stop, unsigned long long* __restrict__ out,
+                                                         long long max_ticks) {
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_amdgcn_s_memtime();
+    while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && (long long)(wall_clock64() - w0) < max_ticks)
+        __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_amdgcn_s_memtime() - c0;
+        out[1] = wall_clock64() - w0;
+    }
+}
+
 }  // namespace svg
+
+extern "C" int svg_debug_clock_probe(const int32_t* stop_flag, uint64_t* out2, int32_t max_ms, void* stream) {
+    if (!stop_flag || !out2 || max_ms <= 0) return SVG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(svg::clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stop_flag, (unsigned long long*)out2,
+                       (long long)max_ms * 100000LL);
+    return svg::launch_status();
+}
 
 extern "C" int svg_bsr_to_block_map(const int32_t* indptr, const int32_t* indices, int32_t MB, int32_t NB, int32_t row_block,
                                     int32_t col_block, int32_t len_text, int32_t heads, uint8_t* block_map, int32_t* q_sizes,

@@ -31,6 +31,9 @@ struct PrologueParams {
     const float* cs;  // cos [rope_hi - rope_lo, D]   (complex: real part [.., D/2])
     const float* sn;  // sin                           (complex: imaginary part)
     int rope_lo, rope_hi;  // positions [rope_lo, rope_hi) are rotated with table row (pos - rope_lo)
+    float q_scale;         // factor folded into the LAST rounding of q (1: none; an exact no-op then).  The attention kernels take a q
+                           // that carries sm_scale * log2(e) (svg_band_attention_prescaled): rotated positions are rounded once either
+                           // way — the factor multiplies the fp32 RoPE result in front of that rounding
 };
 
 template <int LPR>
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
         }
     }
 
-    auto run = [&](T* base, const T* src, int H, const T* wgt, const T* bias) {
+    auto run = [&](T* base, const T* src, int H, const T* wgt, const T* bias, const float oscale) {
         float w[8], bs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = 1.f, bs[j] = 0.f;
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float a = x[2 * i], bq = x[2 * i + 1];
-                        out[2 * i] = E::from_float(a * cs[2 * i] + (-bq) * sn[2 * i]);
-                        out[2 * i + 1] = E::from_float(bq * cs[2 * i + 1] + a * sn[2 * i + 1]);
+                        out[2 * i] = E::from_float((a * cs[2 * i] + (-bq) * sn[2 * i]) * oscale);
+                        out[2 * i + 1] = E::from_float((bq * cs[2 * i + 1] + a * sn[2 * i + 1]) * oscale);
                     }
                 } else if (rot) {
                     // (x[2i] + i x[2i+1]) * (fr + i fi) in fp64 (the reference multiplies complex128 by complex64)
@@ -148,19 +151,19 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
                     for (int i = 0; i < 4; ++i) {
                         const double a = (double)x[2 * i], bq = (double)x[2 * i + 1];
                         const double fr = (double)cs[i], fi = (double)sn[i];
-                        out[2 * i] = E::from_double(a * fr - bq * fi);
-                        out[2 * i + 1] = E::from_double(a * fi + bq * fr);
+                        out[2 * i] = E::from_double((a * fr - bq * fi) * (double)oscale);
+                        out[2 * i + 1] = E::from_double((a * fi + bq * fr) * (double)oscale);
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) out[j] = E::from_float(x[j]);
+                    for (int j = 0; j < 8; ++j) out[j] = E::from_float(x[j] * oscale);
                 }
                 if (valid && h0 + u < H) *(V8*)(row0 + (size_t)(h0 + u) * hstride) = out;
             }
         }
     };
-    if (p.q) run((T*)p.q, (const T*)p.q_src, p.Hq, (const T*)p.qw, (const T*)p.qb);
-    if (p.k) run((T*)p.k, (const T*)p.k_src, p.Hkv, (const T*)p.kw, (const T*)p.kb);
+    if (p.q) run((T*)p.q, (const T*)p.q_src, p.Hq, (const T*)p.qw, (const T*)p.qb, p.q_scale);
+    if (p.k) run((T*)p.k, (const T*)p.k_src, p.Hkv, (const T*)p.kw, (const T*)p.kb, 1.f);
 }
 
 template <typename T>
@@ -192,10 +195,11 @@ static int launch_prologue(const PrologueParams& p, int bsz, int D, int dtype, h
 
 using namespace svg;
 
-extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
-                                int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight,
-                                const void* k_bias, float eps, int32_t rope_kind, const float* cos_or_real,
-                                const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, void* stream) {
+extern "C" int svg_qk_norm_rope_qscale(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                       int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight,
+                                       const void* k_bias, float eps, int32_t rope_kind, const float* cos_or_real,
+                                       const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, float q_scale, void* stream) {
+    if (!(q_scale > 0.f)) return SVG_ERR_BAD_ARG;
     if ((!q && !k) || (q && Hq <= 0) || (k && Hkv <= 0)) return SVG_ERR_BAD_ARG;
     if (norm_kind < 0 || norm_kind > 2 || rope_kind < 0 || rope_kind > 2) return SVG_ERR_BAD_ARG;
     if (rope_kind != kRopeNone) {
@@ -206,14 +210,25 @@ extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32
     p.q = q, p.k = k, p.Hq = Hq, p.Hkv = Hkv, p.S = S, p.norm = norm_kind, p.rope = rope_kind;
     p.qw = q_weight, p.qb = q_bias, p.kw = k_weight, p.kb = k_bias, p.eps = eps;
     p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi;
+    p.q_scale = q_scale;
     return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);
 }
 
-extern "C" int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz, int32_t Hq,
-                                          int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind,
-                                          const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias,
-                                          float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag,
-                                          int32_t rope_lo, int32_t rope_hi, void* stream) {
+extern "C" int svg_qk_norm_rope(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
+                                int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight,
+                                const void* k_bias, float eps, int32_t rope_kind, const float* cos_or_real,
+                                const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, void* stream) {
+    return svg_qk_norm_rope_qscale(q, k, bsz, Hq, Hkv, S, D, dtype, norm_kind, q_weight, q_bias, k_weight, k_bias, eps, rope_kind,
+                                   cos_or_real, sin_or_imag, rope_lo, rope_hi, 1.f, stream);
+}
+
+extern "C" int svg_qk_norm_rope_transpose_qscale(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz,
+                                                 int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind,
+                                                 const void* q_weight, const void* q_bias, const void* k_weight,
+                                                 const void* k_bias, float eps, int32_t rope_kind, const float* cos_or_real,
+                                                 const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, float q_scale,
+                                                 void* stream) {
+    if (!(q_scale > 0.f)) return SVG_ERR_BAD_ARG;
     if ((!q_in && !k_in) || (q_in && (!q_out || Hq <= 0)) || (k_in && (!k_out || Hkv <= 0))) return SVG_ERR_BAD_ARG;
     if (q_in == q_out || (k_in && k_in == k_out)) return SVG_ERR_BAD_ARG;   // the layouts differ: not an in-place operation
     if (norm_kind < 0 || norm_kind > 2 || rope_kind < 0 || rope_kind > 2) return SVG_ERR_BAD_ARG;
@@ -225,7 +240,17 @@ extern "C" int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, vo
     p.Hq = Hq, p.Hkv = Hkv, p.S = S, p.norm = norm_kind, p.rope = rope_kind;
     p.qw = q_weight, p.qb = q_bias, p.kw = k_weight, p.kb = k_bias, p.eps = eps;
     p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi;
+    p.q_scale = q_scale;
     return launch_prologue(p, bsz, D, dtype, (hipStream_t)stream);
+}
+
+extern "C" int svg_qk_norm_rope_transpose(const void* q_in, const void* k_in, void* q_out, void* k_out, int32_t bsz, int32_t Hq,
+                                          int32_t Hkv, int32_t S, int32_t D, int32_t dtype, int32_t norm_kind,
+                                          const void* q_weight, const void* q_bias, const void* k_weight, const void* k_bias,
+                                          float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag,
+                                          int32_t rope_lo, int32_t rope_hi, void* stream) {
+    return svg_qk_norm_rope_transpose_qscale(q_in, k_in, q_out, k_out, bsz, Hq, Hkv, S, D, dtype, norm_kind, q_weight, q_bias,
+                                             k_weight, k_bias, eps, rope_kind, cos_or_real, sin_or_imag, rope_lo, rope_hi, 1.f, stream);
 }
 
 // Rows of a flat [m, n] tensor are independent: view it as [H, S, n] with the largest H in {16, 8, 4, 2, 1} dividing m so that

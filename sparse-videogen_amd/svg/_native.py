@@ -97,6 +97,10 @@ SIGNATURES = {
                                              C.c_float, _I32, _VP, _VP, _I32, _I32, _VP]),
     "svg_qk_norm_rope": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
                                    _VP, _I32, _I32, _VP]),
+    "svg_qk_norm_rope_qscale": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
+                                          _VP, _I32, _I32, C.c_float, _VP]),
+    "svg_qk_norm_rope_transpose_qscale": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
+                                                    C.c_float, _I32, _VP, _VP, _I32, _I32, C.c_float, _VP]),
     "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_inverse_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
@@ -105,6 +109,11 @@ SIGNATURES = {
     "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                      C.POINTER(PermDesc), _I32, _VP]),
     "svg_band_attention_prescaled": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask), C.POINTER(PermDesc), _VP]),
+    "svg_band_attention_switch_prescaled": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask),
+                                                      C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
+    "svg_debug_clock_probe": (C.c_int, [_VP, _VP, _I32, _VP]),
+    "svg_band_attention_prescaled_notify_seg": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask),
+                                                          C.POINTER(PermDesc), _VP, _I32, _I32, _VP]),
     "svg_band_attention_notify_target": (_I32, [_I32, C.POINTER(BandMask)]),
     "svg_band_attention_notify": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                             C.POINTER(PermDesc), _VP, _I32, _VP]),
@@ -278,8 +287,16 @@ def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Band
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    if q_prescaled and done is not None:
+        _dev(done)
+        assert done.dtype == torch.int32 and done.is_contiguous() and variant == 0 and sm_scale is None
+        rc = lib.svg_band_attention_prescaled_notify_seg(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D,
+                                                         _dtype_code(q), C.byref(mask), C.byref(perm) if perm is not None else None,
+                                                         done.data_ptr(), int(done.numel()), int(done_nseg), _stream())
+        _check(rc, "svg_band_attention_prescaled_notify_seg")
+        return o
     if q_prescaled:
-        assert done is None and variant == 0 and sm_scale is None, "q_prescaled: plain default-schedule call, the scale lives in q"
+        assert variant == 0 and sm_scale is None, "q_prescaled: default-schedule call, the scale lives in q"
         rc = lib.svg_band_attention_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
                                               C.byref(mask), C.byref(perm) if perm is not None else None, _stream())
         _check(rc, "svg_band_attention_prescaled")
@@ -387,9 +404,10 @@ def wait_counters(counters: torch.Tensor, target: int, timeout_ms: int = 0, time
 def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, alt_mask: BandMask,
                           use_alt_flag: torch.Tensor, sm_scale: Optional[float] = None,
                           head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1, frame_size: int = 1,
-                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
     """band_attention with a device-side switch: `use_alt_flag` (int32 [1] on the GPU) != 0 selects `alt_mask` without the head
-    placement, otherwise `mask` with it (svg_band_attention_switch) — no host read of the flag."""
+    placement, otherwise `mask` with it (svg_band_attention_switch) — no host read of the flag.
+    q_prescaled: q carries sm_scale * log2(e) (svg_band_attention_switch_prescaled, D = 128)."""
     lib = load()
     _dev(q, k, v, head_perm_flag, use_alt_flag)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
@@ -404,6 +422,13 @@ def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mas
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    if q_prescaled:
+        assert sm_scale is None, "q_prescaled: the scale lives in q"
+        rc = lib.svg_band_attention_switch_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
+                                                     C.byref(mask), C.byref(perm) if perm is not None else None, C.byref(alt_mask),
+                                                     use_alt_flag.data_ptr(), _stream())
+        _check(rc, "svg_band_attention_switch_prescaled")
+        return o
     rc = lib.svg_band_attention_switch(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q), scale,
                                        C.byref(mask), C.byref(perm) if perm is not None else None, C.byref(alt_mask),
                                        use_alt_flag.data_ptr(), _stream())
@@ -469,6 +494,33 @@ def varblock_launch_order(workspace: torch.Tensor, Hkv: int, QB: int, KB: int):
     off = Hkv * (3 * (QB + 1) + (KB + 1)) + Hkv * QB + Hkv * 64
     n = int(w[off].item())
     return w[off + 2: off + 2 + 2 * n].view(n, 2).clone()
+
+
+class ClockProbe:
+    """Sustained shader clock over a span of GPU work (svg_debug_clock_probe): `start()` launches the one-wave probe on its own
+    stream, `stop()` raises its flag from a third stream, waits for it and returns MHz (None if the counters did not move)."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.out = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self.s_probe = torch.cuda.Stream(device=self.dev)
+        self.s_flag = torch.cuda.Stream(device=self.dev)
+
+    def start(self, max_ms: int = 20000) -> None:
+        self.flag.zero_()
+        self.out.zero_()
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.stream(self.s_probe):
+            _check(load().svg_debug_clock_probe(self.flag.data_ptr(), self.out.data_ptr(), int(max_ms), _stream()),
+                   "svg_debug_clock_probe")
+
+    def stop(self):
+        with torch.cuda.stream(self.s_flag):
+            self.flag.fill_(1)
+        self.s_probe.synchronize()
+        c, w = (int(x) for x in self.out.tolist())
+        return round(100.0 * c / w, 1) if w > 0 and c > 0 else None
 
 
 def clear_workspace_cache() -> None:
@@ -636,8 +688,10 @@ def apply_qk_rope_inplace_cossin_complex(q, k, freqs_real, freqs_imag, len_text_
 
 
 def qk_norm_rope(q, k=None, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None, k_bias=None, eps: float = 1e-5,
-                 rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0, rope_hi: Optional[int] = None) -> None:
-    """Fused in-place normalisation + rotary embedding of q and (optionally) k in one pass (svg_qk_norm_rope)."""
+                 rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0, rope_hi: Optional[int] = None,
+                 q_scale: float = 1.0) -> None:
+    """Fused in-place normalisation + rotary embedding of q and (optionally) k in one pass (svg_qk_norm_rope).
+    q_scale != 1: folded into the last rounding of q (svg_qk_norm_rope_qscale; softmax_q_scale(D) for band_attention(q_prescaled=True))."""
     lib = load()
     _dev(q, k, q_weight, q_bias, k_weight, k_bias, cos, sin)
     if k is not None:
@@ -652,16 +706,16 @@ def qk_norm_rope(q, k=None, norm_kind: int = 0, q_weight=None, q_bias=None, k_we
         assert cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
     for w in (q_weight, q_bias, k_weight, k_bias):
         assert w is None or (w.dtype == q.dtype and w.shape == (D,) and w.is_contiguous())
-    _check(lib.svg_qk_norm_rope(q.data_ptr(), _ptr(k), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
-                                _ptr(q_bias), _ptr(k_weight), _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin),
-                                int(rope_lo), int(rope_hi), _stream()), "svg_qk_norm_rope")
+    _check(lib.svg_qk_norm_rope_qscale(q.data_ptr(), _ptr(k), bsz, Hq, Hkv, S, D, _dtype_code(q), int(norm_kind), _ptr(q_weight),
+                                       _ptr(q_bias), _ptr(k_weight), _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin),
+                                       int(rope_lo), int(rope_hi), float(q_scale), _stream()), "svg_qk_norm_rope")
 
 
 def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: int = 0, q_weight=None, q_bias=None, k_weight=None,
                            k_bias=None, eps: float = 1e-5, rope_kind: int = 0, cos=None, sin=None, rope_lo: int = 0,
-                           rope_hi: Optional[int] = None):
+                           rope_hi: Optional[int] = None, q_scale: float = 1.0):
     """q_in [bsz, S, Hq * D] (k_in [bsz, S, Hkv * D] or None) token-major -> new head-major tensors [bsz, H, S, D] with
-    normalisation + rotary embedding applied in the same pass (svg_qk_norm_rope_transpose)."""
+    normalisation + rotary embedding applied in the same pass (svg_qk_norm_rope_transpose); q_scale as in qk_norm_rope."""
     lib = load()
     _dev(q_in, k_in, q_weight, q_bias, k_weight, k_bias, cos, sin)
     bsz, S, HD = q_in.shape
@@ -675,10 +729,10 @@ def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: in
     if rope_kind:
         cols = D // 2 if rope_kind == 2 else D
         assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
-    _check(lib.svg_qk_norm_rope_transpose(q_in.data_ptr(), _ptr(k_in), q_out.data_ptr(), _ptr(k_out), bsz, heads_q, heads_k, S, D,
-                                          _dtype_code(q_in), int(norm_kind), _ptr(q_weight), _ptr(q_bias), _ptr(k_weight),
-                                          _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin), int(rope_lo),
-                                          int(rope_hi), _stream()), "svg_qk_norm_rope_transpose")
+    _check(lib.svg_qk_norm_rope_transpose_qscale(q_in.data_ptr(), _ptr(k_in), q_out.data_ptr(), _ptr(k_out), bsz, heads_q, heads_k, S,
+                                                 D, _dtype_code(q_in), int(norm_kind), _ptr(q_weight), _ptr(q_bias), _ptr(k_weight),
+                                                 _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin), int(rope_lo),
+                                                 int(rope_hi), float(q_scale), _stream()), "svg_qk_norm_rope_transpose")
     return q_out, k_out
 
 

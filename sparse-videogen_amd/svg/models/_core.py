@@ -72,15 +72,21 @@ def is_full_attention(layer_idx: int, timestep, first_layers_fp, first_times_fp)
     return timestep_value(timestep) > first_times_fp   # read back once per transformer forward, not once per layer
 
 
+LN2 = 0.6931471805599453   # sm_scale of a kernel that applies sm_scale * log2(e) itself to a q that already carries the softmax scale
+
+
 @time_logging_decorator("Level 3 - Dense Flash Attention")
-def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, valid_len: Optional[int] = None) -> torch.Tensor:
+def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, valid_len: Optional[int] = None,
+                    q_prescaled: bool = False) -> torch.Tensor:
     """Dense attention [cfg, H, S, D].  valid_len < S: two independent segments [0, valid) and [valid, S) — what the
-    reference gets from flash_attn_varlen_func with cu_seqlens [0, valid, S] (hyvideo/attention.py:452-470)."""
+    reference gets from flash_attn_varlen_func with cu_seqlens [0, valid, S] (hyvideo/attention.py:452-470).
+    q_prescaled: q carries sm_scale * log2(e) (see qkv_from_projections(q_scale=...)); GPU only."""
     S = q.shape[2]
     if q.is_cuda:
         real = S if valid_len is None else int(valid_len)
         mask = _native.BandMask(real_len=real, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
-        return _native.band_attention(q.contiguous(), k.contiguous(), v.contiguous(), mask)
+        return _native.band_attention(q.contiguous(), k.contiguous(), v.contiguous(), mask, q_prescaled=q_prescaled)
+    assert not q_prescaled, "a pre-scaled q only exists on the GPU path"
     if valid_len is None or valid_len >= S:
         return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
     vl = int(valid_len)
@@ -98,7 +104,7 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
 
 @time_logging_decorator("Level 3 - sample_mse")
 def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, skip_flag=None,
-               generator=None):
+               generator=None, q_prescaled: bool = False):
     """ref: sample_mse svg/models/hyvideo/attention.py:376-399.  Rows are drawn with the CPU generator exactly like the
     reference (`torch.randint(low=0, high=sample_mse_max_row, size=(n,))` without device=) unless `generator` is given.
     -> [2, cfg, H] in q's dtype: the reference stores the MSEs in `query.dtype` (:388) before the argmin, so two candidates that
@@ -107,7 +113,8 @@ def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_
     n = min(num_sampled_rows, S)
     rows = torch.randint(low=0, high=sample_max_row, size=(n,), generator=generator)
     mses = _native.sample_mse(q.reshape(cfg * H, S, D), k.reshape(cfg * H, S, D), v.reshape(cfg * H, S, D),
-                              rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag)
+                              rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag,
+                              sm_scale=LN2 if q_prescaled else None)   # (the profiler multiplies its scale by log2(e) itself)
     return mses.reshape(2, cfg, H).to(q.dtype)
 
 
@@ -155,7 +162,7 @@ def dense_flag_on_device(timestep, first_times_fp):
 
 def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask", dense_mask: "_native.BandMask",
                                  prof: "_native.ProfileDesc", num_sampled_rows: int, sample_max_row: int, dense_flag,
-                                 _local: bool = False):
+                                 _local: bool = False, q_prescaled: bool = False):
     """Dense warm-up step or sparse step, decided on the device: the profiler and the attention kernel read
     `dense_flag`; on a dense step the profiler returns at once and the kernel runs `dense_mask` without the head placement.
     Same attention results as the host-side branch of attention_core_logic (ref: hyvideo/attention.py:491-524) for the same sampled
@@ -163,18 +170,20 @@ def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask
     _require_gpu(q, "SVG1 attention")
     if _dist.active() and not _local:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
         return _dist.run_sharded(lambda qh, kh, vh: svg1_attention_device_switch(
-            qh, kh, vh, geo, mask, dense_mask, prof, num_sampled_rows, sample_max_row, dense_flag, _local=True), (q, k, v),
-            _dist.current_group())
+            qh, kh, vh, geo, mask, dense_mask, prof, num_sampled_rows, sample_max_row, dense_flag, _local=True,
+            q_prescaled=q_prescaled), (q, k, v), _dist.current_group())
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag, generator=_switch_generator())
+    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag, generator=_switch_generator(),
+                      q_prescaled=q_prescaled)
     best_mask_idx = torch.argmin(mses, dim=0)
     out = _native.band_attention_switch(q, k, v, mask, dense_mask, dense_flag, head_perm_flag=best_mask_idx, vid0=geo.vid0,
-                                        num_frame=geo.num_frame, frame_size=geo.frame_size)
+                                        num_frame=geo.num_frame, frame_size=geo.frame_size, q_prescaled=q_prescaled)
     return out, torch.where(dense_flag.reshape(()) != 0, torch.full_like(best_mask_idx, -1), best_mask_idx)
 
 
 def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof: "_native.ProfileDesc",
-                          num_sampled_rows: int, sample_max_row: int, fused: bool = True, _local: bool = False):
+                          num_sampled_rows: int, sample_max_row: int, fused: bool = True, _local: bool = False,
+                          q_prescaled: bool = False):
     """The sparse branch of attention_core_logic (ref: hyvideo/attention.py:507-524):
     online profiling -> best_mask_idx -> placement -> block-sparse attention -> inverse placement.
     fused=True folds both placements into the attention kernel (bit-identical result, ~5.9 GB less HBM traffic at
@@ -182,21 +191,25 @@ def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof
     _require_gpu(q, "SVG1 sparse attention")
     if _dist.active() and not _local:   # svg.distributed.enable(): this rank's heads only, outputs all-gathered
         return _dist.run_sharded(lambda qh, kh, vh: svg1_sparse_attention(
-            qh, kh, vh, geo, mask, prof, num_sampled_rows, sample_max_row, fused, _local=True), (q, k, v), _dist.current_group())
+            qh, kh, vh, geo, mask, prof, num_sampled_rows, sample_max_row, fused, _local=True, q_prescaled=q_prescaled), (q, k, v),
+            _dist.current_group())
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row)
+    mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, q_prescaled=q_prescaled)
     best_mask_idx = torch.argmin(mses, dim=0)  # [cfg, H] int64; NaN wins like torch.argmin in the reference
+    pk = dict(head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame, frame_size=geo.frame_size)
     if fused:
         with time_logging_decorator("Level 3 - sparse_flex_attention"):
-            attn = _native.band_attention_fp8 if _use_fp8(q) else _native.band_attention
-            out = attn(q, k, v, mask, head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame, frame_size=geo.frame_size)
+            if _use_fp8(q):   # (the fp8 pre-pass folds whatever scale it is given into its quantisation of q)
+                out = _native.band_attention_fp8(q, k, v, mask, sm_scale=LN2 if q_prescaled else None, **pk)
+            else:
+                out = _native.band_attention(q, k, v, mask, q_prescaled=q_prescaled, **pk)
         return out, best_mask_idx
     qo, ko, vo = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     with time_logging_decorator("Level 3 - fast_sparse_head_placement"):
         _native.head_placement([q, k, v], [qo, ko, vo], best_mask_idx, geo.context_length, geo.num_frame, geo.frame_size,
                                geo.text_first, inverse=False)
     with time_logging_decorator("Level 3 - sparse_flex_attention"):
-        hs = _native.band_attention(qo, ko, vo, mask)
+        hs = _native.band_attention(qo, ko, vo, mask, q_prescaled=q_prescaled)
     out = torch.empty_like(hs)
     with time_logging_decorator("Level 3 - fast_hidden_states_placement"):
         _native.head_placement([hs], [out], best_mask_idx, geo.context_length, geo.num_frame, geo.frame_size, geo.text_first,
@@ -453,7 +466,7 @@ def qk_rope_inplace(query, key, cos, sin, rope_lo: int, rope_hi: int, complex_pa
 
 
 def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin, rope_lo: int, rope_hi: int,
-                         complex_pairs: bool = False):
+                         complex_pairs: bool = False, q_scale: float = 1.0):
     """Projection outputs [bsz, S, heads * D] -> head-major q, k, v [bsz, heads, S, D] with QK-norm + RoPE applied to q, k in
     the same pass (svg_qk_norm_rope_transpose): replaces three transpose copies + norm + norm + rope.  None: not applicable."""
     ts = (query, key, value)
@@ -477,6 +490,7 @@ def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin
         if tb is None:
             return None
         rk = 2 if complex_pairs else 1
-    q, k = _native.qk_norm_rope_transpose(query, key, heads, heads, kind, qw, qb, kw, kb, eps, rk, tb[0], tb[1], rope_lo, rope_hi)
+    q, k = _native.qk_norm_rope_transpose(query, key, heads, heads, kind, qw, qb, kw, kb, eps, rk, tb[0], tb[1], rope_lo, rope_hi,
+                                          q_scale=q_scale)   # q_scale != 1: q leaves the prologue carrying the softmax scale
     v, _ = _native.qk_norm_rope_transpose(value, None, heads, 0)
     return q, k, v

@@ -61,10 +61,15 @@ class _HunyuanProcessorBase:
     (ref: hyvideo/attention.py:252-373)."""
 
     fused_prologue = True   # QK-norm + RoPE in one HIP pass (False: two stages, as in the reference)
+    # True (the SVG1 processor): the fused prologue folds sm_scale * log2(e) into its last rounding of q, and the attention /
+    # profiler kernels run their pre-scaled forms (svg_band_attention_prescaled: one FMA per score less on the vector pipe).  Only
+    # when the fused HIP prologue applies (GPU tensors, head_dim 128); q never leaves the processor, so nothing outside sees it.
+    prescale_q = False
     _valid_len_cache: dict = {}
 
     def __init__(self, layer_idx: int = 0):
         self.layer_idx = layer_idx
+        self._q_prescaled = False   # set by __call__ around attention_core_logic (whose signature is the reference's)
 
     @time_logging_decorator("Level 2 - get_qkv")
     def get_qkv(self, attn, hidden_states):
@@ -88,7 +93,7 @@ class _HunyuanProcessorBase:
         return query, key
 
     @time_logging_decorator("Level 2 - get_transpose_norm_rope")
-    def get_transpose_norm_rope(self, attn, query, key, value, image_rotary_emb, encoder_hidden_states):
+    def get_transpose_norm_rope(self, attn, query, key, value, image_rotary_emb, encoder_hidden_states, q_scale: float = 1.0):
         """get_transpose_qkv + get_qk_norm + get_rotary_emb in one read and one write per element
         (svg_qk_norm_rope_transpose); None when the HIP path does not apply."""
         if not self.fused_prologue:
@@ -98,7 +103,7 @@ class _HunyuanProcessorBase:
         hi = S - (encoder_hidden_states.shape[1] if single else 0)
         cos, sin = image_rotary_emb if image_rotary_emb is not None else (None, None)
         return _core.qkv_from_projections(query, key, value, attn.heads, getattr(attn, "norm_q", None),
-                                          getattr(attn, "norm_k", None), cos, sin, 0, hi)
+                                          getattr(attn, "norm_k", None), cos, sin, 0, hi, q_scale=q_scale)
 
     @time_logging_decorator("Level 2 - get_fused_prologue")
     def get_fused_prologue(self, attn, query, key, image_rotary_emb, encoder_hidden_states) -> bool:
@@ -115,7 +120,7 @@ class _HunyuanProcessorBase:
         return _core.qk_rope_inplace(query, key, cos, sin, 0, hi, norm_q=nq, norm_k=nk)
 
     @time_logging_decorator("Level 2 - get_encoder_condition_and_concat")
-    def get_encoder_condition_and_concat(self, attn, query, key, value, encoder_hidden_states):
+    def get_encoder_condition_and_concat(self, attn, query, key, value, encoder_hidden_states, q_scale: float = 1.0):
         if getattr(attn, "add_q_proj", None) is not None and encoder_hidden_states is not None:
             eq = attn.add_q_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
             ek = attn.add_k_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
@@ -124,6 +129,8 @@ class _HunyuanProcessorBase:
                 eq = attn.norm_added_q(eq)
             if getattr(attn, "norm_added_k", None) is not None:
                 ek = attn.norm_added_k(ek)
+            if q_scale != 1.0:   # the text stream's q joins a pre-scaled q (256 tokens; the torch modules rounded it already)
+                eq = (eq.float() * q_scale).to(eq.dtype)
             query = torch.cat([query, eq], dim=2)
             key = torch.cat([key, ek], dim=2)
             value = torch.cat([value, ev], dim=2)
@@ -167,17 +174,26 @@ class _HunyuanProcessorBase:
         if getattr(attn, "add_q_proj", None) is None and encoder_hidden_states is not None:
             hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
         query, key, value = self.get_qkv(attn, hidden_states)
-        fused = self.get_transpose_norm_rope(attn, query, key, value, image_rotary_emb, encoder_hidden_states)
+        q_scale = 1.0
+        if self.prescale_q and self.fused_prologue and query.is_cuda and query.shape[-1] == attn.heads * 128 \
+                and query.dtype in (torch.bfloat16, torch.float16):
+            q_scale = _core._native.softmax_q_scale(128)
+        fused = self.get_transpose_norm_rope(attn, query, key, value, image_rotary_emb, encoder_hidden_states, q_scale=q_scale)
         if fused is not None:
             query, key, value = fused
         else:
+            q_scale = 1.0   # the staged prologue (torch modules or the in-place HIP ops) delivers a plain q
             query, key, value = self.get_transpose_qkv(attn, query, key, value)
             if not self.get_fused_prologue(attn, query, key, image_rotary_emb, encoder_hidden_states):
                 query, key = self.get_qk_norm(attn, query, key)
                 query, key = self.get_rotary_emb(attn, query, key, image_rotary_emb, encoder_hidden_states)
-        query, key, value = self.get_encoder_condition_and_concat(attn, query, key, value, encoder_hidden_states)
+        query, key, value = self.get_encoder_condition_and_concat(attn, query, key, value, encoder_hidden_states, q_scale=q_scale)
         cu_max_seqlens = self.get_cu_max_seqlen(attention_mask, query.device)
-        hidden_states = self.attention_core_logic(query, key, value, timestep, self.layer_idx, cu_max_seqlens)
+        self._q_prescaled = q_scale != 1.0
+        try:
+            hidden_states = self.attention_core_logic(query, key, value, timestep, self.layer_idx, cu_max_seqlens)
+        finally:
+            self._q_prescaled = False
         hidden_states = hidden_states.transpose(1, 2).flatten(2, 3).to(query.dtype)
         return self.get_o(attn, hidden_states, encoder_hidden_states)
 
@@ -213,6 +229,7 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
     block_mask = None      # svg_band_mask_t descriptor (what the reference's flex BlockMask encodes)
     fused_placement = True  # fold both layout transformations into the attention kernel (bit-identical result)
     device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor (no read-back per forward)
+    prescale_q = True       # q leaves the fused prologue carrying the softmax scale (see _HunyuanProcessorBase.prescale_q)
 
     def __init__(self, layer_idx):
         super().__init__(layer_idx)
@@ -227,7 +244,7 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
         """-> [2, cfg, H] mean-squared errors of the spatial / temporal mask on sampled rows (ref :376-399)"""
         geo = self.geometry()
         return _core.sample_mse(query, key, value, geo, profile_desc(geo.context_length, geo.num_frame, geo.frame_size),
-                                self.num_sampled_rows, self.sample_mse_max_row)
+                                self.num_sampled_rows, self.sample_mse_max_row, q_prescaled=self._q_prescaled)
 
     @time_logging_decorator("Level 2 - attention core logic")
     def attention_core_logic(self, query, key, value, timestep, layer_idx, cu_max_seqlens):
@@ -242,19 +259,21 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
         if self.device_switch and _core.attention_dtype() == "bf16" and self.fused_placement and self.layer_idx >= self.first_layers_fp and self.block_mask is not None \
                 and query.is_cuda:
             dense_flag = _core.dense_flag_on_device(timestep, self.first_times_fp)
+        pre = self._q_prescaled
         if dense_flag is None and _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
-            return _core.dense_attention(query, key, value, valid).reshape(cfg, num_heads, seq_len, dim)
+            return _core.dense_attention(query, key, value, valid, q_prescaled=pre).reshape(cfg, num_heads, seq_len, dim)
         mask = self.block_mask
         if mask is None:
             raise RuntimeError("Hunyuan_SVGAttn_Processor2_0.block_mask is not set: call replace_hyvideo_attention first")
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
         if dense_flag is not None:
             out, best = _core.svg1_attention_device_switch(query, key, value, geo, mask, dense_mask(seq_len, int(valid)), prof,
-                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag)
+                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag,
+                                                           q_prescaled=pre)
             self.last_best_mask_idx = best
             return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, mask, prof, self.num_sampled_rows,
-                                                min(self.sample_mse_max_row, seq_len), fused=self.fused_placement)
+                                                min(self.sample_mse_max_row, seq_len), fused=self.fused_placement, q_prescaled=pre)
         self.last_best_mask_idx = best
         return out.reshape(cfg, num_heads, seq_len, dim)
 
@@ -280,6 +299,7 @@ class Hunyuan_SAPAttn_Processor2_0(Hunyuan_SVGAttn_Processor2_0):
     zero_step_kmeans_init = False
 
     logging_file = None
+    prescale_q = False   # k-means and the block map work on the plain q
     centroid_store = CentroidStore()  # class-level like the reference's dicts; `reset_state()` clears it
 
     @classmethod

@@ -496,10 +496,10 @@ def test_varblock_attention_reference_grid_sample(nat, hq, hkv, D, S, MB, NB, de
     test_varblock_attention(nat, hq, hkv, D, S, MB, NB, density, dtype, -1)
 
 
-@pytest.mark.parametrize("variant", [3, 6])
+@pytest.mark.parametrize("variant", [3, 7])
 @pytest.mark.parametrize("hq,hkv,S,MB,NB", [(4, 2, 5000, 37, 90), (3, 3, 9000, 64, 200), (2, 1, 700, 5, 33)])
 def test_varblock_launch_order_is_a_permutation(nat, variant, hq, hkv, S, MB, NB):
-    """The device-built launch order (variant 3: similarity chain + XCD remap, variant 6: longest-first) lists every (q head,
+    """The device-built launch order (variant 3: longest-first, variant 7: similarity chain + XCD remap) lists every (q head,
     block-row, 256-row sub-tile) exactly once — index work, checked for equality with the host's enumeration as a set — and the
     attention result does not depend on the order (bit-identical between the two orders and the plain block-row order)."""
     gen = torch.Generator().manual_seed(S + MB)

@@ -124,6 +124,52 @@ def test_hunyuan_svg_processor_end_to_end():
         torch.testing.assert_close(outs[0][1].float(), outs[1][1].float(), atol=1e-2, rtol=1e-2)
 
 
+def test_hunyuan_svg_processor_prescaled_q_equals_plain_path():
+    """prescale_q (default of the SVG1 processor: the fused prologue folds sm_scale * log2(e) into its last rounding of q and the
+    kernels run their pre-scaled forms) against prescale_q = False (plain q, scale applied inside the kernel): the same processor
+    output up to the rounding of q — sparse step, dense warm-up step and the device-switched path, double- and single-stream block."""
+    from svg.models import _core
+    from svg.models.hyvideo.inference import replace_hyvideo_attention
+
+    torch.manual_seed(1)
+    heads, hd = 4, 128
+    dim = heads * hd
+    blocks = [Block(Attention(dim, heads, added_kv=True, dtype=DT), "attn"), Block(Attention(dim, heads, dtype=DT), "attn")]
+    tr = Transformer(blocks[:1], "transformer_blocks")
+    tr.single_transformer_blocks = torch.nn.ModuleList(blocks[1:])
+    pipe = Pipe(tr)
+    tr.cuda()
+    L = 21
+    cls = replace_hyvideo_attention(pipe, 160, 320, 17, L, first_layers_fp=0, first_times_fp=900.0, pattern="SVG",
+                                    num_sampled_rows=32, sparsity=0.45)
+    assert cls.prescale_q
+    ctx, F_, P_ = cls.context_length, cls.num_frame, cls.frame_size
+    cls.sample_mse_max_row = F_ * P_
+    V = F_ * P_
+    hidden = (torch.randn(1, V, dim) * 0.3).to(DT).cuda()
+    enc = (torch.randn(1, ctx, dim) * 0.3).to(DT).cuda()
+    amask = torch.zeros(1, V + ctx, dtype=torch.bool)
+    amask[:, : V + L] = True
+    rope = rope_tables(V, hd)
+    try:
+        for blk in blocks:
+            for ts in (torch.tensor([100.0]), torch.tensor([950.0]), torch.tensor([100.0]).cuda(), torch.tensor([950.0]).cuda()):
+                outs = []
+                for pre in (True, False):
+                    cls.prescale_q = pre
+                    torch.manual_seed(7)
+                    _core.reseed_switch_generator(7)
+                    with torch.no_grad():
+                        outs.append(blk.attn(hidden, encoder_hidden_states=enc, attention_mask=amask.cuda(), image_rotary_emb=rope,
+                                             timestep=ts))
+                for a, b in zip(*outs):
+                    torch.testing.assert_close(a.float(), b.float(), atol=2e-2, rtol=2e-2)
+                    e = ((a.float() - b.float()).norm() / b.float().norm()).item()
+                    assert e < 6e-3, e
+    finally:
+        cls.prescale_q = True
+
+
 def _clustered(H, N, D, modes, gen):
     centers = torch.randn(H, modes, D, generator=gen) * 2.0
     lab = torch.randint(0, modes, (H, N), generator=gen)
