@@ -400,15 +400,17 @@ def main():
             clock = None
     barrier()
     if clock:
-        clock.start()
+        clock.start(max_ms=60000)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
+    if clock:
+        clock.arm_stop()   # (stream-ordered behind the last step: the barrier below must not wait for a probe that waits for it)
     barrier()
     dt = time.perf_counter() - t0
     clock_info = None
     if clock:
-        mhz = clock.stop()
+        mhz = clock.result()
         clock_info = {"sclk_mhz_timed_steps": mhz, "frac_of_2400": round(mhz / 2400.0, 4) if mhz else None,
                       "how": "svg_debug_clock_probe: shader-clock ticks / 100 MHz ticks of one sleeping wave while the timed steps ran"}
     if world > 1:
@@ -653,6 +655,25 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         torch.cuda.empty_cache()
+    if world > 1 and not a.no_step and not fp8:
+        # BASELINE.json configs[3] at N > 1: the denoise step token-sharded over the ranks (bench_step.py: tokens/N for norms, GEMMs,
+        # prologue and glue, heads/N for the attention, all-to-all exchanges either side of it, one all-gather of the hidden states per
+        # step).  Every rank takes part; rank 0 reports (the step time is the MAX over ranks).
+        torch.cuda.empty_cache()
+        try:
+            import bench_step
+
+            if a.workload == "hy720p":
+                sd = bench_step.measure(steps=2, warmup=1, rank=rank, world=world, kinds=("sparse",), host_staged=smoke)
+            else:   # reduced workloads (tests, smoke runs): a 1 + 1 block stack on a small geometry
+                sd = bench_step.measure(steps=1, warmup=1, n_double=1, n_single=1, rank=rank, world=world, kinds=("sparse",), host_staged=smoke,
+                                        geo=bench_step.StepGeo(F=F_, P=P_, ctx=ctx, L=L, hid=H * D, heads=H, hd=D, mlp=2 * H * D))
+            if rank == 0:
+                out["denoise_step_hy720p"] = sd
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            raise
     if world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(H, D, S)
     elif rank == 0:

@@ -498,7 +498,8 @@ def varblock_launch_order(workspace: torch.Tensor, Hkv: int, QB: int, KB: int):
 
 class ClockProbe:
     """Sustained shader clock over a span of GPU work (svg_debug_clock_probe): `start()` launches the one-wave probe on its own
-    stream, `stop()` raises its flag from a third stream, waits for it and returns MHz (None if the counters did not move)."""
+    stream, `arm_stop()` raises its flag from a third stream behind the work enqueued so far, `result()` waits for the probe and returns
+    MHz (None if the counters did not move)."""
 
     def __init__(self, device):
         self.dev = torch.device(device)
@@ -515,9 +516,14 @@ class ClockProbe:
             _check(load().svg_debug_clock_probe(self.flag.data_ptr(), self.out.data_ptr(), int(max_ms), _stream()),
                    "svg_debug_clock_probe")
 
-    def stop(self):
+    def arm_stop(self) -> None:
+        """Raise the flag once everything enqueued so far on the CURRENT stream has finished (stream-ordered, no host wait) — call it
+        right after the last launch of the span, BEFORE any device-wide synchronisation (which would wait for the probe itself)."""
+        self.s_flag.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.s_flag):
             self.flag.fill_(1)
+
+    def result(self):
         self.s_probe.synchronize()
         c, w = (int(x) for x in self.out.tolist())
         return round(100.0 * c / w, 1) if w > 0 and c > 0 else None

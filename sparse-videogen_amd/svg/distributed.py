@@ -135,7 +135,7 @@ def _owner_lists(num_heads: int, world: int, head_lists) -> List[List[int]]:
 
 
 def tokens_to_heads(x_local: torch.Tensor, num_tokens: int, group=None, unit: int = 1, head_lists=None, presorted: bool = False,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, recv: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Inbound exchange of a layer-call.  x_local [H, S_r, ...]: ALL heads of this rank's tokens `token_range(num_tokens, rank,
     world, unit)` (head-major, as the fused prologue writes it) -> [H_local, num_tokens, ...]: this rank's heads of ALL tokens.
     One all_to_all_single (every peer sends to every peer directly: the 7 xGMI links of a rank run concurrently), then one
@@ -156,8 +156,13 @@ def tokens_to_heads(x_local: torch.Tensor, num_tokens: int, group=None, unit: in
     order = [h for o in owners for h in o]
     if not presorted and order != list(range(H)):
         x_local = x_local.index_select(0, torch.tensor(order, device=x_local.device))
-    send = x_local.contiguous().view(-1)
-    recv = torch.empty(Hl * num_tokens * E, dtype=x_local.dtype, device=x_local.device)
+    send = x_local.contiguous().view(-1)   # (no copy for the head-major tensor the fused prologue writes)
+    # recv: optional caller-owned staging buffer (a step that runs this exchange 180 times allocates nothing: ExchangeBuffers)
+    if recv is None:
+        recv = torch.empty(Hl * num_tokens * E, dtype=x_local.dtype, device=x_local.device)
+    else:
+        assert recv.dtype == x_local.dtype and recv.numel() >= Hl * num_tokens * E
+        recv = recv.view(-1)[: Hl * num_tokens * E]
     dist.all_to_all_single(recv, send, output_split_sizes=[Hl * (b - a) * E for a, b in tr],
                            input_split_sizes=[len(o) * S_me * E for o in owners], group=group)
     if out is None:
@@ -170,7 +175,8 @@ def tokens_to_heads(x_local: torch.Tensor, num_tokens: int, group=None, unit: in
     return out
 
 
-def heads_to_tokens(o_local: torch.Tensor, num_heads: int, group=None, unit: int = 1, head_lists=None) -> torch.Tensor:
+def heads_to_tokens(o_local: torch.Tensor, num_heads: int, group=None, unit: int = 1, head_lists=None,
+                    send: Optional[torch.Tensor] = None, recv: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Outbound exchange, the inverse of tokens_to_heads: o_local [H_local, S, ...] (this rank's heads, all tokens) ->
     [H, S_r, ...] (all heads of this rank's tokens; heads in global order) — what a token-sharded `to_out` consumes, world
     times fewer received bytes than all-gathering the heads."""
@@ -185,8 +191,21 @@ def heads_to_tokens(o_local: torch.Tensor, num_heads: int, group=None, unit: int
     Hl = len(owners[rank])
     assert o_local.shape[0] == Hl
     S_me = tr[rank][1] - tr[rank][0]
-    send = torch.cat([o_local[:, a:b].reshape(-1) for a, b in tr])
-    recv = torch.empty(num_heads * S_me * E, dtype=o_local.dtype, device=o_local.device)
+    if send is None:
+        send = torch.cat([o_local[:, a:b].reshape(-1) for a, b in tr])
+    else:   # caller-owned staging (see ExchangeBuffers): one strided copy per destination rank, no allocation
+        assert send.dtype == o_local.dtype and send.numel() >= Hl * S * E
+        send = send.view(-1)[: Hl * S * E]
+        off = 0
+        for a, b in tr:
+            n = Hl * (b - a) * E
+            send[off:off + n].view((Hl, b - a) + rest).copy_(o_local[:, a:b])
+            off += n
+    if recv is None:
+        recv = torch.empty(num_heads * S_me * E, dtype=o_local.dtype, device=o_local.device)
+    else:
+        assert recv.dtype == o_local.dtype and recv.numel() >= num_heads * S_me * E
+        recv = recv.view(-1)[: num_heads * S_me * E]
     dist.all_to_all_single(recv, send, output_split_sizes=[len(o) * S_me * E for o in owners],
                            input_split_sizes=[Hl * (b - a) * E for a, b in tr], group=group)
     out = recv.view((num_heads, S_me) + rest)
@@ -196,6 +215,41 @@ def heads_to_tokens(o_local: torch.Tensor, num_heads: int, group=None, unit: int
         inv[torch.tensor(order)] = torch.arange(num_heads)
         out = out.index_select(0, inv.to(out.device))
     return out
+
+
+class ExchangeBuffers:
+    """Staging of the two exchanges either side of a head-sharded attention inside a token-sharded stack, allocated ONCE for a
+    (heads, tokens, head_dim, dtype, group) and reused by every layer of every step: tokens_to_heads receives into `recv_in`
+    and scatters into one of three persistent [H_local, S, D] tensors (q, k, v); heads_to_tokens packs into `send_out` and
+    receives into `recv_out` ([H, S_r, D], returned as a view — consume it before the next call)."""
+
+    def __init__(self, num_heads: int, num_tokens: int, head_dim: int, dtype, device, group=None, unit: int = 1):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        assert num_heads % world == 0, "ExchangeBuffers: equal head shards (use run_sharded for ragged splits)"
+        self.group, self.unit, self.H, self.S, self.D = group, unit, num_heads, num_tokens, head_dim
+        self.Hl = num_heads // world
+        a, b = token_range(num_tokens, rank, world, unit)
+        self.S_me = b - a
+        mk = lambda *shape: torch.empty(shape, dtype=dtype, device=device)   # noqa: E731
+        self.qkv = [mk(self.Hl, num_tokens, head_dim) for _ in range(3)]
+        self.recv_in = mk(self.Hl * num_tokens * head_dim)
+        self.send_out = mk(self.Hl * num_tokens * head_dim)
+        self.recv_out = mk(num_heads * self.S_me * head_dim)
+        self.bytes_in = 0     # received by this rank from OTHER ranks, accumulated (reset by the caller per step)
+        self.bytes_out = 0
+        self._esz = self.recv_in.element_size()
+
+    def tokens_to_heads(self, x_local: torch.Tensor, which: int) -> torch.Tensor:
+        """x_local [H, S_r, D] (all heads of my tokens) -> persistent [H_local, S, D] buffer number `which` (0 q, 1 k, 2 v)"""
+        out = tokens_to_heads(x_local, self.S, self.group, self.unit, out=self.qkv[which], recv=self.recv_in)
+        self.bytes_in += self.Hl * (self.S - self.S_me) * self.D * self._esz
+        return out
+
+    def heads_to_tokens(self, o_local: torch.Tensor) -> torch.Tensor:
+        """o_local [H_local, S, D] -> [H, S_r, D] (a view of the receive buffer)"""
+        out = heads_to_tokens(o_local, self.H, self.group, self.unit, send=self.send_out, recv=self.recv_out)
+        self.bytes_out += (self.H - self.Hl) * self.S_me * self.D * self._esz
+        return out
 
 
 _SIDE_STREAMS: Dict[object, list] = {}

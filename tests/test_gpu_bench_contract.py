@@ -47,6 +47,8 @@ def test_bench_two_rank_control_flow_smoke():
     ex = d["exchange"]
     assert ex["rccl_ranks_seen"] == 2 and ex["fallback_to_chunk_launches"] is False and ex["waiter_timeouts_in_timed_steps"] == 0
     assert ex["inbound_bytes_received_per_rank"] > 0 and ex["outbound_bytes_received_per_rank"] > 0
+    sd = d["denoise_step_hy720p"]     # the token-sharded denoise step at N = 2 (reduced stack on the tiny workload)
+    assert sd["n_gpus"] == 2 and sd["sparse_step"]["ms"] > 0 and sd["sparse_step"]["rccl_bytes_received_per_step_this_rank"] > 0
 
 
 def test_bench_two_rank_watchdog_falls_back():
@@ -81,5 +83,22 @@ def test_bench_step_small_stack():
 
     d = bench_step.measure(steps=1, warmup=0, n_double=1, n_single=1)
     for kind in ("sparse_step", "dense_step"):
-        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflop"] > 0
-    assert d["denoise_steps_per_s"] > 0 and d["speedup_sparse_vs_dense_step"] > 0
+        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflop_this_rank"] > 0
+    assert d["denoise_steps_per_s"] > 0 and d["speedup_sparse_vs_dense_step"] > 0 and d["n_gpus"] == 1
+
+
+def test_bench_step_two_rank_smoke():
+    """bench_step.py --gpus 2 (BASELINE.json configs[3] at N > 1): token-sharded stack, head-sharded attention, the exchanges and the
+    final all-gather — both ranks on cuda:0 over gloo through host memory (SVG_BENCH_SMOKE): control flow and bookkeeping, not speed.
+    The sharded step's hidden states are checked against the single-process step by tests/test_step_sharding_cpu.py."""
+    env = dict(os.environ, SVG_BENCH_SMOKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(ROOT / "bench_step.py"), "--gpus", "2", "--tiny", "--layers-double", "1", "--layers-single", "1",
+           "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "tokens/2" in d["parallelism"] and "gloo" in d["exchange_backend"]
+    for kind in ("sparse_step", "dense_step"):
+        assert d[kind]["ms"] > 0 and d[kind]["rccl_bytes_received_per_step_this_rank"] > 0
+    assert d["denoise_steps_per_s"] > 0

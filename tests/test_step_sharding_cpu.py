@@ -1,0 +1,78 @@
+"""The N-rank denoise step of bench_step.py (BASELINE.json configs[3]: hidden states token-sharded by whole frames, attention
+head-sharded, tokens_to_heads / heads_to_tokens around every attention, one all-gather of the hidden states per step) against the
+single-process step on the same stack: 2 and 3 processes over gloo on CPU with a torch statement of the op table
+(tests/step_ops_torch.py) — what is under test is the sharding: token ranges, RoPE table slices, the text stream living on the last
+rank, head shards, exchange layouts, the final gather.  The HIP ops themselves are tested in tests/test_gpu_*.py."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _setup_paths():
+    for p in (str(ROOT), str(ROOT / "sparse-videogen_amd"), str(ROOT / "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _geo(heads):
+    _setup_paths()
+    import bench_step
+
+    return bench_step.StepGeo(F=5, P=40, ctx=24, L=7, hid=heads * 32, heads=heads, hd=32, mlp=96)
+
+
+def _single(heads, sparse):
+    _setup_paths()
+    import bench_step
+    from step_ops_torch import TorchOps
+
+    geo = _geo(heads)
+    st = bench_step.Stack(1, 1, torch.device("cpu"), geo, dtype=torch.float32)
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(geo.V, geo.hid, generator=g) * 0.5
+    txt = torch.randn(geo.ctx, geo.hid, generator=g) * 0.5
+    return bench_step.run_step(st, img, txt, sparse, 1, [], TorchOps(geo), None, events=False), img, txt
+
+
+def _worker(rank, world, port, heads, sparse, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    _setup_paths()
+    import bench_step
+    from step_ops_torch import TorchOps
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    geo = _geo(heads)
+    ref, img, txt = _single(heads, sparse)
+    st = bench_step.Stack(1, 1, torch.device("cpu"), geo, dtype=torch.float32)
+    sh = bench_step.Sharding(geo, rank, world, torch.device("cpu"), torch.float32)
+    x = bench_step.run_step(st, img[sh.a: sh.a + sh.nv].contiguous(), txt[geo.ctx - sh.nt:].contiguous() if sh.nt else txt[:0], sparse, 1,
+                            [], TorchOps(geo), sh, events=False)
+    full, nbytes = sh.gather_tokens(x)
+    ok = (tuple(x.shape) == (sh.b - sh.a, geo.hid) and torch.allclose(x, ref[sh.a:sh.b], atol=2e-5, rtol=2e-5)
+          and torch.allclose(full, ref, atol=2e-5, rtol=2e-5))
+    # exchange volume bookkeeping: 2 layers x (3 inbound + 1 outbound) all-to-alls
+    Hl = geo.heads // world
+    want_in = 2 * 3 * Hl * (geo.S - (sh.b - sh.a)) * geo.hd * 4
+    want_out = 2 * (geo.heads - Hl) * (sh.b - sh.a) * geo.hd * 4
+    ok = ok and sh.buf.bytes_in == want_in and sh.buf.bytes_out == want_out and nbytes > 0
+    # the text tokens live on the last rank only
+    ok = ok and (sh.nt == (geo.ctx if rank == world - 1 else 0))
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,heads,sparse", [(2, 4, True), (2, 4, False), (3, 6, True)])
+def test_token_sharded_step_equals_single_process(world, heads, sparse):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29650 + world * 7 + heads + int(sparse)
+    mp.spawn(_worker, args=(world, port, heads, sparse, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
