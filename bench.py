@@ -392,15 +392,17 @@ def main():
         torch.cuda.synchronize()
 
     # sustained shader clock of the timed steps: a one-wave probe kernel beside them (s_memtime against the 100 MHz counter)
+    # (N = 1 without side streams only: the probe occupies a hardware queue for the whole span, and a process has few of them — with
+    #  the waiter / exchange streams of the N > 1 path a launch could be queued BEHIND the probe that waits for it)
     clock = None
-    if rank == 0:
+    if rank == 0 and world == 1 and side is None:
         try:
             clock = nat.ClockProbe(dev)
         except Exception:  # noqa: BLE001
             clock = None
     barrier()
     if clock:
-        clock.start(max_ms=60000)
+        clock.start(max_ms=20000)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
