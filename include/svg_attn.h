@@ -156,7 +156,10 @@ int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, con
  * variant: -1 = auto (what the Python layer passes), 0 = 128-row q tiles (4 waves, two workgroups per CU), 1 = 256-row q tiles
  * (8 waves, lock-step), 2 = mixed (full 256-row tiles on 8 waves, the rest of each block-row on 128-row tiles; two launches),
  * 3 = 256-row q tiles with the two-phase ping-pong body of svg_band_attention (waves without query rows idle), workgroups
- * launched longest-first inside every kv head (device-side counting sort on the active keys of the block-rows); 6 = the same;
+ * launched longest-first inside every kv head (device-side counting sort on the active keys of the block-rows), and REMAINDER
+ * PACKING: the ragged last tiles of two block-rows of a kv head that fit into one tile and share many key blocks (a device-side
+ * matching on the map's bitmap rows) run as ONE tile that walks the common key blocks once — exact: a row sees its own block-row's
+ * keys only (two key intervals per row); 6 = variant 3 without the packing (the default of round 2);
  * 4 = the same kernel in block-row order (A/B measurements); 5 = variant 3 recording the launch timeline (svg_debug_wg_trace);
  * 7 = similarity order: block-rows with (nearly) the same active key blocks are neighbours of a device-built nearest-neighbour
  * chain and consecutive workgroups go to the same XCD so that they meet in its L2 (maps whose bitmap does not fit the chain

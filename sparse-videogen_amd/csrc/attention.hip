@@ -99,12 +99,23 @@ struct VarblockPolicy {
         const int32_t* q_off;       // [Hkv, QB + 1] exclusive prefix of q_sizes
         const int32_t* k_off;       // [Hkv, KB + 1]
         const int32_t* tile_off;    // [Hkv, QB + 1] exclusive prefix of ceil(q_size / BM)
-        const int32_t* order;       // longest-first launch order (or nullptr): [0] = #workgroups, then (hq, block-row << 16 | sub-tile)
+        const int32_t* order;       // launch order (or nullptr): [0] = #workgroups, then triples (hq, block-row << 16 | sub-tile, partner):
+                                    // partner >= 0: the ragged last tile of that block-row also carries the ragged last tile of block-row
+                                    // `partner` (same kv head) — "remainder packing", see varblock_pair_kernel
         const int32_t* q_row_idx;   // [Hq, Sq] or null
         const int32_t* kv_row_idx;  // [Hkv, Skv] or null
     };
     struct Ctx {
         int hq, hkv, q0, q_end, nT, total;  // q rows [q0, q_end) in permuted coordinates; total = active keys
+        // Remainder packing: tile rows [0, ra) are the rows [q0, q_end) of the block-row ("member A"), tile rows [ra, ra + rb) the last rb
+        // rows of the partner block-row ("member B", permuted positions jb0 ...).  The run list holds the key blocks both members
+        // attend first (kC keys), then those only A attends (up to kCA), then those only B attends (up to total): a row of A may see
+        // [0, kCA), a row of B [0, kC) u [kCA, total) — two intervals per row, which is what the bodies' masks take.  Without a
+        // partner rb = 0 and kC = kCA = total.
+        int ra, rb, jb0, kC, kCA;
+        // per WAVE (like BandPolicy::fk_lo): key ranges on which every row of the wave may see every key (FULL tiles) and on which some
+        // row may see some key (anything else is SKIP)
+        int f1_lo, f1_hi, f2_lo, f2_hi, any1_hi, any2_lo;
         // LDS run list: .x = inclusive prefix of the run lengths (the end of run j in compact coordinates), .y = permuted start
         // position of run j minus the compact position it starts at — one 8-byte read resolves a key: perm = pos + .y
         const int2* run;
@@ -118,12 +129,13 @@ struct VarblockPolicy {
     };            // keys) and then finds the entry in a register; the read that refills rn has until the next crossing to land
 
     static __device__ __forceinline__ bool init(const Params& p, Ctx& c, char* plds) {
-        int i, sub;
-        if (p.order) {   // 1-D grid in longest-first order (varblock_order_kernel)
+        int i, sub, partner = -1;
+        if (p.order) {   // 1-D grid in longest-first order (varblock_scatter_kernel)
             const int b = blockIdx.x;
             if (b >= p.order[0]) return false;
-            c.hq = p.order[2 + 2 * b];
-            const int e = p.order[3 + 2 * b];
+            c.hq = p.order[2 + 3 * b];
+            const int e = p.order[3 + 3 * b];
+            partner = p.order[4 + 3 * b];
             i = e >> 16, sub = e & 0xFFFF;
             c.hkv = c.hq / p.group;
         } else {
@@ -145,40 +157,62 @@ struct VarblockPolicy {
         const int base = qoff[i] + (p.tile_mode == 2 ? ((qoff[i + 1] - qoff[i]) / kVbFull) * kVbFull : 0);
         c.q0 = base + sub * BM;
         c.q_end = min(qoff[i + 1], c.q0 + BM);
+        c.ra = max(c.q_end - c.q0, 0), c.rb = 0, c.jb0 = 0;
+        if (partner >= 0) {   // the partner's ragged last tile: its last (size % BM) rows
+            const int nj = qoff[partner + 1] - qoff[partner];
+            c.rb = nj % BM;
+            c.jb0 = qoff[partner + 1] - c.rb;
+        }
         c.qidx = p.q_row_idx ? p.q_row_idx + (size_t)c.hq * p.Sq : nullptr;
         c.kidx = p.kv_row_idx ? p.kv_row_idx + (size_t)c.hkv * p.Skv : nullptr;
 
-        // ---- compact the active non-empty column blocks of row i into the LDS run list ----
+        // ---- compact the active non-empty column blocks into the LDS run list: one pass per class of key blocks
+        //      (both members | only A | only B; without a partner everything is the first class) ----
         int2* run = (int2*)plds;
         int32_t* wave_cnt = (int32_t*)(run + p.kb_cap + 2);  // [NW] counts, [NW] lengths
         const uint8_t* mrow = p.block_map + ((size_t)c.hkv * p.QB + i) * p.KB;
+        const uint8_t* mrow2 = partner >= 0 ? p.block_map + ((size_t)c.hkv * p.QB + partner) * p.KB : mrow;
         const int32_t* koff = p.k_off + (size_t)c.hkv * (p.KB + 1);
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
         constexpr int NT = NW * 64;
         int base_cnt = 0, base_len = 0;
-        for (int j0 = 0; j0 < p.KB; j0 += NT) {
-            const int j = j0 + tid;
-            int len = 0, st = 0;
-            if (j < p.KB && mrow[j]) {
-                st = koff[j];
-                len = koff[j + 1] - st;
-            }
-            const int flag = len > 0;
-            int icnt = flag, ilen = len;
+        auto scan_class = [&](int want) {   // want: 3 = both, 1 = only A, 2 = only B
+            for (int j0 = 0; j0 < p.KB; j0 += NT) {
+                const int j = j0 + tid;
+                int len = 0, st = 0;
+                if (j < p.KB) {
+                    const int cls = (mrow[j] ? 1 : 0) | (mrow2[j] ? 2 : 0);
+                    if (cls == want) {
+                        st = koff[j];
+                        len = koff[j + 1] - st;
+                    }
+                }
+                const int flag = len > 0;
+                int icnt = flag, ilen = len;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t1 = __shfl_up(icnt, o), t2 = __shfl_up(ilen, o);
-                if (lane >= o) icnt += t1, ilen += t2;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t1 = __shfl_up(icnt, o), t2 = __shfl_up(ilen, o);
+                    if (lane >= o) icnt += t1, ilen += t2;
+                }
+                __syncthreads();  // previous round's readers of wave_cnt are done
+                if (lane == 63) wave_cnt[wv] = icnt, wave_cnt[NW + wv] = ilen;
+                __syncthreads();
+                int wc = base_cnt, wl = base_len;
+                for (int x = 0; x < wv; ++x) wc += wave_cnt[x], wl += wave_cnt[NW + x];
+                if (flag) {
+                    run[wc + icnt - 1] = make_int2(wl + ilen, st - (wl + ilen - len));
+                }
+                for (int x = 0; x < NW; ++x) base_cnt += wave_cnt[x], base_len += wave_cnt[NW + x];
             }
-            __syncthreads();  // previous round's readers of wave_cnt are done
-            if (lane == 63) wave_cnt[wv] = icnt, wave_cnt[NW + wv] = ilen;
-            __syncthreads();
-            int wc = base_cnt, wl = base_len;
-            for (int x = 0; x < wv; ++x) wc += wave_cnt[x], wl += wave_cnt[NW + x];
-            if (flag) {
-                run[wc + icnt - 1] = make_int2(wl + ilen, st - (wl + ilen - len));
-            }
-            for (int x = 0; x < NW; ++x) base_cnt += wave_cnt[x], base_len += wave_cnt[NW + x];
+        };
+        scan_class(3);
+        c.kC = base_len;
+        if (partner >= 0) {
+            scan_class(1);
+            c.kCA = base_len;
+            scan_class(2);
+        } else {
+            c.kCA = base_len;
         }
         // two sentinels behind the last run: the cursor (kv_phys_at) reads one entry ahead and stops at them
         if (tid < 2) run[base_cnt + tid] = make_int2(0x7fffffff, 0);
@@ -187,6 +221,15 @@ struct VarblockPolicy {
         c.total = base_len;
         c.run = run;
         c.nT = (c.total + kBN - 1) / kBN;
+        // per-wave tile classes: rows of this wave = tile rows [w0, w1)
+        {
+            const int w0 = wave_id() * 32, w1 = min(w0 + 32, c.ra + c.rb);
+            const bool only_a = w1 <= c.ra, only_b = w0 >= c.ra;
+            c.f1_lo = 0, c.f1_hi = only_a ? c.kCA : c.kC;                 // every row of the wave sees all of [f1_lo, f1_hi)
+            c.f2_lo = c.kCA, c.f2_hi = only_b ? c.total : c.kCA;          // ... and of [f2_lo, f2_hi)
+            c.any1_hi = only_a ? c.kCA : (only_b ? c.kC : c.total);        // some row sees some key of [0, any1_hi) u [any2_lo, total)
+            c.any2_lo = only_b ? c.kCA : c.total;
+        }
         return true;
     }
 
@@ -195,11 +238,12 @@ struct VarblockPolicy {
     static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.hkv * p.Skv * D; }
     static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.hq * p.Sq * D; }
 
-    static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
-    static __device__ __forceinline__ bool wave_active(const Ctx& c, int wrow0) { return c.q0 + wrow0 < c.q_end; }
+    // (the "logical" index of a query row is its row inside the tile here: all the mask needs is which member it belongs to)
+    static __device__ __forceinline__ int q_logical(const Ctx&, int row) { return row; }
+    static __device__ __forceinline__ bool wave_active(const Ctx& c, int wrow0) { return wrow0 < c.ra + c.rb; }
     static __device__ __forceinline__ int q_phys(const Params&, const Ctx& c, int row) {
-        const int l = c.q0 + row;
-        if (l >= c.q_end) return -1;
+        if (row >= c.ra + c.rb) return -1;
+        const int l = row < c.ra ? c.q0 + row : c.jb0 + (row - c.ra);
         return c.qidx ? c.qidx[l] : l;
     }
     static __device__ __forceinline__ int tile_key0(const Ctx&, int t) { return t * kBN; }
@@ -212,7 +256,9 @@ struct VarblockPolicy {
     static __device__ __forceinline__ bool tile_cur_ended(const TileCur&) { return false; }
     static __device__ __forceinline__ void tile_cur_fix(const Ctx&, TileCur&) {}
     static constexpr bool kRowStep = false;   // rows come from the run list (kv_phys_at), resolved between the phases
-    static __device__ __forceinline__ bool fast_full(const Ctx& c, int k0) { return k0 + kBN <= c.total; }
+    static __device__ __forceinline__ bool fast_full(const Ctx& c, int k0) {
+        return (k0 >= c.f1_lo && k0 + kBN <= c.f1_hi) || (k0 >= c.f2_lo && k0 + kBN <= c.f2_hi);
+    }
     static __device__ __forceinline__ void kv_cursor_init(const Params&, const Ctx& c, KvCursor& cu, int) {
         cu.j = 0;
         cu.r = c.run[0], cu.rn = c.run[1];   // (entries behind the last run are never used: a key behind the last run is clamped)
@@ -235,13 +281,19 @@ struct VarblockPolicy {
         return c.kidx ? c.kidx[perm] : perm;
     }
     static __device__ __forceinline__ int classify(const Params&, const Ctx& c, int k0, int wrow0) {
-        if (c.q0 + wrow0 >= c.q_end) return TILE_SKIP;
-        return (k0 + kBN <= c.total) ? TILE_FULL : TILE_PARTIAL;
+        if (wrow0 >= c.ra + c.rb) return TILE_SKIP;
+        if (fast_full(c, k0)) return TILE_FULL;
+        // no row of the wave sees any key of the tile (a tile of the other member's own key blocks): nothing to compute
+        const bool any = (k0 < c.any1_hi) || (k0 + kBN > c.any2_lo && k0 < c.total);
+        return any ? TILE_PARTIAL : TILE_SKIP;
     }
-    static __device__ __forceinline__ bool allowed(const Params&, const Ctx& c, int, int k) { return k < c.total; }
-    static __device__ __forceinline__ void row_intervals(const Params&, const Ctx& c, int, int& a0, unsigned& alen, int& b0,
+    static __device__ __forceinline__ bool allowed(const Params&, const Ctx& c, int row, int k) {
+        return row < c.ra ? (k < c.kCA) : ((k < c.kC) | ((k >= c.kCA) & (k < c.total)));
+    }
+    static __device__ __forceinline__ void row_intervals(const Params&, const Ctx& c, int row, int& a0, unsigned& alen, int& b0,
                                                          unsigned& blen) {
-        a0 = 0, alen = (unsigned)c.total, b0 = 0, blen = 0u;
+        const bool a = row < c.ra;
+        a0 = 0, alen = (unsigned)(a ? c.kCA : c.kC), b0 = c.kCA, blen = a ? 0u : (unsigned)(c.total - c.kCA);
     }
     static __device__ __forceinline__ void notify(const Params&, const Ctx&) {}
     static __device__ __forceinline__ float score_fixup(const Params&, float s) { return s; }
@@ -336,26 +388,121 @@ __global__ __launch_bounds__(256) void varblock_plan_kernel(const int32_t* __res
 // instead of 33.6 — and is longest-first inside every kv head.  A counting sort on (head, 64-key tile count / 16), in three small
 // launches: histogram (one wave per block-row), scan, scatter.
 constexpr int kVbBuckets = 64;   // per kv head
-__global__ __launch_bounds__(256) void varblock_work_kernel(const uint8_t* __restrict__ block_map, const int32_t* __restrict__ k_sizes,
-                                                            const int32_t* __restrict__ tile_off, int32_t* __restrict__ work,
-                                                            int32_t* __restrict__ hist, int Hkv, int QB, int KB, int group) {
+
+// Remainder packing (round 3).  k-means clusters are ragged (Wan 720p: 252 +- 160 rows), so the last q-tile of a block-row is mostly
+// padding: only 69 % of the rows of the 256-row tiles are real, and a tile costs its key-tile iterations whatever its row count.
+// Two block-rows i, j of a kv head whose ragged last tiles fit into ONE tile (r_i + r_j <= BM) share that tile: it walks the key
+// blocks both attend once instead of twice (see VarblockPolicy::Ctx).  q-clusters of the same neighbourhood of the data select
+// nearly the same key blocks (median Jaccard of best partners 0.94 on the bench data), so the shared part is most of the list.
+// One workgroup per kv head: bitmap rows of the map in LDS (key blocks without rows count as inactive), every block-row keeps its
+// own row in registers and looks for the unmatched partner with the most common key blocks among those its remainder fits with;
+// mutual choices are matched ("handshake"), a few rounds.  partner[h][i] = j >= 0: i's last tile carries j's too (i is the primary);
+// -2: carried by its partner; -1: alone.  Exactness: the mask inside a shared tile is exact (two key intervals per row), so the
+// result does not depend on which rows are paired.
+constexpr int kVbPairThreads = 512;
+constexpr int kVbPairRounds = 4;
+constexpr int kVbPairMinCommon = 8;   // common key blocks (~ 8 x 76 keys = 10 key tiles) that pay for the three-pass run-list build
+static inline size_t vb_pair_lds(int QB, int KB) {
+    const int W = (KB + 31) / 32;
+    return ((size_t)QB * (W + 1) + 2 * (size_t)QB + 16) * sizeof(int32_t);
+}
+__global__ __launch_bounds__(kVbPairThreads) void varblock_pair_kernel(const uint8_t* __restrict__ block_map,
+                                                                       const int32_t* __restrict__ q_sizes,
+                                                                       const int32_t* __restrict__ k_sizes, int32_t* __restrict__ partner,
+                                                                       int QB, int KB, int BM) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = (KB + 31) / 32, WS = W + 1;   // (row stride W + 1 words: thread i reads word w of row i — conflict-free)
+    uint32_t* bits = (uint32_t*)smem;            // [QB][WS]
+    int32_t* rem = (int32_t*)(bits + (size_t)QB * WS);   // [QB] rows of the ragged last tile; 0: none, or matched already
+    int32_t* best = rem + QB;                    // [QB] this round's choice
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int32_t* ks = k_sizes + (size_t)h * KB;
+    const int32_t* qs = q_sizes + (size_t)h * QB;
+    int32_t* out = partner + (size_t)h * QB;
+    for (int idx = tid; idx < QB * W; idx += kVbPairThreads) {
+        const int i = idx / W, w = idx - i * W;
+        const uint8_t* m = block_map + ((size_t)h * QB + i) * KB + w * 32;
+        uint32_t b = 0;
+        const int n = min(32, KB - w * 32);
+        for (int j = 0; j < n; ++j) b |= (m[j] && ks[w * 32 + j] > 0) ? (1u << j) : 0u;
+        bits[(size_t)i * WS + w] = b;
+    }
+    for (int i = tid; i < QB; i += kVbPairThreads) {
+        rem[i] = qs[i] % BM;
+        best[i] = -1;
+        out[i] = -1;
+    }
+    __syncthreads();
+    constexpr int kRegW = 32;   // bitmap words a thread can hold (KB <= 1024); wider maps re-read their own row from LDS
+    {   // (the host launches this kernel for QB <= kVbPairThreads only: one block-row per thread)
+        const int i = tid;
+        uint32_t mine[kRegW];
+#pragma unroll
+        for (int w = 0; w < kRegW; ++w) mine[w] = (i < QB && w < W) ? bits[(size_t)i * WS + w] : 0u;
+        for (int round = 0; round < kVbPairRounds; ++round) {
+            int bj = -1, bc = kVbPairMinCommon - 1;
+            const int ri = i < QB ? rem[i] : 0;
+            if (ri > 0) {
+                for (int j = 0; j < QB; ++j) {
+                    const int rj = rem[j];
+                    if (j == i || rj <= 0 || ri + rj > BM) continue;
+                    int common = 0;
+                    if (W <= kRegW) {
+#pragma unroll
+                        for (int w = 0; w < kRegW; ++w)
+                            if (w < W) common += __popc(mine[w] & bits[(size_t)j * WS + w]);
+                    } else {
+                        for (int w = 0; w < W; ++w) common += __popc(bits[(size_t)i * WS + w] & bits[(size_t)j * WS + w]);
+                    }
+                    if (common > bc) bc = common, bj = j;   // (ties: the lowest index)
+                }
+            }
+            if (i < QB) best[i] = bj;
+            __syncthreads();
+            const bool matched = bj >= 0 && best[bj] == i;
+            __syncthreads();   // every choice has been read before the remainders change
+            if (matched) {
+                rem[i] = 0;
+                out[i] = i < bj ? bj : -2;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Launch order: counting sort on (head, descending work class).  A block-row contributes its full tiles (work = its active keys)
+// and, unless its partner carries it, its ragged last tile (work = the keys of the union with the partner's list).
+__global__ __launch_bounds__(256) void varblock_work_kernel(const uint8_t* __restrict__ block_map, const int32_t* __restrict__ q_sizes,
+                                                            const int32_t* __restrict__ k_sizes, const int32_t* __restrict__ partner,
+                                                            int32_t* __restrict__ work, int32_t* __restrict__ hist, int Hkv, int QB,
+                                                            int KB, int group, int BM) {
     // (bucket = head-major key: h * kVbBuckets + descending work class)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= Hkv * QB) return;
     const int h = row / QB, i = row - h * QB;
+    const int pj = partner ? partner[row] : -1;
     const uint8_t* m = block_map + (size_t)row * KB;
+    const uint8_t* m2 = pj >= 0 ? block_map + ((size_t)h * QB + pj) * KB : m;
     const int32_t* ks = k_sizes + (size_t)h * KB;
-    int keys = 0;
-    for (int j = lane; j < KB; j += 64) keys += m[j] ? ks[j] : 0;
+    int keys = 0, ukeys = 0;
+    for (int j = lane; j < KB; j += 64) {
+        keys += m[j] ? ks[j] : 0;
+        ukeys += (m[j] | m2[j]) ? ks[j] : 0;
+    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) keys += __shfl_xor(keys, o);
+    for (int o = 32; o >= 1; o >>= 1) keys += __shfl_xor(keys, o), ukeys += __shfl_xor(ukeys, o);
     if (lane == 0) {
-        const int tiles = (keys + kBN - 1) / kBN;
-        const int bucket = h * kVbBuckets + (kVbBuckets - 1 - min(tiles / 16, kVbBuckets - 1));   // descending work inside the head
-        work[row] = bucket;
-        const int32_t* toff = tile_off + (size_t)h * (QB + 1);
-        const int n = (toff[i + 1] - toff[i]) * group;
-        if (n > 0) atomicAdd(hist + bucket, n);
+        auto bucket_of = [&](int k) {
+            const int tiles = (k + kBN - 1) / kBN;
+            return h * kVbBuckets + (kVbBuckets - 1 - min(tiles / 16, kVbBuckets - 1));   // descending work inside the head
+        };
+        const int n = q_sizes[row];
+        const int nfull = n / BM, has_rem = (n % BM) > 0 && pj != -2;
+        const int b_full = bucket_of(keys), b_rem = bucket_of(ukeys);
+        work[2 * row] = b_full;
+        work[2 * row + 1] = has_rem ? b_rem : -1;
+        if (nfull > 0) atomicAdd(hist + b_full, nfull * group);
+        if (has_rem) atomicAdd(hist + b_rem, group);
     }
 }
 __global__ __launch_bounds__(256) void varblock_scan_kernel(int32_t* __restrict__ hist, int32_t* __restrict__ order, int nb) {
@@ -383,21 +530,32 @@ __global__ __launch_bounds__(256) void varblock_scan_kernel(int32_t* __restrict_
         run += t;
     }
 }
-__global__ __launch_bounds__(256) void varblock_scatter_kernel(const int32_t* __restrict__ tile_off, const int32_t* __restrict__ work,
-                                                               int32_t* __restrict__ cursor, int32_t* __restrict__ order, int Hkv,
-                                                               int QB, int group) {
+__global__ __launch_bounds__(256) void varblock_scatter_kernel(const int32_t* __restrict__ q_sizes, const int32_t* __restrict__ partner,
+                                                               const int32_t* __restrict__ work, int32_t* __restrict__ cursor,
+                                                               int32_t* __restrict__ order, int Hkv, int QB, int group, int BM) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= Hkv * QB) return;
     const int h = row / QB, i = row - h * QB;
-    const int32_t* toff = tile_off + (size_t)h * (QB + 1);
-    const int nsub = toff[i + 1] - toff[i];
-    if (nsub <= 0) return;
-    int pos = atomicAdd(cursor + work[row], nsub * group);
-    for (int g = 0; g < group; ++g)
-        for (int sub = 0; sub < nsub; ++sub, ++pos) {
-            order[2 + 2 * pos] = h * group + g;
-            order[3 + 2 * pos] = (i << 16) | sub;
+    const int n = q_sizes[row], nfull = n / BM;
+    const int b_full = work[2 * row], b_rem = work[2 * row + 1];
+    if (nfull > 0) {
+        int pos = atomicAdd(cursor + b_full, nfull * group);
+        for (int g = 0; g < group; ++g)
+            for (int sub = 0; sub < nfull; ++sub, ++pos) {
+                order[2 + 3 * pos] = h * group + g;
+                order[3 + 3 * pos] = (i << 16) | sub;
+                order[4 + 3 * pos] = -1;
+            }
+    }
+    if (b_rem >= 0) {
+        int pos = atomicAdd(cursor + b_rem, group);
+        const int pj = partner ? partner[row] : -1;
+        for (int g = 0; g < group; ++g, ++pos) {
+            order[2 + 3 * pos] = h * group + g;
+            order[3 + 3 * pos] = (i << 16) | nfull;
+            order[4 + 3 * pos] = pj >= 0 ? pj : -1;
         }
+    }
 }
 
 // Similarity order of the 256-row variable-block kernel (variant 7; measured in round 3, NOT the default: see svg_varblock_attention).  The longest-first order above hands an XCD 32
@@ -542,8 +700,9 @@ __global__ __launch_bounds__(kVbChainThreads) void varblock_chain_kernel(const u
                     const int win = pos / (kNumXCD * 32), r = pos - win * (kNumXCD * 32);
                     b = win * (kNumXCD * 32) + (r % 32) * kNumXCD + r / 32;
                 }
-                order[2 + 2 * b] = h * group + g;
-                order[3 + 2 * b] = (i << 16) | sub;
+                order[2 + 3 * b] = h * group + g;
+                order[3 + 3 * b] = (i << 16) | sub;
+                order[4 + 3 * b] = -1;
             }
     }
 }
@@ -840,9 +999,10 @@ extern "C" int svg_debug_pp_trace(uint64_t* out104) {
 
 extern "C" size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq) {
     if (Hq <= 0 || Hkv <= 0 || QB <= 0 || KB <= 0 || Sq <= 0) return 0;
-    // plan (prefix sums) + longest-first order: per-block-row bucket, histogram / cursors, (count, pad, entries[2 * max workgroups])
+    // plan (prefix sums) + launch order: two buckets and the packing partner per block-row, histogram / cursors,
+    // (count, pad, entries[3 * max workgroups])
     const size_t plan = (size_t)Hkv * (3 * (size_t)(QB + 1) + (size_t)(KB + 1));
-    const size_t order = (size_t)Hkv * QB + (size_t)Hkv * kVbBuckets + 2 + 2 * ((size_t)Sq / 64 + QB) * Hq;   // (q tiles of >= 64 rows)
+    const size_t order = 3 * (size_t)Hkv * QB + (size_t)Hkv * kVbBuckets + 2 + 3 * ((size_t)Sq / 64 + QB) * Hq;   // (q tiles of >= 64 rows)
     return (plan + order) * sizeof(int32_t);
 }
 
@@ -855,7 +1015,7 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, bool longest_first = true) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
@@ -878,21 +1038,28 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         if constexpr (NW == -8 || NW == -9) {
             const int group = Hq / Hkv;
             if (!block_row_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
-                int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);
-                int32_t* hist = work + (size_t)Hkv * QB;
+                int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);          // [2 * Hkv * QB]
+                int32_t* partner = work + 2 * (size_t)Hkv * QB;              // [Hkv * QB]
+                int32_t* hist = partner + (size_t)Hkv * QB;
                 const int nb = Hkv * kVbBuckets;
                 int32_t* order = hist + nb;
+                constexpr int BMo = W * 32;
                 const size_t chain_lds = vb_chain_lds(QB, KB);
-                if (!longest_first && chain_lds <= 64 * 1024 && QB <= 4096) {   // similarity order, consecutive workgroups on one XCD
+                if (order_mode == 2 && chain_lds <= 64 * 1024 && QB <= 4096) {   // similarity order, consecutive workgroups on one XCD (variant 7)
                     hipLaunchKernelGGL(varblock_chain_kernel, dim3(Hkv), dim3(kVbChainThreads), chain_lds, st, block_map, k_sizes, toff,
                                        order, Hkv, QB, KB, group);
-                } else {   // longest-first inside every kv head (variant 6; also maps whose bitmap does not fit the chain kernel's LDS)
+                } else {   // longest-first inside every kv head, ragged last tiles packed in pairs (order_mode 0) or not (1)
+                    const size_t pair_lds = vb_pair_lds(QB, KB);
+                    const bool pack = order_mode == 0 && pair_lds <= 64 * 1024 && QB <= kVbPairThreads;   // (one block-row per thread)
+                    if (pack)
+                        hipLaunchKernelGGL(varblock_pair_kernel, dim3(Hkv), dim3(kVbPairThreads), pair_lds, st, block_map, q_sizes, k_sizes,
+                                           partner, QB, KB, BMo);
                     if (hipMemsetAsync(hist, 0, (size_t)nb * sizeof(int32_t), st) != hipSuccess) return SVG_ERR_LAUNCH;
-                    hipLaunchKernelGGL(varblock_work_kernel, dim3((Hkv * QB + 3) / 4), dim3(256), 0, st, block_map, k_sizes, toff, work,
-                                       hist, Hkv, QB, KB, group);
+                    hipLaunchKernelGGL(varblock_work_kernel, dim3((Hkv * QB + 3) / 4), dim3(256), 0, st, block_map, q_sizes, k_sizes,
+                                       pack ? partner : nullptr, work, hist, Hkv, QB, KB, group, BMo);
                     hipLaunchKernelGGL(varblock_scan_kernel, dim3(1), dim3(256), 0, st, hist, order, nb);
-                    hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, toff, work, hist, order,
-                                       Hkv, QB, group);
+                    hipLaunchKernelGGL(varblock_scatter_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, q_sizes,
+                                       pack ? partner : nullptr, work, hist, order, Hkv, QB, group, BMo);
                 }
                 p.order = order;
                 if constexpr (NW == -9) {
@@ -955,8 +1122,9 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
     // (6 = 3: the longest-first order is the default again — the similarity order, variant 7, raised the L2 hit rate from 31 % to 48 %
     //  and cut the L2 <-> fabric traffic by a quarter but not the kernel time, and its chain kernel costs 0.7 - 1.0 ms per call)
-    const bool block_row_order = (variant == 4), trace = (variant == 5), longest_first = (variant != 7);
-#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, longest_first
+    const bool block_row_order = (variant == 4), trace = (variant == 5);
+    const int order_mode = variant == 7 ? 2 : (variant == 6 ? 1 : 0);   // 0: longest-first + remainder packing, 1: longest-first, 2: similarity order
+#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \

@@ -487,13 +487,14 @@ def varblock_workspace(Hq: int, Hkv: int, QB: int, KB: int, Sq: int, device) -> 
 
 
 def varblock_launch_order(workspace: torch.Tensor, Hkv: int, QB: int, KB: int):
-    """The launch order a 256-row variable-block call (variants 3 / 6) left in its workspace: int32 [n, 2] rows of
-    (q head, block-row << 16 | sub-tile) in dispatch order (layout: csrc/attention.hip run_varblock — plan prefix sums, per-row
-    buckets, histogram, then [count, pad, entries])."""
+    """The launch order a 256-row variable-block call (variants 3 / 6 / 7) left in its workspace: int32 [n, 3] rows of
+    (q head, block-row << 16 | sub-tile, partner) in dispatch order — partner >= 0: the tile also carries the ragged last tile of
+    that block-row (remainder packing) — (layout: csrc/attention.hip run_varblock: plan prefix sums, two buckets + the partner per
+    block-row, histogram, then [count, pad, entries])."""
     w = workspace.view(torch.int32)
-    off = Hkv * (3 * (QB + 1) + (KB + 1)) + Hkv * QB + Hkv * 64
+    off = Hkv * (3 * (QB + 1) + (KB + 1)) + 3 * Hkv * QB + Hkv * 64
     n = int(w[off].item())
-    return w[off + 2: off + 2 + 2 * n].view(n, 2).clone()
+    return w[off + 2: off + 2 + 3 * n].view(n, 3).clone()
 
 
 class ClockProbe:

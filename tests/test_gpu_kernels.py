@@ -496,12 +496,14 @@ def test_varblock_attention_reference_grid_sample(nat, hq, hkv, D, S, MB, NB, de
     test_varblock_attention(nat, hq, hkv, D, S, MB, NB, density, dtype, -1)
 
 
-@pytest.mark.parametrize("variant", [3, 7])
+@pytest.mark.parametrize("variant", [3, 6, 7])
 @pytest.mark.parametrize("hq,hkv,S,MB,NB", [(4, 2, 5000, 37, 90), (3, 3, 9000, 64, 200), (2, 1, 700, 5, 33)])
 def test_varblock_launch_order_is_a_permutation(nat, variant, hq, hkv, S, MB, NB):
-    """The device-built launch order (variant 3: longest-first, variant 7: similarity chain + XCD remap) lists every (q head,
-    block-row, 256-row sub-tile) exactly once — index work, checked for equality with the host's enumeration as a set — and the
-    attention result does not depend on the order (bit-identical between the two orders and the plain block-row order)."""
+    """The device-built launch order (variant 3: longest-first with the ragged last tiles of similar block-rows packed in pairs,
+    6: longest-first, 7: similarity chain + XCD remap) covers every (q head, block-row, 256-row sub-tile) exactly once — a packed
+    tile counts for its own block-row and for its partner's last tile; index work, checked for equality with the host's enumeration
+    as a set — pairs only ever join last tiles that fit into one tile, and the attention result does not depend on order or packing
+    (equal to the plain block-row order up to the summation order of a packed tile's keys, bit-identical without packing)."""
     gen = torch.Generator().manual_seed(S + MB)
     rsz = random_partition_batch(S, MB, hkv, gen)
     rsz[0, 3] += rsz[0, 4]          # an empty block-row and an empty key block
@@ -511,16 +513,37 @@ def test_varblock_launch_order_is_a_permutation(nat, variant, hq, hkv, S, MB, NB
     csz[-1, 8] = 0
     bmap = torch.rand(hkv, MB, NB, generator=gen) > 0.6
     bmap[:, 1::3] = bmap[:, 0:-1:3][:, : bmap[:, 1::3].shape[1]]      # groups of block-rows with identical key lists
+    flip = torch.rand(hkv, MB, NB, generator=gen) > 0.97                # ... some of them only nearly identical
+    bmap[:, 2::3] = (bmap[:, 1::3] ^ flip[:, 1::3])[:, : bmap[:, 2::3].shape[1]]
     q, k, v = (torch.randn(n, S, 128, generator=gen).to(torch.bfloat16) for n in (hq, hkv, hkv))
     ws = nat.varblock_workspace(hq, hkv, MB, NB, S, "cuda")
     o = nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=variant, workspace=ws)
     order = nat.varblock_launch_order(ws, hkv, MB, NB).cpu().tolist()
     g = hq // hkv
-    want = {(h * g + gg, (i << 16) | sub) for h in range(hkv) for i in range(MB) for sub in range((int(rsz[h, i]) + 255) // 256)
+    want = {(h * g + gg, i, sub) for h in range(hkv) for i in range(MB) for sub in range((int(rsz[h, i]) + 255) // 256)
             for gg in range(g)}
-    assert len(order) == len(want) and {tuple(e) for e in order} == want
+    got, pairs = [], 0
+    for head, e, partner in order:
+        i, sub = e >> 16, e & 0xFFFF
+        got.append((head, i, sub))
+        if partner >= 0:
+            pairs += 1
+            h = head // g
+            ni, nj = int(rsz[h, i]), int(rsz[h, partner])
+            assert sub == ni // 256 and 0 < ni % 256 and 0 < nj % 256 and ni % 256 + nj % 256 <= 256, (i, partner, ni, nj)
+            got.append((head, partner, nj // 256))
+    assert len(got) == len(want) and set(got) == want
+    assert (pairs > 0) == (variant == 3), pairs     # the planted similar block-rows do get packed, and only by variant 3
     o4 = nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=4)
-    assert torch.equal(o, o4)
+    if variant == 3:
+        torch.testing.assert_close(o.float(), o4.float(), atol=4e-3, rtol=2e-2)      # (a packed tile walks its keys in another order)
+    else:
+        assert torch.equal(o, o4)
+    for h in range(hkv):   # and against the oracle
+        em = O.block_mask_to_element_mask(bmap[h], rsz[h], csz[h])
+        ref = O.masked_attention(q[h * g:(h + 1) * g], k[h:h + 1], v[h:h + 1], em)
+        torch.testing.assert_close(o[h * g:(h + 1) * g].float().cpu(), ref, atol=1e-2, rtol=1e-2)
+        assert rel_l2(o[h * g:(h + 1) * g].float().cpu(), ref) <= 3e-3
 
 
 def test_varblock_golden_and_edge_cases(nat, golden):

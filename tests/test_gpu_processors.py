@@ -298,6 +298,64 @@ def test_wan_and_cog_svg_processors_run_and_match():
     torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
 
 
+def test_wan_i2v_image_cross_attention_branch_and_fp8():
+    """Wan 2.1 I2V (BASELINE.json configs[4] names it): blocks carry `add_k_proj` / `add_v_proj` / `norm_added_k`; in the cross
+    attention the first 257 encoder tokens are CLIP image tokens that get their own small dense attention whose output is added to
+    the text cross attention (ref: svg/models/wan/attention.py:174-188) — checked against a torch restatement; the self attention of
+    the same block runs the sparse path with the package's fp8 opt-in (`set_attention_dtype("fp8")`; head_dim 128) and stays within the
+    e4m3 tolerance of its 16-bit result."""
+    import torch.nn.functional as F
+    from standins import RMSNorm
+
+    from svg.models import _core
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as WanP
+    from svg.models.wan.utils import generate_temporal_head_mask_mod as wan_mm
+
+    torch.manual_seed(2)
+    heads, hd = 2, 128
+    dim = heads * hd
+    F_, P_ = 5, 160
+    S = F_ * P_
+    WanP.context_length, WanP.num_frame, WanP.frame_size = 0, F_, P_
+    WanP.first_layers_fp, WanP.first_times_fp, WanP.num_sampled_rows, WanP.sample_mse_max_row = 0, 900.0, 16, 400
+    WanP.block_mask = wan_mm(0, 0, F_, P_, mul=1.2)
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=DT)
+    attn.add_k_proj, attn.add_v_proj, attn.norm_added_k = torch.nn.Linear(dim, dim), torch.nn.Linear(dim, dim), RMSNorm(dim)
+    attn.to(DT).cuda()
+    attn.set_processor(WanP(0))
+    hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
+    n_txt = 40
+    enc = (torch.randn(1, 257 + n_txt, dim) * 0.3).to(DT).cuda()
+    with torch.no_grad():
+        out = attn(hidden, encoder_hidden_states=enc)          # cross attention: timestep None, no rotary embedding
+        a = attn.cpu().float()
+        x, e = hidden.float().cpu(), enc.float().cpu()
+        e_img, e_txt = e[:, :257], e[:, 257:]
+        split = lambda t: t.unflatten(2, (heads, -1)).transpose(1, 2)   # noqa: E731
+        q = split(a.norm_q(a.to_q(x)))
+        k, v = split(a.norm_k(a.to_k(e_txt))), split(a.to_v(e_txt))
+        k_img, v_img = split(a.norm_added_k(a.add_k_proj(e_img))), split(a.add_v_proj(e_img))
+        o = F.scaled_dot_product_attention(q, k, v) + F.scaled_dot_product_attention(q, k_img, v_img)
+        ref = a.to_out[0](o.transpose(1, 2).flatten(2, 3))
+        attn.to(DT).cuda()
+    torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
+    # self attention of the same I2V block: sparse step, 16-bit and fp8 kernels
+    ang = torch.rand(S, hd // 2) * 6.28
+    rope = (ang.cos().cuda(), ang.sin().cuda())
+    outs = {}
+    try:
+        for name in ("bf16", "fp8"):
+            _core.set_attention_dtype(name)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                outs[name] = attn(hidden, rotary_emb=rope, timestep=torch.tensor([100.0])).float()
+    finally:
+        _core.set_attention_dtype("bf16")
+    assert torch.isfinite(outs["fp8"]).all()
+    e8 = ((outs["fp8"] - outs["bf16"]).norm() / outs["bf16"].norm()).item()
+    assert 1e-4 < e8 < 0.1, e8      # e4m3 QK^T / PV really ran (not bit-equal) and stays inside its tolerance
+
+
 def test_cosmos_svg_processor_matches_torch():
     """Cosmos (4th model family): per-head RMS qk-norm after the head split, half-split RoPE, no text; sparse core = Wan's."""
     from svg.models.cosmos.attention import Cosmos_SVG_AttnProcessor2_0 as CosP, apply_rotary_emb_half
