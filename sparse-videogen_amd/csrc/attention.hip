@@ -400,74 +400,96 @@ constexpr int kVbBuckets = 64;   // per kv head
 // -2: carried by its partner; -1: alone.  Exactness: the mask inside a shared tile is exact (two key intervals per row), so the
 // result does not depend on which rows are paired.
 constexpr int kVbPairThreads = 512;
-constexpr int kVbPairRounds = 4;
+constexpr int kVbPairRounds = 3;
 constexpr int kVbPairMinCommon = 8;   // common key blocks (~ 8 x 76 keys = 10 key tiles) that pay for the three-pass run-list build
-static inline size_t vb_pair_lds(int QB, int KB) {
-    const int W = (KB + 31) / 32;
-    return ((size_t)QB * (W + 1) + 2 * (size_t)QB + 16) * sizeof(int32_t);
-}
-__global__ __launch_bounds__(kVbPairThreads) void varblock_pair_kernel(const uint8_t* __restrict__ block_map,
-                                                                       const int32_t* __restrict__ q_sizes,
-                                                                       const int32_t* __restrict__ k_sizes, int32_t* __restrict__ partner,
-                                                                       int QB, int KB, int BM) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int W = (KB + 31) / 32, WS = W + 1;   // (row stride W + 1 words: thread i reads word w of row i — conflict-free)
-    uint32_t* bits = (uint32_t*)smem;            // [QB][WS]
-    int32_t* rem = (int32_t*)(bits + (size_t)QB * WS);   // [QB] rows of the ragged last tile; 0: none, or matched already
-    int32_t* best = rem + QB;                    // [QB] this round's choice
-    const int h = blockIdx.x, tid = threadIdx.x;
-    const int32_t* ks = k_sizes + (size_t)h * KB;
-    const int32_t* qs = q_sizes + (size_t)h * QB;
-    int32_t* out = partner + (size_t)h * QB;
-    for (int idx = tid; idx < QB * W; idx += kVbPairThreads) {
-        const int i = idx / W, w = idx - i * W;
-        const uint8_t* m = block_map + ((size_t)h * QB + i) * KB + w * 32;
-        uint32_t b = 0;
+constexpr int kVbPairRows = 64;       // block-rows scored by one workgroup (8 threads each, an eighth of the candidates per thread)
+static inline int vb_pair_ws(int KB) { return (((KB + 31) / 32) + 3) & ~3; }   // bitmap row stride in words (16-byte rows)
+static inline size_t vb_pair_lds(int QB, int KB) { return ((size_t)QB * vb_pair_ws(KB) + (size_t)QB + kVbPairRows) * sizeof(int32_t); }
+
+// bitmap rows of the map: bit j of word w of row (h, i) = block (i, 32 w + j) active and key block 32 w + j not empty
+__global__ __launch_bounds__(256) void varblock_bitmap_kernel(const uint8_t* __restrict__ block_map, const int32_t* __restrict__ k_sizes,
+                                                              uint32_t* __restrict__ bits, int Hkv, int QB, int KB, int WS) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)Hkv * QB * WS) return;
+    const int w = (int)(idx % WS);
+    const long long row = idx / WS;
+    const int h = (int)(row / QB);
+    uint32_t b = 0;
+    if (w * 32 < KB) {
+        const uint8_t* m = block_map + row * KB + w * 32;
+        const int32_t* ks = k_sizes + (size_t)h * KB + w * 32;
         const int n = min(32, KB - w * 32);
-        for (int j = 0; j < n; ++j) b |= (m[j] && ks[w * 32 + j] > 0) ? (1u << j) : 0u;
-        bits[(size_t)i * WS + w] = b;
+        for (int j = 0; j < n; ++j) b |= (m[j] && ks[j] > 0) ? (1u << j) : 0u;
     }
-    for (int i = tid; i < QB; i += kVbPairThreads) {
-        rem[i] = qs[i] % BM;
-        best[i] = -1;
-        out[i] = -1;
+    bits[idx] = b;
+}
+// one round, scoring half: grid = (ceil(QB / 64), Hkv).  Thread (il, part): block-row i = 64 blockIdx.x + il looks at an eighth of
+// the candidates j for the unmatched one with the most common key blocks whose remainder fits beside its own; the eight partial
+// results meet in an LDS arg-max (key = common << 12 | inverted index: ties go to the lowest index).  Branch-free scan, 16-byte
+// broadcast loads of the candidates' rows; the thread's own row lives in registers.
+__global__ __launch_bounds__(kVbPairThreads) void varblock_pair_score_kernel(const uint32_t* __restrict__ bits_g,
+                                                                             const int32_t* __restrict__ q_sizes,
+                                                                             const int32_t* __restrict__ rem_g, int32_t* __restrict__ best_g,
+                                                                             int QB, int WS, int BM, int round) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* bits = (uint32_t*)smem;                     // [QB][WS]
+    int32_t* rem = (int32_t*)(bits + (size_t)QB * WS);    // [QB]
+    int32_t* sbest = rem + QB;                            // [kVbPairRows]
+    const int h = blockIdx.y, tid = threadIdx.x, il = tid & (kVbPairRows - 1), part = tid / kVbPairRows;
+    constexpr int kParts = kVbPairThreads / kVbPairRows;
+    {
+        const u32x4* src = (const u32x4*)(bits_g + (size_t)h * QB * WS);
+        u32x4* dst = (u32x4*)bits;
+        for (int x = tid; x < QB * WS / 4; x += kVbPairThreads) dst[x] = src[x];
     }
+    for (int x = tid; x < QB; x += kVbPairThreads) rem[x] = round == 0 ? q_sizes[(size_t)h * QB + x] % BM : rem_g[(size_t)h * QB + x];
+    if (tid < kVbPairRows) sbest[tid] = (kVbPairMinCommon << 12) - 1;
     __syncthreads();
-    constexpr int kRegW = 32;   // bitmap words a thread can hold (KB <= 1024); wider maps re-read their own row from LDS
-    {   // (the host launches this kernel for QB <= kVbPairThreads only: one block-row per thread)
-        const int i = tid;
-        uint32_t mine[kRegW];
+    const int i = blockIdx.x * kVbPairRows + il;
+    constexpr int kRegW = 32;
+    u32x4 mine[kRegW / 4];
 #pragma unroll
-        for (int w = 0; w < kRegW; ++w) mine[w] = (i < QB && w < W) ? bits[(size_t)i * WS + w] : 0u;
-        for (int round = 0; round < kVbPairRounds; ++round) {
-            int bj = -1, bc = kVbPairMinCommon - 1;
-            const int ri = i < QB ? rem[i] : 0;
-            if (ri > 0) {
-                for (int j = 0; j < QB; ++j) {
-                    const int rj = rem[j];
-                    if (j == i || rj <= 0 || ri + rj > BM) continue;
-                    int common = 0;
-                    if (W <= kRegW) {
+    for (int w4 = 0; w4 < kRegW / 4; ++w4)
+        mine[w4] = (i < QB && 4 * w4 < WS) ? *(const u32x4*)(bits + (size_t)i * WS + 4 * w4) : u32x4{0u, 0u, 0u, 0u};
+    const int ri = i < QB ? rem[i] : 0;
+    const int chunk = (QB + kParts - 1) / kParts, j_lo = part * chunk, j_hi = min(QB, j_lo + chunk);
+    int bkey = -1;
+    for (int j = j_lo; j < j_hi; ++j) {
+        const int rj = rem[j];
+        const u32x4* row = (const u32x4*)(bits + (size_t)j * WS);
+        int common = 0;
 #pragma unroll
-                        for (int w = 0; w < kRegW; ++w)
-                            if (w < W) common += __popc(mine[w] & bits[(size_t)j * WS + w]);
-                    } else {
-                        for (int w = 0; w < W; ++w) common += __popc(bits[(size_t)i * WS + w] & bits[(size_t)j * WS + w]);
-                    }
-                    if (common > bc) bc = common, bj = j;   // (ties: the lowest index)
-                }
+        for (int w4 = 0; w4 < kRegW / 4; ++w4) {
+            if (4 * w4 < WS) {
+                const u32x4 r = row[w4];
+                common += __popc(mine[w4][0] & r[0]) + __popc(mine[w4][1] & r[1]) + __popc(mine[w4][2] & r[2]) + __popc(mine[w4][3] & r[3]);
             }
-            if (i < QB) best[i] = bj;
-            __syncthreads();
-            const bool matched = bj >= 0 && best[bj] == i;
-            __syncthreads();   // every choice has been read before the remainders change
-            if (matched) {
-                rem[i] = 0;
-                out[i] = i < bj ? bj : -2;
-            }
-            __syncthreads();
         }
+        const bool ok = (j != i) & (rj > 0) & (ri > 0) & (ri + rj <= BM);
+        const int key = ok ? ((common << 12) | (0xFFF - j)) : -1;
+        bkey = key > bkey ? key : bkey;
     }
+    if (bkey >= (kVbPairMinCommon << 12)) atomicMax(&sbest[il], bkey);
+    __syncthreads();
+    if (part == 0 && i < QB) {
+        const int k2 = sbest[il];
+        best_g[(size_t)h * QB + i] = k2 >= (kVbPairMinCommon << 12) ? 0xFFF - (k2 & 0xFFF) : -1;
+    }
+}
+// one round, matching half ("handshake"): mutual choices become pairs.  partner[h][i] = j >= 0: i's last tile carries j's too (the
+// lower index is the primary); -2: carried by its partner; -1: alone.
+__global__ __launch_bounds__(256) void varblock_pair_match_kernel(const int32_t* __restrict__ q_sizes, const int32_t* __restrict__ best,
+                                                                  int32_t* __restrict__ rem, int32_t* __restrict__ partner, int n_rows,
+                                                                  int QB, int BM, int round) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int h = row / QB, i = row - h * QB;
+    const int bj = best[row];
+    const bool matched = bj >= 0 && best[(size_t)h * QB + bj] == i;
+    const int r = round == 0 ? q_sizes[row] % BM : rem[row];
+    rem[row] = matched ? 0 : r;
+    if (matched) partner[row] = i < bj ? bj : -2;
+    else if (round == 0) partner[row] = -1;
 }
 
 // Launch order: counting sort on (head, descending work class).  A block-row contributes its full tiles (work = its active keys)
@@ -1003,7 +1025,8 @@ extern "C" size_t svg_varblock_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t 
     // (count, pad, entries[3 * max workgroups])
     const size_t plan = (size_t)Hkv * (3 * (size_t)(QB + 1) + (size_t)(KB + 1));
     const size_t order = 3 * (size_t)Hkv * QB + (size_t)Hkv * kVbBuckets + 2 + 3 * ((size_t)Sq / 64 + QB) * Hq;   // (q tiles of >= 64 rows)
-    return (plan + order) * sizeof(int32_t);
+    const size_t bitmap = KB <= 1024 ? (size_t)Hkv * QB * vb_pair_ws(KB) + 4 : 0;   // remainder packing: bitmap rows of the map (16-byte aligned)
+    return (plan + order + bitmap) * sizeof(int32_t);
 }
 
 namespace svg {
@@ -1050,10 +1073,23 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                                        order, Hkv, QB, KB, group);
                 } else {   // longest-first inside every kv head, ragged last tiles packed in pairs (order_mode 0) or not (1)
                     const size_t pair_lds = vb_pair_lds(QB, KB);
-                    const bool pack = order_mode == 0 && pair_lds <= 64 * 1024 && QB <= kVbPairThreads;   // (one block-row per thread)
-                    if (pack)
-                        hipLaunchKernelGGL(varblock_pair_kernel, dim3(Hkv), dim3(kVbPairThreads), pair_lds, st, block_map, q_sizes, k_sizes,
-                                           partner, QB, KB, BMo);
+                    const bool pack = order_mode == 0 && pair_lds <= 64 * 1024 && QB <= 4095 && KB <= 1024;   // (bitmap row in registers; 12-bit index in the arg-max key)
+                    if (pack) {   // bitmap rows once, then kVbPairRounds x (score, match); scratch: the bitmap area behind the order, and
+                                  // the bucket array `work` (free until varblock_work_kernel runs) for the remainders and choices
+                        const int WSp = vb_pair_ws(KB);
+                        uint32_t* bits = (uint32_t*)(((uintptr_t)(order + 2 + 3 * ((size_t)Sq / 64 + QB) * Hq) + 15) & ~(uintptr_t)15);
+                        int32_t* rem = work;
+                        int32_t* best = work + (size_t)Hkv * QB;
+                        const long long nw = (long long)Hkv * QB * WSp;
+                        hipLaunchKernelGGL(varblock_bitmap_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, block_map, k_sizes,
+                                           bits, Hkv, QB, KB, WSp);
+                        for (int round = 0; round < kVbPairRounds; ++round) {
+                            hipLaunchKernelGGL(varblock_pair_score_kernel, dim3((QB + kVbPairRows - 1) / kVbPairRows, Hkv),
+                                               dim3(kVbPairThreads), pair_lds, st, bits, q_sizes, rem, best, QB, WSp, BMo, round);
+                            hipLaunchKernelGGL(varblock_pair_match_kernel, dim3((Hkv * QB + 255) / 256), dim3(256), 0, st, q_sizes, best, rem,
+                                               partner, Hkv * QB, QB, BMo, round);
+                        }
+                    }
                     if (hipMemsetAsync(hist, 0, (size_t)nb * sizeof(int32_t), st) != hipSuccess) return SVG_ERR_LAUNCH;
                     hipLaunchKernelGGL(varblock_work_kernel, dim3((Hkv * QB + 3) / 4), dim3(256), 0, st, block_map, q_sizes, k_sizes,
                                        pack ? partner : nullptr, work, hist, Hkv, QB, KB, group, BMo);
