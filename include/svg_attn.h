@@ -226,6 +226,20 @@ int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, v
                     int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N, int32_t K, int32_t D,
                     int32_t dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole Lloyd loop of batch_kmeans_Euclid (ref: svg/kmeans_utils.py:684-733) as ONE call, launches only — no host
+ * synchronisation: max_iters x (svg_kmeans_iter into scratch + a commit kernel that applies the reference's stopping rule on the
+ * device).  Iteration `it` assigns with the current centroids and computes new ones; while the loop has not stopped its labels /
+ * sizes / stable sorted indices are the result; if the largest centre shift (over all batches) is < tol the loop stops THERE and the
+ * OLD centroids are the result (:723-724), otherwise the new centroids become current — without convergence the returned centroids
+ * are one update ahead of the returned labels, exactly like the reference.  Later iterations still run (no read-back decides how
+ * many to launch) but cannot change the result.  n_iters: device int32, the iterations the reference's loop would have run.
+ * c_init [B, K, D] is not written; c_work_a / c_work_b [B, K, D] are scratch; centroids_out [B, K, D]; labels / sorted_idx int32
+ * [B, N]; counts int32 [B, K].  Replaces ~10 framework micro-launches per iteration of the host-driven loop. */
+size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D);
+int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
+                    int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N, int32_t K,
+                    int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Top-p block selection.
  * ref: identify_dynamic_map + weighted_softmax, svg/kmeans_utils.py:852-896.

@@ -270,6 +270,47 @@ static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, vo
     return launch_status();
 }
 
+// ---- the Lloyd loop on the device (svg_kmeans_loop): commit of one iteration's result under the reference's stopping rule ----
+// state[0..1]: "the reference's loop has left" before iteration `it` (ping-pong by iteration parity: every thread of the commit
+// kernel reads the flag of the iterations before, one thread writes the flag for the next), state[2]: n_iters, state[3]: which
+// centroid buffer holds the result (0 initial, 1 / 2 the two work buffers).
+__global__ __launch_bounds__(256) void kmeans_commit_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ sorted_idx,
+                                                            const int32_t* __restrict__ counts, int32_t* __restrict__ labels_r,
+                                                            int32_t* __restrict__ sorted_r, int32_t* __restrict__ counts_r,
+                                                            const float* __restrict__ shift, int32_t* __restrict__ state, long long bn,
+                                                            long long bk, int B, float tol, int it, int sel_cur, int sel_out) {
+    const bool stopped = state[it & 1] != 0;
+    if (!stopped) {   // ref svg/kmeans_utils.py:716-733: the labels / sizes of the iteration the loop is in are the result
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < bn; i += (long long)gridDim.x * 256) {
+            labels_r[i] = labels[i];
+            sorted_r[i] = sorted_idx[i];
+        }
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < bk; i += (long long)gridDim.x * 256) counts_r[i] = counts[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float mx = 0.f;
+        for (int b = threadIdx.x; b < B; b += 64) mx = fmaxf(mx, shift[b]);
+        mx = wave_max(mx);
+        if (threadIdx.x == 0) {
+            const bool conv = mx < tol;   // `center_shift < tol` (:723) — NaN compares false like the reference's `.item() < tol`
+            if (!stopped) {
+                state[2] += 1;
+                state[3] = conv ? sel_cur : sel_out;   // converged: the OLD centroids are returned; otherwise the new ones become current
+            }
+            state[(it + 1) & 1] = (stopped || conv) ? 1 : 0;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void kmeans_select_kernel(const T* __restrict__ c0, const T* __restrict__ c1, const T* __restrict__ c2,
+                                                            T* __restrict__ out, const int32_t* __restrict__ state, long long n8) {
+    const int sel = state[3];
+    const T* src = sel == 0 ? c0 : (sel == 1 ? c1 : c2);
+    using V8 = typename Elt<T>::v8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256)
+        ((V8*)out)[i] = ((const V8*)src)[i];
+}
+
 }  // namespace svg
 
 using namespace svg;
@@ -321,4 +362,59 @@ extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* cent
                                                  K, workspace, workspace_bytes, st);
     }
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D) {
+    const size_t it = svg_kmeans_workspace_bytes(B, N, K, D);
+    if (it == 0) return 0;
+    // per-iteration scratch of svg_kmeans_iter + scratch labels / sorted indices / counts / shift of one iteration + the state words
+    const size_t a = ((size_t)B * N * 4 + 255) / 256 * 256, c = ((size_t)B * K * 4 + 255) / 256 * 256, sh = ((size_t)B * 4 + 255) / 256 * 256;
+    return (it + 255) / 256 * 256 + 2 * a + c + sh + 256;
+}
+
+extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
+                               int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
+                               int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!x || !xsq || !c_init || !c_work_a || !c_work_b || !labels || !counts || !sorted_idx || !centroids_out || !n_iters || !workspace)
+        return SVG_ERR_BAD_ARG;
+    if (B <= 0 || N <= 0 || K <= 0 || max_iters <= 0) return SVG_ERR_BAD_ARG;
+    if (K > 8192 || (D != 64 && D != 128) || (dtype != SVG_DTYPE_BF16 && dtype != SVG_DTYPE_F16)) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_kmeans_loop_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
+    if (c_init == c_work_a || c_init == c_work_b || c_work_a == c_work_b || centroids_out == c_work_a || centroids_out == c_work_b)
+        return SVG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t it_bytes = (svg_kmeans_workspace_bytes(B, N, K, D) + 255) / 256 * 256;
+    const size_t a = ((size_t)B * N * 4 + 255) / 256 * 256, c = ((size_t)B * K * 4 + 255) / 256 * 256, sh = ((size_t)B * 4 + 255) / 256 * 256;
+    char* w = (char*)workspace;
+    void* it_ws = w;
+    int32_t* t_labels = (int32_t*)(w + it_bytes);
+    int32_t* t_sorted = (int32_t*)(w + it_bytes + a);
+    int32_t* t_counts = (int32_t*)(w + it_bytes + 2 * a);
+    float* t_shift = (float*)(w + it_bytes + 2 * a + c);
+    int32_t* state = (int32_t*)(w + it_bytes + 2 * a + c + sh);
+    if (hipMemsetAsync(state, 0, 4 * sizeof(int32_t), st) != hipSuccess) return SVG_ERR_LAUNCH;
+    const void* cur = c_init;
+    int sel_cur = 0;
+    const long long bn = (long long)B * N, bk = (long long)B * K;
+    const unsigned grid = (unsigned)std::min<long long>(2048, (bn + 255) / 256);
+    for (int it = 0; it < max_iters; ++it) {
+        void* out = (it & 1) ? c_work_b : c_work_a;
+        const int sel_out = (it & 1) ? 2 : 1;
+        const int rc = svg_kmeans_iter(x, xsq, cur, out, t_labels, t_counts, t_sorted, t_shift, B, N, K, D, dtype, it_ws, it_bytes, stream);
+        if (rc != SVG_OK) return rc;
+        hipLaunchKernelGGL(kmeans_commit_kernel, dim3(grid), dim3(256), 0, st, t_labels, t_sorted, t_counts, labels, sorted_idx, counts,
+                           t_shift, state, bn, bk, B, tol, it, sel_cur, sel_out);
+        cur = out, sel_cur = sel_out;
+    }
+    const long long n8 = bk * D / 8;
+    const unsigned g2 = (unsigned)std::min<long long>(1024, (n8 + 255) / 256);
+    if (dtype == SVG_DTYPE_BF16)
+        hipLaunchKernelGGL((kmeans_select_kernel<__bf16>), dim3(g2), dim3(256), 0, st, (const __bf16*)c_init, (const __bf16*)c_work_a,
+                           (const __bf16*)c_work_b, (__bf16*)centroids_out, state, n8);
+    else
+        hipLaunchKernelGGL((kmeans_select_kernel<_Float16>), dim3(g2), dim3(256), 0, st, (const _Float16*)c_init, (const _Float16*)c_work_a,
+                           (const _Float16*)c_work_b, (_Float16*)centroids_out, state, n8);
+    if (hipMemcpyAsync(n_iters, state + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return SVG_ERR_LAUNCH;
+    return launch_status();
 }

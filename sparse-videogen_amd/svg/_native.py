@@ -141,6 +141,8 @@ SIGNATURES = {
     "svg_kmeans_xsq": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_kmeans_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
     "svg_kmeans_iter": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
+    "svg_kmeans_loop_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
+    "svg_kmeans_loop": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _SZ, _VP]),
     "svg_identify_dynamic_map": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, _I32, _VP]),
     "svg_map_density": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
 }
@@ -591,6 +593,34 @@ def kmeans_iter(x: torch.Tensor, xsq: torch.Tensor, c_in: torch.Tensor, c_out: t
                              buf.counts.data_ptr(), buf.sorted_idx.data_ptr(), buf.shift.data_ptr(), B, N, K, D,
                              _dtype_code(x), buf.ws.data_ptr(), buf.ws.numel(), _stream())
     _check(rc, "svg_kmeans_iter")
+
+
+def kmeans_loop(x: torch.Tensor, xsq: torch.Tensor, c_init: torch.Tensor, max_iters: int, tol: float, work=None):
+    """The whole Lloyd loop as one library call without host synchronisation (svg_kmeans_loop) -> (labels int32 [B, N], centroids
+    [B, K, D], counts int32 [B, K], n_iters int32 [] on the device, sorted_idx int32 [B, N]).  `work`: optional dict that keeps the
+    scratch tensors of a (B, N, K, D) shape between calls."""
+    lib = load()
+    _dev(x, xsq, c_init)
+    B, N, D = x.shape
+    K = c_init.shape[1]
+    assert c_init.shape == (B, K, D) and c_init.dtype == x.dtype and c_init.is_contiguous() and x.is_contiguous()
+    key = (B, N, K, D, x.dtype, x.device)
+    w = None if work is None else work.get(key)
+    if w is None:
+        w = dict(ca=torch.empty_like(c_init), cb=torch.empty_like(c_init),
+                 ws=torch.empty(lib.svg_kmeans_loop_workspace_bytes(B, N, K, D), dtype=torch.uint8, device=x.device))
+        if work is not None:
+            work[key] = w
+    labels = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    sorted_idx = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    counts = torch.empty((B, K), dtype=torch.int32, device=x.device)
+    cent = torch.empty_like(c_init)
+    n_it = torch.zeros((), dtype=torch.int32, device=x.device)
+    rc = lib.svg_kmeans_loop(x.data_ptr(), xsq.data_ptr(), c_init.data_ptr(), w["ca"].data_ptr(), w["cb"].data_ptr(), labels.data_ptr(),
+                             counts.data_ptr(), sorted_idx.data_ptr(), cent.data_ptr(), n_it.data_ptr(), B, N, K, D, _dtype_code(x),
+                             int(max_iters), float(tol), w["ws"].data_ptr(), w["ws"].numel(), _stream())
+    _check(rc, "svg_kmeans_loop")
+    return labels, cent, counts, n_it, sorted_idx
 
 
 def identify_dynamic_map(qc: torch.Tensor, kc: torch.Tensor, k_sizes: torch.Tensor, top_p: float,

@@ -48,6 +48,7 @@ class KMeansState:
 
 
 _STATE_CACHE: dict = {}
+_LOOP_WORK: dict = {}   # scratch of svg_kmeans_loop per (B, N, K, D, dtype, device)
 
 
 @time_logging_decorator("Level 4 - batch kmeans euclid")
@@ -105,6 +106,13 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
             return out + (st.buf.sorted_idx.clone(),)
         return out
     # ---- device-side convergence: nothing below reads a value back to the host ----
+    if shift_reduce is None and not verbose:
+        # the whole loop inside the library (svg_kmeans_loop): the iterations and a commit kernel that applies the stopping rule on the
+        # device — the same result as the torch statement below (kept for the sharded path, whose stopping rule needs an all-reduce
+        # between the iterations), without its ~10 framework launches per iteration
+        labels_r, cent_r, counts_r, n_r, sorted_r = _native.kmeans_loop(x, xsq, c_in, max_iters, tol, work=_LOOP_WORK)
+        out = (labels_r.to(torch.int64), cent_r, counts_r, n_r.to(torch.int64))
+        return out + (sorted_r,) if return_sorted_indices else out
     labels_r = cent_r = counts_r = sorted_r = None
     stopped = torch.zeros((), dtype=torch.bool, device=x.device)   # the reference's loop has left at an earlier iteration
     n_r = torch.zeros((), dtype=torch.int64, device=x.device)

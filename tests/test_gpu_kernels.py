@@ -720,6 +720,11 @@ def test_kmeans_loop_vs_oracle(nat, N, K, D, spread):
                                                              check_every=0)
         assert isinstance(nit, int) and nit == m and int(nit0) == m and nit0.is_cuda   # not converged: all m iterations count
         assert torch.equal(lab, lab0) and torch.equal(cent, cent0) and torch.equal(cnt, cnt0) and torch.equal(sidx, sidx0)
+        # check_every=0 is svg_kmeans_loop (the loop inside the library); with a shift_reduce hook (the head-sharded path) it is
+        # the torch statement of the same rule: bit-identical
+        lab2, cent2, cnt2, nit2, sidx2 = batch_kmeans_Euclid(xd, K, max_iters=m, init_centroids=c0d, return_sorted_indices=True,
+                                                             check_every=0, shift_reduce=lambda t: t)
+        assert int(nit2) == m and torch.equal(lab, lab2) and torch.equal(cent, cent2) and torch.equal(cnt, cnt2) and torch.equal(sidx, sidx2)
         assert lab.dtype == torch.int64 and cnt.dtype == torch.int32
         lab, cent, cnt, sidx = lab.cpu(), cent.cpu(), cnt.cpu(), sidx.cpu()
         # end to end vs the oracle's loop
@@ -763,6 +768,9 @@ def test_kmeans_loop_early_exit(nat):
                                                          check_every=0)
     assert nit0.is_cuda and int(nit0) == rit
     assert torch.equal(lab, lab0) and torch.equal(cent, cent0) and torch.equal(cnt, cnt0) and torch.equal(sidx, sidx0)
+    lab2, cent2, cnt2, nit2, sidx2 = batch_kmeans_Euclid(xd, K, max_iters=20, init_centroids=c0d, return_sorted_indices=True,
+                                                         check_every=0, shift_reduce=lambda t: t)     # the torch statement of the rule
+    assert int(nit2) == rit and torch.equal(lab, lab2) and torch.equal(cent, cent2) and torch.equal(cnt, cnt2) and torch.equal(sidx, sidx2)
     lab3, cent3, cnt3, nit3 = batch_kmeans_Euclid(xd, K, max_iters=20, init_centroids=c0d, check_every=3)
     assert nit3 == -(-rit // 3) * 3 and torch.equal(lab3, lab) and torch.equal(cnt3, cnt)
     # max_iters below the convergence point: all iterations run, centroids one ahead
