@@ -216,3 +216,88 @@ def test_varblock_run_cursor_model(seed):
         want = [flat[min(t * 64 + row, total - 1)] for t in range(n_tiles)]
         assert got == want
         assert reads <= len(runs)   # every list entry is read at most once per lane
+
+
+# ---- remainder packing (round 3): a tile shared by the ragged last tiles of two block-rows (VarblockPolicy::init / classify /
+#      allowed / row_intervals, csrc/attention.hip) ----
+def vb_packed_run_list(row_a, row_b, k_off):
+    """host model of the three-class run list: key blocks both members attend, then only A's, then only B's (each class in
+    ascending block order); returns (runs, kC, kCA, total)"""
+    runs, total, marks = [], 0, []
+    for want in (3, 1, 2):
+        for j in range(len(row_a)):
+            cls = (1 if row_a[j] else 0) | (2 if row_b[j] else 0)
+            ln = k_off[j + 1] - k_off[j]
+            if cls == want and ln > 0:
+                runs.append((total + ln, k_off[j] - total))
+                total += ln
+        marks.append(total)
+    return runs + [(0x7FFFFFFF, 0)] * 2, marks[0], marks[1], total
+
+
+def vb_packed_allowed(row, k, ra, kC, kCA, total):
+    return k < kCA if row < ra else (k < kC or (kCA <= k < total))
+
+
+def vb_packed_classify(w0, k0, ra, rb, kC, kCA, total, BN=64):
+    """the per-wave FULL / PARTIAL / SKIP classification (0 skip, 1 full, 2 partial)"""
+    if w0 >= ra + rb:
+        return 0
+    w1 = min(w0 + 32, ra + rb)
+    only_a, only_b = w1 <= ra, w0 >= ra
+    f1_hi = kCA if only_a else kC
+    f2_lo, f2_hi = kCA, (total if only_b else kCA)
+    if (k0 >= 0 and k0 + BN <= f1_hi) or (k0 >= f2_lo and k0 + BN <= f2_hi):
+        return 1
+    any1_hi = kCA if only_a else (kC if only_b else total)
+    any2_lo = kCA if only_b else total
+    return 2 if (k0 < any1_hi or (k0 + BN > any2_lo and k0 < total)) else 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_varblock_packed_tile_model(seed):
+    """For random pairs of map rows: every key of the union appears exactly once in the run list; a row of member A may see exactly
+    the keys of A's blocks, a row of member B exactly B's (brute force over all rows x keys, through the same cursor walk the
+    kernel uses); FULL tiles are fully allowed and SKIP tiles fully masked for every row of the wave, whatever the member mix."""
+    g = torch.Generator().manual_seed(100 + seed)
+    KB = int(torch.randint(2, 30, (1,), generator=g))
+    sizes = torch.randint(0, 150, (KB,), generator=g)
+    sizes[torch.rand(KB, generator=g) < 0.15] = 0
+    k_off = [0] + torch.cumsum(sizes, 0).tolist()
+    row_a = (torch.rand(KB, generator=g) < 0.6).tolist()
+    row_b = [(a if torch.rand(1, generator=g).item() < 0.8 else not a) for a in row_a]   # similar key lists, like real partners
+    ra, rb = int(torch.randint(1, 200, (1,), generator=g)), int(torch.randint(1, 57, (1,), generator=g))
+    runs, kC, kCA, total = vb_packed_run_list(row_a, row_b, k_off)
+    owner = {}                                   # permuted key position -> which members attend it
+    for j in range(KB):
+        for p in range(k_off[j], k_off[j + 1]):
+            if row_a[j] or row_b[j]:
+                owner[p] = (row_a[j], row_b[j])
+    assert total == len(owner) and 0 <= kC <= kCA <= total
+    if total == 0:
+        return
+    n_tiles = (total + 63) // 64
+    perm_of = {}                                 # compact position -> permuted position, through the kernel's cursor
+    for row in range(64):
+        got, _ = vb_walk(runs, total, row, n_tiles)
+        for t in range(n_tiles):
+            if t * 64 + row < total:
+                perm_of[t * 64 + row] = got[t]
+    assert sorted(perm_of.values()) == sorted(owner)          # a permutation of the union: nothing twice, nothing missing
+    for row in (0, ra - 1, ra, ra + rb - 1):
+        if not 0 <= row < ra + rb:
+            continue
+        for kpos in range(total):
+            a_on, b_on = owner[perm_of[kpos]]
+            assert vb_packed_allowed(row, kpos, ra, kC, kCA, total) == (a_on if row < ra else b_on), (row, kpos)
+    for w0 in range(0, 256, 32):
+        rows = [r for r in range(w0, w0 + 32) if r < ra + rb]
+        for t in range(n_tiles):
+            cls = vb_packed_classify(w0, t * 64, ra, rb, kC, kCA, total)
+            cells = [vb_packed_allowed(r, k, ra, kC, kCA, total) and k < total for r in rows for k in range(t * 64, t * 64 + 64)]
+            if not rows:
+                assert cls == 0
+            elif cls == 1:
+                assert all(cells) and t * 64 + 64 <= total
+            elif cls == 0:
+                assert not any(cells)

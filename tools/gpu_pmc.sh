@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-B="python bench.py --steps 1 --warmup 1 --no-cpu --no-dense --no-profiler $@"
+B="python bench.py --steps 1 --warmup 1 --no-cpu --no-dense --no-profiler --no-ab $@"
 rocprofv3 -L > $out/counters_list.txt 2>&1
 i=0
 for set in \
