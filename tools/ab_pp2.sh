@@ -1,10 +1,10 @@
 #!/bin/bash
-# same-box A/B of the band schedules at HunyuanVideo 720p (kernel ms, HIP events): libsvgattn.so variant 2 (two-phase, max-free
-# softmax) vs variant 3 (one wave per SIMD), plus optional comparison builds lib/libsvgattn_<tag>.so given as arguments
+# same-box A/B of the default band schedule at HunyuanVideo 720p (kernel ms, HIP events; pre-scaled q as bench.py runs it):
+# libsvgattn.so vs comparison builds lib/libsvgattn_<tag>.so given as arguments (python sparse-videogen_amd/build.py --tag <tag> with
+# SVG_EXTRA_HIPCC_FLAGS="-DSVG_PP2_...")
 for i in 1 2 3; do
-  for spec in cur:2 cur:3 "$@"; do
-    l=${spec%%:*}; v=${spec#*:}; [ "$v" = "$spec" ] && v=2
-    [ "$l" = "cur" ] && f=libsvgattn.so || f=libsvgattn_$l.so
-    SVG_ATTN_LIB=$PWD/sparse-videogen_amd/lib/$f python bench.py --steps 8 --warmup 3 --no-cpu --no-profiler --no-dense --no-svg2 --no-step --variant $v 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l v$v', d['roofline']['kernel_ms'])"
+  for t in cur "$@"; do
+    [ "$t" = "cur" ] && f=libsvgattn.so || f=libsvgattn_$t.so
+    SVG_ATTN_LIB=$PWD/sparse-videogen_amd/lib/$f timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu --no-profiler --no-dense --no-svg2 --no-step --no-ab 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$t', d['roofline']['kernel_ms'], d['roofline']['frac'], d['clock']['sclk_mhz_timed_steps'])"
   done
 done
