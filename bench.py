@@ -69,6 +69,25 @@ def allowed_pairs_hy(V: int, ctx: int, L: int, tf: int) -> int:
     return band + 2 * V * L + L * L + (ctx - L) ** 2
 
 
+def band_pairs(m, S: int) -> int:
+    """#allowed (q, k) pairs of a BandMask (the kernels' interval form, BandPolicy::row_intervals) — algorithmic FLOPs = 4 D H pairs"""
+    import numpy as np
+
+    q = np.arange(S, dtype=np.int64)
+    real = m.real_len
+    rq = q < real
+    rowf = (q >= m.rowfull_lo) & (q < m.rowfull_hi)
+    lo = np.where(rq, np.where(rowf, 0, np.maximum(q - m.band + 1, 0)), real)
+    hi = np.where(rq, np.where(rowf, real, np.minimum(q + m.band, real)), S)
+    alen = np.maximum(hi - lo, 0)
+    ch = min(m.colfull_hi, real)
+    b0, b1 = m.colfull_lo, max(ch, m.colfull_lo)
+    use_b = rq & ~rowf
+    inter = np.maximum(np.minimum(hi, b1) - np.maximum(lo, b0), 0)
+    blen = np.where(use_b, (b1 - b0) - inter, 0)
+    return int((alen + blen).sum())
+
+
 BAND_KERNELS = {0: "band_attn_pp2_kernel<bf16,128>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
                 1: "band_attn_kernel<bf16,128,4>"}
 
@@ -178,7 +197,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 2 at D = 128), "
+    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 2), "
                     "1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per SIMD")
     ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 QK^T / PV (svg_band_attention_fp8: quantise + "
@@ -593,6 +612,45 @@ def main():
             del ref16
         except Exception as e:  # noqa: BLE001
             out["fp8_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+
+    if world == 1 and not fp8 and a.workload == "hy720p" and not a.no_ab and a.variant == 0:
+        # the same kernel on the reference's other SVG1 geometries (production masks of svg/models/{wan,cog}/utils.py, alternating
+        # spatial / temporal heads, pre-scaled q like their processors hand it over): Wan 2.1 720p and CogVideoX-v1.5 (head_dim 64)
+        try:
+            from svg.models.cog import utils as cog_u
+            from svg.models.wan import utils as wan_u
+
+            others = {}
+            for name, BHo, Do, Fo, Po, ctxo, text_first, mk in (
+                    ("wan21_720p_svg1", 40, 128, 21, 3600, 0, False,
+                     lambda: wan_u.generate_temporal_head_mask_mod(0, 0, 21, 3600, mul=sparsity_to_width(0.30, 0, 21, 3600))),
+                    ("cogvideox15_768p_svg1", 96, 64, 11, 4080, 226, True,
+                     lambda: cog_u.generate_temporal_head_mask_mod(226, 11, 4080, mul=sparsity_to_width(0.25, 226, 11, 4080)))):
+                So = Fo * Po + ctxo
+                mo = mk()
+                go = torch.Generator(device=dev).manual_seed(77)
+                qo_, ko_, vo_ = (torch.randn(1, BHo, So, Do, device=dev, dtype=torch.bfloat16, generator=go) for _ in range(3))
+                qo_ = (qo_.float() * nat.softmax_q_scale(Do)).to(torch.bfloat16)
+                oo_ = torch.empty_like(qo_)
+                besto = torch.tensor([[h % 2 for h in range(BHo)]], device=dev, dtype=torch.int64)
+                call = lambda: nat.band_attention(qo_, ko_, vo_, mo, head_perm_flag=besto, vid0=ctxo if text_first else 0,  # noqa: E731
+                                                  num_frame=Fo, frame_size=Po, out=oo_, q_prescaled=True)
+                call()
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                evs[0].record()
+                for i in range(3):
+                    call()
+                    evs[i + 1].record()
+                torch.cuda.synchronize()
+                ms_o = evs[0].elapsed_time(evs[3]) / 3
+                fl = 4.0 * Do * BHo * band_pairs(mo, So)
+                others[name] = {"H": BHo, "D": Do, "S": So, "density": round(fl / (4.0 * Do * BHo * So * So), 4), "kernel_ms": round(ms_o, 3),
+                                "tflops": round(fl / (ms_o * 1e-3) / 1e12, 1), "frac_of_2500": round(fl / (ms_o * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                del qo_, ko_, vo_, oo_
+            out["svg1_other_models"] = others
+        except Exception as e:  # noqa: BLE001
+            out["svg1_other_models"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        torch.cuda.empty_cache()
 
     # ---- extras on rank 0 at N = 1: dense comparator on the same GPU, CPU baseline ----
     if world == 1 and not a.no_dense:

@@ -105,8 +105,7 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = default (2 for D = 128, 3 for D = 64; launches that count completions always 2).  All schedules produce the same
- * result up to rounding.
+/* variant: 0 = default (= 2).  All schedules produce the same result up to rounding.
  *   1 = lock-step, 4 waves x 32 query rows, 128-row q-tiles, two workgroups per CU (register-staged K/V) — the plain schedule
  *       the test-suite uses as the in-library reference;
  *   2 = two-phase ping-pong, 8 waves x 32 rows: the two waves that share a SIMD alternate a matrix phase (PV of tile t + QK^T
@@ -133,8 +132,7 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
 int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                  int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* stream);
 
-/* svg_band_attention_switch (device-side dense / sparse switch, below) for a pre-scaled q; D = 128 (other head sizes:
- * SVG_ERR_UNSUPPORTED — take the decision on the host and call svg_band_attention_prescaled). */
+/* svg_band_attention_switch (device-side dense / sparse switch, below) for a pre-scaled q. */
 int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                         int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                                         const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream);

@@ -23,15 +23,15 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPoli
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
 }
-// Device-side switch between two masks on the pre-scaled two-phase body (svg_band_attention_switch_prescaled, D = 128): `flag[0] != 0`
+// Device-side switch between two masks on the pre-scaled two-phase body (svg_band_attention_switch_prescaled): `flag[0] != 0`
 // selects prm_alt — the dense warm-up mask without the layout transformation — otherwise prm (see band_attn_w4_switch_kernel)
-template <typename T>
-__global__ __launch_bounds__(512, 2) void band_attn_pp2q_switch_kernel(typename BandPolicy<T, 128, 8, false>::Params prm,
-                                                                       typename BandPolicy<T, 128, 8, false>::Params prm_alt,
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void band_attn_pp2q_switch_kernel(typename BandPolicy<T, D, 8, false>::Params prm,
+                                                                       typename BandPolicy<T, D, 8, false>::Params prm_alt,
                                                                        const int32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (flag[0] != 0) attn_body_pp2<T, 128, BandPolicy<T, 128, 8, false>, false, 0, true>(prm_alt, smem, nullptr);
-    else attn_body_pp2<T, 128, BandPolicy<T, 128, 8, false>, false, 0, true>(prm, smem, nullptr);
+    if (flag[0] != 0) attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, false, 0, true>(prm_alt, smem, nullptr);
+    else attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, false, 0, true>(prm, smem, nullptr);
 }
 
 // Frozen reference schedule (variant 6; bf16 / D = 128 only): the two-phase body as it stood at the end of round 1 — running row
@@ -737,7 +737,9 @@ enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, 
 // one-wave-per-SIMD body on the same box), the one-wave-per-SIMD body for head_dim 64 (2.60 vs 2.67 ms, 13.6 vs 13.8 ms on the
 // CogVideoX geometries).  Launches that count completions (svg_band_attention_notify*) always run the two-phase body: their targets
 // (svg_band_attention_notify_target / _layout) do not know the head size.
-static inline int band_default(int D, bool counting) { return (D == 128 || counting) ? kBandPingPong : kBandW4; }
+// Round 3: with the carried operands the two-phase body is the faster one at head_dim 64 too (CogVideoX-v1 2.62 vs 2.73 ms, v1.5
+// 13.80 vs 13.84 ms; pre-scaled 2.45 / 13.03 ms): one default for both head sizes.
+static inline int band_default(int, bool) { return kBandPingPong; }
 
 int band_waves_per_tile(int variant) {
     const int v = variant == kBandAuto ? kBandPingPong : variant;
@@ -971,20 +973,22 @@ extern "C" int svg_band_attention_switch_prescaled(const void* q_scaled, const v
     int rc = band_check_args(q_scaled, k, v, o, BH, S, D, mask, perm);
     if (rc == SVG_OK) rc = band_check_args(q_scaled, k, v, o, BH, S, D, alt_mask, nullptr);
     if (rc != SVG_OK) return rc;
-    if (D != 128) return SVG_ERR_UNSUPPORTED;
-    auto go = [&](auto t_c) -> int {
+    auto go = [&](auto t_c, auto d_c) -> int {
         using T = decltype(t_c);
-        using Pol = BandPolicy<T, 128, 8, false>;
+        constexpr int DD = decltype(d_c)::value;
+        using Pol = BandPolicy<T, DD, 8, false>;
         const typename Pol::Params a = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, mask, perm);
         const typename Pol::Params b = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, alt_mask, nullptr);
-        auto kern = band_attn_pp2q_switch_kernel<T>;
-        if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<128>()); r2 != SVG_OK) return r2;
-        hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<128>(), (hipStream_t)stream, a, b,
+        auto kern = band_attn_pp2q_switch_kernel<T, DD>;
+        if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<DD>()); r2 != SVG_OK) return r2;
+        hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<DD>(), (hipStream_t)stream, a, b,
                            use_alt_flag);
         return launch_status();
     };
-    if (dtype == SVG_DTYPE_BF16) return go(__bf16{});
-    if (dtype == SVG_DTYPE_F16) return go(_Float16{});
+    if (dtype == SVG_DTYPE_BF16 && D == 128) return go(__bf16{}, std::integral_constant<int, 128>{});
+    if (dtype == SVG_DTYPE_BF16 && D == 64) return go(__bf16{}, std::integral_constant<int, 64>{});
+    if (dtype == SVG_DTYPE_F16 && D == 128) return go(_Float16{}, std::integral_constant<int, 128>{});
+    if (dtype == SVG_DTYPE_F16 && D == 64) return go(_Float16{}, std::integral_constant<int, 64>{});
     return SVG_ERR_UNSUPPORTED;
 }
 

@@ -446,9 +446,10 @@ def _tables(a, b, rows: int, cols: int, device):
 
 
 def qk_rope_inplace(query, key, cos, sin, rope_lo: int, rope_hi: int, complex_pairs: bool = False, norm_q=None,
-                    norm_k=None) -> bool:
+                    norm_k=None, q_scale: float = 1.0) -> bool:
     """In-place rotary embedding of positions [rope_lo, rope_hi) — optionally fused with the QK normalisation (one pass over
-    q and k instead of three).  cos / sin: [rope_hi - rope_lo, D] fp32 (complex_pairs: real / imag [.., D / 2])."""
+    q and k instead of three).  cos / sin: [rope_hi - rope_lo, D] fp32 (complex_pairs: real / imag [.., D / 2]).
+    q_scale != 1: folded into the pass's last rounding of q (the attention core then runs its pre-scaled kernels)."""
     if not _fast_ok(query, key) or rope_hi <= rope_lo:
         return False
     D = query.shape[-1]
@@ -461,8 +462,14 @@ def qk_rope_inplace(query, key, cos, sin, rope_lo: int, rope_hi: int, complex_pa
         if dq is None or dk is None or dq[0] != dk[0] or dq[3] != dk[3]:
             return False
         kind, qw, qb, kw, kb, eps = dq[0], dq[1], dq[2], dk[1], dk[2], dq[3]
-    _native.qk_norm_rope(query, key, kind, qw, qb, kw, kb, eps, 2 if complex_pairs else 1, tb[0], tb[1], rope_lo, rope_hi)
+    _native.qk_norm_rope(query, key, kind, qw, qb, kw, kb, eps, 2 if complex_pairs else 1, tb[0], tb[1], rope_lo, rope_hi,
+                         q_scale=q_scale)
     return True
+
+
+def prescale_supported(query) -> bool:
+    """the pre-scaled attention kernels exist for 16-bit GPU tensors with head_dim 64 / 128"""
+    return bool(query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and query.shape[-1] in (64, 128))
 
 
 def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin, rope_lo: int, rope_hi: int,

@@ -23,12 +23,14 @@ def qk_norm(attn, query, key):
     return query, key
 
 
-def rotary_emb(image_rotary_emb, query, key, text_seq_length):
-    """ref: cog/attention.py:47-50 — RoPE on the video tokens only (text first)"""
+def rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale: float = 1.0):
+    """ref: cog/attention.py:47-50 — RoPE on the video tokens only (text first).  q_scale != 1 (HIP path only): folded into the
+    pass's last rounding of q (the text tokens, which the pass does not rotate, are multiplied and rounded once more)."""
     if image_rotary_emb is not None:
         cos, sin = image_rotary_emb   # HIP fast path = `_kernels.apply_qk_rope_inplace_cossin` (text first), :31-34
-        if _core.qk_rope_inplace(query, key, cos, sin, text_seq_length, query.shape[2]):
+        if _core.qk_rope_inplace(query, key, cos, sin, text_seq_length, query.shape[2], q_scale=q_scale):
             return query, key
+        assert q_scale == 1.0, "a pre-scaled q needs the HIP RoPE pass"
         query[:, :, text_seq_length:] = apply_rotary_emb(query[:, :, text_seq_length:], image_rotary_emb)
         key[:, :, text_seq_length:] = apply_rotary_emb(key[:, :, text_seq_length:], image_rotary_emb)
     return query, key
@@ -50,10 +52,12 @@ class CogVideoX_SparseAttn_Processor2_0:
     block_mask = None
     fused_placement = True
     device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor
+    prescale_q = True       # the HIP RoPE pass folds sm_scale * log2(e) into its rounding of q; pre-scaled attention kernels
 
     def __init__(self, layer_idx):
         self.layer_idx = layer_idx
         self.last_best_mask_idx = None
+        self._q_prescaled = False
 
     @classmethod
     def geometry(cls) -> Geometry:
@@ -81,13 +85,13 @@ class CogVideoX_SparseAttn_Processor2_0:
         return hidden_states.split([text_seq_length, hidden_states.size(1) - text_seq_length], dim=1)
 
     def flash_attention(self, query, key, value):
-        return _core.dense_attention(query, key, value)
+        return _core.dense_attention(query, key, value, q_prescaled=self._q_prescaled)
 
     def sample_mse(self, query, key, value):
         """Cog samples rows from the WHOLE sequence (ref :126)"""
         geo = self.geometry()
         return _core.sample_mse(query, key, value, geo, profile_desc(geo.context_length, geo.num_frame, geo.frame_size),
-                                self.num_sampled_rows, query.shape[2])
+                                self.num_sampled_rows, query.shape[2], q_prescaled=self._q_prescaled)
 
     def attention_core_logic(self, query, key, value, timestep):
         cfg, num_heads, seq_len, dim = query.size()
@@ -107,11 +111,11 @@ class CogVideoX_SparseAttn_Processor2_0:
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
         if dense_flag is not None:
             out, best = _core.svg1_attention_device_switch(query, key, value, geo, self.block_mask, dense_mask(seq_len), prof,
-                                                           self.num_sampled_rows, seq_len, dense_flag)
+                                                           self.num_sampled_rows, seq_len, dense_flag, q_prescaled=self._q_prescaled)
             self.last_best_mask_idx = best
             return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, self.block_mask, prof, self.num_sampled_rows, seq_len,
-                                                fused=self.fused_placement)
+                                                fused=self.fused_placement, q_prescaled=self._q_prescaled)
         self.last_best_mask_idx = best
         return out.reshape(cfg, num_heads, seq_len, dim)
 
@@ -126,8 +130,17 @@ class CogVideoX_SparseAttn_Processor2_0:
         query, key, value = self.get_qkv(attn, hidden_states)
         query, key, value, head_dim = self.transpose_qkv(attn, query, key, value, batch_size)
         query, key = qk_norm(attn, query, key)
-        query, key = rotary_emb(image_rotary_emb, query, key, text_seq_length)
-        hidden_states = self.attention_core_logic(query, key, value, timestep)
+        q_scale = 1.0
+        if self.prescale_q and image_rotary_emb is not None and _core.prescale_supported(query) and _core._fast_ok(query, key):
+            cos = image_rotary_emb[0]
+            if tuple(cos.shape[-2:]) == (query.shape[2] - text_seq_length, query.shape[-1]):   # the HIP RoPE pass will take it
+                q_scale = _core._native.softmax_q_scale(query.shape[-1])
+        query, key = rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale=q_scale)
+        self._q_prescaled = q_scale != 1.0
+        try:
+            hidden_states = self.attention_core_logic(query, key, value, timestep)
+        finally:
+            self._q_prescaled = False
         hidden_states = self.get_o(attn, hidden_states, batch_size, head_dim)
         encoder_hidden_states, hidden_states = self.split_hidden_states(hidden_states, text_seq_length)
         return hidden_states, encoder_hidden_states

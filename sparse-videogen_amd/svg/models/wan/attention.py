@@ -14,17 +14,19 @@ from .._core import CentroidStore, Geometry
 from .utils import dense_mask, generate_temporal_head_mask_mod, profile_desc
 
 
-def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs):
+def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs, q_scale: float = 1.0):
     """ref: wan/attention.py:40-66.  `freqs` is either the complex tensor [1, 1, S, D/2] of diffusers or the
-    (real, imag) fp32 pair [S, D/2] the reference's patched model forward produces for its CUDA kernel."""
+    (real, imag) fp32 pair [S, D/2] the reference's patched model forward produces for its CUDA kernel.
+    q_scale != 1 (HIP path only; the caller checks the returned flag): folded into the last rounding of q."""
     # HIP fast path (ref: `_kernels.apply_qk_rope_inplace_cossin_complex(query, key, freqs_real, freqs_imag, 0)`, :45-48)
     S = query.shape[2]
     if isinstance(freqs, (tuple, list)):
         fr, fi = freqs
     else:
         fr, fi = freqs.real, freqs.imag
-    if _core.qk_rope_inplace(query, key, fr, fi, 0, S, complex_pairs=True):
+    if _core.qk_rope_inplace(query, key, fr, fi, 0, S, complex_pairs=True, q_scale=q_scale):
         return query, key
+    assert q_scale == 1.0, "a pre-scaled q needs the HIP RoPE pass"
     if isinstance(freqs, (tuple, list)):
         freqs = torch.complex(fr.double(), fi.double())[None, None]
 
@@ -55,10 +57,14 @@ class WanAttn_SVGAttn_Processor2_0:
     block_mask = None
     temporal_mask_metadata = None
     fused_placement = True
+    # self attention: the HIP RoPE pass folds sm_scale * log2(e) into its (last) rounding of q and the attention core runs its
+    # pre-scaled kernels (see Hunyuan's processor); not for the cross attention and the I2V image branch, whose q feeds torch SDPA
+    prescale_q = True
 
     def __init__(self, layer_idx):
         self.layer_idx = layer_idx
         self.last_best_mask_idx = None
+        self._q_prescaled = False
 
     @classmethod
     def geometry(cls) -> Geometry:
@@ -82,9 +88,9 @@ class WanAttn_SVGAttn_Processor2_0:
         return tuple(x.unflatten(2, (attn.heads, -1)).transpose(1, 2).contiguous() for x in (query, key, value))
 
     @time_logging_decorator("Level 2 - rotary_emb")
-    def get_rotary_emb(self, query, key, rotary_emb):
+    def get_rotary_emb(self, query, key, rotary_emb, q_scale: float = 1.0):
         if rotary_emb is not None:
-            query, key = apply_rotary_emb(query, key, rotary_emb)
+            query, key = apply_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
         return query, key
 
     @time_logging_decorator("Level 2 - output")
@@ -110,7 +116,13 @@ class WanAttn_SVGAttn_Processor2_0:
         query, key, value = self.get_qkv(attn, hidden_states, encoder_hidden_states)
         query, key = self.get_qk_norm(attn, query, key)
         query, key, value = self.get_transpose_qkv(attn, query, key, value)
-        query, key = self.get_rotary_emb(query, key, rotary_emb)
+        q_scale = 1.0
+        if (self.prescale_q and not cross and timestep is not None and rotary_emb is not None and _core.prescale_supported(query)
+                and _core._fast_ok(query, key)):
+            fr = rotary_emb[0] if isinstance(rotary_emb, (tuple, list)) else rotary_emb
+            if fr.shape[-2] == query.shape[2] and fr.shape[-1] == query.shape[-1] // 2:   # the HIP RoPE pass will take it
+                q_scale = _core._native.softmax_q_scale(query.shape[-1])
+        query, key = self.get_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
         hidden_states_img = None
         if encoder_hidden_states_img is not None:  # I2V: CLIP image tokens, small dense cross attention (ref :174-188)
             key_img = attn.norm_added_k(attn.add_k_proj(encoder_hidden_states_img))
@@ -124,18 +136,22 @@ class WanAttn_SVGAttn_Processor2_0:
             hidden_states = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=0.0,
                                                            is_causal=False)
         else:
-            hidden_states = self.attention_core_logic(query, key, value, timestep)
+            self._q_prescaled = q_scale != 1.0
+            try:
+                hidden_states = self.attention_core_logic(query, key, value, timestep)
+            finally:
+                self._q_prescaled = False
         return self.get_o(attn, query, hidden_states, hidden_states_img)
 
     @time_logging_decorator("Level 3 - sample mse")
     def sample_mse(self, query, key, value):
         geo = self.geometry()
         return _core.sample_mse(query, key, value, geo, profile_desc(geo.context_length, geo.num_frame, geo.frame_size),
-                                self.num_sampled_rows, min(self.sample_mse_max_row, query.shape[2]))
+                                self.num_sampled_rows, min(self.sample_mse_max_row, query.shape[2]), q_prescaled=self._q_prescaled)
 
     @time_logging_decorator("Level 3 - Dense Flash Attention")
     def flash_attention(self, query, key, value):
-        return _core.dense_attention(query, key, value)
+        return _core.dense_attention(query, key, value, q_prescaled=self._q_prescaled)
 
     @time_logging_decorator("Level 2 - attention core logic")
     def attention_core_logic(self, query, key, value, timestep):
@@ -154,11 +170,13 @@ class WanAttn_SVGAttn_Processor2_0:
         prof = profile_desc(geo.context_length, geo.num_frame, geo.frame_size)
         if dense_flag is not None:
             out, best = _core.svg1_attention_device_switch(query, key, value, geo, self.block_mask, dense_mask(seq_len), prof,
-                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag)
+                                                           self.num_sampled_rows, min(self.sample_mse_max_row, seq_len), dense_flag,
+                                                           q_prescaled=self._q_prescaled)
             self.last_best_mask_idx = best
             return out.reshape(cfg, num_heads, seq_len, dim)
         out, best = _core.svg1_sparse_attention(query, key, value, geo, self.block_mask, prof, self.num_sampled_rows,
-                                                min(self.sample_mse_max_row, seq_len), fused=self.fused_placement)
+                                                min(self.sample_mse_max_row, seq_len), fused=self.fused_placement,
+                                                q_prescaled=self._q_prescaled)
         self.last_best_mask_idx = best
         return out.reshape(cfg, num_heads, seq_len, dim)
 
@@ -185,6 +203,7 @@ class WanAttn_SAPAttn_Processor(WanAttn_SVGAttn_Processor2_0):
     zero_step_kmeans_init = False
 
     logging_file = None
+    prescale_q = False   # k-means and the block map work on the plain q
 
     def __init__(self, layer_idx):
         super().__init__(layer_idx)

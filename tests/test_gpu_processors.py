@@ -298,6 +298,67 @@ def test_wan_and_cog_svg_processors_run_and_match():
     torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("hd", [64, 128])
+def test_wan_and_cog_prescaled_q_equals_plain_path(hd):
+    """Wan / Cog SVG1 processors: prescale_q (default — the HIP RoPE pass folds the softmax scale into its rounding of q, pre-scaled
+    kernels downstream, at head_dim 64 and 128) against prescale_q = False: the same processor output up to the rounding of q, on
+    sparse and dense steps, host- and device-switched.  Cross attention (Wan) never pre-scales: its q feeds torch SDPA."""
+    from svg.models import _core
+    from svg.models.cog.attention import CogVideoX_SparseAttn_Processor2_0 as CogP
+    from svg.models.cog.utils import generate_temporal_head_mask_mod as cog_mm
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as WanP
+    from svg.models.wan.utils import generate_temporal_head_mask_mod as wan_mm
+
+    torch.manual_seed(4)
+    heads = 2
+    dim = heads * hd
+
+    def both(cls, run):
+        outs = []
+        try:
+            for pre in (True, False):
+                cls.prescale_q = pre
+                torch.manual_seed(9)
+                _core.reseed_switch_generator(9)
+                with torch.no_grad():
+                    outs.append(run())
+        finally:
+            cls.prescale_q = True
+        for a, b in zip(*outs):
+            torch.testing.assert_close(a.float(), b.float(), atol=2e-2, rtol=2e-2)
+            assert ((a.float() - b.float()).norm() / b.float().norm()).item() < 6e-3
+        return outs[0]
+
+    # ---- Wan (self attention with complex RoPE; then a cross attention call, which must not touch q)
+    F_, P_ = 5, 160
+    S = F_ * P_
+    WanP.context_length, WanP.num_frame, WanP.frame_size = 0, F_, P_
+    WanP.first_layers_fp, WanP.first_times_fp, WanP.num_sampled_rows, WanP.sample_mse_max_row = 0, 900.0, 16, 400
+    WanP.block_mask = wan_mm(0, 0, F_, P_, mul=1.2)
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=DT).cuda()
+    attn.set_processor(WanP(0))
+    hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
+    ang = torch.rand(S, hd // 2) * 6.28
+    rope = (ang.cos().cuda(), ang.sin().cuda())
+    for ts in (torch.tensor([100.0]), torch.tensor([950.0]), torch.tensor([100.0]).cuda(), torch.tensor([950.0]).cuda()):
+        both(WanP, lambda: (attn(hidden, rotary_emb=rope, timestep=ts),))
+    enc = (torch.randn(1, 33, dim) * 0.3).to(DT).cuda()
+    xo = both(WanP, lambda: (attn(hidden, encoder_hidden_states=enc),))
+    assert torch.isfinite(xo[0].float()).all()
+    # ---- Cog (text first, LayerNorm qk-norm, cos / sin RoPE on the video tokens only)
+    ctx, F_, P_ = 26, 4, 180
+    CogP.context_length, CogP.num_frame, CogP.frame_size = ctx, F_, P_
+    CogP.first_layers_fp, CogP.first_times_fp, CogP.num_sampled_rows = 0.0, 0.2, 16
+    CogP.block_mask = cog_mm(ctx, F_, P_, mul=1.5)
+    cattn = Attention(dim, heads, qk_norm="layer", dtype=DT).cuda()
+    cattn.set_processor(CogP(0))
+    ch = (torch.randn(2, F_ * P_, dim) * 0.3).to(DT).cuda()
+    ce = (torch.randn(2, ctx, dim) * 0.3).to(DT).cuda()
+    crope = tuple(t.cuda() for t in rope_tables(F_ * P_, hd))
+    for ts in (torch.tensor([100.0]), torch.tensor([950.0]), torch.tensor([100.0]).cuda()):
+        both(CogP, lambda: cattn(ch, encoder_hidden_states=ce, image_rotary_emb=crope, timestep=ts))
+
+
 def test_wan_i2v_image_cross_attention_branch_and_fp8():
     """Wan 2.1 I2V (BASELINE.json configs[4] names it): blocks carry `add_k_proj` / `add_v_proj` / `norm_added_k`; in the cross
     attention the first 257 encoder tokens are CLIP image tokens that get their own small dense attention whose output is added to

@@ -48,8 +48,10 @@ CASES = [
 
 def main():
     fp8 = len(sys.argv) > 1 and sys.argv[1] == "fp8"         # e4m3 kernels (head_dim 128 geometries only), pre-pass included
-    variant = int(sys.argv[1]) if len(sys.argv) > 1 and not fp8 else 0   # schedule of svg_band_attention (include/svg_attn.h)
-    print("fp8 (e4m3) kernels, quantise pre-pass included" if fp8 else f"schedule variant {variant}")
+    pre = len(sys.argv) > 1 and sys.argv[1] == "pre"         # svg_band_attention_prescaled on a q that carries the softmax scale
+    variant = int(sys.argv[1]) if len(sys.argv) > 1 and not fp8 and not pre else 0   # schedule of svg_band_attention (include/svg_attn.h)
+    print("fp8 (e4m3) kernels, quantise pre-pass included" if fp8 else
+          ("pre-scaled q (svg_band_attention_prescaled: two-phase body at every head_dim)" if pre else f"schedule variant {variant}"))
     dev = torch.device("cuda", 0)
     print("| model geometry | S | density | sparse ms | PFLOP/s (algorithmic) | dense ms | dense PFLOP/s | speed-up |")
     print("|---|---|---|---|---|---|---|---|")
@@ -80,6 +82,11 @@ def main():
         if fp8:
             ms = t(lambda: nat.band_attention_fp8(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o))
             dms = t(lambda: nat.band_attention_fp8(q, k, v, dmask, out=o))
+        elif pre:
+            qs = (q.float() * nat.softmax_q_scale(D)).to(q.dtype)
+            ms = t(lambda: nat.band_attention(qs, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o, q_prescaled=True))
+            dms = t(lambda: nat.band_attention(qs, k, v, dmask, out=o, q_prescaled=True))
+            del qs
         else:
             ms = t(lambda: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_, out=o, variant=variant))
             dms = t(lambda: nat.band_attention(q, k, v, dmask, out=o, variant=variant))
