@@ -79,6 +79,7 @@ struct VarblockPolicy {
     static constexpr bool kIntervalMask = true;
     static constexpr bool kFastPartial = false;
     static constexpr int kShadow128 = 2;   // the vector phase also resolves rows through the run list and the index arrays
+    static constexpr bool kOneBarrier = true;   // two-phase body: one barrier per tile (attn_core.h kOneBar: -1.7 % at Wan 720p)
     static constexpr int kAbl = 0;
     static constexpr bool kSetPrio = false;
     static constexpr bool kSkew = false;

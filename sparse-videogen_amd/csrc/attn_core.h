@@ -484,6 +484,14 @@ __device__ __forceinline__ void pp_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// pp_barrier for the waves whose (wave-uniform) `flag` is non-zero; the others fall through.  The branch lives INSIDE the asm
+// block: no control-flow merge at IR level (a C-level `if` around a barrier in the tile loop costs a second register set)
+__device__ __forceinline__ void pp_barrier_if(int flag) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int f = __builtin_amdgcn_readfirstlane(flag);
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n1:" ::"s"(f) : "memory", "scc");
+    __builtin_amdgcn_sched_barrier(0);
+}
 // one LDS-DMA piece: lane l's 16 bytes at (base + voff_l) land at LDS byte address lds + 16 * l (probe: tools/probe_dma.hip)
 __device__ __forceinline__ void lds_dma16(unsigned lds, unsigned voff, const void* base) {
     // (s_nop: an SALU write of M0 needs one wait state before an LDS-DMA reads it; hipcc does not look inside inline asm)
@@ -562,6 +570,19 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
 #define SVG_PP2_DOTSUM 0
 #endif
     constexpr bool kDotSum = SVG_PP2_DOTSUM != 0 && kMaxFree;   // (the max-free softmax computes whole 8-key steps: always pairs)
+#ifndef SVG_PP2_ONEBAR
+#define SVG_PP2_ONEBAR -1   // -1: as the policy says (P::kOneBarrier); 0 / 1: force (A/B builds)
+#endif
+    // ONE workgroup barrier per tile instead of two.  Of the two barriers of a tile only the one in front of the leading waves'
+    // matrix phase (= in front of the lagging waves' vector phase) carries data: it publishes the DMA pieces the leading waves have
+    // just waited for (tile t + 1, read by their M(t) right behind it) and orders every request of a stage behind the last read of
+    // its previous tenant.  The other one (in front of the leading waves' vector phase) only re-aligns the phases; without it a wave
+    // runs N and M back to back and the two waves of a SIMD meet once per tile: a slot no longer costs max(M, N) + barrier but the
+    // tile costs M + N + one barrier.  Leading waves: [N(t), barrier, M(t)]; lagging waves: [barrier, N(t), M(t)].
+    // Measured (round 3, same box): band kernel 32.06 vs 32.13 ms — nothing: at the power limit the clock takes back what a schedule
+    // saves without saving energy —, variable-block kernel (whose vector phase, with the gather, is the longer one) 28.07 vs 28.62 ms:
+    // on for the variable-block policy, off for the band policy.
+    constexpr bool kOneBar = (SVG_PP2_ONEBAR < 0 ? P::kOneBarrier : SVG_PP2_ONEBAR != 0) && ABL == 0;
     constexpr int kShadow = kMaxFree ? 0 : (D == 64) ? 2 : P::kShadow128;   // 16-key probability steps computed in the shadow of the PV MFMAs (0..3); the rest in the vector phase
     constexpr int NS = kDma ? 4 : 3;
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
@@ -718,7 +739,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pp_barrier();
-    if (lagging) pp_barrier();  // waves 4..7 run one phase behind
+    if (!kOneBar && lagging) pp_barrier();  // waves 4..7 run one phase behind
 
     // A wave without query rows (ragged q tiles of the variable-block policy, the last q tile of a sequence) keeps the barrier
     // and staging protocol but computes nothing: its partner then has the SIMD to itself.  (A separate loop, not a branch
@@ -1001,13 +1022,13 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
 
     if (idle) {
         for (int t = 0; t < nT; ++t) {
-            pp_barrier();
+            if (!kOneBar || lagging) pp_barrier();
             stage_resolve_next(t, kGuarded);
             stage_request(t);
-            pp_barrier();
+            if (!kOneBar || !lagging) pp_barrier();
         }
         pp_barrier();
-        if (!lagging) pp_barrier();
+        if (!kOneBar && !lagging) pp_barrier();
         P::notify(prm, ctx);
         return;
     }
@@ -1025,15 +1046,20 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     }
     // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc hoist the common VALU work above
     //  the branch and keep two register sets for O with 32 copies per tile)
+    // (kOneBar: which of the two barriers of a tile a wave keeps is a run-time property of the wave — the skip is a branch inside
+    //  the asm block of pp_barrier_if, one copy of the loop)
+    const int bar_n = lagging ? 1 : 0, bar_m = lagging ? 0 : 1;
     auto tile = [&](int t, auto has_next_c, auto guard_c) {
         tick(std::integral_constant<int, 0>{});
-        pp_barrier();
+        if constexpr (kOneBar) pp_barrier_if(bar_n);
+        else pp_barrier();
         tick(std::integral_constant<int, 1>{});
         if (kPrioV) __builtin_amdgcn_s_setprio(1);
         vector_phase(t, guard_c);
         if (kPrioV) __builtin_amdgcn_s_setprio(0);
         tick(std::integral_constant<int, 2>{});
-        pp_barrier();
+        if constexpr (kOneBar) pp_barrier_if(bar_m);
+        else pp_barrier();
         tick(std::integral_constant<int, 3>{});
         if (kPrioM && !kPrioStatic) __builtin_amdgcn_s_setprio(1);   // the matrix phase wins the VALU / MFMA issue arbitration against the partner's vector phase
         matrix_phase(t, has_next_c);
@@ -1047,7 +1073,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     if (nT > 0) tile(nT - 1, std::false_type{}, kGuarded);
     // the leading waves wait until the lagging waves have read V of the last tile: the epilogue reuses the stages
     pp_barrier();
-    if (!lagging) pp_barrier();
+    if (!kOneBar && !lagging) pp_barrier();
     if constexpr (TRACE) {
         if (blockIdx.x == kPpTraceBlock && lane == 0) {
 #pragma unroll

@@ -31,6 +31,7 @@ struct BandPolicy {
     static constexpr int kShadow128 = 1;   // two-phase body, D = 128: probability steps in the MFMA shadow (measured best)
     static constexpr int kAbl = ABL;  // > 0 only for the ablation variants (timing experiments)
     static constexpr bool kSetPrio = false;  // measured: s_setprio around the MFMA clusters costs 2 % here
+    static constexpr bool kOneBarrier = false;   // two-phase body: two barriers per tile (one measured neutral for this policy)
     static constexpr bool kSkew = SKEW;
     static constexpr int kRowBlocks = RB;    // 32-row blocks per wave
     static constexpr int kWR = 32 * RB;      // rows per wave
