@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r03y; mkdir -p $O
+O=gpurun_out/r03zc; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -12 $O/pytest_gpu.txt
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
 python - <<PY
