@@ -358,8 +358,17 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef SVG_F8PP_ONEBAR
+#define SVG_F8PP_ONEBAR 0
+#endif
+    // one barrier per tile (attn_core.h kOneBar: only the barrier in front of the leading waves' matrix phase carries data) — measured
+    // for this body and NOT shipped: 22.55 vs 21.98 ms (same box, round 3).  Its phases are unbalanced (matrix ~550, vector ~1000
+    // cycles), so without the second barrier the two vector phases of a SIMD overlap for half a tile, and unlike the 16-bit kernel
+    // this one is not at the power limit (2.33 GHz sustained): the strict opposition of the phases is worth more than the barrier.
+    constexpr bool kOneBar = SVG_F8PP_ONEBAR != 0;
+    const int bar_n = lagging ? 1 : 0, bar_m = lagging ? 0 : 1;
     pp_barrier();
-    if (lagging) pp_barrier();      // waves 4..7 run one phase behind
+    if (!kOneBar && lagging) pp_barrier();      // waves 4..7 run one phase behind
 
     const bool idle = !P::wave_active(ctx, wave * 32);
     // request half of a vector phase: tile t + dist, then wait for the pieces of the previous request
@@ -372,12 +381,12 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     };
     if (idle) {      // a wave without query rows keeps the barrier / staging protocol and computes nothing
         for (int t = 0; t < nT; ++t) {
-            pp_barrier();
+            if (!kOneBar || lagging) pp_barrier();
             stage_request(t);
-            pp_barrier();
+            if (!kOneBar || !lagging) pp_barrier();
         }
         pp_barrier();
-        if (!lagging) pp_barrier();
+        if (!kOneBar && !lagging) pp_barrier();
         P::notify(prm, ctx);
         return;
     }
@@ -502,9 +511,11 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
         asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
     }
     auto tile = [&](int t, auto has_next_c) {
-        pp_barrier();
+        if constexpr (kOneBar) pp_barrier_if(bar_n);
+        else pp_barrier();
         vector_phase(t);
-        pp_barrier();
+        if constexpr (kOneBar) pp_barrier_if(bar_m);
+        else pp_barrier();
         matrix_phase(t, has_next_c);       // (no s_setprio around it, unlike attn_body_pp2: with 8 MFMAs per phase it costs 1.5 %)
     };
     {   // (the last tile is peeled: a run-time "has next" test inside the loop makes hipcc keep two register sets for O)
@@ -514,7 +525,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     }
     // the leading waves wait until the lagging waves have read V of the last tile: the epilogue reuses the stages
     pp_barrier();
-    if (!lagging) pp_barrier();
+    if (!kOneBar && !lagging) pp_barrier();
 
     // ---------------- epilogue: as attn_body_f8 ----------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
