@@ -419,6 +419,20 @@ def main():
             clock = nat.ClockProbe(dev)
         except Exception:  # noqa: BLE001
             clock = None
+    if clock:
+        # rehearsal: one untimed step beside a short-lived probe.  Should the runtime ever put the probe and the main stream on the same
+        # hardware queue, the step would sit behind the probe until its deadline — seen here as a step that takes about the deadline
+        # instead of milliseconds — and the probe is then left out of the timed region (clock: null) instead of poisoning it.
+        torch.cuda.synchronize()
+        clock.start(max_ms=1500)
+        tr0 = time.perf_counter()
+        step(False)
+        torch.cuda.current_stream().synchronize()
+        rehearsal_s = time.perf_counter() - tr0
+        clock.arm_stop()
+        clock.result()
+        if rehearsal_s > 1.0:
+            clock = None
     barrier()
     if clock:
         clock.start(max_ms=20000)
