@@ -503,3 +503,41 @@ def modulate_shift(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, ou
 def modulate_gate_residual(residual: torch.Tensor, x: torch.Tensor, gate: torch.Tensor, out_dtype) -> torch.Tensor:
     """ref: `(hidden_states.float() + attn_output * gate_msa).type_as(hidden_states)`, custom_models.py:69"""
     return (residual.float() + x.float() * gate.float()).to(out_dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# remainder packing of the variable-block kernel (no reference counterpart: an execution detail of this engine whose RESULT —
+# index work — has to be reproducible; restated here so that the device-side matching can be checked for equality)
+# ----------------------------------------------------------------------------------------------------------
+
+
+def varblock_pair_partners(block_map: torch.Tensor, q_sizes: torch.Tensor, k_sizes: torch.Tensor, tile_rows: int = 256,
+                           rounds: int = 3, min_common: int = 8) -> torch.Tensor:
+    """block_map bool [H, QB, KB], q_sizes [H, QB], k_sizes [H, KB] -> int32 [H, QB]: the partner array of
+    csrc/attention.hip varblock_pair_score_kernel / varblock_pair_match_kernel.  Per head and round every block-row with an unmatched
+    ragged last tile (q_size % tile_rows > 0) chooses, among the other unmatched ones whose remainder fits beside its own, the one
+    with the most active non-empty key blocks in common (at least `min_common`; ties: the lowest index); mutual choices become pairs
+    (partner[i] = j for the lower index i, -2 for j); -1: alone."""
+    H, QB, KB = block_map.shape
+    out = torch.full((H, QB), -1, dtype=torch.int32)
+    for h in range(H):
+        bits = (block_map[h].bool() & (k_sizes[h] > 0)[None]).to(torch.float32)
+        common = (bits @ bits.T).to(torch.int64)                 # [QB, QB] exact counts
+        rem = (q_sizes[h].to(torch.int64) % tile_rows).clone()
+        for _ in range(rounds):
+            best = torch.full((QB,), -1, dtype=torch.int64)
+            for i in range(QB):
+                if rem[i] <= 0:
+                    continue
+                ok = (rem > 0) & (rem + rem[i] <= tile_rows)
+                ok[i] = False
+                sc = torch.where(ok, common[i], torch.full_like(common[i], -1))
+                j = int(torch.argmax(sc))                        # first maximum = lowest index
+                if sc[j] >= min_common:
+                    best[i] = j
+            for i in range(QB):
+                j = int(best[i])
+                if j >= 0 and int(best[j]) == i:
+                    rem[i] = 0
+                    out[h, i] = j if i < j else -2
+    return out

@@ -499,6 +499,14 @@ def varblock_launch_order(workspace: torch.Tensor, Hkv: int, QB: int, KB: int):
     return w[off + 2: off + 2 + 3 * n].view(n, 3).clone()
 
 
+def varblock_partners(workspace: torch.Tensor, Hkv: int, QB: int, KB: int) -> torch.Tensor:
+    """The remainder-packing partners a variant-3 call left in its workspace: int32 [Hkv, QB]; j >= 0: block-row i's ragged last tile
+    also carries block-row j's, -2: carried by its partner, -1: alone (csrc/attention.hip varblock_pair_*_kernel)."""
+    w = workspace.view(torch.int32)
+    off = Hkv * (3 * (QB + 1) + (KB + 1)) + 2 * Hkv * QB
+    return w[off: off + Hkv * QB].view(Hkv, QB).clone()
+
+
 class ClockProbe:
     """Sustained shader clock over a span of GPU work (svg_debug_clock_probe): `start()` launches the one-wave probe on its own
     stream, `arm_stop()` raises its flag from a third stream behind the work enqueued so far, `result()` waits for the probe and returns

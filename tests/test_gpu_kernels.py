@@ -546,6 +546,30 @@ def test_varblock_launch_order_is_a_permutation(nat, variant, hq, hkv, S, MB, NB
         assert rel_l2(o[h * g:(h + 1) * g].float().cpu(), ref) <= 3e-3
 
 
+@pytest.mark.parametrize("hkv,S,MB,NB,BMseed", [(2, 6000, 45, 120, 0), (3, 9000, 64, 200, 1), (1, 20000, 130, 1000, 2)])
+def test_varblock_pairing_equals_host_statement(nat, hkv, S, MB, NB, BMseed):
+    """Index work is bit-exact: the partner array the device-side matching leaves in the workspace (remainder packing, variant 3)
+    equals the host statement of the same rule, O.varblock_pair_partners, entry for entry — maps with groups of similar block-rows,
+    empty block-rows and empty key blocks."""
+    gen = torch.Generator().manual_seed(50 + BMseed)
+    rsz = random_partition_batch(S, MB, hkv, gen)
+    rsz[0, 2] += rsz[0, 3]
+    rsz[0, 3] = 0
+    csz = random_partition_batch(S, NB, hkv, gen)
+    csz[0, 5] += csz[0, 6]
+    csz[0, 6] = 0
+    base = torch.rand(hkv, 8, NB, generator=gen) > 0.7                      # 8 "modes": block-rows of a mode share most key blocks
+    mode = torch.randint(0, 8, (hkv, MB), generator=gen)
+    bmap = torch.gather(base, 1, mode[..., None].expand(-1, -1, NB)) ^ (torch.rand(hkv, MB, NB, generator=gen) > 0.96)
+    q, k, v = (torch.randn(hkv, S, 128, generator=gen).to(torch.bfloat16) for _ in range(3))
+    ws = nat.varblock_workspace(hkv, hkv, MB, NB, S, "cuda")
+    nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=3, workspace=ws)
+    got = nat.varblock_partners(ws, hkv, MB, NB).cpu()
+    want = O.varblock_pair_partners(bmap, rsz, csz)
+    assert torch.equal(got, want), (got != want).nonzero()[:8]
+    assert int((want >= 0).sum()) > 0
+
+
 def test_varblock_golden_and_edge_cases(nat, golden):
     """Reference dynamic_block_sparse_fwd_torch output (empty q block, empty k block, q block with no active keys)."""
     q, k, v = (torch.from_numpy(golden[n])[0].to(torch.float16) for n in ("vb_q", "vb_k", "vb_v"))
