@@ -215,8 +215,9 @@ int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* r
  *   c_new[b,k]    = mean of assigned points (fp32 accumulate, deterministic order), old centroid if empty
  *   counts[b,k]   = cluster sizes;  sorted_idx = stable argsort(labels);  shift[b] = max_k ||c_new - c||
  * x: [B, N, D]; centroids_in/out: [B, K, D] (same dtype as x); labels int32 [B, N]; counts int32 [B, K];
- * sorted_idx int32 [B, N]; shift float [B].  xsq float [B, N] must be pre-computed by svg_kmeans_xsq (it is
- * constant over iterations, ref :704).
+ * sorted_idx int32 [B, N]; shift float [B].  xsq float [B, N] is the reference's `x_sq` (svg_kmeans_xsq; constant over
+ * iterations, ref :704) and MAY BE NULL: the kernel assigns by argmax_k (<x, c_k> - |c_k|^2 / 2), which has the same arg-min as
+ * the distance form and never reads |x|^2 — pass it only if you compute it anyway.
  * ---------------------------------------------------------------------------------------------- */
 int svg_kmeans_xsq(const void* x, float* xsq, int32_t B, int32_t N, int32_t D, int32_t dtype, void* stream);
 size_t svg_kmeans_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D);

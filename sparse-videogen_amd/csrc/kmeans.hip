@@ -340,7 +340,9 @@ extern "C" size_t svg_kmeans_workspace_bytes(int32_t B, int32_t N, int32_t K, in
 extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, void* centroids_out,
                                int32_t* labels, int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N,
                                int32_t K, int32_t D, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !xsq || !centroids_in || !centroids_out || !labels || !counts || !sorted_idx || !shift || !workspace)
+    // (xsq may be NULL: the argmax form of the assignment does not use |x|^2 — see kmeans_assign_kernel; the parameter stays in the
+    //  signature because the reference's distance form carries it, svg/kmeans_utils.py:704)
+    if (!x || !centroids_in || !centroids_out || !labels || !counts || !sorted_idx || !shift || !workspace)
         return SVG_ERR_BAD_ARG;
     if (B <= 0 || N <= 0 || K <= 0) return SVG_ERR_BAD_ARG;
     if (K > 8192) return SVG_ERR_UNSUPPORTED;
@@ -376,8 +378,8 @@ extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_in
                                int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
                                int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    if (!x || !xsq || !c_init || !c_work_a || !c_work_b || !labels || !counts || !sorted_idx || !centroids_out || !n_iters || !workspace)
-        return SVG_ERR_BAD_ARG;
+    if (!x || !c_init || !c_work_a || !c_work_b || !labels || !counts || !sorted_idx || !centroids_out || !n_iters || !workspace)
+        return SVG_ERR_BAD_ARG;   // (xsq may be NULL, see svg_kmeans_iter)
     if (B <= 0 || N <= 0 || K <= 0 || max_iters <= 0) return SVG_ERR_BAD_ARG;
     if (K > 8192 || (D != 64 && D != 128) || (dtype != SVG_DTYPE_BF16 && dtype != SVG_DTYPE_F16)) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_kmeans_loop_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;

@@ -591,19 +591,20 @@ class KmeansBuffers:
         self.ws = torch.empty(lib.svg_kmeans_workspace_bytes(B, N, K, D), dtype=torch.uint8, device=device)
 
 
-def kmeans_iter(x: torch.Tensor, xsq: torch.Tensor, c_in: torch.Tensor, c_out: torch.Tensor, buf: KmeansBuffers) -> None:
+def kmeans_iter(x: torch.Tensor, xsq: Optional[torch.Tensor], c_in: torch.Tensor, c_out: torch.Tensor, buf: KmeansBuffers) -> None:
+    """xsq: the reference's x_sq or None (the assignment kernel does not read it)"""
     lib = load()
     _dev(x, xsq, c_in, c_out)
     B, N, D = x.shape
     K = c_in.shape[1]
     assert c_in.shape == (B, K, D) and c_out.shape == (B, K, D) and c_in.dtype == x.dtype == c_out.dtype
-    rc = lib.svg_kmeans_iter(x.data_ptr(), xsq.data_ptr(), c_in.data_ptr(), c_out.data_ptr(), buf.labels.data_ptr(),
+    rc = lib.svg_kmeans_iter(x.data_ptr(), _ptr(xsq), c_in.data_ptr(), c_out.data_ptr(), buf.labels.data_ptr(),
                              buf.counts.data_ptr(), buf.sorted_idx.data_ptr(), buf.shift.data_ptr(), B, N, K, D,
                              _dtype_code(x), buf.ws.data_ptr(), buf.ws.numel(), _stream())
     _check(rc, "svg_kmeans_iter")
 
 
-def kmeans_loop(x: torch.Tensor, xsq: torch.Tensor, c_init: torch.Tensor, max_iters: int, tol: float, work=None):
+def kmeans_loop(x: torch.Tensor, xsq: Optional[torch.Tensor], c_init: torch.Tensor, max_iters: int, tol: float, work=None):
     """The whole Lloyd loop as one library call without host synchronisation (svg_kmeans_loop) -> (labels int32 [B, N], centroids
     [B, K, D], counts int32 [B, K], n_iters int32 [] on the device, sorted_idx int32 [B, N]).  `work`: optional dict that keeps the
     scratch tensors of a (B, N, K, D) shape between calls."""
@@ -624,7 +625,7 @@ def kmeans_loop(x: torch.Tensor, xsq: torch.Tensor, c_init: torch.Tensor, max_it
     counts = torch.empty((B, K), dtype=torch.int32, device=x.device)
     cent = torch.empty_like(c_init)
     n_it = torch.zeros((), dtype=torch.int32, device=x.device)
-    rc = lib.svg_kmeans_loop(x.data_ptr(), xsq.data_ptr(), c_init.data_ptr(), w["ca"].data_ptr(), w["cb"].data_ptr(), labels.data_ptr(),
+    rc = lib.svg_kmeans_loop(x.data_ptr(), _ptr(xsq), c_init.data_ptr(), w["ca"].data_ptr(), w["cb"].data_ptr(), labels.data_ptr(),
                              counts.data_ptr(), sorted_idx.data_ptr(), cent.data_ptr(), n_it.data_ptr(), B, N, K, D, _dtype_code(x),
                              int(max_iters), float(tol), w["ws"].data_ptr(), w["ws"].numel(), _stream())
     _check(rc, "svg_kmeans_loop")

@@ -82,7 +82,7 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
     st = _STATE_CACHE.get(key)
     if st is None:
         st = _STATE_CACHE[key] = KMeansState(x, n_clusters)
-    xsq = _native.kmeans_xsq(x)
+    xsq = None   # the reference's x_sq (:704) is not needed: the assignment kernel takes argmax_k (<x, c_k> - |c_k|^2 / 2)
     if init_centroids is None:
         # ref :706-709 — random points of x as initial centres (device RNG, not reproducible across platforms)
         indices = torch.randint(0, N, (B, n_clusters), device=x.device)
