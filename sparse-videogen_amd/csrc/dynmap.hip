@@ -31,31 +31,53 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
     const int N2 = 1 << (32 - __builtin_clz(max(KC, 2) - 1));
     unsigned long long* keys = (unsigned long long*)smem;
     double* prob = (double*)(keys + N2);
-    __shared__ float qrow[D];
+    __shared__ double qrow[D];   // the query centroid as doubles: converted once, read as 8-byte broadcasts
     __shared__ double red[4];
     __shared__ int cut_s;
     const int row = blockIdx.x, bh = blockIdx.y, tid = threadIdx.x;
     const T* q = qc + ((size_t)bh * QC + row) * D;
     const T* kb = kc + (size_t)bh * KC * D;
     const int32_t* ks = k_sizes + (size_t)bh * KC;
-    if (tid < D) qrow[tid] = Elt<T>::to_float(q[tid]);
+    if (tid < D) qrow[tid] = (double)Elt<T>::to_float(q[tid]);
     __syncthreads();
 
-    // 1. scores (kept in prob[]), running max
+    // 1. scores (kept in prob[]), running max.  A thread works on kJB key centroids at once: every q value is read from LDS once
+    //    per kJB dot products and the kJB row loads are in flight together; each dot product still accumulates d = 0 .. D - 1 in
+    //    order, in fp64 (the order-independent rounding argument of the header does not even need that, but it keeps the sums
+    //    identical to the previous form).
     float lmax = -INFINITY;
-    for (int j = tid; j < KC; j += kDynThreads) {
-        const T* kr = kb + (size_t)j * D;
-        double acc = 0.0;
-#pragma unroll 4
-        for (int d0 = 0; d0 < D; d0 += 8) {
-            const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(kr + d0);
+    constexpr int kJB = 4;
+    for (int j0 = tid; j0 < KC; j0 += kJB * kDynThreads) {
+        const T* kr[kJB];
+        double acc[kJB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = __builtin_fma((double)qrow[d0 + e], (double)Elt<T>::to_float(v[e]), acc);
+        for (int u = 0; u < kJB; ++u) {
+            const int j = j0 + u * kDynThreads;
+            kr[u] = kb + (size_t)(j < KC ? j : j0) * D;    // (columns behind KC re-read a valid row; nothing is stored for them)
+            acc[u] = 0.0;
         }
-        float s = Elt<T>::to_float(Elt<T>::from_double(acc));
-        s = Elt<T>::to_float(Elt<T>::from_float(s / sqrt_d));
-        prob[j] = (double)s;
-        lmax = fmaxf(lmax, s);
+#pragma unroll 2
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            typename Elt<T>::v8 v[kJB];
+#pragma unroll
+            for (int u = 0; u < kJB; ++u) v[u] = *(const typename Elt<T>::v8*)(kr[u] + d0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double qd = qrow[d0 + e];
+#pragma unroll
+                for (int u = 0; u < kJB; ++u) acc[u] = __builtin_fma(qd, (double)Elt<T>::to_float(v[u][e]), acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kJB; ++u) {
+            const int j = j0 + u * kDynThreads;
+            if (j < KC) {
+                float s = Elt<T>::to_float(Elt<T>::from_double(acc[u]));
+                s = Elt<T>::to_float(Elt<T>::from_float(s / sqrt_d));
+                prob[j] = (double)s;
+                lmax = fmaxf(lmax, s);
+            }
+        }
     }
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = (double)lmax;
