@@ -127,10 +127,26 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
         const float p_cmp = Elt<T>::to_float(Elt<T>::from_float(top_p));
         float acc = 0.f, prev_cum = 0.f;
         int r = 0;
-        for (; r < KC; ++r) {
-            if (r > 0 && prev_cum > p_cmp) break;   // position r (and all later ones) is removed unless r < preserve
-            acc += __uint_as_float(0xffffffffu - (unsigned)(keys[r] >> 32));
-            prev_cum = Elt<T>::to_float(Elt<T>::from_float(acc));
+        bool done = false;
+        // (the same sequence of fp32 additions as a one-by-one walk; the keys of a block of 8 are loaded together, so the walk pays
+        //  one LDS round trip per 8 positions instead of one per position — N2 is a power of two >= 2, entries behind KC hold the
+        //  probability 0 sentinel and are never reached: the r < KC test comes first)
+        for (int r0 = 0; r0 < KC && !done; r0 += 8) {
+            unsigned long long kq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kq[u] = keys[min(r0 + u, N2 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (done) continue;
+                r = r0 + u;
+                if (r >= KC || (r > 0 && prev_cum > p_cmp)) {   // position r (and all later ones) is removed unless r < preserve
+                    done = true;
+                    continue;
+                }
+                acc += __uint_as_float(0xffffffffu - (unsigned)(kq[u] >> 32));
+                prev_cum = Elt<T>::to_float(Elt<T>::from_float(acc));
+                r = r0 + u + 1;
+            }
         }
         cut_s = max(r, preserve);
     }
