@@ -45,7 +45,8 @@ FLAGS = [
 STRICT_FP = {"prologue.hip", "glue.hip", "dynmap.hip"}
 # Files whose gfx950 assembly is always kept (build/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s): their MFMAs are inline asm, which
 # hipcc's hazard recognizer does not see — tools/asm_hazards.py audits the listing (tests/test_w4_asm_audit.py).
-KEEP_ASM = {"attention_w4.hip"}
+# (attention.hip / attention_f8.hip: the first contraction step of a tile of the fp8 bodies, csrc/attn_f8.h mfma_qk_first)
+KEEP_ASM = {"attention_w4.hip", "attention.hip", "attention_f8.hip"}
 
 
 def _newest_header() -> float:

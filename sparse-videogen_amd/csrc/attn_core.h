@@ -894,8 +894,15 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 l_run *= alpha;
                 if constexpr (PRE) {
                     pre_shift = m_prev - m_use;
+                    // what the next S^T accumulators start from.  Rewritten IN PLACE (tied asm operands): as plain assignments hipcc
+                    // keeps the old and the new value in two tuples and copies one into the other on the FAST path of every tile
+                    const float nm = -m_use;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) neg_ref[r] = -m_use;   // what the next S^T accumulators start from
+                    for (int r = 0; r < 16; ++r) {
+                        float c = neg_ref[r];
+                        asm volatile("v_mov_b32 %0, %1" : "+v"(c) : "v"(nm));
+                        neg_ref[r] = c;
+                    }
                 }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
@@ -1013,7 +1020,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 if (i == NPV - 1) l_run += psum;
             } else {
                 const int j = i - NPV, ks = j >> 1, b = j & 1;
-                sc[b] = E::mfma(ring[i % (kPF + 1)], qf[ks], ks == 0 ? (PRE ? neg_ref : zero) : sc[b]);
+                // (PRE, first step: D = A B + neg_ref with neg_ref left where it is — E::mfma_keep_c.  Its result is read by the next
+                //  step's MFMA of the same key block only, as C, same tuple: legal back to back; neg_ref is written on the exact path
+                //  of a vector phase, a barrier away from any matrix phase.)
+                if constexpr (PRE) sc[b] = (ks == 0) ? E::mfma_keep_c(ring[i % (kPF + 1)], qf[ks], neg_ref) : E::mfma(ring[i % (kPF + 1)], qf[ks], sc[b]);
+                else sc[b] = E::mfma(ring[i % (kPF + 1)], qf[ks], ks == 0 ? zero : sc[b]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -158,6 +158,10 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
     constexpr float kPShift = 4.f, kPSumMax = 448.f;
     float m_ref = -INFINITY, m_off = -kPShift;    // m_off = (m_ref finite ? m_ref : 0) - kPShift
     float psum_thr = -1.f;   // kPSumMax once every row of the wave has a finite reference (see attn_body_pp2)
+    // Packed probabilities.  Lives outside the loop on purpose: v_cvt_pk_fp8_f32 writes one half of its destination and keeps the
+    // other, so the builtin takes the destination's old value — a literal 0 there costs a v_mov per word and tile (8 of the ~100
+    // VALU instructions of a tile), the word's own stale contents cost nothing, and both halves are rewritten anyway.
+    i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -180,7 +184,6 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
                     }
             }
             // probabilities of this lane's 32 keys at reference offset `off`: packed e4m3 operand + their fp32 sum
-            i32x8 pf;
             float psum;
             auto probs = [&](float off) {
                 psum = 0.f;
@@ -193,7 +196,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
                         p4[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e >> 4][e & 15], c_log2, -off));
                         psum += p4[i];
                     }
-                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
                     pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
                 }
             };
@@ -392,13 +395,41 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     }
 
     f32x16 sc[2];          // S(t) until the vector phase has turned it into pf, then S(t + 1) accumulates here
-    i32x8 pf;              // probabilities of tile t (e4m3, slot order of the file header)
+    i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // probabilities of tile t (e4m3, slot order of the file header); every word is rewritten
+                                           // per tile with its own stale contents as the conversions' "old" operand (see attn_body_f8)
     constexpr float kPShift = 4.f, kPSumMax = 448.f;     // softmax without a running maximum: see attn_body_f8
     float m_ref = -INFINITY, m_off = -kPShift, psum = 0.f;
     float psum_thr = -1.f;   // kPSumMax once every row of the wave has a finite reference (see attn_body_pp2)
     f32x16 cneg;           // -m_off in every register: the C operand of the first QK MFMA of a tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
+    // cneg is rewritten IN PLACE (tied asm operands) on the exact path: written as plain assignments hipcc keeps the old and the new
+    // value in two register tuples and copies one into the other on the FAST path of every tile (8 v_mov_b64 per tile)
+    auto set_cneg = [&](float x) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float c = cneg[r];
+            asm volatile("v_mov_b32 %0, %1" : "+v"(c) : "v"(x));
+            cneg[r] = c;
+        }
+    };
+    // First contraction step of a tile: D = A B + cneg with D != C.  Inline asm, because hipcc selects the tied form (D == C) of the
+    // builtin for one of the two key blocks and pays for it with a 16-register copy of cneg per tile (8 v_mov_b64 on the vector
+    // pipe, which is what bounds the fp8 kernels).  Hazards the compiler cannot see (it does not look inside): the only reader of
+    // D is the next step's MFMA of the same key block, as its C operand, same tuple — legal back to back on gfx950; A / B come from
+    // LDS reads the compiler waits for (it sees the operands); cneg is written on the exact path only, a barrier or a whole
+    // softmax away.  tools/asm_hazards.py audits the listing (tests/test_w4_asm_audit.py).
+    // (the two block-scale words live in VGPRs of their own for the whole loop — opaque to the compiler, so it cannot re-materialise
+    //  one with a v_mov directly in front of the asm MFMA, where nobody would pad the VALU-write -> MFMA-read wait states)
+    int scale_a_v = kF8Scale127, scale_q_v = q_scale;
+    asm volatile("" : "+v"(scale_a_v), "+v"(scale_q_v));
+    auto mfma_qk_first = [&](i32x8 a, i32x8 b) -> f32x16 {
+        f32x16 d;
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]"
+                     : "=&v"(d)
+                     : "v"(a), "v"(b), "v"(cneg), "v"(scale_a_v), "v"(scale_q_v));
+        return d;
+    };
     typename P::TileCur vc;          // tile of the next vector phase
     P::tile_cur_init(ctx, vc);
 
@@ -428,7 +459,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 else p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
                 psum += p4[i];
             }
-            const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+            const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
             pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
         }
     };
@@ -466,8 +497,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             m_ref = m_new;
             psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
             m_off = m_use - kPShift;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cneg[r] = -m_off;
+            set_cneg(-m_off);
             probs(std::true_type{}, delta);
             l_run *= alpha;
 #pragma unroll
@@ -497,7 +527,8 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 acc_o[i] = mfma_f8(ring[i % (kPF + 1)], pf, acc_o[i]);
             } else {
                 const int j = i - 4, ks = j >> 1, b = j & 1;
-                sc[b] = mfma_qk(ring[i % (kPF + 1)], qf[ks], ks == 0 ? cneg : sc[b]);
+                if (ks == 0) sc[b] = mfma_qk_first(ring[i % (kPF + 1)], qf[ks]);
+                else sc[b] = mfma_qk(ring[i % (kPF + 1)], qf[ks], sc[b]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -680,6 +711,34 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
     f32x16 cneg;           // -m_off in every register
 #pragma unroll
     for (int r = 0; r < 16; ++r) cneg[r] = kPShift;
+    // cneg is rewritten IN PLACE (tied asm operands) on the exact path: written as plain assignments hipcc keeps the old and the new
+    // value in two register tuples and copies one into the other on the FAST path of every tile (8 v_mov_b64 per tile)
+    auto set_cneg = [&](float x) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float c = cneg[r];
+            asm volatile("v_mov_b32 %0, %1" : "+v"(c) : "v"(x));
+            cneg[r] = c;
+        }
+    };
+    // First contraction step of a tile: D = A B + cneg with D != C.  Inline asm, because hipcc selects the tied form (D == C) of the
+    // builtin for one of the two key blocks and pays for it with a 16-register copy of cneg per tile (8 v_mov_b64 on the vector
+    // pipe, which is what bounds the fp8 kernels).  Hazards the compiler cannot see (it does not look inside): the only reader of
+    // D is the next step's MFMA of the same key block, as its C operand, same tuple — legal back to back on gfx950; A / B come from
+    // LDS reads the compiler waits for (it sees the operands); cneg is written on the exact path only, a barrier or a whole
+    // softmax away.  tools/asm_hazards.py audits the listing (tests/test_w4_asm_audit.py).
+    // (the two block-scale words live in VGPRs of their own for the whole loop — opaque to the compiler, so it cannot re-materialise
+    //  one with a v_mov directly in front of the asm MFMA, where nobody would pad the VALU-write -> MFMA-read wait states)
+    int scale_a_v = kF8Scale127, scale_q_v = q_scale;
+    asm volatile("" : "+v"(scale_a_v), "+v"(scale_q_v));
+    auto mfma_qk_first = [&](i32x8 a, i32x8 b) -> f32x16 {
+        f32x16 d;
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]"
+                     : "=&v"(d)
+                     : "v"(a), "v"(b), "v"(cneg), "v"(scale_a_v), "v"(scale_q_v));
+        return d;
+    };
+    i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // (outside the loop: its stale words are the conversions' "old" operand, see attn_body_f8)
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -695,7 +754,8 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                     const u32x4 lo = *(const u32x4*)(rowp + (((4 * ks + 2 * g) ^ ksw) << 4));
                     const u32x4 hi = *(const u32x4*)(rowp + (((4 * ks + 2 * g + 1) ^ ksw) << 4));
                     const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                    s_cur[b] = mfma_qk(kf, qf[ks], ks == 0 ? cneg : s_cur[b]);
+                    if (ks == 0) s_cur[b] = mfma_qk_first(kf, qf[ks]);
+                    else s_cur[b] = mfma_qk(kf, qf[ks], s_cur[b]);
                 }
             if (cls == TILE_PARTIAL) {
                 asm volatile("; element-wise mask of a partial tile" ::: "memory");
@@ -707,7 +767,6 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                         s_cur[b][r] = P::allowed(prm, ctx, q_log, tk0 + key) ? s_cur[b][r] : -INFINITY;
                     }
             }
-            i32x8 pf;
             float psum;
             auto probs = [&](auto shifted_c, float delta) {
                 psum = 0.f;
@@ -721,7 +780,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                         else p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]);
                         psum += p4[i];
                     }
-                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], 0, false);
+                    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
                     pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
                 }
             };
@@ -741,8 +800,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 m_ref = m_new;
                 psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
                 m_off = m_use - kPShift;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cneg[r] = -m_off;
+                set_cneg(-m_off);
                 probs(std::true_type{}, delta);
                 l_run *= alpha;
 #pragma unroll

@@ -42,6 +42,14 @@ struct Elt<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // D = A B + C with D and C in DIFFERENT registers, as inline asm: for a C that stays live hipcc selects the tied form (D == C) of
+    // the builtin and copies C first (16 registers per call).  The caller owns the hazards (the compiler does not look inside):
+    // see attn_body_pp2 / attn_f8.h mfma_qk_first and tools/asm_hazards.py --asm-mfma.
+    static __device__ __forceinline__ f32x16 mfma_keep_c(v8 a, v8 b, const f32x16& c) {
+        f32x16 d;
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
     static __device__ __forceinline__ float to_float(__bf16 x) { return (float)x; }
     static __device__ __forceinline__ __bf16 from_float(float x) { return (__bf16)x; }
     static __device__ __forceinline__ __bf16 from_double(double x) { return (__bf16)(float)x; }  // torch: double -> float -> bf16
@@ -59,6 +67,11 @@ struct Elt<_Float16> {
     using v4 = f16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma_keep_c(v8 a, v8 b, const f32x16& c) {   // (see Elt<__bf16>)
+        f32x16 d;
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
     }
     static __device__ __forceinline__ float to_float(_Float16 x) { return (float)x; }
     static __device__ __forceinline__ _Float16 from_float(float x) { return (_Float16)x; }

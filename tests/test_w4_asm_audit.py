@@ -55,3 +55,49 @@ def test_no_mfma_hazards_no_spills(listing, capsys):
     assert rc == 0, out
     for l in kernels:
         assert " 0 hazards, 0 spill moves" in l, l
+
+
+F8_LISTINGS = [PKG / "build" / f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s" for stem in ("attention", "attention_f8")]
+
+
+@pytest.fixture(scope="module")
+def f8_listings():
+    srcs = [PKG / "csrc" / n for n in ("attention.hip", "attention_f8.hip", "attn_f8.h", "attn_core.h", "band_policy.h")]
+    newest = max(s.stat().st_mtime for s in srcs)
+    if any(not f.exists() or f.stat().st_mtime < newest for f in F8_LISTINGS):
+        _load(PKG / "build.py", "svg_build").build(force=False, asm=False, verbose=False)
+    return F8_LISTINGS
+
+
+def _audit(audit, capsys, pattern, listing):
+    argv = sys.argv
+    sys.argv = ["asm_hazards.py", pattern, str(listing), "--asm-mfma"]
+    try:
+        rc = audit.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    return rc, out, [l for l in out.splitlines() if l.startswith("_Z")]
+
+
+def test_first_step_mfmas_have_no_hazards(f8_listings, capsys):
+    """The first contraction step of a tile of the pre-scaled-q two-phase body (attn_core.h, E::mfma_keep_c) and of the fp8 bodies
+    (attn_f8.h, mfma_qk_first) is an inline-asm MFMA (D != C: saves a 16-register copy of the loop-invariant C per tile).  Nothing
+    may write one of its operands — A, B, C or the block-scale words — within two wait states in front of it, and nothing but the
+    next step's MFMA (as C, same tuple) may touch its destination inside the MFMA's latency."""
+    audit = _load(ROOT / "tools" / "asm_hazards.py", "asm_hazards")
+    for f in f8_listings:
+        assert f.exists(), f"build.py keeps the assembly of {f.name}"
+    seen = 0
+    for f in f8_listings:                                    # {band, varblock} x {bf16, f16} fp8 kernels: 2 asm MFMAs each
+        rc, out, kernels = _audit(audit, capsys, "attn_f8", f)
+        seen += len(kernels)
+        assert rc == 0, out
+        for l in kernels:
+            assert "2 asm MFMAs, 0 hazards" in l, l
+    assert seen == 4, seen
+    rc, out, kernels = _audit(audit, capsys, "pp2q", f8_listings[0])   # pre-scaled band kernels: {plain, switch} x dtype x head_dim
+    assert rc == 0, out
+    assert len(kernels) == 8, out
+    for l in kernels:
+        assert (" 8 asm MFMAs, 0 hazards" if "switch" in l else " 4 asm MFMAs, 0 hazards") in l, l

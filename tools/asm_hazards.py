@@ -71,14 +71,15 @@ def reads(line):
     return set()
 
 
-def audit(name, lines, mfma_states):
+def audit(name, lines, mfma_states, only=None):
+    """only: set of line indices to audit (the MFMAs inside asm statements), None = every MFMA"""
     bad = []
     n = len(lines)
     for i, l in enumerate(lines):
-        if not l.startswith("v_mfma"):
+        if not l.startswith("v_mfma") or (only is not None and i not in only):
             continue
         op, ops = split_ops(l)
-        dst, srcs = regs(ops[0]), set().union(*[regs(x) for x in ops[1:4]])
+        dst, srcs = regs(ops[0]), set().union(*[regs(x) for x in ops[1:6]])   # A, B, C (+ the two block-scale words of v_mfma_scale_*)
         # W->M: look back 2 wait states
         st, j = 0, i - 1
         while j >= 0 and st < 2:
@@ -120,6 +121,9 @@ def main():
         if a.startswith("--mfma-states="):
             mfma_states = int(a.split("=")[1])
     pat = argv[0] if argv else "w4"
+    # --asm-mfma: kernels with VGPR-destination MFMAs too, and only the MFMAs written as inline asm are audited (csrc/attn_f8.h:
+    # the first contraction step of a tile; every other MFMA there is a builtin hipcc pads itself)
+    asm_only = "--asm-mfma" in sys.argv[1:]
     files = [Path(argv[1])] if len(argv) > 1 else sorted(BUILD.glob("*-hip-amdgcn-amd-amdhsa-gfx950.s"))
     total = 0
     for f in files:
@@ -147,9 +151,15 @@ def main():
                     else:
                         spill_moves += 1
                 lines.append(l)
-            if not any(l.startswith("v_mfma") and "a[" in l.split(",")[0] for l in lines):
-                continue   # kernels whose MFMAs are compiler builtins: hipcc pads those itself
-            bad = audit(name, lines, mfma_states)
+            if asm_only:
+                only = {i for i in asm_lines if lines[i].startswith("v_mfma")}
+                if not only:
+                    continue
+                bad = audit(name, lines, mfma_states, only)
+            else:
+                if not any(l.startswith("v_mfma") and "a[" in l.split(",")[0] for l in lines):
+                    continue   # kernels whose MFMAs are compiler builtins: hipcc pads those itself
+                bad = audit(name, lines, mfma_states)
             TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
             for i, l in enumerate(lines):
                 if l.startswith(TRANS):
@@ -163,7 +173,8 @@ def main():
                         st += states(pl)
                         j += 1
             bad += [(-1, "AGPR", l, "outside an asm statement") for l in foreign]
-            print(f"{name[:100]}: {sum(l.startswith('v_mfma') for l in lines)} MFMAs, {len(bad)} hazards, {spill_moves} spill moves")
+            n_mfma = len(only) if asm_only else sum(l.startswith('v_mfma') for l in lines)
+            print(f"{name[:100]}: {n_mfma} {'asm ' if asm_only else ''}MFMAs, {len(bad)} hazards, {spill_moves} spill moves")
             for i, kind, p, l in bad[:12]:
                 print(f"   {kind} line {i}: `{p}`  vs  `{l}`")
             total += len(bad)
