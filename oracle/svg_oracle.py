@@ -15,9 +15,18 @@ Pinning status (see tests/golden/make_golden.py, which imports the reference its
       (svg/kmeans_utils.py:258-554; their bodies are restated here from the Triton source and the commented torch form :631-635).
   pinned by the reference's own torch references / generators: QK-norm + RoPE prologue (make_golden_prologue.py), BSR masks of
       the uniform-block ops (make_golden_bsr.py).
-  PARITY UNPINNED (third-party, GPU-only): the Triton kernel BODIES of flash-kmeans and the flashinfer variable-block kernel
-      (anchored on the reference's own test, svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:38-133, i.e. dense attention
-      under the repeat-interleaved block mask).
+  pinned at KERNEL level by executing the reference's own `@triton.jit` sources with Triton's interpreter (TRITON_INTERPRET=1, fp32 and
+      fp16; tests/golden/make_golden_triton.py, tests/test_triton_golden.py): the flash-kmeans assignment and update kernels and the
+      loop on both of them, the reference's Triton statement of the variable-block attention (_dynamic_block_sparse_fwd_kernel), the
+      head-placement and permutation kernels of the three models, the LayerNorm / RMSNorm / modulate kernels of the Wan block.
+      Found that way: the LayerNorm kernels count the zero padding up to the next power of two in the VARIANCE (a reference quirk for
+      hidden sizes such as 1536 / 5120; `fp32_layernorm` below states FP32LayerNorm, the specification — see its docstring).
+  PARITY UNPINNED: (a) the bf16 rounding points of the two k-means norms (`kmeans_xsq`, `kmeans_csq`): the interpreter of this
+      image's Triton cannot compute in bfloat16, and on the GPU `tl.sum` of a 16-bit tensor reduces in that type in an
+      implementation-chosen order, so they are not bit-defined by the reference either — labels are compared up to that noise;
+      (b) the flashinfer variable-block kernel (third-party, GPU-only), anchored on the reference's own test
+      (svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:38-133: dense attention under the repeat-interleaved block mask) and now also
+      on the reference's Triton kernel for the same operator.
 """
 from __future__ import annotations
 
@@ -489,7 +498,11 @@ def apply_qk_rope(q, k, a, b, len_text_prompt: int, kind: str):
 # reference's block forward (svg/models/wan/custom_models.py:44-108), which its Triton kernels replace.
 # =====================================================================================================================
 def fp32_layernorm(x: torch.Tensor, weight=None, bias=None, eps: float = 1e-5) -> torch.Tensor:
-    """ref: `self.norm1(hidden_states.float())` with diffusers FP32LayerNorm, custom_models.py:44-47 — fp32 in, fp32 out"""
+    """ref: `self.norm1(hidden_states.float())` with diffusers FP32LayerNorm, custom_models.py:44-47 — fp32 in, fp32 out.
+    NOT what the reference's Triton kernels compute when the hidden size is not a power of two: they load the row zero-padded to
+    N2 = next_power_of_2(N) and the padding enters the variance, var' = var + (N2 - N) / N * mean^2 (svg/kernels/triton/layernorm.py:35-41,
+    :134-140; shown by executing them, tests/test_triton_golden.py::test_glue_kernels).  The two agree when the row mean is 0 — the
+    reference's own test feeds randn — and differ by (N2 - N) / (2 N) * mean^2 / var relative otherwise (Wan 14B, N = 5120: 0.3 mean^2 / var)."""
     w = weight.float() if weight is not None else None
     b = bias.float() if bias is not None else None
     return F.layer_norm(x.float(), (x.shape[-1],), w, b, eps)

@@ -65,7 +65,9 @@ def _compile(src: Path, force: bool, asm: bool, ablations: bool = False, tag: st
     if ablations:
         flags.append("-DSVG_ABLATIONS")
     cmd = [HIPCC, *flags, "-c", str(src), "-o", str(obj)]
-    if asm or src.name in KEEP_ASM:
+    # (the kept listing is named after the source: only the PRODUCT build writes it — an ablation or tagged A/B build would overwrite
+    #  the file the audit tests read with the listing of a different binary)
+    if asm or (src.name in KEEP_ASM and not ablations and not tag):
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(OBJ))
     if r.returncode != 0:

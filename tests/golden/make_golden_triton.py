@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Kernel-level pin of the reference's Triton kernels: EXECUTES the reference's own `@triton.jit` sources with Triton's interpreter
+(TRITON_INTERPRET=1: the kernel body runs on the CPU, tl.* ops on numpy arrays) through the reference's own Python wrappers, and
+stores inputs + outputs as fixtures (tests/golden/triton_golden.npz, checked by tests/test_triton_golden.py against the oracle).
+
+What that pins that the loop-level fixtures (make_golden_kmeans.py: launches REPLACED by torch statements) could not:
+  * flash-kmeans assignment  `_euclid_assign_kernel`            svg/kmeans_utils.py:464-554   (chunked strict-'<' update, first-index
+        argmin inside a chunk, clamp at 0, masking of the ragged last chunk / tile, int64 output of the wrapper :562-627)
+  * flash-kmeans update      `_centroid_update_chunk_kernel`    svg/kmeans_utils.py:258-322 + host half :375-421
+  * the whole loop           `batch_kmeans_Euclid`              svg/kmeans_utils.py:685-733 on BOTH real kernels
+  * variable-block attention `_dynamic_block_sparse_fwd_kernel` svg/kmeans_utils.py:1001-1317 (the reference's Triton statement of the
+        SVG2 attention; the flashinfer kernel that replaces it in production is third-party and stays anchored on the reference's test)
+  * head placement           `*_sparse_head_placement_kernel`, `*_hidden_states_placement_kernel`  svg/models/{hyvideo,wan,cog}/placement.py
+  * token permutation        `_permute_kernel`, `_inverse_permute_kernel`   svg/kernels/triton/permute.py
+  * block glue               RMSNorm / LayerNorm / modulate kernels         svg/kernels/triton/{rmsnorm,layernorm,modulate}.py
+Limits, stated: the interpreter of the Triton in this image (3.6.0) mis-handles bfloat16 (numpy has no such type; a 16 x 16
+bf16 `tl.dot` returns garbage), so the fixtures are float32 and float16 — the dtype-independent structure of every kernel is pinned,
+the bf16 rounding points of the two k-means norms stay a restatement (svg_oracle.kmeans_xsq / kmeans_csq); `triton.autotune`
+needs a GPU to time its candidates, so the assign kernel is launched on its `.fn` with each tile configuration of the reference's
+list given explicitly (the result must not depend on it, and does not).  Atomic float adds are order-free only up to fp32
+rounding: update results are compared with a tolerance of one ulp of the stored dtype.
+
+    python tests/golden/make_golden_triton.py        (a few minutes: the interpreter runs program by program)"""
+import os
+import sys
+from pathlib import Path
+
+os.environ["TRITON_INTERPRET"] = "1"          # before triton is imported
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import make_golden as MG  # noqa: E402  (stubs for the third-party modules the reference imports)
+
+
+class ExplicitConfig:
+    """stand-in for a triton.autotune object: launches the jitted function underneath with ONE explicit configuration"""
+
+    def __init__(self, auto, **meta):
+        self.fn, self.meta = auto.fn, meta
+
+    def __getitem__(self, grid):
+        def launch(*args, **kw):
+            return self.fn[grid(self.meta) if callable(grid) else grid](*args, **kw, **self.meta)
+
+        return launch
+
+
+def clustered(B, N, D, modes, g, spread=0.3, scale=2.0):
+    centers = torch.randn(B, modes, D, generator=g) * scale
+    lab = torch.randint(0, modes, (B, N), generator=g)
+    return torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + spread * torch.randn(B, N, D, generator=g)
+
+
+def main():
+    MG.install_stubs()
+    sys.path.insert(0, MG.REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.is_cuda = property(lambda self: True)      # the wrappers assert .is_cuda
+    import svg.kmeans_utils as KU
+
+    out = {}
+    auto = KU._euclid_assign_kernel
+
+    # ---------------- 1. assignment kernel ----------------
+    cases = {
+        # tag: (dtype, B, N, D, K, [(BLOCK_N, BLOCK_K), ...])
+        "as_a": (torch.float32, 2, 333, 64, 37, [(32, 32), (64, 128), (128, 64)]),
+        "as_b": (torch.float32, 1, 300, 128, 100, [(64, 32), (128, 128)]),
+        "as_c": (torch.float16, 2, 333, 64, 37, [(32, 32), (128, 64)]),
+        "as_d": (torch.float16, 1, 300, 128, 70, [(64, 64)]),
+    }
+    for tag, (dt, B, N, D, K, cfgs) in cases.items():
+        g = torch.Generator().manual_seed(len(tag) + B * N)
+        x = clustered(B, N, D, 9, g).to(dt)
+        c = x[:, :K].clone()
+        # exact ties: duplicated centroids inside one chunk (first index wins) and across chunks (the earlier chunk wins: strict '<')
+        c[:, 5] = c[:, 2]
+        if K > 40:
+            c[:, 36] = c[:, 3]
+            c[:, K - 1] = c[:, 1]
+        x_sq = (x ** 2).sum(dim=-1)                      # ref: batch_kmeans_Euclid :704
+        res = []
+        for bn, bk in cfgs:
+            KU._euclid_assign_kernel = ExplicitConfig(auto, BLOCK_N=bn, BLOCK_K=bk)
+            ids = KU.euclid_assign_triton(x, c, x_sq)
+            assert ids.dtype == torch.int64 and ids.shape == (B, N)
+            res.append(ids)
+        agree = all(torch.equal(res[0], r) for r in res[1:])
+        print(f"{tag}: {dt} B={B} N={N} D={D} K={K}: {len(cfgs)} tile configurations agree: {agree}")
+        out[f"{tag}_x"], out[f"{tag}_c"], out[f"{tag}_ids"] = x.numpy(), c.numpy(), res[0].numpy().astype(np.int32)
+        out[f"{tag}_meta"] = np.array([{torch.float32: 2, torch.float16: 1}[dt], int(agree)], dtype=np.int64)
+    KU._euclid_assign_kernel = ExplicitConfig(auto, BLOCK_N=64, BLOCK_K=64)
+
+    # ---------------- 2. centroid update (sorted, chunked) ----------------
+    for tag, (dt, B, N, D, K, block_n) in {"up_a": (torch.float32, 2, 400, 64, 23, 256), "up_b": (torch.float16, 1, 500, 128, 40, 64)}.items():
+        g = torch.Generator().manual_seed(7 + N)
+        x = clustered(B, N, D, 7, g).to(dt)
+        ids = torch.randint(0, K, (B, N), generator=g)
+        ids[ids == 4] = 5                                   # cluster 4 is empty: keeps its old centroid (:416-418)
+        ids[:, :3] = K - 1
+        old = torch.randn(B, K, D, generator=g).to(dt)
+        cent, cnt = KU.triton_centroid_update_sorted_euclid(x, ids, old, BLOCK_N=block_n)
+        assert cent.dtype == dt and cnt.dtype == torch.int32
+        out[f"{tag}_x"], out[f"{tag}_ids"], out[f"{tag}_old"] = x.numpy(), ids.numpy().astype(np.int32), old.numpy()
+        out[f"{tag}_cent"], out[f"{tag}_cnt"] = cent.numpy(), cnt.numpy()
+        out[f"{tag}_meta"] = np.array([{torch.float32: 2, torch.float16: 1}[dt]], dtype=np.int64)
+        print(f"{tag}: update {dt} B={B} N={N} K={K}: empty clusters {int((cnt == 0).sum())}")
+
+    # ---------------- 3. the loop on both real kernels ----------------
+    KU._euclid_iter_compiled = KU._euclid_iter
+    for tag, (dt, B, N, D, K, iters) in {"lp_a": (torch.float16, 2, 400, 64, 10, 4), "lp_b": (torch.float32, 1, 300, 64, 8, 30)}.items():
+        g = torch.Generator().manual_seed(3 + N)
+        x = clustered(B, N, D, 6, g).to(dt)
+        init = x[:, :K].clone()
+        if tag == "lp_a":
+            init[:, -2:] = 20.0                             # far-away seeds stay empty (20^2 x 64 still fits fp16)
+        ids, cent, sizes, n_it = KU.batch_kmeans_Euclid(x, K, max_iters=iters, tol=1e-4, init_centroids=init.clone())
+        out[f"{tag}_x"], out[f"{tag}_init"] = x.numpy(), init.numpy()
+        out[f"{tag}_ids"], out[f"{tag}_cent"], out[f"{tag}_sizes"] = ids.numpy().astype(np.int32), cent.numpy(), sizes.numpy().astype(np.int32)
+        out[f"{tag}_meta"] = np.array([{torch.float32: 2, torch.float16: 1}[dt], K, iters, int(n_it)], dtype=np.int64)
+        print(f"{tag}: loop {dt}: {int(n_it)} iterations of at most {iters}, sizes {sizes[0].tolist()}")
+
+    # ---------------- 4. variable-block attention: the reference's Triton statement ----------------
+    for tag, (dt, H, D, qsz, ksz, seed) in {
+        "vb_a": (torch.float16, 2, 64, [70, 1, 129, 0, 56], [33, 64, 0, 100, 59], 11),      # ragged + EMPTY clusters on both sides
+        "vb_b": (torch.float32, 1, 32, [40, 88, 72], [128, 8, 64], 12),
+    }.items():
+        g = torch.Generator().manual_seed(seed)
+        S = sum(qsz)
+        assert S == sum(ksz)
+        q, k, v = (torch.randn(1, H, S, D, generator=g).to(dt) for _ in range(3))
+        qc = torch.tensor(qsz).expand(1, H, -1).contiguous()
+        kc = torch.tensor(ksz).expand(1, H, -1).contiguous()
+        dmap = torch.rand(1, H, len(qsz), len(ksz), generator=g) < 0.55
+        for h in range(H):                                 # every q block with rows sees at least one key block with rows
+            for i in range(len(qsz)):
+                if qsz[i] and not any(bool(dmap[0, h, i, j]) and ksz[j] for j in range(len(ksz))):
+                    dmap[0, h, i, max(range(len(ksz)), key=lambda j: ksz[j])] = True
+        o = KU.dynamic_block_sparse_fwd_triton(q, k, v, dmap, qc, kc)
+        o_torch = KU.dynamic_block_sparse_fwd_torch(q, k, v, dmap, qc, kc)      # the reference's own torch statement, same inputs
+        out[f"{tag}_q"], out[f"{tag}_k"], out[f"{tag}_v"] = q.numpy(), k.numpy(), v.numpy()
+        out[f"{tag}_map"], out[f"{tag}_qc"], out[f"{tag}_kc"] = dmap.numpy(), qc.numpy().astype(np.int32), kc.numpy().astype(np.int32)
+        out[f"{tag}_o"], out[f"{tag}_o_torch"] = o.numpy(), o_torch.numpy()
+        print(f"{tag}: varblock {dt} S={S}: triton vs the reference's torch statement max abs diff {float((o.float() - o_torch.float()).abs().max()):.2e}")
+
+    # ---------------- 5. head placement kernels (the reference ships a torch reference beside each: both are stored) ----------------
+    import svg.models.cog.placement as cog_pl
+    import svg.models.hyvideo.placement as hy_pl
+    import svg.models.wan.placement as wan_pl
+
+    for tag, (mod, fwd, inv, ctx, F_, P_) in {
+        "pl_hy": (hy_pl, "hunyuan_sparse_head_placement", "hunyuan_hidden_states_placement", 20, 5, 37),
+        "pl_wan": (wan_pl, "wan_sparse_head_placement", "wan_hidden_states_placement", 0, 4, 50),
+        "pl_cog": (cog_pl, "sparse_head_placement", "hidden_states_placement", 17, 3, 61),
+    }.items():
+        g = torch.Generator().manual_seed(len(tag))
+        cfg, H, D = 2, 3, 16
+        S = ctx + F_ * P_
+        q, k, v = (torch.randn(cfg, H, S, D, generator=g).to(torch.float16) for _ in range(3))
+        best = torch.randint(0, 2, (cfg, H), generator=g).to(torch.int32)
+        best[0, 0], best[0, 1] = 0, 1
+        qo, ko, vo = (torch.zeros_like(q) for _ in range(3))
+        getattr(mod, fwd)(q, k, v, qo, ko, vo, best, ctx, F_, P_)
+        back = torch.zeros_like(q)
+        getattr(mod, inv)(qo, back, best, ctx, F_, P_)
+        assert torch.equal(back, q)                                        # (the round trip is asserted here, not stored)
+        out[f"{tag}_q"], out[f"{tag}_best"], out[f"{tag}_qo"] = q.numpy(), best.numpy(), qo.numpy()
+        if tag == "pl_hy":                                                 # k and v go through the same index arithmetic: one model keeps them
+            out[f"{tag}_k"], out[f"{tag}_v"], out[f"{tag}_ko"], out[f"{tag}_vo"] = k.numpy(), v.numpy(), ko.numpy(), vo.numpy()
+        out[f"{tag}_geo"] = np.array([ctx, F_, P_], dtype=np.int64)
+        print(f"{tag}: placement S={S}: inverse(placement(q)) == q: {torch.equal(back, q)}")
+
+    # ---------------- 6. token permutation by labels ----------------
+    import svg.kernels.triton.permute as TP
+
+    g = torch.Generator().manual_seed(21)
+    B, H, S, D = 1, 3, 203, 32
+    x = torch.randn(B, H, S, D, generator=g).to(torch.float16)
+    labels = torch.randint(0, 9, (B, H, S), generator=g)
+    sidx = torch.stack([torch.argsort(labels[0, h], stable=True) for h in range(H)])[None]    # (torch.argsort without stable=True is
+    xp, sidx_out = TP.permute_tensor_by_labels_triton(x, None, 2, sorted_indices=sidx)         #  not reproducible: indices are passed in)
+    xb = TP.apply_inverse_permutation_triton(xp, sidx_out.reshape(B, H, S), 2)
+    assert torch.equal(xb, x)
+    out["pm_x"], out["pm_labels"], out["pm_sidx"], out["pm_xp"] = x.numpy(), labels.numpy().astype(np.int32), sidx.numpy().astype(np.int32), xp.numpy()
+    print(f"pm: permute S={S}: inverse(permute(x)) == x: {torch.equal(xb, x)}")
+
+    # ---------------- 7. block glue: RMSNorm, LayerNorm (with / without affine), modulate ----------------
+    from svg.kernels.triton.layernorm import triton_layernorm_forward
+    from svg.kernels.triton.modulate import triton_modulate_gate_residual_forward, triton_modulate_shift_forward
+    from svg.kernels.triton.rmsnorm import triton_rmsnorm_forward
+
+    g = torch.Generator().manual_seed(31)
+    M, N = 5, 1536                                         # Wan 1.3B hidden size: not a power of two (N2 = 2048, masked), BLOCK_M = 1
+    for dt, sfx in ((torch.float16, "h"), (torch.float32, "f")):
+        x = (torch.randn(1, M, N, generator=g) * 1.7 + 0.3).to(dt)
+        w, b = (torch.randn(N, generator=g) * 0.2 + 1).float(), (torch.randn(N, generator=g) * 0.1).float()
+        scale, shift, gate = (torch.randn(1, 1, N, generator=g) * 0.3).float(), torch.randn(1, 1, N, generator=g).float(), torch.randn(1, 1, N, generator=g).float()
+        ln_p = triton_layernorm_forward(x, w, b, 1e-6, True)
+        ln_n = triton_layernorm_forward(x, None, None, 1e-6, False)
+        ms = triton_modulate_shift_forward(ln_n, scale, shift, output_dtype=dt)
+        att = torch.randn(1, M, N, generator=g).to(dt)
+        gr = triton_modulate_gate_residual_forward(x, att, gate, output_dtype=dt)
+        rms = triton_rmsnorm_forward(x.reshape(M, N).contiguous(), w.to(dt), 1e-6)
+        rms_y = rms[0] if isinstance(rms, (tuple, list)) else rms
+        for name, t in (("x", x), ("w", w), ("b", b), ("scale", scale), ("shift", shift), ("gate", gate), ("att", att), ("ln_p", ln_p),
+                        ("ln_n", ln_n), ("ms", ms), ("gr", gr), ("rms", rms_y)):
+            out[f"gl_{sfx}_{name}"] = t.numpy()
+        print(f"gl_{sfx}: glue {dt} M={M} N={N}: layernorm out {ln_p.dtype}, modulate out {ms.dtype}, rmsnorm out {rms_y.dtype}")
+
+    p = HERE / "triton_golden.npz"
+    np.savez_compressed(p, **out)
+    print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,197 @@
+"""The oracle against the reference's own Triton kernels, EXECUTED here by Triton's interpreter (tests/golden/make_golden_triton.py
+imports /root/reference and runs its `@triton.jit` sources on the CPU; the fixtures travel, the reference does not).  This is the
+kernel-level pin the loop-level fixtures of tests/golden/make_golden_kmeans.py could not give: there the two k-means launches were
+replaced by torch statements, here they are the reference's code.
+
+float32: everything the oracle states must EQUAL the kernels' results (labels, sizes, iteration counts, copies), sums to fp32 rounding.
+float16: `tl.sum(c_tile * c_tile)` reduces IN the input dtype (triton/language/standard.py `_pick_sum_dtype`: only small integers are
+widened) and in an order the implementation chooses — the interpreter adds the rows of the [D, BLOCK_K] tile one after the other —,
+so the centroid norms carry about one percent of rounding noise that decides near-ties.  Given the norms as the interpreter computed
+them (restated below: a sequential fp16 sum) the oracle's assignment again EQUALS the kernel's, which pins everything else in the
+kernel: the fp32 cross term, the clamp, the strict-'<' chunk update, the first-index argmin, the masks.  With its own norms (fp32 sum
+of the rounded products — what csrc/kmeans.hip computes, the more accurate statement) the oracle may differ from the kernel only on
+points whose two candidate distances are closer than that noise.  bfloat16, the production dtype, cannot be run: the interpreter of
+this image's Triton mis-computes bf16 (see the generator); its rounding points stay a restatement — stated in oracle/svg_oracle.py."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+G = Path(__file__).resolve().parent / "golden" / "triton_golden.npz"
+
+
+@pytest.fixture(scope="module")
+def g():
+    assert G.exists(), "tests/golden/triton_golden.npz is committed (python tests/golden/make_golden_triton.py regenerates it)"
+    return np.load(G)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def csq_sequential(c: torch.Tensor) -> torch.Tensor:
+    """the interpreter's `tl.sum(c_tile * c_tile, axis=0)` for a 16-bit c: products rounded to the dtype, added row by row IN the dtype"""
+    if c.dtype == torch.float32:
+        return (c * c).sum(-1)      # (fp32: torch's blocked sum and a sequential one agree to a few ulp; ties are exact duplicates)
+    p = (c * c)
+    acc = torch.zeros(c.shape[:-1], dtype=c.dtype)
+    for d in range(c.shape[-1]):
+        acc = acc + p[..., d]
+    return acc.float()
+
+
+def assign_with_csq(x, c, csq):
+    cross = torch.einsum("bnd,bkd->bnk", x.float(), c.float())
+    return (O.kmeans_xsq(x)[:, :, None] + csq[:, None, :] - 2.0 * cross).clamp_min(0.0)
+
+
+@pytest.mark.parametrize("tag", ["as_a", "as_b", "as_c", "as_d"])
+def test_assign_kernel(g, tag):
+    """ref: _euclid_assign_kernel svg/kmeans_utils.py:464-554 through euclid_assign_triton :562-627, several tile configurations"""
+    x, c, ids = T(g[tag + "_x"]), T(g[tag + "_c"]), T(g[tag + "_ids"]).long()
+    assert int(g[tag + "_meta"][1]) == 1, "the reference's tile configurations disagreed among themselves"
+    # duplicated centroids: the LOWER index wins, inside a chunk and across chunks
+    assert not (ids == 5).any() and (ids == 2).any()
+    K = c.shape[1]
+    if K > 40:
+        assert not (ids == 36).any() and not (ids == K - 1).any()
+    if x.dtype == torch.float32:
+        assert torch.equal(O.kmeans_assign(x, O.kmeans_xsq(x), c), ids)
+        return
+    d_seq = assign_with_csq(x, c, csq_sequential(c))
+    assert torch.equal(d_seq.argmin(-1), ids), "with the kernel's own norms the assignment is the oracle's, label for label"
+    # the oracle's own statement (fp32 sum of the rounded products): different labels only inside the norms' rounding noise
+    d = O.kmeans_distances(x, O.kmeans_xsq(x), c)
+    mine = d.argmin(-1)
+    noise = (csq_sequential(c) - O.kmeans_csq(c)).abs().max().item()
+    bad = mine != ids
+    gap = (d.gather(2, ids[..., None]) - d.gather(2, mine[..., None]))[..., 0][bad]
+    assert bad.float().mean().item() < 0.2 and (gap.abs() <= 2 * noise + 1e-3).all(), (int(bad.sum()), float(gap.abs().max()), noise)
+
+
+@pytest.mark.parametrize("tag", ["up_a", "up_b"])
+def test_centroid_update_kernel(g, tag):
+    """ref: _centroid_update_chunk_kernel :258-322 + triton_centroid_update_sorted_euclid :375-421 (sort, fp32 atomics per run, clamp,
+    empty clusters keep the old centroid, cast)"""
+    x, ids, old = T(g[tag + "_x"]), T(g[tag + "_ids"]).long(), T(g[tag + "_old"])
+    ref, cnt = T(g[tag + "_cent"]), T(g[tag + "_cnt"])
+    cent, counts = O.kmeans_update(x, ids, old)
+    assert torch.equal(counts, cnt)
+    empty = cnt == 0
+    assert empty.any() and torch.equal(cent[empty], old[empty]) and torch.equal(ref[empty], old[empty])
+    if x.dtype == torch.float32:
+        torch.testing.assert_close(cent, ref, rtol=1e-6, atol=2e-6)      # the order of the atomic adds
+    else:
+        ulp = torch.finfo(x.dtype).eps * ref.float().abs().clamp_min(2.0 ** -14)
+        assert ((cent.float() - ref.float()).abs() <= ulp).all()
+        assert (cent == ref).float().mean().item() > 0.99
+
+
+def test_loop_on_the_real_kernels_fp32(g):
+    """ref: batch_kmeans_Euclid :685-733 with BOTH Triton kernels executed: labels, sizes and the iteration count are the oracle's"""
+    x, init, meta = T(g["lp_b_x"]), T(g["lp_b_init"]), g["lp_b_meta"]
+    lab, c, cnt, n = O.batch_kmeans_euclid(x, int(meta[1]), max_iters=int(meta[2]), tol=1e-4, init_centroids=init.clone())
+    assert n == int(meta[3]) and n < int(meta[2]), "converged before max_iters: the tol break is exercised"
+    assert torch.equal(lab, T(g["lp_b_ids"]).long()) and torch.equal(cnt, T(g["lp_b_sizes"]))
+    torch.testing.assert_close(c, T(g["lp_b_cent"]), rtol=1e-5, atol=1e-5)
+
+
+def test_loop_on_the_real_kernels_fp16(g):
+    """the same loop in fp16: iteration by iteration with the kernel's own norms (see the module docstring) the labels are the oracle's"""
+    x, init, meta = T(g["lp_a_x"]), T(g["lp_a_init"]), g["lp_a_meta"]
+    K, iters = int(meta[1]), int(meta[2])
+    c = init.clone()
+    for _ in range(iters):                     # ref loop :712-731; no early exit in this fixture (n_iters == max_iters)
+        lab = assign_with_csq(x, c, csq_sequential(c)).argmin(-1)
+        c_new, cnt = O.kmeans_update(x, lab, c)
+        c = c_new
+    assert int(meta[3]) == iters
+    assert torch.equal(cnt, T(g["lp_a_sizes"])) and (cnt[:, -2:] == 0).all(), "the far-away seeds stay empty"
+    assert torch.equal(lab, T(g["lp_a_ids"]).long())
+    ref = T(g["lp_a_cent"])
+    assert ((c.float() - ref.float()).abs() <= torch.finfo(torch.float16).eps * ref.float().abs().clamp_min(2.0 ** -14)).all()
+
+
+@pytest.mark.parametrize("tag", ["vb_a", "vb_b"])
+def test_variable_block_attention_triton_statement(g, tag):
+    """ref: _dynamic_block_sparse_fwd_kernel :1001-1203 through dynamic_block_sparse_fwd_triton :1205-1317 — the reference's own kernel
+    for the SVG2 attention (ragged and EMPTY clusters on both sides) against the oracle's dense-attention-under-the-block-mask"""
+    q, k, v = (T(g[f"{tag}_{n}"]) for n in "qkv")
+    dmap, qc, kc = T(g[tag + "_map"]), T(g[tag + "_qc"]).long(), T(g[tag + "_kc"]).long()
+    o, o_torch = T(g[tag + "_o"]), T(g[tag + "_o_torch"])
+    mine = O.dynamic_block_sparse_fwd(q.float(), k.float(), v.float(), dmap, qc, kc)
+    tol = dict(rtol=2e-3, atol=2e-3) if q.dtype == torch.float16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(mine, o.float(), **tol)
+    torch.testing.assert_close(mine, o_torch.float(), **tol)      # and the reference's torch statement (:902-995), same inputs
+    assert (qc == 0).any() == (tag == "vb_a")
+
+
+@pytest.mark.parametrize("tag,text_first", [("pl_hy", False), ("pl_wan", False), ("pl_cog", True)])
+def test_placement_kernels(g, tag, text_first):
+    """ref: {hunyuan,wan,}_sparse_head_placement_kernel svg/models/{hyvideo,wan,cog}/placement.py:34-153 — byte moves: bit-exact"""
+    ctx, F_, P_ = (int(x) for x in g[tag + "_geo"])
+    best = T(g[tag + "_best"])
+    for n in ("q", "k", "v") if tag == "pl_hy" else ("q",):
+        x, ref = T(g[f"{tag}_{n}"]), T(g[f"{tag}_{n}o"])
+        got = O.head_placement(x, best, ctx, F_, P_, text_first=text_first)
+        assert torch.equal(got, ref)
+        assert torch.equal(O.head_placement(got, best, ctx, F_, P_, text_first=text_first, inverse=True), x)
+    assert (best == 0).any() and (best == 1).any()
+
+
+def test_permute_kernels(g):
+    """ref: _permute_kernel / _inverse_permute_kernel svg/kernels/triton/permute.py:12-77 with the stable order passed in"""
+    x, labels, sidx, xp = T(g["pm_x"]), T(g["pm_labels"]).long(), T(g["pm_sidx"]), T(g["pm_xp"])
+    B, H, S, D = x.shape
+    mine, idx = O.permute_by_labels(x, labels.reshape(B * H, S))
+    assert torch.equal(idx.reshape(B, H, S), sidx) and torch.equal(mine, xp)
+    assert torch.equal(O.inverse_permutation(xp, idx.reshape(B, H, S)), x)
+
+
+@pytest.mark.parametrize("sfx", ["h", "f"])
+def test_glue_kernels(g, sfx):
+    """ref: svg/kernels/triton/{layernorm,modulate,rmsnorm}.py as the Wan block calls them (custom_models.py:36-108): fp32 statistics and
+    arithmetic, ONE rounding to the output dtype"""
+    t = {n: T(g[f"gl_{sfx}_{n}"]) for n in ("x", "w", "b", "scale", "shift", "gate", "att", "ln_p", "ln_n", "ms", "gr", "rms")}
+    x = t["x"]
+    dt = x.dtype
+    assert t["ln_p"].dtype == torch.float32 and t["ms"].dtype == dt and t["gr"].dtype == dt
+    # LayerNorm.  A quirk of the reference's kernels, found by running them: the row is loaded padded to the next power of two with
+    # zeros (`other=0.0`, layernorm.py:35 / :134) and the padding takes part in the VARIANCE — (0 - mean)^2 for N2 - N columns — so
+    # for a hidden size that is not a power of two (Wan: 1536 -> 2048, 5120 -> 8192) the kernels compute
+    #     var' = var + (N2 - N) / N * mean^2
+    # instead of the variance of diffusers' FP32LayerNorm, the branch they replace (custom_models.py:44-47).  The oracle and
+    # csrc/glue.hip state FP32LayerNorm (the specification; the two agree whenever the row mean is 0).  Here the kernels are pinned
+    # WITH their quirk restated — everything else in them is then the oracle's arithmetic — and the size of the deviation is shown.
+    N = x.shape[-1]
+    N2 = 1 << (N - 1).bit_length()
+    assert N2 > N
+    xf = x.float()
+    mean = xf.mean(-1, keepdim=True)
+    var = (xf - mean).pow(2).mean(-1, keepdim=True)
+    for w, b, ref in ((t["w"], t["b"], t["ln_p"]), (None, None, t["ln_n"])):
+        quirk = (xf - mean) * torch.rsqrt(var + (N2 - N) / N * mean * mean + 1e-6)
+        if w is not None:
+            quirk = quirk * w + b
+        torch.testing.assert_close(quirk, ref, rtol=2e-5, atol=2e-5)
+        spec = O.fp32_layernorm(x, w, b, 1e-6)
+        dev = (spec - ref).abs().max().item()
+        expect = (N2 - N) / N * (mean * mean / var).max().item() / 2      # first order: relative change of rstd = var' / var / 2
+        assert 1e-3 < dev < 10 * expect * spec.abs().max().item(), (dev, expect)
+    # modulate on the KERNEL's layernorm output, so that only the op under test differs: one rounding, at most 1 ulp from fma contraction
+    ms = O.modulate_shift(t["ln_n"], t["scale"], t["shift"], dt)
+    gr = O.modulate_gate_residual(x, t["att"], t["gate"], dt)
+    for mine, ref in ((ms, t["ms"]), (gr, t["gr"])):
+        ulp = torch.finfo(dt).eps * ref.float().abs().clamp_min(1e-3)
+        assert ((mine.float() - ref.float()).abs() <= ulp).all()
+        assert (mine == ref).float().mean().item() > 0.99
+    # RMSNorm kernel (rmsnorm.py:8-48: fp32 normalise AND weight multiply, one rounding at the end — unlike diffusers' RMSNorm, which
+    # rounds before the weight; O.rms_norm states the latter, the QK-norm of the prologue, so the Triton form is restated here)
+    xf = x.float().reshape(-1, x.shape[-1])
+    mine = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * t["w"].to(dt).float()).to(dt)
+    ulp = torch.finfo(dt).eps * t["rms"].float().abs().clamp_min(1e-3)
+    assert ((mine.float() - t["rms"].float()).abs() <= (1 if dt == torch.float16 else 8) * ulp).all()   # (fp32: 1 / sqrt vs rsqrt, sum order)
