@@ -341,6 +341,17 @@ int svg_modulate_gate_residual_forward(const void* residual, const void* x, cons
 int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, const void* bias, const float* scale,
                                    const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
                                    int32_t y_dtype, int32_t w_dtype, float eps, void* stream);
+/* The same two with `reference_padding`.  0: as above — diffusers' FP32LayerNorm, the branch the reference's kernels replace
+ * (svg/models/wan/custom_models.py:44-47).  != 0: the variance of the reference's Triton kernels AS THEY ARE: they load a row
+ * zero-padded to N2 = next_power_of_2(N) and the padding takes part in the variance, var' = var + (N2 - N) / N * mean^2
+ * (svg/kernels/triton/layernorm.py:35-41, :134-140; found by executing the kernels with Triton's interpreter,
+ * tests/test_triton_golden.py).  For a maintainer who needs the reference's ENABLE_FAST_KERNEL numbers rather than LayerNorm's;
+ * no difference when N is a power of two or the row mean is 0. */
+int svg_layernorm_forward_ex(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N, int32_t x_dtype,
+                             int32_t y_dtype, int32_t w_dtype, float eps, int32_t reference_padding, void* stream);
+int svg_layernorm_modulate_forward_ex(const void* x, void* y, const void* weight, const void* bias, const float* scale,
+                                      const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
+                                      int32_t y_dtype, int32_t w_dtype, float eps, int32_t reference_padding, void* stream);
 
 /* Device-side dense / sparse switch.  The reference decides per layer on the host,
  * `timestep[0] > first_times_fp` (svg/models/hyvideo/attention.py:491-496), which reads the GPU tensor back in every layer-call.

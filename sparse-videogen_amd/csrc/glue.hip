@@ -22,6 +22,8 @@ struct GlueParams {
     int x_dt, r_dt, y_dt, w_dt;
     float eps;
     int do_ln;
+    float pad_cols;      // 0: LayerNorm.  > 0: the reference's Triton kernels' variance, which counts the zero padding of the row up to
+                         // the next power of two — (0 - mean)^2 for N2 - N columns (svg/kernels/triton/layernorm.py:35-41): opt-in
 };
 
 __device__ __forceinline__ void load8(const void* base, size_t elem, int dt, float (&v)[8]) {
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
                 for (int j = 0; j < 8; ++j) vs += (x[i][j] - mean) * (x[i][j] - mean);
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(vs) / (float)p.N + p.eps);
+        // (pad_cols == 0: + 0 * mean^2 is exact, the result is bit for bit what it was without the term)
+        const float rstd = 1.0f / sqrtf((wave_sum(vs) + p.pad_cols * (mean * mean)) / (float)p.N + p.eps);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 64 * i;
@@ -161,14 +164,29 @@ static int launch_row_glue(const GlueParams& p, hipStream_t st) {
 
 using namespace svg;
 
-extern "C" int svg_layernorm_forward(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N,
-                                     int32_t x_dtype, int32_t y_dtype, int32_t w_dtype, float eps, void* stream) {
+// columns the reference's Triton kernels pad a row of N with: next_power_of_2(N) - N (layernorm.py:76)
+static float reference_pad_cols(int N, int reference_padding) {
+    if (!reference_padding || N <= 0) return 0.f;
+    int n2 = 1;
+    while (n2 < N) n2 <<= 1;
+    return (float)(n2 - N);
+}
+
+extern "C" int svg_layernorm_forward_ex(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N,
+                                        int32_t x_dtype, int32_t y_dtype, int32_t w_dtype, float eps, int32_t reference_padding,
+                                        void* stream) {
     if (!x || !y || (weight == nullptr) != (bias == nullptr) || M <= 0 || M > 0x7fffffff) return SVG_ERR_BAD_ARG;
     if (weight && !dt_ok(w_dtype)) return SVG_ERR_UNSUPPORTED;
     GlueParams p{};
     p.x = x, p.y = y, p.w = weight, p.b = bias, p.M = (int)M, p.N = N, p.rows_per_batch = (int)M;
     p.x_dt = x_dtype, p.y_dt = y_dtype, p.w_dt = w_dtype, p.eps = eps, p.do_ln = 1;
+    p.pad_cols = reference_pad_cols(N, reference_padding);
     return launch_row_glue(p, (hipStream_t)stream);
+}
+
+extern "C" int svg_layernorm_forward(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N,
+                                     int32_t x_dtype, int32_t y_dtype, int32_t w_dtype, float eps, void* stream) {
+    return svg_layernorm_forward_ex(x, y, weight, bias, M, N, x_dtype, y_dtype, w_dtype, eps, 0, stream);
 }
 
 extern "C" int svg_modulate_shift_forward(const void* x, void* y, const float* scale, const float* shift, int64_t M, int32_t N,
@@ -180,16 +198,24 @@ extern "C" int svg_modulate_shift_forward(const void* x, void* y, const float* s
     return launch_row_glue(p, (hipStream_t)stream);
 }
 
-extern "C" int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, const void* bias, const float* scale,
-                                              const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
-                                              int32_t y_dtype, int32_t w_dtype, float eps, void* stream) {
+extern "C" int svg_layernorm_modulate_forward_ex(const void* x, void* y, const void* weight, const void* bias, const float* scale,
+                                                 const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
+                                                 int32_t y_dtype, int32_t w_dtype, float eps, int32_t reference_padding, void* stream) {
     if (!x || !y || (weight == nullptr) != (bias == nullptr) || (scale == nullptr) != (shift == nullptr)) return SVG_ERR_BAD_ARG;
     if (M <= 0 || M > 0x7fffffff || rows_per_batch <= 0 || M % rows_per_batch != 0) return SVG_ERR_BAD_ARG;
     if (weight && !dt_ok(w_dtype)) return SVG_ERR_UNSUPPORTED;
     GlueParams p{};
     p.x = x, p.y = y, p.w = weight, p.b = bias, p.scale = scale, p.shift = shift, p.M = (int)M, p.N = N;
     p.rows_per_batch = (int)rows_per_batch, p.x_dt = x_dtype, p.y_dt = y_dtype, p.w_dt = w_dtype, p.eps = eps, p.do_ln = 1;
+    p.pad_cols = reference_pad_cols(N, reference_padding);
     return launch_row_glue(p, (hipStream_t)stream);
+}
+
+extern "C" int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, const void* bias, const float* scale,
+                                              const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
+                                              int32_t y_dtype, int32_t w_dtype, float eps, void* stream) {
+    return svg_layernorm_modulate_forward_ex(x, y, weight, bias, scale, shift, M, N, rows_per_batch, x_dtype, y_dtype, w_dtype, eps, 0,
+                                             stream);
 }
 
 extern "C" int svg_modulate_gate_residual_forward(const void* residual, const void* x, const float* gate, void* y, int64_t M,

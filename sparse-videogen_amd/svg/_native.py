@@ -89,10 +89,13 @@ SIGNATURES = {
     "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_bsr_to_block_map": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
     "svg_layernorm_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "svg_layernorm_forward_ex": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _I32, _VP]),
     "svg_modulate_shift_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _VP]),
     "svg_modulate_gate_residual_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32, _VP]),
     "svg_layernorm_modulate_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32,
                                                  C.c_float, _VP]),
+    "svg_layernorm_modulate_forward_ex": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32,
+                                                    C.c_float, _I32, _VP]),
     "svg_qk_norm_rope_transpose": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                              C.c_float, _I32, _VP, _VP, _I32, _I32, _VP]),
     "svg_qk_norm_rope": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, C.c_float, _I32, _VP,
@@ -802,7 +805,9 @@ def _per_batch(t: torch.Tensor, x: torch.Tensor, N: int) -> torch.Tensor:
     return t.contiguous()
 
 
-def layernorm_forward(x, weight=None, bias=None, eps: float = 1e-5, out_dtype=torch.float32) -> torch.Tensor:
+def layernorm_forward(x, weight=None, bias=None, eps: float = 1e-5, out_dtype=torch.float32, reference_padding: bool = False) -> torch.Tensor:
+    """fp32 LayerNorm of the rows of x.  reference_padding: the variance of the reference's Triton kernels as they are — the zero
+    padding of a row up to the next power of two counted in (svg_layernorm_forward_ex; include/svg_attn.h) — instead of LayerNorm's."""
     lib = load()
     _dev(x, weight, bias)
     M, N, _ = _rows(x)
@@ -810,8 +815,9 @@ def layernorm_forward(x, weight=None, bias=None, eps: float = 1e-5, out_dtype=to
     wdt = _GLUE_DT[weight.dtype] if weight is not None else 2
     if weight is not None:
         assert bias is not None and weight.shape == (N,) and bias.shape == (N,) and bias.dtype == weight.dtype
-    _check(lib.svg_layernorm_forward(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), M, N, _GLUE_DT[x.dtype],
-                                     _GLUE_DT[out_dtype], wdt, float(eps), _stream()), "svg_layernorm_forward")
+    _check(lib.svg_layernorm_forward_ex(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), M, N, _GLUE_DT[x.dtype],
+                                        _GLUE_DT[out_dtype], wdt, float(eps), int(bool(reference_padding)), _stream()),
+           "svg_layernorm_forward_ex")
     return y
 
 
@@ -842,8 +848,10 @@ def modulate_gate_residual_forward(residual, x, gate, out_dtype=torch.float32) -
     return y
 
 
-def layernorm_modulate_forward(x, weight=None, bias=None, scale=None, shift=None, eps: float = 1e-5, out_dtype=None) -> torch.Tensor:
-    """Fused fp32 LayerNorm (+ affine) (+ y * (1 + scale) + shift), one pass; out_dtype defaults to x.dtype."""
+def layernorm_modulate_forward(x, weight=None, bias=None, scale=None, shift=None, eps: float = 1e-5, out_dtype=None,
+                               reference_padding: bool = False) -> torch.Tensor:
+    """Fused fp32 LayerNorm (+ affine) (+ y * (1 + scale) + shift), one pass; out_dtype defaults to x.dtype.
+    reference_padding: see layernorm_forward."""
     lib = load()
     _dev(x, weight, bias)
     M, N, rpb = _rows(x)
@@ -853,9 +861,10 @@ def layernorm_modulate_forward(x, weight=None, bias=None, scale=None, shift=None
     _dev(sc, sh)
     wdt = _GLUE_DT[weight.dtype] if weight is not None else 2
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    _check(lib.svg_layernorm_modulate_forward(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), _ptr(sc), _ptr(sh), M, N, rpb,
-                                              _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], wdt, float(eps), _stream()),
-           "svg_layernorm_modulate_forward")
+    _check(lib.svg_layernorm_modulate_forward_ex(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), _ptr(sc), _ptr(sh), M, N, rpb,
+                                                 _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], wdt, float(eps), int(bool(reference_padding)),
+                                                 _stream()),
+           "svg_layernorm_modulate_forward_ex")
     return y
 
 

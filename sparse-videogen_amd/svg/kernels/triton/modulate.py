@@ -20,4 +20,6 @@ def triton_modulate_gate_residual_forward(residual, x, gate, output_dtype=torch.
 def layernorm_modulate_forward(x, w, b, eps, scale=None, shift=None, output_dtype=None):
     """fp32 LayerNorm + modulate in one pass (replaces triton_layernorm_forward + triton_modulate_shift_forward,
     svg/models/wan/custom_models.py:37-60)"""
-    return _native.layernorm_modulate_forward(x.contiguous(), w, b, scale, shift, eps, output_dtype)
+    from . import layernorm as _ln   # (its REFERENCE_PADDING switch applies to the fused form too)
+
+    return _native.layernorm_modulate_forward(x.contiguous(), w, b, scale, shift, eps, output_dtype, reference_padding=_ln.REFERENCE_PADDING)

@@ -28,7 +28,10 @@ def wan_block_forward(self, hidden_states, encoder_hidden_states, temb, rotary_e
         affine = getattr(norm, "elementwise_affine", getattr(norm, "weight", None) is not None)
         w, b = (norm.weight, norm.bias) if affine else (None, None)
         if fast:
-            return _native.layernorm_modulate_forward(x, w, b, scale, shift, norm.eps, hidden_states.dtype)
+            from ...kernels.triton import layernorm as _ln   # (REFERENCE_PADDING: the reference's fast-path variance, opt-in)
+
+            return _native.layernorm_modulate_forward(x, w, b, scale, shift, norm.eps, hidden_states.dtype,
+                                                      reference_padding=_ln.REFERENCE_PADDING)
         y = norm(x.float())
         return (y * (1 + scale) + shift).type_as(hidden_states) if scale is not None else y.type_as(hidden_states)
 

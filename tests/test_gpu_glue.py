@@ -153,3 +153,43 @@ def test_full_size_wan_block_glue(nat):
     rows = torch.tensor([0, 1, 4097, 75599])
     ref = O.modulate_shift(O.fp32_layernorm(x[:, rows].cpu(), None, None, 1e-6), sc.cpu(), sh.cpu(), torch.bfloat16)
     assert (y[:, rows].cpu() != ref).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("sfx", ["h", "f"])
+def test_layernorm_reference_padding_equals_the_references_triton_kernels(nat, sfx):
+    """reference_padding=True against fixtures PRODUCED BY the reference's own Triton kernels (executed with Triton's interpreter,
+    tests/golden/make_golden_triton.py; N = 1536 -> N2 = 2048): the HIP kernel reproduces layernorm.py:13-62 / :113-156 as they are,
+    padding quirk included; reference_padding=False stays FP32LayerNorm — the two differ by what tests/test_triton_golden.py shows."""
+    import numpy as np
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+    x = torch.from_numpy(g[f"gl_{sfx}_x"]).cuda()
+    w, b = torch.from_numpy(g[f"gl_{sfx}_w"]).cuda(), torch.from_numpy(g[f"gl_{sfx}_b"]).cuda()
+    ln_p, ln_n = torch.from_numpy(g[f"gl_{sfx}_ln_p"]), torch.from_numpy(g[f"gl_{sfx}_ln_n"])
+    for (ww, bb), ref in (((w, b), ln_p), ((None, None), ln_n)):
+        quirk = nat.layernorm_forward(x, ww, bb, 1e-6, torch.float32, reference_padding=True).cpu()
+        spec = nat.layernorm_forward(x, ww, bb, 1e-6, torch.float32).cpu()
+        torch.testing.assert_close(quirk, ref, atol=2e-5, rtol=2e-5)
+        torch.testing.assert_close(spec, O.fp32_layernorm(x.cpu(), None if ww is None else ww.cpu(), None if bb is None else bb.cpu(), 1e-6),
+                                   atol=2e-5, rtol=2e-5)
+        assert (spec - ref).abs().max().item() > 1e-3
+    # the fused form honours the switch too, and the module-level switch of the reference-named shim reaches it
+    sc, sh = torch.from_numpy(g[f"gl_{sfx}_scale"]).cuda(), torch.from_numpy(g[f"gl_{sfx}_shift"]).cuda()
+    ms = torch.from_numpy(g[f"gl_{sfx}_ms"])
+    fused = nat.layernorm_modulate_forward(x, None, None, sc, sh, 1e-6, x.dtype, reference_padding=True).cpu()
+    if x.dtype == torch.float32:
+        torch.testing.assert_close(fused, ms, atol=5e-5, rtol=5e-5)          # reduction order of the statistics
+    else:
+        ulp = torch.finfo(x.dtype).eps * ms.float().abs().clamp_min(1e-2)
+        assert ((fused.float() - ms.float()).abs() <= 2 * ulp).all()
+    import svg.kernels.triton.layernorm as LN
+
+    try:
+        LN.REFERENCE_PADDING = True
+        torch.testing.assert_close(LN.triton_layernorm_forward(x, w, b, 1e-6, True).cpu(), ln_p, atol=2e-5, rtol=2e-5)
+    finally:
+        LN.REFERENCE_PADDING = False
+    # a power-of-two row: the switch changes nothing, bit for bit
+    x2 = torch.randn(3, 7, 2048, device="cuda").to(x.dtype) + 0.4
+    assert torch.equal(nat.layernorm_forward(x2, None, None, 1e-6, torch.float32, reference_padding=True),
+                       nat.layernorm_forward(x2, None, None, 1e-6, torch.float32))
