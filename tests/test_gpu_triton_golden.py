@@ -1,0 +1,124 @@
+"""The HIP kernels against fixtures PRODUCED BY THE REFERENCE'S OWN TRITON KERNELS (tests/golden/triton_golden.npz: the reference's
+`@triton.jit` sources executed with Triton's interpreter through the reference's wrappers, tests/golden/make_golden_triton.py).
+tests/test_triton_golden.py checks the oracle against the same fixtures on the CPU; here the product path is compared with them
+directly, through the C ABI — no oracle in between except where a tolerance has to be derived."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden" / "triton_golden.npz"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "sparse-videogen_amd"))
+    from svg import _native
+    _native.load()
+    return _native
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(G)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("tag,text_first", [("pl_hy", False), ("pl_wan", False), ("pl_cog", True)])
+def test_head_placement_equals_the_references_triton_kernels(nat, g, tag, text_first):
+    """svg_head_placement == {hunyuan,wan,}_sparse_head_placement_kernel / *_hidden_states_placement_kernel, bit for bit"""
+    ctx, F_, P_ = (int(x) for x in g[tag + "_geo"])
+    best = T(g[tag + "_best"]).cuda()
+    names = ("q", "k", "v") if tag == "pl_hy" else ("q",)
+    srcs = [T(g[f"{tag}_{n}"]).cuda() for n in names]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    nat.head_placement(srcs, dsts, best, ctx, F_, P_, text_first, False)
+    for n, d in zip(names, dsts):
+        assert torch.equal(d.cpu(), T(g[f"{tag}_{n}o"]))
+    back = [torch.zeros_like(s) for s in srcs]
+    nat.head_placement(dsts, back, best, ctx, F_, P_, text_first, True)
+    for s, b in zip(srcs, back):
+        assert torch.equal(s, b)
+
+
+def test_permutation_equals_the_references_triton_kernels(nat, g):
+    """svg_argsort_labels (stable) + svg_permute_rows / svg_inverse_permute_rows == _permute_kernel / _inverse_permute_kernel"""
+    x, labels, sidx, xp = T(g["pm_x"]), T(g["pm_labels"]), T(g["pm_sidx"]), T(g["pm_xp"])
+    B, H, S, D = x.shape
+    idx, counts = nat.argsort_labels(labels.reshape(B * H, S).cuda().contiguous(), 9)
+    assert torch.equal(idx.cpu().reshape(B, H, S), sidx)
+    assert torch.equal(counts.cpu().long(), torch.stack([torch.bincount(l, minlength=9) for l in labels.reshape(B * H, S).long()]))
+    y = nat.permute_rows(x.reshape(B * H, S, D).cuda().contiguous(), idx)
+    assert torch.equal(y.cpu().reshape(B, H, S, D), xp)
+    assert torch.equal(nat.permute_rows(y, idx, inverse=True).cpu().reshape(B, H, S, D), x)
+
+
+@pytest.mark.parametrize("sfx", ["h", "f"])
+def test_modulate_equals_the_references_triton_kernels(nat, g, sfx):
+    """svg_modulate_shift_forward / svg_modulate_gate_residual_forward == _modulate_shift_fwd_fused / _modulate_gate_residual_fwd_fused
+    (fp32 arithmetic, one rounding: at most one ulp of the output type apart — contraction of the multiply-add)"""
+    t = {n: T(g[f"gl_{sfx}_{n}"]) for n in ("x", "scale", "shift", "gate", "att", "ln_n", "ms", "gr")}
+    dt = t["x"].dtype
+    ms = nat.modulate_shift_forward(t["ln_n"].cuda(), t["scale"].cuda(), t["shift"].cuda(), dt).cpu()
+    gr = nat.modulate_gate_residual_forward(t["x"].cuda(), t["att"].cuda(), t["gate"].cuda(), dt).cpu()
+    for mine, ref in ((ms, t["ms"]), (gr, t["gr"])):
+        ulp = torch.finfo(dt).eps * ref.float().abs().clamp_min(1e-3)
+        assert ((mine.float() - ref.float()).abs() <= ulp).all()
+        assert (mine == ref).float().mean().item() > 0.99
+
+
+def test_variable_block_attention_equals_the_references_triton_kernel(nat, g):
+    """svg_varblock_attention == _dynamic_block_sparse_fwd_kernel (fp16, head_dim 64, ragged clusters, EMPTY clusters on both sides)"""
+    q, k, v, o = (T(g[f"vb_a_{n}"])[0] for n in ("q", "k", "v", "o"))       # [H, S, D]
+    dmap, qc, kc = T(g["vb_a_map"])[0], T(g["vb_a_qc"])[0], T(g["vb_a_kc"])[0]
+    assert (qc == 0).any() and (kc == 0).any()
+    for variant in (-1, 0, 1, 3):
+        got = nat.varblock_attention(q.cuda(), k.cuda(), v.cuda(), dmap.cuda(), qc.cuda().contiguous(), kc.cuda().contiguous(),
+                                     variant=variant).cpu()
+        torch.testing.assert_close(got.float(), o.float(), atol=2e-3, rtol=2e-3)
+        e = ((got.float() - o.float()).norm() / o.float().norm()).item()
+        assert e < 1e-3, (variant, e)      # (two fp16 kernels with different summation orders)
+
+
+@pytest.mark.parametrize("tag", ["as_c", "as_d"])
+def test_kmeans_assignment_against_the_references_triton_kernel(nat, g, tag):
+    """svg_kmeans_iter's labels vs _euclid_assign_kernel in fp16.  The Triton kernel reduces the centroid norms IN fp16
+    (tests/test_triton_golden.py), the HIP kernel in fp32: the labels must agree except on points whose two candidate distances are
+    closer than that rounding noise — and must agree EXACTLY with the oracle's fp32-norm statement wherever the gap is not a tie."""
+    x, c, ids = T(g[tag + "_x"]), T(g[tag + "_c"]), T(g[tag + "_ids"]).long()
+    B, N, D = x.shape
+    K = c.shape[1]
+    buf = nat.KmeansBuffers(B, N, K, D, "cuda")
+    c_out = torch.empty_like(c).cuda()
+    nat.kmeans_iter(x.cuda(), None, c.cuda(), c_out, buf)
+    lab = buf.labels.cpu().long()
+    d = O.kmeans_distances(x, O.kmeans_xsq(x), c)
+    mine = d.argmin(-1)
+    # vs the oracle (same norms): equal unless the two distances are within fp32 rounding of each other
+    dif = lab != mine
+    assert ((d.gather(2, lab[..., None]) - d.gather(2, mine[..., None]))[..., 0][dif].abs() <= 1e-3 * d.abs().max()).all()
+    assert dif.float().mean().item() < 0.01
+    # duplicated centroids: the lower index wins
+    assert not (lab == 5).any()
+    # vs the reference's kernel: inside the fp16 noise of ITS norms
+    p = c * c
+    acc = torch.zeros(c.shape[:-1], dtype=c.dtype)
+    for j in range(D):
+        acc = acc + p[..., j]
+    noise = (acc.float() - O.kmeans_csq(c)).abs().max().item()
+    bad = lab != ids
+    gap = (d.gather(2, ids[..., None]) - d.gather(2, lab[..., None]))[..., 0][bad]
+    assert bad.float().mean().item() < 0.2 and (gap.abs() <= 2 * noise + 1e-3).all(), (int(bad.sum()), float(gap.abs().max()), noise)
+    # and the update half on the kernel's own labels: the new centroids are the fp32 means of the assigned points, cast
+    cent, cnt = O.kmeans_update(x, lab, c)
+    assert torch.equal(buf.counts.cpu(), cnt)
+    ulp = torch.finfo(x.dtype).eps * cent.float().abs().clamp_min(2.0 ** -14)
+    assert ((c_out.cpu().float() - cent.float()).abs() <= ulp).all()
