@@ -210,6 +210,67 @@ def main():
             out[f"gl_{sfx}_{name}"] = t.numpy()
         print(f"gl_{sfx}: glue {dt} M={M} N={N}: layernorm out {ln_p.dtype}, modulate out {ms.dtype}, rmsnorm out {rms_y.dtype}")
 
+    # ---------------- 8. SVG2 layer-call of the reference's PROCESSORS on the reference's kernels ----------------
+    # attention_core_logic of Hunyuan_SAPAttn_Processor2_0 (hyvideo/attention.py:715-804) and WanAttn_SAPAttn_Processor (wan/attention.py:500-556)
+    # as they are: k-means (both Triton kernels) from given centroids, identify_dynamic_map, Triton permutation, the prompt / unused-prompt
+    # post-processing (Hunyuan), inverse permutation.  The only substitution: `dynamic_block_sparse_fwd_flashinfer` (third-party, GPU-only) ->
+    # the reference's own Triton kernel for the same operator, `dynamic_block_sparse_fwd_triton`.
+    import json
+    import tempfile
+
+    MG._stub("diffusers.models.normalization", RMSNorm=type("RMSNorm", (), {}))     # (wan/attention.py:11 imports it; unused on this path)
+    import svg.models.hyvideo.attention as hy_attn
+    import svg.models.wan.attention as wan_attn
+
+    def own_triton(q, k, v, m, qc, kc, is_cpu=False):
+        return KU.dynamic_block_sparse_fwd_triton(q.contiguous(), k.contiguous(), v.contiguous(), m, qc, kc)
+
+    hy_attn.dynamic_block_sparse_fwd_flashinfer = own_triton
+    wan_attn.dynamic_block_sparse_fwd_flashinfer = own_triton
+    for tag, (model, H, D, F_, P_, ctx, L, QC, KC) in {"sap_hy": ("hy", 2, 64, 4, 48, 32, 20, 6, 8), "sap_wan": ("wan", 2, 64, 3, 64, 0, 0, 5, 7)}.items():
+        g = torch.Generator().manual_seed(41 + QC)
+        V, S = F_ * P_, F_ * P_ + ctx
+        # well-separated modes, one warm-start centroid inside every mode: no point sits near a decision boundary, so the labels do not
+        # depend on how the centroid norms are rounded (the fp16 reduction of the Triton kernel vs an fp32 one) and the layer-call is
+        # comparable across implementations; mode sizes are ragged
+        def modes(n_modes):
+            centers = torch.randn(H, n_modes, D, generator=g) * 0.9
+            lab = torch.randint(0, n_modes, (H, S), generator=g)
+            lab[:, :n_modes] = torch.arange(n_modes)                                 # every mode has at least its seed point
+            x = torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + 0.15 * torch.randn(H, S, D, generator=g)
+            return x.to(torch.float16)[None]
+
+        q, k = modes(QC), modes(KC)
+        v = torch.randn(1, H, S, D, generator=g).to(torch.float16)
+        init_q, init_k = q[0, :, :QC].clone(), k[0, :, :KC].clone()                 # [H, QC, D] warm-start centroids: the seed points
+        log = tempfile.NamedTemporaryFile("w", suffix=".jsonl", delete=False)
+        log.close()
+        if model == "hy":
+            proc = hy_attn.Hunyuan_SAPAttn_Processor2_0(0)
+            proc.centroids_init, proc.q_centroids, proc.k_centroids = {0: True}, {0: init_q.clone()}, {0: init_k.clone()}
+            proc.prompt_length = L
+        else:
+            proc = wan_attn.WanAttn_SAPAttn_Processor(0)
+            proc.centroids_init, proc.q_centroids, proc.k_centroids = True, init_q.clone(), init_k.clone()
+        proc.context_length, proc.num_frame, proc.frame_size = ctx, F_, P_
+        proc.num_q_centroids, proc.num_k_centroids, proc.top_p_kmeans, proc.min_kc_ratio = QC, KC, 0.8, 0.1
+        proc.kmeans_iter_init, proc.kmeans_iter_step, proc.first_layers_fp, proc.first_times_fp = 0, 2, 0, 1.0
+        proc.logging_file = log.name
+        ts = torch.tensor([0.5])
+        if model == "hy":
+            o = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None)
+            cq, ck = proc.q_centroids[0], proc.k_centroids[0]
+        else:
+            o = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts)
+            cq, ck = proc.q_centroids, proc.k_centroids
+        entry = json.loads(open(log.name).read().strip().splitlines()[-1])
+        os.unlink(log.name)
+        out[f"{tag}_q"], out[f"{tag}_k"], out[f"{tag}_v"], out[f"{tag}_o"] = q.numpy(), k.numpy(), v.numpy(), o.numpy()
+        out[f"{tag}_init_q"], out[f"{tag}_init_k"], out[f"{tag}_cq"], out[f"{tag}_ck"] = init_q.numpy(), init_k.numpy(), cq.numpy(), ck.numpy()
+        out[f"{tag}_density"] = np.array(entry["density"], dtype=np.float64)
+        out[f"{tag}_geo"] = np.array([H, D, F_, P_, ctx, L, QC, KC], dtype=np.int64)
+        print(f"{tag}: processor layer-call S={S}: density per head {np.round(out[tag + '_density'], 3).tolist()}, output finite {bool(torch.isfinite(o.float()).all())}")
+
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)
     print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")

@@ -122,3 +122,50 @@ def test_kmeans_assignment_against_the_references_triton_kernel(nat, g, tag):
     assert torch.equal(buf.counts.cpu(), cnt)
     ulp = torch.finfo(x.dtype).eps * cent.float().abs().clamp_min(2.0 ** -14)
     assert ((c_out.cpu().float() - cent.float()).abs() <= ulp).all()
+
+
+@pytest.mark.parametrize("tag", ["sap_hy", "sap_wan"])
+def test_sap_processors_equal_the_references_processors(nat, g, tag):
+    """The product's SAP processors (`attention_core_logic`: HIP k-means, block map, fused permutation + variable-block attention)
+    against the OUTPUT of the reference's processors run as they are on the reference's Triton kernels (fixture; the flashinfer kernel
+    replaced by the reference's own Triton attention kernel).  Same warm-start centroids, two k-means iterations, top-p 0.8."""
+    from svg.models.hyvideo.attention import Hunyuan_SAPAttn_Processor2_0
+    from svg.models.wan.attention import WanAttn_SAPAttn_Processor
+
+    H, D, F_, P_, ctx, L, QC, KC = (int(x) for x in g[tag + "_geo"])
+    q, k, v = (T(g[f"{tag}_{n}"]).cuda() for n in ("q", "k", "v"))
+    o = T(g[tag + "_o"])
+    cls = Hunyuan_SAPAttn_Processor2_0 if tag == "sap_hy" else WanAttn_SAPAttn_Processor
+    names = ("context_length", "num_frame", "frame_size", "num_q_centroids", "num_k_centroids", "top_p_kmeans", "min_kc_ratio",
+             "kmeans_iter_init", "kmeans_iter_step", "first_layers_fp", "first_times_fp", "prompt_length")
+    saved = {n: getattr(cls, n) for n in names if hasattr(cls, n)}
+    try:
+        for n, val in zip(names, (ctx, F_, P_, QC, KC, 0.8, 0.1, 0, 2, 0, 1.0, L)):
+            setattr(cls, n, val)
+        proc = cls(0)
+        if tag == "sap_hy":
+            cls.reset_state()
+        store = proc.centroid_store
+        store.q[0], store.k[0] = T(g[tag + "_init_q"]).cuda(), T(g[tag + "_init_k"]).cuda()
+        ts = torch.tensor([0.5], device="cuda")
+        if tag == "sap_hy":
+            out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None)
+        else:
+            out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts)
+        torch.cuda.synchronize()
+        assert out.shape == o.shape
+        e = ((out.float().cpu() - o.float()).norm() / o.float().norm()).item()
+        assert e < 2e-3, e
+        torch.testing.assert_close(out.float().cpu(), o.float(), atol=4e-3, rtol=4e-3)
+        # the k-means state the processors leave behind: the reference's, to one fp16 ulp
+        for mine, ref in ((store.q[0], T(g[tag + "_cq"])), (store.k[0], T(g[tag + "_ck"]))):
+            mine = mine.reshape(ref.shape).float().cpu()
+            assert ((mine - ref.float()).abs() <= torch.finfo(torch.float16).eps * ref.float().abs().clamp_min(2.0 ** -14)).all()
+    finally:
+        for n in names:
+            if n in saved:
+                setattr(cls, n, saved[n])
+            elif n in cls.__dict__:
+                delattr(cls, n)
+        if tag == "sap_hy":
+            cls.reset_state()
