@@ -169,3 +169,35 @@ def test_sap_processors_equal_the_references_processors(nat, g, tag):
                 delattr(cls, n)
         if tag == "sap_hy":
             cls.reset_state()
+
+
+@pytest.mark.parametrize("device_switch", [False, True])
+def test_svg1_processor_equals_the_references_processor(nat, g, device_switch):
+    """The product's Hunyuan_SVGAttn_Processor2_0.attention_core_logic (HIP online profiler, block-sparse band attention with the fused
+    layout transformation) against the OUTPUT of the reference's processor run as it is (its sample_mse, Triton placement kernels, torch
+    flex_attention under its BlockMask).  The heads are built so that the profiler's choice is unambiguous (MSE ratio > 200x between the
+    two masks): the decisions must be the reference's, the output the reference's to 16-bit accuracy."""
+    from svg.models.hyvideo.attention import Hunyuan_SVGAttn_Processor2_0 as cls
+    from svg.models.hyvideo.utils import generate_temporal_head_mask_mod
+
+    H, D, F_, P_, ctx, L = (int(x) for x in g["svg1_geo"])
+    mul = float(g["svg1_mul"])
+    q, k, v = (T(g[f"svg1_{n}"]).cuda() for n in "qkv")              # fp16
+    best, o = T(g["svg1_best"]), T(g["svg1_o"]).float()
+    names = ("context_length", "num_frame", "frame_size", "prompt_length", "num_sampled_rows", "sample_mse_max_row", "first_layers_fp",
+             "first_times_fp", "block_mask", "device_switch")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (ctx, F_, P_, L, 32, F_ * P_, 0, 1.0, generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), device_switch)):
+            setattr(cls, n, val)
+        proc = cls(0)
+        ts = torch.tensor([0.5], device="cuda" if device_switch else "cpu")
+        out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(proc.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
+        e = ((out.float().cpu() - o).norm() / o.norm()).item()
+        assert e < 3e-3, e
+        torch.testing.assert_close(out.float().cpu(), o, atol=6e-3, rtol=6e-3)
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)

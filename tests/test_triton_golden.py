@@ -257,3 +257,25 @@ def test_sap_processor_layer_call(g, tag):
     e = ((out2 - o[0].float()).norm() / o[0].float().norm()).item()
     print(f"[{tag}] fp32-norm statement vs the reference processors: rel L2 {e:.2e}, density {dens2.tolist()} vs {dens.tolist()}")
     assert e < 3e-3 and torch.allclose(dens2, dens, atol=1e-6)   # (the fixtures' modes are well separated: no label depends on the norms' rounding)
+
+
+def test_svg1_processor_layer_call(g):
+    """Fixture: `attention_core_logic` of the reference's Hunyuan_SVGAttn_Processor2_0 as it is — sample_mse on its two profiling masks,
+    argmin, the Triton head placement (interpreted), torch flex_attention under the BlockMask of its mask_mod, the Triton inverse
+    placement.  The oracle's statement: the same decisions from `sample_mse`, placement -> attention under `hy_mask` -> inverse placement."""
+    H, D, F_, P_, ctx, L = (int(x) for x in g["svg1_geo"])
+    mul = float(g["svg1_mul"])
+    V, S = F_ * P_, F_ * P_ + ctx
+    q, k, v = (T(g[f"svg1_{n}"]).float() for n in "qkv")
+    best, o = T(g["svg1_best"]), T(g["svg1_o"]).float()
+    assert best.tolist() == [[0, 1, 1, 0]]
+    masks = O.profile_masks("hy", ctx, F_, P_)
+    rows = torch.randperm(V, generator=torch.Generator().manual_seed(1))[:32]          # any rows: the choice is unambiguous by construction
+    mine_mse = O.sample_mse_fp32(q, k, v, rows, masks)
+    assert torch.equal(mine_mse.argmin(0), best)
+    ref_mse = T(g["svg1_mse"])
+    assert (ref_mse.max(0).values / ref_mse.min(0).values).min() > 50
+    qp, kp, vp = (O.head_placement(t, best, ctx, F_, P_) for t in (q, k, v))
+    out = O.head_placement(O.masked_attention(qp, kp, vp, O.hy_mask(S, ctx, L, F_, P_, mul)), best, ctx, F_, P_, inverse=True)
+    torch.testing.assert_close(out, o, atol=2e-3, rtol=2e-3)        # (the fixture stores the fp32 output rounded to fp16)
+    assert ((out - o).norm() / o.norm()).item() < 5e-4
