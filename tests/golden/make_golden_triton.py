@@ -271,59 +271,81 @@ def main():
         out[f"{tag}_geo"] = np.array([H, D, F_, P_, ctx, L, QC, KC], dtype=np.int64)
         print(f"{tag}: processor layer-call S={S}: density per head {np.round(out[tag + '_density'], 3).tolist()}, output finite {bool(torch.isfinite(o.float()).all())}")
 
-    # ---------------- 9. SVG1 layer-call of the reference's Hunyuan processor ----------------
-    # Hunyuan_SVGAttn_Processor2_0.attention_core_logic (hyvideo/attention.py:473-524) as it is: sample_mse on its two profiling masks,
-    # argmin, the Triton head placement, torch flex_attention (eager, CPU) under the BlockMask of the reference's mask_mod, the Triton
-    # inverse placement.  Heads are built so that the online profiler's choice is unambiguous: two heads attend their neighbours in
-    # frame-major order (spatial), two in token-major order (temporal) — whatever rows are sampled.
+    # ---------------- 9. SVG1 layer-call of the reference's processors (Hunyuan, Wan, CogVideoX) ----------------
+    # attention_core_logic of Hunyuan_SVGAttn_Processor2_0 (hyvideo/attention.py:473-524), WanAttn_SVGAttn_Processor2_0 (wan/attention.py:284-330)
+    # and CogVideoX_SparseAttn_Processor2_0 (cog/attention.py:164-193) as they are: sample_mse on the two profiling masks, argmin, the Triton
+    # head placement, torch flex_attention (eager, CPU) under the BlockMask of the model's mask_mod, the Triton inverse placement.  Heads are
+    # built so that the online profiler's choice is unambiguous: one head attends its neighbours in frame-major order (spatial), one in
+    # token-major order (temporal) — whatever rows are sampled.
     import math
 
     from torch.nn.attention.flex_attention import create_block_mask
 
+    import svg.models.cog.attention as cog_attn
+    import svg.models.cog.utils as cog_u
     import svg.models.hyvideo.utils as hy_u
+    import svg.models.wan.utils as wan_u
 
-    H, D, F_, P_, ctx, L, mul = 4, 64, 4, 128, 32, 20, 1.4
-    V, S = F_ * P_, F_ * P_ + ctx
-    g = torch.Generator().manual_seed(77)
-    i = torch.arange(V)
-    pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}                  # frame-major / token-major position of video token i
-    freqs = torch.arange(1, D // 2 + 1).float()
+    for tag, (H, D, F_, P_, ctx, L, mul) in {"svg1": (2, 64, 4, 128, 32, 20, 1.4), "svg1_wan": (2, 64, 4, 128, 0, 0, 0.9), "svg1_cog": (2, 64, 3, 128, 32, 0, 1.4)}.items():
+        V, S = F_ * P_, F_ * P_ + ctx
+        g = torch.Generator().manual_seed(77 + ctx + F_)
+        i = torch.arange(V)
+        pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}              # frame-major / token-major position of video token i
+        freqs = torch.arange(1, D // 2 + 1).float()
 
-    def features(kind):                                                          # nearby positions -> nearly parallel vectors
-        ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * V)
-        return torch.cat([torch.cos(ang), torch.sin(ang)], 1) * 1.6
+        def features(kind):                                                      # nearby positions -> nearly parallel vectors
+            ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * V)
+            return torch.cat([torch.cos(ang), torch.sin(ang)], 1) * 1.6
 
-    q = torch.zeros(1, H, S, D)
-    for h, kind in enumerate((0, 1, 1, 0)):
-        q[0, h, :V] = features(kind)
-    q[0, :, V:] = torch.randn(H, ctx, D, generator=g) * 0.3
-    q = (q + 0.05 * torch.randn(1, H, S, D, generator=g)).to(torch.float16).float()   # fp16-representable values, fp32 arithmetic
-    k = (q + 0.05 * torch.randn(1, H, S, D, generator=g)).to(torch.float16).float()
-    v = torch.randn(1, H, S, D, generator=g).to(torch.float16).float()
-    cls = hy_attn.Hunyuan_SVGAttn_Processor2_0
-    cls.context_length, cls.num_frame, cls.frame_size, cls.prompt_length = ctx, F_, P_, L
-    cls.num_sampled_rows, cls.sample_mse_max_row, cls.first_layers_fp, cls.first_times_fp = 32, V, 0, 1.0
-    cls.attention_masks = [hy_u.get_attention_mask("spatial", V, ctx, F_, P_), hy_u.get_attention_mask("temporal", V, ctx, F_, P_, device="cpu")]
-    cls.block_mask = create_block_mask(hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), None, None, S, S, device="cpu")
-    proc = cls(0)
-    seen = {}
-    orig_mse = proc.sample_mse
+        vid0 = ctx if tag == "svg1_cog" else 0                                    # CogVideoX: text first
+        q = torch.randn(1, H, S, D, generator=g) * 0.3                            # (text rows stay noise)
+        for h, kind in enumerate((0, 1)):
+            q[0, h, vid0:vid0 + V] = features(kind)
+        q = (q + 0.05 * torch.randn(1, H, S, D, generator=g)).to(torch.float16).float()   # fp16-representable values, fp32 arithmetic
+        k = (q + 0.05 * torch.randn(1, H, S, D, generator=g)).to(torch.float16).float()
+        v = torch.randn(1, H, S, D, generator=g).to(torch.float16).float()
+        if tag == "svg1":
+            cls = hy_attn.Hunyuan_SVGAttn_Processor2_0
+            cls.prompt_length, cls.sample_mse_max_row, cls.first_times_fp = L, V, 1.0
+            cls.attention_masks = [hy_u.get_attention_mask("spatial", V, ctx, F_, P_), hy_u.get_attention_mask("temporal", V, ctx, F_, P_, device="cpu")]
+            mask_mod = hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul)
+        elif tag == "svg1_wan":
+            cls = wan_attn.WanAttn_SVGAttn_Processor2_0
+            cls.sample_mse_max_row, cls.first_times_fp = V, 1.0
+            cls.attention_masks = [wan_u.get_attention_mask("spatial", V, 0, F_, P_), wan_u.get_attention_mask("temporal", V, 0, F_, P_)]
+            mask_mod = wan_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul)
+        else:
+            cls = cog_attn.CogVideoX_SparseAttn_Processor2_0
+            cls.first_times_fp = 0.0                                              # Cog: dense iff timestep > 1000 * (1 - first_times_fp)
+            cls.attention_masks = [cog_u.get_attention_mask("spatial", ctx, F_, P_), cog_u.get_attention_mask("temporal", ctx, F_, P_)]
+            mask_mod = cog_u.generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul)
+        cls.context_length, cls.num_frame, cls.frame_size, cls.num_sampled_rows, cls.first_layers_fp = ctx, F_, P_, 32, 0
+        cls.block_mask = create_block_mask(mask_mod, None, None, S, S, device="cpu")
+        proc = cls(0)
+        seen = {}
+        orig_mse = proc.sample_mse
 
-    def spy(qq, kk, vv):
-        seen["mse"] = orig_mse(qq, kk, vv)
-        return seen["mse"]
+        def spy(qq, kk, vv, _orig=orig_mse, _seen=seen):
+            _seen["mse"] = _orig(qq, kk, vv)
+            return _seen["mse"]
 
-    proc.sample_mse = spy
-    torch.manual_seed(5)
-    o = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), torch.tensor([0.5]), 0, None)
-    mse = seen["mse"].float()
-    best = mse.argmin(0)
-    margin = (mse.max(0).values / mse.min(0).values).min().item()
-    out["svg1_q"], out["svg1_k"], out["svg1_v"] = (t.to(torch.float16).numpy() for t in (q, k, v))
-    out["svg1_o"], out["svg1_best"], out["svg1_mse"] = o.to(torch.float16).numpy(), best.numpy(), mse.numpy()
-    out["svg1_geo"] = np.array([H, D, F_, P_, ctx, L], dtype=np.int64)
-    out["svg1_mul"] = np.float64(mul)
-    print(f"svg1: Hunyuan SVG processor S={S}: best_mask_idx {best.tolist()}, worst MSE ratio between the two masks {margin:.1f}x")
+        proc.sample_mse = spy
+        torch.manual_seed(5)
+        ts = torch.tensor([0.5])
+        o = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None) if tag == "svg1" else proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts)
+        mse = seen["mse"].float()
+        best = mse.argmin(0)
+        margin = (mse.max(0).values / mse.min(0).values).min().item()
+        torch.manual_seed(5)                                                      # the rows sample_mse drew: its randint is the first draw after the seed
+        out[f"{tag}_rows"] = torch.randint(low=0, high=S if tag == "svg1_cog" else V, size=(32,)).numpy()
+        out[f"{tag}_q"], out[f"{tag}_k"], out[f"{tag}_v"] = (t.to(torch.float16).numpy() for t in (q, k, v))
+        out[f"{tag}_o"], out[f"{tag}_best"], out[f"{tag}_mse"] = o.to(torch.float16).numpy(), best.numpy(), mse.numpy()
+        out[f"{tag}_geo"] = np.array([H, D, F_, P_, ctx, L], dtype=np.int64)
+        out[f"{tag}_mul"] = np.float64(mul)
+        n_txt = int((torch.from_numpy(out[f"{tag}_rows"]) < vid0).sum()) if tag == "svg1_cog" else 0
+        print(f"{tag}: SVG1 processor S={S}: best_mask_idx {best.tolist()}, worst MSE ratio between the two masks {margin:.1f}x"
+              + (f"; {n_txt} sampled TEXT rows -> NaN under the temporal profiling mask (no key allowed, cog/utils.py get_attention_mask) -> argmin picks it"
+                 if n_txt else ""))
 
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)

@@ -171,33 +171,70 @@ def test_sap_processors_equal_the_references_processors(nat, g, tag):
             cls.reset_state()
 
 
+@pytest.mark.parametrize("tag", ["svg1", "svg1_wan"])
 @pytest.mark.parametrize("device_switch", [False, True])
-def test_svg1_processor_equals_the_references_processor(nat, g, device_switch):
-    """The product's Hunyuan_SVGAttn_Processor2_0.attention_core_logic (HIP online profiler, block-sparse band attention with the fused
-    layout transformation) against the OUTPUT of the reference's processor run as it is (its sample_mse, Triton placement kernels, torch
-    flex_attention under its BlockMask).  The heads are built so that the profiler's choice is unambiguous (MSE ratio > 200x between the
-    two masks): the decisions must be the reference's, the output the reference's to 16-bit accuracy."""
-    from svg.models.hyvideo.attention import Hunyuan_SVGAttn_Processor2_0 as cls
-    from svg.models.hyvideo.utils import generate_temporal_head_mask_mod
+def test_svg1_processor_equals_the_references_processor(nat, g, tag, device_switch):
+    """The product's Hunyuan / Wan SVG1 processors' attention_core_logic (HIP online profiler, block-sparse band attention with the fused
+    layout transformation) against the OUTPUT of the reference's processors run as they are (their sample_mse, Triton placement kernels,
+    torch flex_attention under their BlockMask).  The heads are built so that the profiler's choice is unambiguous (MSE ratio > 20x between
+    the two masks): the decisions must be the reference's, the output the reference's to 16-bit accuracy."""
+    H, D, F_, P_, ctx, L = (int(x) for x in g[tag + "_geo"])
+    mul = float(g[tag + "_mul"])
+    q, k, v = (T(g[f"{tag}_{n}"]).cuda() for n in "qkv")              # fp16
+    best, o = T(g[tag + "_best"]), T(g[tag + "_o"]).float()
+    if tag == "svg1":
+        from svg.models.hyvideo.attention import Hunyuan_SVGAttn_Processor2_0 as cls
+        from svg.models.hyvideo.utils import generate_temporal_head_mask_mod
 
-    H, D, F_, P_, ctx, L = (int(x) for x in g["svg1_geo"])
-    mul = float(g["svg1_mul"])
-    q, k, v = (T(g[f"svg1_{n}"]).cuda() for n in "qkv")              # fp16
-    best, o = T(g["svg1_best"]), T(g["svg1_o"]).float()
+        mask = generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul)
+    else:
+        from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as cls
+        from svg.models.wan.utils import generate_temporal_head_mask_mod
+
+        mask = generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul)
     names = ("context_length", "num_frame", "frame_size", "prompt_length", "num_sampled_rows", "sample_mse_max_row", "first_layers_fp",
              "first_times_fp", "block_mask", "device_switch")
-    saved = {n: getattr(cls, n) for n in names}
+    saved = {n: getattr(cls, n) for n in names if hasattr(cls, n)}
     try:
-        for n, val in zip(names, (ctx, F_, P_, L, 32, F_ * P_, 0, 1.0, generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), device_switch)):
+        for n, val in zip(names, (ctx, F_, P_, L, 32, F_ * P_, 0, 1.0, mask, device_switch)):
             setattr(cls, n, val)
         proc = cls(0)
         ts = torch.tensor([0.5], device="cuda" if device_switch else "cpu")
-        out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None)
+        if tag == "svg1":
+            out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts, 0, None)
+        else:
+            out = proc.attention_core_logic(q.clone(), k.clone(), v.clone(), ts)
         torch.cuda.synchronize()
         assert torch.equal(proc.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
         e = ((out.float().cpu() - o).norm() / o.norm()).item()
         assert e < 3e-3, e
         torch.testing.assert_close(out.float().cpu(), o, atol=6e-3, rtol=6e-3)
     finally:
-        for n, val in saved.items():
-            setattr(cls, n, val)
+        for n in names:
+            if n in saved:
+                setattr(cls, n, saved[n])
+            elif n in cls.__dict__:
+                delattr(cls, n)
+
+
+def test_cog_profiler_nan_quirk_and_attention_equal_the_references_processor(nat, g):
+    """CogVideoX (text first).  The reference's processor drew a TEXT row; its temporal profiling mask admits no key on text rows, the
+    softmax of that row is NaN, the mask's MSE is NaN and torch.argmin picks it for every head (tests/test_triton_golden.py).  With the
+    rows the reference drew, svg_sample_mse reproduces that — NaN under the temporal mask, the spatial MSE equal to the reference's —,
+    and svg_band_attention with the resulting decisions (text-first placement fused in) gives the reference processor's output."""
+    from svg.models.cog.utils import generate_temporal_head_mask_mod, profile_desc
+
+    tag = "svg1_cog"
+    H, D, F_, P_, ctx, L = (int(x) for x in g[tag + "_geo"])
+    mul = float(g[tag + "_mul"])
+    q, k, v = (T(g[f"{tag}_{n}"]).cuda() for n in "qkv")
+    best, o, rows, ref_mse = T(g[tag + "_best"]), T(g[tag + "_o"]).float(), T(g[tag + "_rows"]).long(), T(g[tag + "_mse"])
+    mse = nat.sample_mse(q[0], k[0], v[0], rows.cuda(), profile_desc(ctx, F_, P_, emulate_bf16=False)).cpu()   # [2, H], fp32 arithmetic like the fixture
+    assert torch.isnan(mse[1]).all() and torch.isnan(ref_mse[1]).all()
+    torch.testing.assert_close(mse[0], ref_mse[0, 0], rtol=3e-2, atol=1e-6)     # fp16 inputs / bf16-emulating profiler vs the reference's fp32 run
+    mine_best = mse.argmin(0)[None]
+    assert torch.equal(mine_best, best.long())
+    out = nat.band_attention(q, k, v, generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul), head_perm_flag=mine_best.cuda(), vid0=ctx,
+                             num_frame=F_, frame_size=P_).float().cpu()
+    e = ((out - o).norm() / o.norm()).item()
+    assert e < 3e-3, e

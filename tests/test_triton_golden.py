@@ -259,23 +259,37 @@ def test_sap_processor_layer_call(g, tag):
     assert e < 3e-3 and torch.allclose(dens2, dens, atol=1e-6)   # (the fixtures' modes are well separated: no label depends on the norms' rounding)
 
 
-def test_svg1_processor_layer_call(g):
-    """Fixture: `attention_core_logic` of the reference's Hunyuan_SVGAttn_Processor2_0 as it is — sample_mse on its two profiling masks,
-    argmin, the Triton head placement (interpreted), torch flex_attention under the BlockMask of its mask_mod, the Triton inverse
-    placement.  The oracle's statement: the same decisions from `sample_mse`, placement -> attention under `hy_mask` -> inverse placement."""
-    H, D, F_, P_, ctx, L = (int(x) for x in g["svg1_geo"])
-    mul = float(g["svg1_mul"])
+@pytest.mark.parametrize("tag,model", [("svg1", "hy"), ("svg1_wan", "wan"), ("svg1_cog", "cog")])
+def test_svg1_processor_layer_call(g, tag, model):
+    """Fixture: `attention_core_logic` of the reference's SVG1 processors (Hunyuan, Wan, CogVideoX) as they are — sample_mse on the two
+    profiling masks, argmin, the Triton head placement (interpreted), torch flex_attention under the BlockMask of the model's mask_mod,
+    the Triton inverse placement.  The oracle's statement: the same decisions from `sample_mse` on the rows the processor drew,
+    placement -> attention under the model's mask -> inverse placement.
+    CogVideoX shows a reference quirk: its TEMPORAL profiling mask leaves the text rows without a single allowed key
+    (cog/utils.py get_attention_mask), its sample_mse draws rows from the whole sequence (cog/attention.py:126), so a sampled text row
+    makes that mask's MSE NaN, and torch.argmin picks the NaN: every head goes temporal.  The oracle and the HIP profiler reproduce it
+    (include/svg_attn.h: 'a sampled row whose mask admits no key yields NaN like the reference's softmax')."""
+    H, D, F_, P_, ctx, L = (int(x) for x in g[tag + "_geo"])
+    mul = float(g[tag + "_mul"])
     V, S = F_ * P_, F_ * P_ + ctx
-    q, k, v = (T(g[f"svg1_{n}"]).float() for n in "qkv")
-    best, o = T(g["svg1_best"]), T(g["svg1_o"]).float()
-    assert best.tolist() == [[0, 1, 1, 0]]
-    masks = O.profile_masks("hy", ctx, F_, P_)
-    rows = torch.randperm(V, generator=torch.Generator().manual_seed(1))[:32]          # any rows: the choice is unambiguous by construction
+    q, k, v = (T(g[f"{tag}_{n}"]).float() for n in "qkv")
+    best, o, rows = T(g[tag + "_best"]), T(g[tag + "_o"]).float(), T(g[tag + "_rows"]).long()
+    ref_mse = T(g[tag + "_mse"])
+    masks = O.profile_masks(model, ctx, F_, P_)
     mine_mse = O.sample_mse_fp32(q, k, v, rows, masks)
     assert torch.equal(mine_mse.argmin(0), best)
-    ref_mse = T(g["svg1_mse"])
-    assert (ref_mse.max(0).values / ref_mse.min(0).values).min() > 50
-    qp, kp, vp = (O.head_placement(t, best, ctx, F_, P_) for t in (q, k, v))
-    out = O.head_placement(O.masked_attention(qp, kp, vp, O.hy_mask(S, ctx, L, F_, P_, mul)), best, ctx, F_, P_, inverse=True)
+    if model == "cog":
+        assert (rows < ctx).any() and torch.isnan(ref_mse[1]).all() and torch.isnan(mine_mse[1]).all() and best.tolist() == [[1, 1]]
+        torch.testing.assert_close(mine_mse[0], ref_mse[0], rtol=1e-4, atol=1e-7)
+    else:
+        assert best.tolist() == [[0, 1]] and (ref_mse.max(0).values / ref_mse.min(0).values).min() > 15
+        torch.testing.assert_close(mine_mse, ref_mse, rtol=1e-4, atol=1e-7)
+        other = torch.randperm(V, generator=torch.Generator().manual_seed(1))[:32]      # any rows: the choice is unambiguous by construction
+        assert torch.equal(O.sample_mse_fp32(q, k, v, other, masks).argmin(0), best)
+    text_first = model == "cog"
+    mask = {"hy": lambda: O.hy_mask(S, ctx, L, F_, P_, mul), "wan": lambda: O.wan_mask(S, F_, P_, mul),
+            "cog": lambda: O.cog_mask(S, ctx, F_, P_, mul)}[model]()
+    qp, kp, vp = (O.head_placement(t, best, ctx, F_, P_, text_first=text_first) for t in (q, k, v))
+    out = O.head_placement(O.masked_attention(qp, kp, vp, mask), best, ctx, F_, P_, text_first=text_first, inverse=True)
     torch.testing.assert_close(out, o, atol=2e-3, rtol=2e-3)        # (the fixture stores the fp32 output rounded to fp16)
     assert ((out - o).norm() / o.norm()).item() < 5e-4
