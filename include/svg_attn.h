@@ -341,6 +341,12 @@ int svg_modulate_gate_residual_forward(const void* residual, const void* x, cons
 int svg_layernorm_modulate_forward(const void* x, void* y, const void* weight, const void* bias, const float* scale,
                                    const float* shift, int64_t M, int32_t N, int64_t rows_per_batch, int32_t x_dtype,
                                    int32_t y_dtype, int32_t w_dtype, float eps, void* stream);
+/* RMSNorm of the rows as the reference's TRITON kernel computes it — y = T(x * rsqrt(mean(x^2) + eps) * w), fp32, ONE rounding —:
+ * ref: triton_rmsnorm_forward svg/kernels/triton/rmsnorm.py:51-105, the q / k normalisation across all heads of the reference's Wan
+ * processors (svg/models/wan/attention.py:105-120).  (svg_rms_norm_forward above is the CUDA extension's form, rounded before the
+ * weight like diffusers' RMSNorm; the two differ by at most one ulp of T.)  weight may be NULL. */
+int svg_rmsnorm_forward(const void* x, void* y, const void* weight, int64_t M, int32_t N, int32_t x_dtype, int32_t y_dtype,
+                        int32_t w_dtype, float eps, void* stream);
 /* The same two with `reference_padding`.  0: as above — diffusers' FP32LayerNorm, the branch the reference's kernels replace
  * (svg/models/wan/custom_models.py:44-47).  != 0: the variance of the reference's Triton kernels AS THEY ARE: they load a row
  * zero-padded to N2 = next_power_of_2(N) and the padding takes part in the variance, var' = var + (N2 - N) / N * mean^2

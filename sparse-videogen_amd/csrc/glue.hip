@@ -21,7 +21,7 @@ struct GlueParams {
     int M, N, rows_per_batch;
     int x_dt, r_dt, y_dt, w_dt;
     float eps;
-    int do_ln;
+    int do_ln;           // 0: none, 1: LayerNorm, 2: RMSNorm (the reference's Triton form: fp32 x * rstd * w, ONE rounding; rmsnorm.py:8-48)
     float pad_cols;      // 0: LayerNorm.  > 0: the reference's Triton kernels' variance, which counts the zero padding of the row up to
                          // the next power of two — (0 - mean)^2 for N2 - N columns (svg/kernels/triton/layernorm.py:35-41): opt-in
 };
@@ -80,7 +80,27 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
             for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
         }
     }
-    if (p.do_ln) {
+    if (p.do_ln == 2) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2 += x[i][j] * x[i][j];      // (chunks behind the row hold zeros)
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)p.N + p.eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) {
+                float w[8];
+                if (p.w) load8(p.w, (size_t)c * 8, p.w_dt, w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = x[i][j] * rstd;
+                    x[i][j] = p.w ? xh * w[j] : xh;
+                }
+            }
+        }
+    } else if (p.do_ln) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
@@ -187,6 +207,19 @@ extern "C" int svg_layernorm_forward_ex(const void* x, void* y, const void* weig
 extern "C" int svg_layernorm_forward(const void* x, void* y, const void* weight, const void* bias, int64_t M, int32_t N,
                                      int32_t x_dtype, int32_t y_dtype, int32_t w_dtype, float eps, void* stream) {
     return svg_layernorm_forward_ex(x, y, weight, bias, M, N, x_dtype, y_dtype, w_dtype, eps, 0, stream);
+}
+
+// RMSNorm over the last dimension of [M, N] as the reference's Triton kernel computes it (svg/kernels/triton/rmsnorm.py:8-48, the
+// q / k normalisation of its Wan processors, wan/attention.py:105-120): fp32 statistics, y = T(x * rstd * w) — ONE rounding, unlike
+// diffusers' RMSNorm (and svg_rms_norm_forward, the head_dim-wide QK norm of the other models), which round before the weight.
+extern "C" int svg_rmsnorm_forward(const void* x, void* y, const void* weight, int64_t M, int32_t N, int32_t x_dtype, int32_t y_dtype,
+                                   int32_t w_dtype, float eps, void* stream) {
+    if (!x || !y || M <= 0 || M > 0x7fffffff) return SVG_ERR_BAD_ARG;
+    if (weight && !dt_ok(w_dtype)) return SVG_ERR_UNSUPPORTED;
+    GlueParams p{};
+    p.x = x, p.y = y, p.w = weight, p.M = (int)M, p.N = N, p.rows_per_batch = (int)M;
+    p.x_dt = x_dtype, p.y_dt = y_dtype, p.w_dt = w_dtype, p.eps = eps, p.do_ln = 2;
+    return launch_row_glue(p, (hipStream_t)stream);
 }
 
 extern "C" int svg_modulate_shift_forward(const void* x, void* y, const float* scale, const float* shift, int64_t M, int32_t N,

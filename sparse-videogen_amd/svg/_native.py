@@ -89,6 +89,7 @@ SIGNATURES = {
     "svg_apply_qk_rope_inplace_cossin_complex": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_bsr_to_block_map": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
     "svg_layernorm_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
+    "svg_rmsnorm_forward": (C.c_int, [_VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _VP]),
     "svg_layernorm_forward_ex": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, _I32, _I32, _I32, C.c_float, _I32, _VP]),
     "svg_modulate_shift_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _VP]),
     "svg_modulate_gate_residual_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int64, _I32, C.c_int64, _I32, _I32, _I32, _VP]),
@@ -818,6 +819,22 @@ def layernorm_forward(x, weight=None, bias=None, eps: float = 1e-5, out_dtype=to
     _check(lib.svg_layernorm_forward_ex(x.data_ptr(), y.data_ptr(), _ptr(weight), _ptr(bias), M, N, _GLUE_DT[x.dtype],
                                         _GLUE_DT[out_dtype], wdt, float(eps), int(bool(reference_padding)), _stream()),
            "svg_layernorm_forward_ex")
+    return y
+
+
+def rmsnorm_forward(x, weight=None, eps: float = 1e-6, out_dtype=None) -> torch.Tensor:
+    """RMSNorm of the rows of x ([M, N] or [B, S, N]) in the reference's Triton form: fp32, x * rstd * w, one rounding
+    (svg_rmsnorm_forward); out_dtype defaults to x.dtype."""
+    lib = load()
+    _dev(x, weight)
+    M, N, _ = _rows(x)
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    wdt = _GLUE_DT[weight.dtype] if weight is not None else 2
+    if weight is not None:
+        assert weight.shape == (N,) and weight.is_contiguous()
+    _check(lib.svg_rmsnorm_forward(x.data_ptr(), y.data_ptr(), _ptr(weight), M, N, _GLUE_DT[x.dtype], _GLUE_DT[out_dtype], wdt,
+                                   float(eps), _stream()), "svg_rmsnorm_forward")
     return y
 
 

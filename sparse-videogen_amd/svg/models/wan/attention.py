@@ -8,6 +8,7 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
+from ...kernels.triton.rmsnorm import triton_rmsnorm_forward
 from ...timer import time_logging_decorator
 from .. import _core
 from .._core import CentroidStore, Geometry
@@ -76,11 +77,20 @@ class WanAttn_SVGAttn_Processor2_0:
 
     @time_logging_decorator("Level 2 - qk_norm")
     def get_qk_norm(self, attn, query, key):
-        # Wan normalises across all heads, before the head split (ref :107-121)
+        # Wan normalises across all heads, before the head split, and the reference does it with its Triton RMSNorm kernel whatever the
+        # module is (ref :105-120: `triton_rmsnorm_forward(query, attn.norm_q.weight, attn.norm_q.eps)` — fp32, one rounding), not with
+        # the module's forward (diffusers rounds before the weight): same here on the GPU; other tensors take the module
+        def norm(mod, x):
+            w = getattr(mod, "weight", None)
+            if (x.is_cuda and w is not None and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
+                    and w.shape == (x.shape[-1],) and hasattr(mod, "eps") and mod.eps is not None):
+                return triton_rmsnorm_forward(x.contiguous(), w, mod.eps)
+            return mod(x)
+
         if getattr(attn, "norm_q", None) is not None:
-            query = attn.norm_q(query)
+            query = norm(attn.norm_q, query)
         if getattr(attn, "norm_k", None) is not None:
-            key = attn.norm_k(key)
+            key = norm(attn.norm_k, key)
         return query, key
 
     @time_logging_decorator("Level 2 - transpose")

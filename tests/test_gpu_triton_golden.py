@@ -238,3 +238,23 @@ def test_cog_profiler_nan_quirk_and_attention_equal_the_references_processor(nat
                              num_frame=F_, frame_size=P_).float().cpu()
     e = ((out - o).norm() / o.norm()).item()
     assert e < 3e-3, e
+
+
+@pytest.mark.parametrize("sfx", ["h", "f"])
+def test_rmsnorm_equals_the_references_triton_kernel(nat, g, sfx):
+    """svg_rmsnorm_forward (and the reference-named shim svg.kernels.triton.rmsnorm.triton_rmsnorm_forward, which the Wan processors call
+    for their q / k normalisation like the reference's do) == _rms_norm_fwd_fused: fp32 x * rstd * w, ONE rounding"""
+    from svg.kernels.triton.rmsnorm import triton_rmsnorm_forward
+
+    x, w, ref = T(g[f"gl_{sfx}_x"]), T(g[f"gl_{sfx}_w"]), T(g[f"gl_{sfx}_rms"])
+    dt = x.dtype
+    y = triton_rmsnorm_forward(x.cuda(), w.to(dt).cuda(), 1e-6).cpu().reshape(ref.shape)
+    assert y.dtype == dt
+    ulp = torch.finfo(dt).eps * ref.float().abs().clamp_min(1e-3)
+    assert ((y.float() - ref.float()).abs() <= (1 if dt == torch.float16 else 8) * ulp).all()
+    if dt == torch.float16:
+        assert (y == ref).float().mean().item() > 0.99
+        # and it is NOT diffusers' two-rounding form everywhere (what the module's forward would have computed)
+        xf = x.float()
+        two = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dt) * w.to(dt)).reshape(ref.shape)
+        assert (two != ref).any()
