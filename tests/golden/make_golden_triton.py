@@ -347,6 +347,26 @@ def main():
               + (f"; {n_txt} sampled TEXT rows -> NaN under the temporal profiling mask (no key allowed, cog/utils.py get_attention_mask) -> argmin picks it"
                  if n_txt else ""))
 
+    # ---------------- 10. the Wan uniform-block (BSR) op's mask generator ----------------
+    # svg/kernels/ops/attention_ops_wan.py: get_factor (block size = largest divisor of the frame size below 256) and ref_gen_temporal_mask
+    import types
+
+    if "matplotlib" not in sys.modules:
+        try:
+            import matplotlib  # noqa: F401
+        except ImportError:
+            MG._stub("matplotlib", pyplot=types.SimpleNamespace())
+            MG._stub("matplotlib.pyplot")
+    import svg.kernels.ops.attention_ops_wan as ops_wan
+
+    for F_, P_, mul in ((5, 40, 1.4), (4, 150, 0.6), (3, 96, 2.0), (21, 3600, 1.8)):
+        bs = ops_wan.get_factor(F_, P_)
+        blk = ops_wan.ref_gen_temporal_mask(F_, P_, mul) != -1
+        out[f"wbsr_{F_}_{P_}_{mul}"] = np.packbits(blk.reshape(-1))
+        out[f"wbsr_{F_}_{P_}_{mul}_bs"] = np.int64(bs)
+    out["wbsr_factors"] = np.array([[p_, ops_wan.get_factor(1, p_)] for p_ in (40, 96, 150, 255, 256, 257, 1350, 3600, 4080, 509)], dtype=np.int64)
+    print("wbsr: block sizes", {int(a): int(b) for a, b in out["wbsr_factors"]})
+
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)
     print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")

@@ -95,3 +95,58 @@ def test_sparse_attn_forward_reference_grid_fullsize(ops, kind, mul, heads, D):
     for h in (0, heads // 2, heads - 1):
         ref = O.masked_attention(q[rows, h].float().cpu(), k[:, h].float().cpu(), v[:, h].float().cpu(), mask)
         close(o[rows, h], ref.to(dt))
+
+
+@pytest.mark.parametrize("F,P_,mul,heads,D", [(5, 40, 1.4, 4, 64), (4, 150, 0.6, 2, 128), (3, 96, 2.0, 4, 64)])
+def test_wan_sparse_attn_forward(F, P_, mul, heads, D):
+    """The Wan (video-only) BSR op, svg/kernels/ops/attention_ops_wan.py mirror: dense attention under the element mask expanded from
+    the block mask the REFERENCE's generator returns (fixture), like the reference's test_sparse_attn_wan.py"""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "sparse-videogen_amd"))
+    from svg.kernels.ops import attention_ops_wan as W
+
+    g = np.load(str(Path(__file__).parent / "golden" / "triton_golden.npz"))
+    bs = int(g[f"wbsr_{F}_{P_}_{mul}_bs"])
+    S = F * P_
+    nb = S // bs
+    blk = torch.from_numpy(np.unpackbits(g[f"wbsr_{F}_{P_}_{mul}"])[: nb * nb].reshape(nb, nb).astype(bool))
+    torch.manual_seed(F + P_)
+    dt = torch.float16
+    q, k, v = (torch.randn(S, heads, D).to(dt) for _ in range(3))
+    meta = W.WanFAMetadata(F, P_, W.gen_temporal_mask(F, P_, mul), None)
+    assert meta.temporal_mask_metadata[2] == (bs, bs)
+    o = W.wan_sparse_attn_forward(q.cuda(), k.cuda(), v.cuda(), meta)
+    mask = blk.repeat_interleave(bs, 0).repeat_interleave(bs, 1)
+    ref = O.masked_attention(q.permute(1, 0, 2)[None], k.permute(1, 0, 2)[None], v.permute(1, 0, 2)[None], mask)[0].permute(1, 0, 2)
+    close(o, ref.to(dt))
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,S,MB,NB,density,dt", [(4, 4, 64, 256, 10, 50, 0.7, torch.float16), (16, 4, 128, 512, 20, 50, 0.2, torch.bfloat16)])
+def test_variable_block_operator_module(Hq, Hkv, D, S, MB, NB, density, dt):
+    """svg/kernels/ops/attention_ops_wan_dyn_blk._test_variable_block_sparse_attention — the function the reference's own test calls
+    (svg/kernels/test/test_sparse_attn_dyn_blk_wan.py:74-133), with that test's inputs and check (GQA included)"""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "sparse-videogen_amd"))
+    from svg.kernels.ops.attention_ops_wan_dyn_blk import _test_variable_block_sparse_attention
+
+    gen = torch.Generator().manual_seed(S + MB)
+
+    def partition(n_blocks):                      # random_partition_batch of the reference's test (:9-36)
+        out = torch.empty(Hkv, n_blocks, dtype=torch.int32)
+        for i in range(Hkv):
+            cuts = torch.sort(torch.randperm(S - 1, generator=gen)[: n_blocks - 1] + 1).values
+            out[i] = torch.diff(torch.cat([torch.tensor([0]), cuts, torch.tensor([S])]))
+        return out
+
+    rows, cols = partition(MB), partition(NB)
+    bmap = torch.rand(Hkv, MB, NB, generator=gen) > density
+    q = torch.randn(Hq, S, D, generator=gen).to(dt)
+    k, v = torch.randn(Hkv, S, D, generator=gen).to(dt), torch.randn(Hkv, S, D, generator=gen).to(dt)
+    o = _test_variable_block_sparse_attention(q.cuda(), k.cuda(), v.cuda(), Hq, Hkv, D, bmap, rows, cols)
+    assert o.shape == (Hkv, Hq // Hkv, S, D)
+    qg = q.reshape(Hkv, -1, S, D)
+    for h in range(Hkv):
+        em = O.block_mask_to_element_mask(bmap[h], rows[h], cols[h])
+        for gi in range(Hq // Hkv):
+            ref = O.masked_attention(qg[h, gi].float(), k[h].float(), v[h].float(), em)
+            torch.testing.assert_close(o[h, gi].float().cpu(), ref, atol=1e-2, rtol=1e-2)      # the reference's tolerance (:133)
