@@ -222,3 +222,11 @@ def apply_inverse_permutation(permuted_tensor, sorted_indices, dim):
     for _ in range(dim + 1, permuted_tensor.dim()):
         gi = gi.unsqueeze(-1)
     return torch.gather(permuted_tensor, dim, gi.expand(permuted_tensor.shape))
+
+
+def dynamic_block_sparse_fwd_triton(q, k, v, dynamic_map, qc_size, kc_size):
+    """ref: svg/kmeans_utils.py:1205-1317 — the reference's Triton implementation of the variable-block attention, same arguments
+    (q, k, v [B, H, S, D] in cluster order, dynamic_map bool [B, H, QC, KC], sizes [B, H, QC] / [B, H, KC]).  Here it is the same HIP
+    kernel as `dynamic_block_sparse_fwd_flashinfer` (tests/test_gpu_triton_golden.py compares that kernel with the OUTPUT of the
+    reference's Triton kernel)."""
+    return dynamic_block_sparse_fwd_flashinfer(q, k, v, dynamic_map, qc_size, kc_size, is_cpu=False)

@@ -47,3 +47,17 @@ def torch_placement(x: torch.Tensor, best_mask_idx, context_length, num_frame, f
     out = x.clone()
     out[:, :, lo:hi] = torch.where(best_mask_idx.to(torch.bool)[:, :, None, None], perm, vid)
     return out
+
+
+def token_reorder(tensor: torch.Tensor, fix_len: int, reorder_len: int, reorder_num_frame: int, frame_size: int, text_first: bool,
+                  to_token_major: bool) -> torch.Tensor:
+    """The reference's `*_token_reorder_to_token_major` / `*_token_reorder_to_frame_major` helpers (hyvideo/placement.py:6-31,
+    cog/placement.py:6-31): IN PLACE on the video part of EVERY head of `tensor` [B, H, fix_len + reorder_len, D] (text last, or first
+    for CogVideoX), returns the tensor.  Correct for fix_len == 0 too (the reference's text-last helpers slice `[:-0]` there)."""
+    assert reorder_len == reorder_num_frame * frame_size
+    assert tensor.shape[2] == fix_len + reorder_len
+    lo, hi = _video_range(tensor.shape[2], fix_len, text_first)
+    a, b = (reorder_num_frame, frame_size) if to_token_major else (frame_size, reorder_num_frame)
+    vid = tensor[:, :, lo:hi]
+    tensor[:, :, lo:hi] = vid.reshape(tensor.shape[0], tensor.shape[1], a, b, tensor.shape[3]).transpose(2, 3).reshape(vid.shape)
+    return tensor

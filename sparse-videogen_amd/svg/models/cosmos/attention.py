@@ -11,7 +11,12 @@ import torch.nn.functional as F
 
 from ...timer import time_logging_decorator
 from .. import _core
-from ..wan.attention import WanAttn_SAPAttn_Processor, WanAttn_SVGAttn_Processor2_0, prepare_flexattention  # noqa: F401
+from ..wan.attention import (  # noqa: F401
+    WanAttn_SAPAttn_Processor,
+    WanAttn_SVGAttn_Processor2_0,
+    prepare_flashinfer_attention,
+    prepare_flexattention,
+)
 
 
 def apply_rotary_emb_half(x: torch.Tensor, freqs_cis) -> torch.Tensor:

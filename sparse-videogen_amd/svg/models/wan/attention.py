@@ -198,6 +198,16 @@ def prepare_flexattention(cfg_size, num_head, head_dim, dtype, device, context_l
     return generate_temporal_head_mask_mod(context_length, prompt_length, num_frame, frame_size, mul=multiplier)
 
 
+def prepare_flashinfer_attention(cfg_size, num_head, head_dim, dtype, device, context_length, prompt_length, num_frame, frame_size,
+                                 diag_width=1, multiplier=2):
+    """ref: wan/attention.py:358-375 — the BSR metadata (row pointer, column indices, block size) of the temporal mask for the
+    uniform-block alternative backend (`flashinfer_sparse_attn_forward`, svg/models/wan/utils.py)"""
+    from .utils import gen_temporal_mask
+
+    assert diag_width == multiplier, f"{diag_width} is not equivalent to {multiplier}"
+    return gen_temporal_mask(num_frame, frame_size, multiplier)
+
+
 class WanAttn_SAPAttn_Processor(WanAttn_SVGAttn_Processor2_0):
     """Sparse VideoGen 2 for Wan 2.1 (ref: wan/attention.py:379-559).  Centroids are kept per processor instance (one
     per layer), as in the reference."""

@@ -25,3 +25,17 @@ def ref_wan_hidden_states_placement(hidden_states, output_hidden_states, best_ma
                                     frame_size):
     output_hidden_states.copy_(_tp(hidden_states, best_mask_idx, context_length, num_frame, frame_size, TEXT_FIRST, True))
     return output_hidden_states
+
+
+def wan_token_reorder_to_token_major(tensor, fix_len, reorder_len, reorder_num_frame, frame_size):
+    """ref: wan/placement.py:6-17 — frame major -> token major, in place"""
+    from .._placement_common import token_reorder
+
+    return token_reorder(tensor, fix_len, reorder_len, reorder_num_frame, frame_size, TEXT_FIRST, True)
+
+
+def wan_token_reorder_to_frame_major(tensor, fix_len, reorder_len, reorder_num_frame, frame_size):
+    """ref: wan/placement.py:20-31 — token major -> frame major, in place"""
+    from .._placement_common import token_reorder
+
+    return token_reorder(tensor, fix_len, reorder_len, reorder_num_frame, frame_size, TEXT_FIRST, False)

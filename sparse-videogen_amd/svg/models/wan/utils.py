@@ -38,3 +38,20 @@ def profile_desc(context_length, num_frame, frame_size, emulate_bf16=True) -> _n
     d.variant[0] = get_attention_mask("spatial", 0, context_length, num_frame, frame_size)
     d.variant[1] = get_attention_mask("temporal", 0, context_length, num_frame, frame_size)
     return d
+
+
+# ---- the uniform-block (BSR) alternative backend of the reference's Wan processors (ref wan/utils.py:63-240; its generators live in
+#      svg/kernels/ops/attention_ops_wan.py, which wan/utils.py duplicates) ----
+from ...kernels.ops.attention_ops_wan import gen_temporal_mask, get_factor  # noqa: E402,F401
+
+
+def flashinfer_sparse_attn_forward(q, k, v, temporal_mask_metadata):
+    """ref: wan/utils.py:188-240 — q, k, v [cfg, H, S, D] -> [cfg, H, S, D] under the BSR temporal mask (name kept; the BSR pattern runs on
+    the variable-block HIP kernel, see svg/kernels/ops/attention_ops_wan.py).  cfg and heads are folded into the head axis like the
+    reference does."""
+    from ...kernels.ops.attention_ops_wan import WanFAMetadata, wan_sparse_attn_forward
+
+    cfg, num_heads, seq_len, head_dim = q.shape
+    qs, ks, vs = (x.permute(2, 0, 1, 3).reshape(seq_len, cfg * num_heads, head_dim) for x in (q, k, v))
+    o = wan_sparse_attn_forward(qs, ks, vs, WanFAMetadata(0, 0, temporal_mask_metadata, None))
+    return o.reshape(seq_len, cfg, num_heads, head_dim).permute(1, 2, 0, 3).contiguous()

@@ -8,6 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import svg_oracle as O
 from standins import Attention, Block, Pipe, Transformer
 
 
@@ -154,3 +155,77 @@ def test_switch_generator_follows_seeding():
     assert not torch.equal(c, a)
     _core.reseed_switch_generator()          # what replace_*_attention calls
     assert torch.equal(draw(), c)
+
+
+def test_token_reorder_helpers_match_the_reference():
+    """`*_token_reorder_to_token_major / _frame_major` of svg/models/{hyvideo,wan,cog,cosmos}/placement.py: in place on every head, text
+    last (first for CogVideoX); the reference's own torch helpers are run beside them when /root/reference is there (this container)."""
+    import importlib
+    import sys
+    import types
+    from pathlib import Path
+
+    F_, P_, ctx = 3, 5, 4
+    for model, prefix, text_first in (("hyvideo", "hunyuan_", False), ("wan", "wan_", False), ("cog", "", True), ("cosmos", "cosmos_", False)):
+        mod = importlib.import_module(f"svg.models.{model}.placement")
+        to_tok, to_frm = getattr(mod, prefix + "token_reorder_to_token_major"), getattr(mod, prefix + "token_reorder_to_frame_major")
+        x = torch.arange(2 * 3 * (F_ * P_ + ctx) * 2, dtype=torch.float32).reshape(2, 3, F_ * P_ + ctx, 2)
+        y = to_tok(x.clone(), ctx, F_ * P_, F_, P_)
+        ones = torch.ones(2, 3, dtype=torch.int32)
+        assert torch.equal(y, O.head_placement(x, ones, ctx, F_, P_, text_first=text_first))
+        assert torch.equal(to_frm(y.clone(), ctx, F_ * P_, F_, P_), x)
+        t = x.clone()
+        assert to_tok(t, ctx, F_ * P_, F_, P_) is t                      # in place, returns its argument
+        x0 = x[:, :, : F_ * P_].contiguous() if not text_first else x[:, :, ctx:].contiguous()
+        assert torch.equal(to_frm(to_tok(x0.clone(), 0, F_ * P_, F_, P_), 0, F_ * P_, F_, P_), x0)     # fix_len == 0 works here
+    ref_root = Path("/root/reference")
+    if ref_root.exists():       # the reference's own helpers (torch only; its module imports triton, which this image has)
+        spec = importlib.util.spec_from_file_location("_ref_cog_placement", ref_root / "svg/models/cog/placement.py")
+        ref = importlib.util.module_from_spec(spec)
+        try:
+            spec.loader.exec_module(ref)
+        except Exception:
+            ref = None
+        if ref is not None:
+            from svg.models.cog import placement as mine
+
+            x = torch.randn(1, 2, F_ * P_ + ctx, 4)
+            assert torch.equal(mine.token_reorder_to_token_major(x.clone(), ctx, F_ * P_, F_, P_),
+                               ref.token_reorder_to_token_major(x.clone(), ctx, F_ * P_, F_, P_))
+            assert torch.equal(mine.token_reorder_to_frame_major(x.clone(), ctx, F_ * P_, F_, P_),
+                               ref.token_reorder_to_frame_major(x.clone(), ctx, F_ * P_, F_, P_))
+
+
+def test_wan_bsr_backend_helpers_layout(monkeypatch):
+    """svg/models/wan/utils.py flashinfer_sparse_attn_forward / prepare_flashinfer_attention (the uniform-block alternative backend of the
+    reference's Wan processors): the [cfg, H, S, D] <-> [S, cfg * H, D] plumbing around the BSR op, checked on the CPU with the op
+    replaced by the oracle under the same block mask (the op itself is tested on the GPU, tests/test_gpu_bsr.py)."""
+    import numpy as np
+
+    from svg.kernels.ops import attention_ops_wan as W
+    from svg.models.cosmos import utils as cosmos_u
+    from svg.models.wan import attention as wan_attn
+    from svg.models.wan import utils as wan_u
+
+    F_, P_, mul, cfg, H, D = 3, 8, 1.2, 2, 2, 16
+    S = F_ * P_
+    meta = wan_attn.prepare_flashinfer_attention(cfg, H, D, torch.float32, "cpu", 0, 0, F_, P_, diag_width=mul, multiplier=mul)
+    indptr, cols, (bs, _) = meta
+    assert bs == W.get_factor(F_, P_) == 8 and cosmos_u.gen_temporal_mask is wan_u.gen_temporal_mask
+    blk = torch.from_numpy(W.ref_gen_temporal_mask(F_, P_, mul) != -1)
+    mask = blk.repeat_interleave(bs, 0).repeat_interleave(bs, 1)
+
+    def fake_op(q, k, v, metadata):          # [S, heads, D] like the op
+        assert metadata.temporal_mask_metadata is meta and q.shape == (S, cfg * H, D)
+        return O.masked_attention(q.permute(1, 0, 2), k.permute(1, 0, 2), v.permute(1, 0, 2), mask).permute(1, 0, 2)
+
+    monkeypatch.setattr(W, "wan_sparse_attn_forward", fake_op)
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(cfg, H, S, D, generator=g) for _ in range(3))
+    o = wan_u.flashinfer_sparse_attn_forward(q, k, v, meta)
+    ref = O.masked_attention(q, k, v, mask)
+    torch.testing.assert_close(o, ref, atol=1e-6, rtol=1e-6)
+    # BSR arrays: row pointer + active column indices in row-major order (+ the reference's 256 padding zeros)
+    n_active = int(blk.sum())
+    assert indptr.tolist() == [0] + np.cumsum(blk.sum(1).numpy()).tolist() and cols.numel() == n_active + 256
+    assert cols[:n_active].tolist() == blk.nonzero()[:, 1].tolist()
