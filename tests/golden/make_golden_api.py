@@ -51,3 +51,18 @@ for s in SCRIPTS:
                 out.append({"script": s, "line": node.lineno, "module": node.module, "name": al.name, "kind": kind, "params": params})
 Path(__file__).with_name("api_surface.json").write_text(json.dumps(out, indent=1) + "\n")
 print(len(out), "imports recorded;", sum(o["kind"] == "missing" for o in out), "unresolved")
+
+
+# ---- the whole public surface of the non-deprecated package: module -> top-level functions / classes (names only) ----
+# (`*_orig` forks, the CUDA extension sources, tests and third-party trees are not part of the path)
+surface = {}
+for f in sorted((REF / "svg").rglob("*.py")):
+    rel = f.relative_to(REF / "svg")
+    parts = rel.parts
+    if any(p.endswith("_orig") for p in parts) or "3rdparty" in parts or "test" in parts or "csrc" in parts or f.name == "__init__.py":
+        continue
+    names = [n.name for n in ast.parse(f.read_text()).body
+             if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and not n.name.startswith(("_", "test", "benchmark"))]
+    surface["svg." + ".".join(rel.with_suffix("").parts)] = names
+Path(__file__).with_name("api_public_names.json").write_text(json.dumps(surface, indent=1) + "\n")
+print(len(surface), "modules,", sum(len(v) for v in surface.values()), "public names recorded")
