@@ -367,6 +367,64 @@ def main():
     out["wbsr_factors"] = np.array([[p_, ops_wan.get_factor(1, p_)] for p_ in (40, 96, 150, 255, 256, 257, 1350, 3600, 4080, 509)], dtype=np.int64)
     print("wbsr: block sizes", {int(a): int(b) for a, b in out["wbsr_factors"]})
 
+    # ---------------- 11. the whole `__call__` of the reference's Wan SVG processor ----------------
+    # WanAttn_SVGAttn_Processor2_0.__call__ (wan/attention.py:151-208) on a duck-typed attention module (tests/standins.py): q / k / v projections,
+    # the Triton RMSNorm across heads (interpreted), head split, the torch RoPE fall-back (complex multiply in fp64, :58-66), attention_core_logic
+    # as in section 9, output projection.  q and k projections are the identity so that the two heads keep the spatial / temporal structure
+    # of the hidden states (unambiguous profiler choice); weights and inputs are fp16-representable, the arithmetic is the reference's fp32.
+    sys.path.insert(0, str(HERE.parent))
+    import standins
+
+    wan_attn.DiffusersRMSNorm = standins.RMSNorm           # `isinstance(attn.norm_q, DiffusersRMSNorm)` (:108)
+    heads, hd, F_, P_, mul = 2, 64, 4, 128, 0.9
+    dim, S = heads * hd, F_ * P_
+    g = torch.Generator().manual_seed(123)
+    attn = standins.Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=torch.float32)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_((torch.randn(dim, dim, generator=g) / dim ** 0.5).half().float())
+        attn.to_v.bias.copy_((torch.randn(dim, generator=g) * 0.1).half().float())
+        attn.to_out[0].weight.copy_((torch.randn(dim, dim, generator=g) / dim ** 0.5).half().float())
+        attn.to_out[0].bias.copy_((torch.randn(dim, generator=g) * 0.1).half().float())
+        # per head: 48 structure channels (q / k see them), 16 noise channels the q / k norm weights all but switch off — v, a random
+        # projection of everything, is dominated by them and so differs from one position to the next (a wrong mask costs a large MSE)
+        chan_w = torch.cat([torch.full((48,), 1.6), torch.full((16,), 0.03)]).repeat(heads)
+        attn.norm_q.weight.copy_((chan_w * (1 + 0.1 * torch.randn(dim, generator=g))).half().float())
+        attn.norm_k.weight.copy_((chan_w * (1 + 0.1 * torch.randn(dim, generator=g))).half().float())
+    i = torch.arange(S)
+    pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}
+    freqs = torch.arange(1, 25).float()
+    feats = []
+    for kind in (0, 1):
+        ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * S)
+        feats.append(torch.cat([torch.cos(ang) * 2.2, torch.sin(ang) * 2.2, 1.5 * torch.randn(S, 16, generator=g)], 1))
+    hidden = (torch.cat(feats, 1)[None] + 0.05 * torch.randn(1, S, dim, generator=g)).half().float()
+    rope_ang = 0.03 * torch.rand(S, hd // 2, generator=g)                                  # small rotations: the structure survives
+    cls = wan_attn.WanAttn_SVGAttn_Processor2_0
+    cls.context_length, cls.num_frame, cls.frame_size, cls.num_sampled_rows, cls.sample_mse_max_row = 0, F_, P_, 32, S
+    cls.first_layers_fp, cls.first_times_fp = 0, 1.0
+    cls.attention_masks = [wan_u.get_attention_mask("spatial", S, 0, F_, P_), wan_u.get_attention_mask("temporal", S, 0, F_, P_)]
+    cls.block_mask = create_block_mask(wan_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul), None, None, S, S, device="cpu")
+    proc = cls(0)
+    seen = {}
+    orig_mse = proc.sample_mse
+    proc.sample_mse = lambda a, b, c: seen.setdefault("mse", orig_mse(a, b, c))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        o = proc(attn, hidden, rotary_emb=torch.polar(torch.ones_like(rope_ang).double(), rope_ang.double())[None, None], timestep=torch.tensor([0.5]))
+    best = seen["mse"].float().argmin(0)
+    out["call_wan_hidden"], out["call_wan_o"], out["call_wan_best"] = hidden.half().numpy(), o.half().numpy(), best.numpy()
+    out["call_wan_rope_ang"] = rope_ang.numpy()
+    for n, t in (("wv", attn.to_v.weight), ("bv", attn.to_v.bias), ("wo", attn.to_out[0].weight), ("bo", attn.to_out[0].bias),
+                 ("nq", attn.norm_q.weight), ("nk", attn.norm_k.weight)):
+        out[f"call_wan_{n}"] = t.detach().half().numpy()
+    out["call_wan_geo"] = np.array([heads, hd, F_, P_], dtype=np.int64)
+    out["call_wan_mul"] = np.float64(mul)
+    m_ = seen["mse"].float()
+    print(f"call_wan: Wan SVG processor __call__ S={S}: best_mask_idx {best.tolist()}, MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, out {tuple(o.shape)}")
+
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)
     print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")

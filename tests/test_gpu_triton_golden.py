@@ -258,3 +258,48 @@ def test_rmsnorm_equals_the_references_triton_kernel(nat, g, sfx):
         xf = x.float()
         two = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dt) * w.to(dt)).reshape(ref.shape)
         assert (two != ref).any()
+
+
+def test_wan_processor_call_equals_the_references_call(nat, g):
+    """The product's WanAttn_SVGAttn_Processor2_0.__call__ on a duck-typed attention module (fp16 weights and inputs, everything on the
+    HIP path: RMSNorm across heads, fused RoPE with the softmax scale folded into q, online profiler, band attention with fused layout
+    transformation) against the OUTPUT of the reference's processor `__call__` run as it is in fp32 on the same (fp16-representable)
+    weights and inputs: same profiler decisions, output equal to 16-bit accuracy."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from standins import Attention
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as cls
+    from svg.models.wan.utils import generate_temporal_head_mask_mod
+
+    heads, hd, F_, P_ = (int(x) for x in g["call_wan_geo"])
+    mul, best = float(g["call_wan_mul"]), T(g["call_wan_best"])
+    dim, S = heads * hd, F_ * P_
+    dt = torch.float16
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=dt)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(T(g["call_wan_wv"])), attn.to_v.bias.copy_(T(g["call_wan_bv"]))
+        attn.to_out[0].weight.copy_(T(g["call_wan_wo"])), attn.to_out[0].bias.copy_(T(g["call_wan_bo"]))
+        attn.norm_q.weight.copy_(T(g["call_wan_nq"])), attn.norm_k.weight.copy_(T(g["call_wan_nk"]))
+    attn.cuda()
+    names = ("context_length", "num_frame", "frame_size", "num_sampled_rows", "sample_mse_max_row", "first_layers_fp", "first_times_fp",
+             "block_mask")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (0, F_, P_, 32, S, 0, 1.0, generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul))):
+            setattr(cls, n, val)
+        attn.set_processor(cls(0))
+        ang = T(g["call_wan_rope_ang"]).float().cuda()
+        with torch.no_grad():
+            out = attn(T(g["call_wan_hidden"]).cuda(), rotary_emb=(ang.cos(), ang.sin()), timestep=torch.tensor([0.5]))
+        torch.cuda.synchronize()
+        assert torch.equal(attn.processor.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
+        ref = T(g["call_wan_o"]).float()
+        e = ((out.float().cpu() - ref).norm() / ref.norm()).item()
+        assert e < 5e-3, e
+        torch.testing.assert_close(out.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)

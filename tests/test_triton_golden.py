@@ -293,3 +293,33 @@ def test_svg1_processor_layer_call(g, tag, model):
     out = O.head_placement(O.masked_attention(qp, kp, vp, mask), best, ctx, F_, P_, text_first=text_first, inverse=True)
     torch.testing.assert_close(out, o, atol=2e-3, rtol=2e-3)        # (the fixture stores the fp32 output rounded to fp16)
     assert ((out - o).norm() / o.norm()).item() < 5e-4
+
+
+def _wan_call_inputs(g):
+    heads, hd, F_, P_ = (int(x) for x in g["call_wan_geo"])
+    t = {n: T(g["call_wan_" + n]).float() for n in ("hidden", "o", "wv", "bv", "wo", "bo", "nq", "nk", "rope_ang")}
+    return heads, hd, F_, P_, float(g["call_wan_mul"]), T(g["call_wan_best"]), t
+
+
+def test_wan_processor_call_end_to_end(g):
+    """Fixture: the whole `__call__` of the reference's WanAttn_SVGAttn_Processor2_0 on a duck-typed attention module — projections,
+    the Triton RMSNorm across heads (one rounding; interpreted), head split, the torch RoPE fall-back (complex multiply in fp64),
+    attention_core_logic (profiler, placement, flex_attention, inverse placement), output projection.  The oracle's statement of the
+    same call, piece by piece."""
+    heads, hd, F_, P_, mul, best, t = _wan_call_inputs(g)
+    S, dim = F_ * P_, heads * hd
+    x = t["hidden"]
+    assert best.tolist() == [[0, 1]]
+
+    def rms(y, w):                                   # svg/kernels/triton/rmsnorm.py:8-48 (fp32 in this run: no rounding at all)
+        return y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+
+    q, k, v = rms(x, t["nq"]), rms(x, t["nk"]), x @ t["wv"].T + t["bv"]          # to_q / to_k are the identity in the fixture
+    q, k, v = (y.unflatten(2, (heads, -1)).transpose(1, 2) for y in (q, k, v))
+    fr = torch.polar(torch.ones_like(t["rope_ang"]).double(), t["rope_ang"].double())
+    q, k = (O.rope_complex(y, fr.real.float(), fr.imag.float()) for y in (q, k))
+    qp, kp, vp = (O.head_placement(y, best, 0, F_, P_) for y in (q, k, v))
+    o = O.head_placement(O.masked_attention(qp, kp, vp, O.wan_mask(S, F_, P_, mul)), best, 0, F_, P_, inverse=True)
+    out = o.transpose(1, 2).flatten(2, 3) @ t["wo"].T + t["bo"]
+    torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
+    assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
