@@ -145,6 +145,47 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[bb][rq * 4 + j] = h4[j];
             }
+#ifndef SVG_KMEANS_V2
+#define SVG_KMEANS_V2 0
+#endif
+        // SVG_KMEANS_V2 (experiment prepared at the end of round 3, NOT measured yet — default off, the default binary is unchanged):
+        //   * the centroid operands of the 2 KS MFMAs are kept kPF reads ahead in a register ring, steps fenced with sched_barrier
+        //     (as compiled, every MFMA of the loop below waits for a read issued one MFMA earlier: `s_waitcnt lgkmcnt(1)` in front of each);
+        //   * the arg-max runs as TWO independent chains, one per 32-centroid block, merged at the end (shorter dependence chain; the
+        //     instruction count stays 3 VALU per score: compare to an SGPR pair + two selects, and hipcc still serialises the two chains
+        //     on one SGPR pair with its two wait states — an explicit 4-chain form would drop those).  Same result: every index of
+        //     block 0 is lower than every index of block 1, so "block 1 wins only if strictly greater" is the lowest-index tie rule.
+        float tb;
+        int ti;
+        if constexpr (SVG_KMEANS_V2 != 0) {
+            constexpr int NOP = 2 * KS, kPF = 4;
+            auto frag = [&](int i) -> V8 {      // operand i: contraction step i >> 1, centroid block i & 1
+                const int cch = ((2 * (i >> 1) + g) ^ ksw0) << 4;
+                return *(const V8*)(kbuf + (32 * (i & 1) + ql) * L::kRowBytes + cch);
+            };
+            V8 ring[kPF + 1];
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) ring[i] = frag(i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NOP; ++i) {
+                if (i + kPF < NOP) ring[(i + kPF) % (kPF + 1)] = frag(i + kPF);
+                s[i & 1] = E::mfma(ring[i % (kPF + 1)], xf[i >> 1], s[i & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float b0 = s[0][0], b1 = s[1][0];
+            int i0 = 0, i1 = 32;
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                const int c = 8 * (r >> 2) + (r & 3);
+                const bool u0 = s[0][r] > b0, u1 = s[1][r] > b1;
+                b0 = u0 ? s[0][r] : b0, i0 = u0 ? c : i0;
+                b1 = u1 ? s[1][r] : b1, i1 = u1 ? 32 + c : i1;
+            }
+            const bool u = b1 > b0;
+            tb = u ? b1 : b0;
+            ti = (u ? i1 : i0) + 4 * g;
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cch = ((2 * ks + g) ^ ksw0) << 4;
@@ -154,8 +195,8 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
                 s[bb] = E::mfma(a, xf[ks], s[bb]);
             }
         }
-        float tb = s[0][0];
-        int ti = 4 * g;
+        tb = s[0][0];
+        ti = 4 * g;
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -165,6 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
                 tb = upd ? s[bb][r] : tb;
                 ti = upd ? c + 4 * g : ti;
             }
+        }
         const bool upd = tb > best;
         best = upd ? tb : best;
         best_idx = upd ? t * kBN + ti : best_idx;
