@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bit-exactness + timing A/B of the fp8 and the pre-scaled-q attention kernels of two builds of the library, in ONE process on the same inputs:
-    python tools/ab_bitexact.py sparse-videogen_amd/lib/libsvgattn_prev.so [sparse-videogen_amd/lib/libsvgattn.so]
+    python tools/ab_bitexact.py sparse-videogen_amd/lib/libsvgattn_prev.so [sparse-videogen_amd/lib/libsvgattn.so] [--kmeans]
 Both libraries are loaded side by side (svg._native is re-pointed between the calls); for every case the outputs are compared with
 torch.equal — two builds that differ only in instruction selection / scheduling must agree bit for bit — and the kernel times are
 printed (A, B, A again: the third column shows the drift of the box).
@@ -68,8 +68,9 @@ def ab(name, fn, n):
 
 def main():
     dev = torch.device("cuda", 0)
-    LIBS["A"] = str(Path(sys.argv[1]).resolve())
-    LIBS["B"] = str(Path(sys.argv[2]).resolve()) if len(sys.argv) > 2 else str(ROOT / "sparse-videogen_amd" / "lib" / "libsvgattn.so")
+    LIBS["A"] = str(Path([a for a in sys.argv[1:] if not a.startswith("--")][0]).resolve())
+    paths = [a for a in sys.argv[1:] if not a.startswith("--")]
+    LIBS["B"] = str(Path(paths[1]).resolve()) if len(paths) > 1 else str(ROOT / "sparse-videogen_amd" / "lib" / "libsvgattn.so")
     print("A =", LIBS["A"], "\nB =", LIBS["B"])
     ok = True
     BH, D, F_, P_, ctx = 24, 128, 33, 3600, 256
@@ -131,6 +132,21 @@ def main():
         torch.cuda.empty_cache()
 
 
+    if "--kmeans" in sys.argv:
+        # flash-kmeans loop at the Wan 720p geometry (8 of the 40 heads): labels, counts and centroids of two builds must be identical
+        # (e.g. B = `SVG_EXTRA_HIPCC_FLAGS=-DSVG_KMEANS_V2=1 python sparse-videogen_amd/build.py --tag km2` -> lib/libsvgattn_km2.so)
+        from tests.test_gpu_fullsize_svg2 import clustered
+
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        for N, K in ((75600, 1000), (75600, 300)):
+            x = clustered(8, N, 128, 64, gen)
+            init = x[:, :K].contiguous()
+
+            def loop():
+                lab, cent, cnt, n_it, _ = nat.kmeans_loop(x, None, init, 2, 1e-4)
+                return torch.cat([lab.reshape(-1).float(), cnt.reshape(-1).float(), cent.reshape(-1).float()])
+
+            ok &= ab(f"k-means loop N={N} K={K} (8 heads, 2 iterations)", loop, 5)
     print("ALL BIT-IDENTICAL" if ok else "MISMATCH")
     return 0 if ok else 1
 
