@@ -739,6 +739,26 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
         return d;
     };
     i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // (outside the loop: its stale words are the conversions' "old" operand, see attn_body_f8)
+#ifndef SVG_F8_MFMA_ROWSUM
+#define SVG_F8_MFMA_ROWSUM 0
+#endif
+    // SVG_F8_MFMA_ROWSUM (experiment prepared at the end of round 3, NOT measured yet — default off, the default binary is unchanged).
+    // The softmax denominator from the matrix pipe instead of the vector pipe, which is what bounds this kernel:
+    //   * l += one more MFMA per tile, A = a fragment of e4m3 ones: D[d][q] = sum over the tile's 64 keys of the QUANTISED probabilities,
+    //     the same in every row — the whole row sum (both lane halves) lands in every lane of column q: no 32 v_add per tile, no
+    //     cross-lane add at the end, and the normaliser is the sum of exactly what the PV MFMAs multiply (O becomes a true convex
+    //     combination of the quantised weights: the probabilities' rounding no longer biases the scale of the row);
+    //   * the "does every probability fit e4m3" test on the exponent ARGUMENTS (a v_max3 chain: 16 instead of 32 VALU): p <= 448 per
+    //     element is what e4m3 needs, not the sum.
+    // Numerics change (different normaliser, later renormalisation): needs the fp8 tolerances re-measured before it may ship.
+    constexpr bool kRowSumMfma = SVG_F8_MFMA_ROWSUM != 0;
+    f32x16 acc_l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_l[r] = 0.f;
+    const int one4 = 0x38383838;              // four e4m3 ones
+    const i32x8 ones8 = {one4, one4, one4, one4, one4, one4, one4, one4};
+    constexpr float kArgMax = 8.75f;          // 2^8.75 = 430 < 448
+    float arg_thr = -INFINITY;                // kArgMax once every row of the wave has a finite reference
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -778,19 +798,30 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                         const int e = 4 * w8 + i;
                         if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15] + delta);
                         else p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]);
-                        psum += p4[i];
+                        if constexpr (!kRowSumMfma) psum += p4[i];
                     }
                     const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
                     pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
                 }
             };
             probs(std::false_type{}, 0.f);
-            if (__any(!(psum <= psum_thr))) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
-                float mx = s_cur[0][0];
+            float mx = s_cur[0][0];
+            bool exact;
+            if constexpr (kRowSumMfma) {
 #pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
+                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, s_cur[e >> 4][e & 15], s_cur[(e + 1) >> 4][(e + 1) & 15]);
+                mx = vmax2(mx, s_cur[1][15]);
+                exact = __any(!(mx <= arg_thr));
+            } else {
+                exact = __any(!(psum <= psum_thr));
+            }
+            if (exact) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
+                if constexpr (!kRowSumMfma) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
+                }
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_prev = m_off + kPShift;
                 const float m_new = fmaxf(m_ref, mx + m_off);      // (s_cur holds x = scaled score - m_off)
@@ -799,16 +830,22 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 const float delta = m_prev - m_use;
                 m_ref = m_new;
                 psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
+                arg_thr = __any(m_new == -INFINITY) ? -INFINITY : kArgMax;
                 m_off = m_use - kPShift;
                 set_cneg(-m_off);
                 probs(std::true_type{}, delta);
                 l_run *= alpha;
+                if constexpr (kRowSumMfma) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc_l[r] *= alpha;
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
             }
-            l_run += psum;
+            if constexpr (kRowSumMfma) acc_l = mfma_f8(ones8, pf, acc_l);
+            else l_run += psum;
             // ---------------- O^T += V^T P^T: 4 MFMAs, V^T through 4 transpose reads each ----------------
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -829,7 +866,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
         buf ^= 1;
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = kRowSumMfma ? acc_l[0] : l_run + __shfl_xor(l_run, 32);   // (MFMA row sum: every lane of a column holds the whole sum)
     constexpr int kEpiStride = D * 2 + 8;
     char* erow = smem + (size_t)(wave * 32) * kEpiStride;
     {
