@@ -15,7 +15,10 @@ template <typename T>
 __global__ __launch_bounds__(512, 2) void band_attn_f8_kernel(typename BandF8<T>::Params prm, F8Args fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if SVG_F8_PINGPONG
-    attn_body_f8pp<T, BandF8<T>>(prm, fa, smem);
+#ifndef SVG_F8_MFMA_ROWSUM
+#define SVG_F8_MFMA_ROWSUM 0
+#endif
+    attn_body_f8pp<T, BandF8<T>, SVG_F8_MFMA_ROWSUM != 0>(prm, fa, smem);
 #else
     attn_body_f8<T, BandF8<T>>(prm, fa, smem);
 #endif

@@ -292,7 +292,11 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
 // (leading waves) / N(w - 3) (lagging waves), and every wave waits at the end of a vector phase for what it requested in the
 // previous one.  Inputs are those of attn_body_f8 (pre-pass images in logical token order: nothing is gathered).
 // =====================================================================================================================
-template <typename T, typename P>
+// RS (experiment prepared at the end of round 3, NOT measured yet; the kernel instantiates RS = false unless built with
+// -DSVG_F8_MFMA_ROWSUM=1): the row sums from one more MFMA per tile (A = e4m3 ones) in the matrix phase and the e4m3 range test of the
+// vector phase on the exponent arguments — see attn_body_f8g.  A TEMPLATE parameter, so that the discarded statements are not even
+// instantiated for RS = false and the product kernel's code stays what it was, byte for byte.
+template <typename T, typename P, bool RS = false>
 __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, const F8Args& fa, char* smem) {
     using E = Elt<T>;
     constexpr int D = 128, DB = D / 32, KS = D / 64, NW = 8, NS = 4;
@@ -394,6 +398,18 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
         return;
     }
 
+    constexpr bool kRowSumMfma = RS;
+    constexpr float kArgMax = 8.75f;          // 2^8.75 = 430 < 448
+    struct RowSum { f32x16 acc; i32x8 ones; float arg_thr; };
+    struct Nothing {};
+    std::conditional_t<RS, RowSum, Nothing> rs;
+    if constexpr (RS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs.acc[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rs.ones[j] = 0x38383838;      // four e4m3 ones per word
+        rs.arg_thr = -INFINITY;
+    }
     f32x16 sc[2];          // S(t) until the vector phase has turned it into pf, then S(t + 1) accumulates here
     i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // probabilities of tile t (e4m3, slot order of the file header); every word is rewritten
                                            // per tile with its own stale contents as the conversions' "old" operand (see attn_body_f8)
@@ -457,7 +473,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 const int e = 4 * w8 + i;
                 if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15] + delta);
                 else p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
-                psum += p4[i];
+                if constexpr (!RS) psum += p4[i];
             }
             const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
             pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
@@ -482,11 +498,26 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 }
         }
         probs(std::false_type{}, 0.f);
-        if (__any(!(psum <= psum_thr))) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
-            float mx = sc[0][0];
+        bool exact;
+        float mx_args = 0.f;
+        if constexpr (RS) {
+            mx_args = sc[0][0];
 #pragma unroll
-            for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
-            mx = vmax2(mx, sc[1][15]);
+            for (int e = 1; e < 31; e += 2) mx_args = vmax3(mx_args, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+            mx_args = vmax2(mx_args, sc[1][15]);
+            exact = __any(!(mx_args <= rs.arg_thr));
+        } else {
+            exact = __any(!(psum <= psum_thr));
+        }
+        if (exact) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
+            float mx = sc[0][0];
+            if constexpr (RS) {
+                mx = mx_args;
+            } else {
+#pragma unroll
+                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+                mx = vmax2(mx, sc[1][15]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // (sc holds x = scaled score - m_off: the row maximum of the scaled scores is mx + m_off)
             const float m_prev = m_off + kPShift;
@@ -496,16 +527,21 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             const float delta = m_prev - m_use;       // new exponent argument = x + (m_off_old - m_off_new)
             m_ref = m_new;
             psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
+            if constexpr (RS) rs.arg_thr = __any(m_new == -INFINITY) ? -INFINITY : kArgMax;
             m_off = m_use - kPShift;
             set_cneg(-m_off);
             probs(std::true_type{}, delta);
             l_run *= alpha;
+            if constexpr (RS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs.acc[r] *= alpha;
+            }
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
         }
-        l_run += psum;
+        if constexpr (!RS) l_run += psum;
         asm volatile("" : "+v"(pf), "+v"(l_run));      // stays in this phase
         stage_request(t);
     };
@@ -525,6 +561,9 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             if (i + kPF < NALL) ring[(i + kPF) % (kPF + 1)] = fetch(i + kPF);
             if (i < 4) {
                 acc_o[i] = mfma_f8(ring[i % (kPF + 1)], pf, acc_o[i]);
+                if constexpr (RS) {
+                    if (i == 3) rs.acc = mfma_f8(rs.ones, pf, rs.acc);
+                }
             } else {
                 const int j = i - 4, ks = j >> 1, b = j & 1;
                 if (ks == 0) sc[b] = mfma_qk_first(ring[i % (kPF + 1)], qf[ks]);
@@ -559,7 +598,8 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
     if (!kOneBar && !lagging) pp_barrier();
 
     // ---------------- epilogue: as attn_body_f8 ----------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    if constexpr (RS) l_tot = rs.acc[0];      // (every lane of a column holds the whole row sum)
     constexpr int kEpiStride = D * 2 + 8;
     char* erow = smem + (size_t)(wave * 32) * kEpiStride;
     {
