@@ -404,6 +404,16 @@ int svg_varblock_attention_fp8(const void* q, const void* k, const void* v, void
                                const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* EXPERIMENTAL (written at the end of round 3; compiled, NOT yet run on a GPU; nothing in the package calls it by default).
+ * svg_varblock_attention with 16-bit QK^T and e4m3 PV (csrc/attn_f8pv.h): the scores keep their accuracy — on the clustered SVG2
+ * data the error of the all-e4m3 kernel is the scores' (8.6 % all e4m3, 3.6 % with 16-bit QK^T: tools/fp8_precision_study.py) —
+ * while V and the probabilities are e4m3.  Same arguments as svg_varblock_attention_fp8; head_dim 128. */
+size_t svg_varblock_attention_fp8pv_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv, int32_t D);
+int svg_varblock_attention_fp8pv(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
+                                 int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
+                                 const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx,
+                                 const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
  * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is
  * scratch of the library) after its last store of head h, so done_per_head[h] == svg_band_attention_notify_target(S, mask)

@@ -5,6 +5,7 @@
 
 #include "attn_core.h"
 #include "attn_f8.h"
+#include "attn_f8pv.h"
 #include "band_policy.h"
 
 namespace svg {
@@ -335,6 +336,14 @@ __global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8_kernel(ty
                                                                               F8GArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_f8g<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8_lds_bytes<128, kVbF8Waves>());
+}
+
+// mixed form (EXPERIMENTAL, attn_f8pv.h): 16-bit QK^T, e4m3 PV; the same tiling as the fp8 kernel
+template <typename T>
+__global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8pv_kernel(typename VarblockPolicy<T, 128, kVbF8Waves>::Params prm,
+                                                                                F8PVArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_f8pv<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8pv_lds_bytes<kVbF8Waves>());
 }
 
 static inline int vb_policy_lds(int kb_cap) { return (2 * (kb_cap + 2) + 32) * (int)sizeof(int32_t); }
@@ -1043,13 +1052,13 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0, const F8PVArgs* pv = nullptr) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
     int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
     hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
-                       KB, (NW == -9 ? kVbF8Waves : NW < 0 ? 8 : NW) * 32);
+                       KB, ((NW == -9 || NW == -10) ? kVbF8Waves : NW < 0 ? 8 : NW) * 32);
     auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
         constexpr int W = decltype(nw_c)::value;
         using Pol = VarblockPolicy<T, D, W>;
@@ -1063,7 +1072,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
         p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
         p.order = nullptr;
-        if constexpr (NW == -8 || NW == -9) {
+        if constexpr (NW == -8 || NW == -9 || NW == -10) {
             const int group = Hq / Hkv;
             if (!block_row_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
                 int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);          // [2 * Hkv * QB]
@@ -1103,7 +1112,16 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                                        pack ? partner : nullptr, work, hist, order, Hkv, QB, group, BMo);
                 }
                 p.order = order;
-                if constexpr (NW == -9) {
+                if constexpr (NW == -10) {
+                    if constexpr (D == 128) {
+                        auto kern = varblock_attn_f8pv_kernel<T>;
+                        const int lds = attn_f8pv_lds_bytes<kVbF8Waves>() + vb_policy_lds(p.kb_cap);
+                        if (const int rc = configure_lds((const void*)kern, lds); rc != SVG_OK) return rc;
+                        hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(kVbF8Waves * 64), lds, st, p, *pv);
+                        return launch_status();
+                    }
+                    return SVG_ERR_UNSUPPORTED;
+                } else if constexpr (NW == -9) {
                     if constexpr (D == 128) {
                         auto kern = varblock_attn_f8_kernel<T>;
                         const int lds = attn_f8_lds_bytes<128, kVbF8Waves>() + vb_policy_lds(p.kb_cap);
@@ -1125,8 +1143,8 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                                        attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
                 }
             }
-            if constexpr (NW == -9)
-                return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
+            if constexpr (NW == -9 || NW == -10)
+                return SVG_ERR_UNSUPPORTED;   // (the fp8 kernels take the ordered 1-D launch only)
             else
                 return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
                                    attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
@@ -1139,7 +1157,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
         if (rc != SVG_OK) return rc;
         return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
-    } else if constexpr (NW == -9) {   // fp8 body
+    } else if constexpr (NW == -9 || NW == -10) {   // fp8 bodies
         return launch(std::integral_constant<int, kVbF8Waves>{}, 0, tile_off, Sq / (kVbF8Waves * 32) + QB);
     } else if constexpr (NW == -8) {   // two-phase ping-pong body, 256-row q tiles
         return launch(std::integral_constant<int, 8>{}, 0, tile_off, Sq / 256 + QB);
@@ -1220,5 +1238,38 @@ extern "C" int svg_varblock_attention_fp8(const void* q, const void* k, const vo
     if (dtype == SVG_DTYPE_F16)
         return run_varblock<_Float16, 128, -9>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
                                               kv_row_idx, workspace, false, false, st, &fa);
+    return SVG_ERR_UNSUPPORTED;
+}
+
+// EXPERIMENTAL (end of round 3, not yet run on a GPU): variable-block attention with 16-bit QK^T and e4m3 PV (attn_f8pv.h).
+extern "C" size_t svg_varblock_attention_fp8pv_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv,
+                                                               int32_t D) {
+    if (D != 128) return 0;
+    const size_t plan = svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq);
+    if (plan == 0 || Skv <= 0) return 0;
+    return ((plan + 255) & ~(size_t)255) + f8pv_ws_bytes(Hq, Hkv, Sq, Skv);
+}
+
+extern "C" int svg_varblock_attention_fp8pv(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
+                                            int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
+                                            const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
+                                            const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
+    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
+    if (D != 128 || KB > kVbMaxKB || QB >= 32768 || Sq / 256 + 1 >= 65536) return SVG_ERR_UNSUPPORTED;
+    if ((int64_t)Skv * D * 2 >= (1ll << 32) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_varblock_attention_fp8pv_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plan = (svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq) + 255) & ~(size_t)255;
+    F8PVArgs fa;
+    int rc = f8pv_prepare(q, v, Hq, Hkv, Sq, Skv, dtype, sm_scale, (char*)workspace + plan, &fa, st);
+    if (rc != SVG_OK) return rc;
+    if (dtype == SVG_DTYPE_BF16)
+        return run_varblock<__bf16, 128, -10>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
+                                             kv_row_idx, workspace, false, false, st, nullptr, 0, &fa);
+    if (dtype == SVG_DTYPE_F16)
+        return run_varblock<_Float16, 128, -10>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
+                                               kv_row_idx, workspace, false, false, st, nullptr, 0, &fa);
     return SVG_ERR_UNSUPPORTED;
 }

@@ -459,6 +459,12 @@ size_t f8g_ws_bytes(int Hq, int Hkv, int Sq, int Skv);
 int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws,
                  F8GArgs* fa, hipStream_t st);
 
+// mixed body (attn_f8pv.h, EXPERIMENTAL): pre-pass in attention_f8.hip — q * sm_scale * log2(e) rounded to T, v quantised to e4m3
+struct F8PVArgs;
+size_t f8pv_ws_bytes(int Hq, int Hkv, int Sq, int Skv);
+int f8pv_prepare(const void* q, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws, F8PVArgs* fa,
+                 hipStream_t st);
+
 // 4 waves x 64 rows, one wave per SIMD (attn_body_w4, attention_w4.hip)
 int run_band_w4(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,
                 const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const BandOpts& opts, hipStream_t st);

@@ -89,13 +89,13 @@ def test_first_step_mfmas_have_no_hazards(f8_listings, capsys):
     for f in f8_listings:
         assert f.exists(), f"build.py keeps the assembly of {f.name}"
     seen = 0
-    for f in f8_listings:                                    # {band, varblock} x {bf16, f16} fp8 kernels: 2 asm MFMAs each
+    for f in f8_listings:                                    # {band, varblock, varblock mixed (attn_f8pv.h)} x {bf16, f16}: 2 asm MFMAs each
         rc, out, kernels = _audit(audit, capsys, "attn_f8", f)
         seen += len(kernels)
         assert rc == 0, out
         for l in kernels:
             assert "2 asm MFMAs, 0 hazards" in l, l
-    assert seen == 4, seen
+    assert seen == 6, seen
     rc, out, kernels = _audit(audit, capsys, "pp2q", f8_listings[0])   # pre-scaled band kernels: {plain, switch} x dtype x head_dim
     assert rc == 0, out
     assert not any("trace" in l for l in kernels), "the kept listing is the PRODUCT build's (an -DSVG_ABLATIONS build has the trace kernels)"

@@ -20,3 +20,5 @@ for t in cur ms64 cur ms64; do
   echo "== $t"; SVG_ATTN_LIB=$L/$f timeout 200 python tools/svg1_models.py pre 2>>$O/err.txt | grep -i "cog"
 done 2>&1 | tee $O/ab_cog_mfmasum.txt
 SVG_ATTN_LIB=$L/libsvgattn_ms64.so timeout 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_prescaled.py tests/test_gpu_fullsize.py -q -k "64 or cog" 2>&1 | tail -3 | tee $O/pytest_d64_mfmasum.txt
+# 4. the mixed-precision SVG2 body (csrc/attn_f8pv.h): first run ever
+SVG_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gpu_experimental.py -q -s 2>&1 | tail -8 | tee $O/pytest_experimental.txt
