@@ -234,6 +234,14 @@ int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, v
  * many to launch) but cannot change the result.  n_iters: device int32, the iterations the reference's loop would have run.
  * c_init [B, K, D] is not written; c_work_a / c_work_b [B, K, D] are scratch; centroids_out [B, K, D]; labels / sorted_idx int32
  * [B, N]; counts int32 [B, K].  Replaces ~10 framework micro-launches per iteration of the host-driven loop. */
+/* The two halves of svg_kmeans_iter as entry points of their own (host plumbing added at the end of round 3; the kernels are the ones
+ * svg_kmeans_iter launches): ref euclid_assign_triton svg/kmeans_utils.py:562-627 and triton_centroid_update_sorted_euclid :375-421.
+ * workspace: svg_kmeans_workspace_bytes(B, N, K, D).  labels int32 [B, N]; counts int32 [B, K]; sorted_idx int32 [B, N]; shift float [B]. */
+int svg_kmeans_assign(const void* x, const void* centroids, int32_t* labels, int32_t B, int32_t N, int32_t K, int32_t D, int32_t dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int svg_kmeans_update(const void* x, const int32_t* labels, const void* centroids_in, void* centroids_out, int32_t* counts,
+                      int32_t* sorted_idx, float* shift, int32_t B, int32_t N, int32_t K, int32_t D, int32_t dtype, void* workspace,
+                      size_t workspace_bytes, void* stream);
 size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D);
 int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
                     int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N, int32_t K,

@@ -288,21 +288,28 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict_
     }
 }
 
+// the two halves of an iteration (the reference's euclid_assign_triton / triton_centroid_update_sorted_euclid, svg/kmeans_utils.py:562-627,
+// 375-421) as host functions of their own: svg_kmeans_iter runs one after the other, svg_kmeans_assign / svg_kmeans_update expose them
 template <typename T, int D>
-static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, void* c_out, int32_t* labels, int32_t* counts,
-                           int32_t* sorted_idx, float* shift, int B, int N, int K, void* ws, size_t ws_bytes,
-                           hipStream_t st) {
+static int run_kmeans_assign(const void* x, const float* xsq, const void* c_in, int32_t* labels, int B, int N, int K, void* ws,
+                             hipStream_t st) {
     constexpr int NW = 8;
     float* csq = (float*)ws;
-    const size_t csq_bytes = ((size_t)B * K * sizeof(float) + 255) / 256 * 256;
-    char* sort_ws = (char*)ws + csq_bytes;
-    const size_t sort_bytes = svg_argsort_workspace_bytes(B, N, K);
     hipLaunchKernelGGL((csq_kernel<T>), dim3(std::min<long long>(2048, ((long long)B * K + 15) / 16)), dim3(256), 0, st,
                        (const T*)c_in, csq, (long long)B * K, D);
     constexpr int lds = 2 * (LdsLayout<D>::kKBytes + kBN * 4);
     auto kern = kmeans_assign_kernel<T, D, NW>;
     hipLaunchKernelGGL(kern, dim3((N + NW * 32 - 1) / (NW * 32), B), dim3(NW * 64), lds, st, (const T*)x, (const T*)c_in, xsq,
                        csq, labels, N, K);
+    return launch_status();
+}
+
+template <typename T, int D>
+static int run_kmeans_update(const void* x, const void* c_in, void* c_out, const int32_t* labels, int32_t* counts, int32_t* sorted_idx,
+                             float* shift, int B, int N, int K, void* ws, hipStream_t st) {
+    const size_t csq_bytes = ((size_t)B * K * sizeof(float) + 255) / 256 * 256;
+    char* sort_ws = (char*)ws + csq_bytes;
+    const size_t sort_bytes = svg_argsort_workspace_bytes(B, N, K);
     int rc = svg_argsort_labels(labels, sorted_idx, counts, B, N, K, sort_ws, sort_bytes, (void*)st);
     if (rc) return rc;
     (void)hipMemsetAsync(shift, 0, (size_t)B * sizeof(float), st);
@@ -310,6 +317,15 @@ static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, vo
     hipLaunchKernelGGL((kmeans_update_kernel<T, D>), dim3(K, B), dim3(256), 0, st, (const T*)x, (const T*)c_in, (T*)c_out,
                        sorted_idx, (const int32_t*)sort_ws, counts, shift, N, K, (size_t)nchunks * K);
     return launch_status();
+}
+
+template <typename T, int D>
+static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, void* c_out, int32_t* labels, int32_t* counts,
+                           int32_t* sorted_idx, float* shift, int B, int N, int K, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    (void)ws_bytes;
+    if (const int rc = run_kmeans_assign<T, D>(x, xsq, c_in, labels, B, N, K, ws, st); rc != SVG_OK) return rc;
+    return run_kmeans_update<T, D>(x, c_in, c_out, labels, counts, sorted_idx, shift, B, N, K, ws, st);
 }
 
 // ---- the Lloyd loop on the device (svg_kmeans_loop): commit of one iteration's result under the reference's stopping rule ----
@@ -407,6 +423,44 @@ extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* cent
     }
     return SVG_ERR_UNSUPPORTED;
 }
+
+#define SVG_KM_DISPATCH(CALL)                                                                  \
+    if (dtype == SVG_DTYPE_BF16) {                                                             \
+        if (D == 128) return CALL(__bf16, 128);                                                \
+        if (D == 64) return CALL(__bf16, 64);                                                  \
+    } else if (dtype == SVG_DTYPE_F16) {                                                       \
+        if (D == 128) return CALL(_Float16, 128);                                              \
+        if (D == 64) return CALL(_Float16, 64);                                                \
+    }                                                                                          \
+    return SVG_ERR_UNSUPPORTED;
+
+// labels[b, n] = argmin_k |x[b, n] - centroids[b, k]|^2 (lowest index on ties): the assignment half of svg_kmeans_iter on its own.
+extern "C" int svg_kmeans_assign(const void* x, const void* centroids, int32_t* labels, int32_t B, int32_t N, int32_t K, int32_t D,
+                                 int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !centroids || !labels || !workspace || B <= 0 || N <= 0 || K <= 0) return SVG_ERR_BAD_ARG;
+    if (K > 8192) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_kmeans_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+#define SVG_KM_ASSIGN(T, DD) run_kmeans_assign<T, DD>(x, nullptr, centroids, labels, B, N, K, workspace, st)
+    SVG_KM_DISPATCH(SVG_KM_ASSIGN)
+#undef SVG_KM_ASSIGN
+}
+
+// The update half on GIVEN labels: stable sort of the labels, per-cluster fp32 means in a fixed order, empty clusters keep
+// centroids_in, shift[b] = the largest centre movement (as svg_kmeans_iter).
+extern "C" int svg_kmeans_update(const void* x, const int32_t* labels, const void* centroids_in, void* centroids_out, int32_t* counts,
+                                 int32_t* sorted_idx, float* shift, int32_t B, int32_t N, int32_t K, int32_t D, int32_t dtype,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !labels || !centroids_in || !centroids_out || !counts || !sorted_idx || !shift || !workspace) return SVG_ERR_BAD_ARG;
+    if (B <= 0 || N <= 0 || K <= 0) return SVG_ERR_BAD_ARG;
+    if (K > 8192) return SVG_ERR_UNSUPPORTED;
+    if (workspace_bytes < svg_kmeans_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+#define SVG_KM_UPDATE(T, DD) run_kmeans_update<T, DD>(x, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K, workspace, st)
+    SVG_KM_DISPATCH(SVG_KM_UPDATE)
+#undef SVG_KM_UPDATE
+}
+#undef SVG_KM_DISPATCH
 
 extern "C" size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t D) {
     const size_t it = svg_kmeans_workspace_bytes(B, N, K, D);

@@ -148,6 +148,8 @@ SIGNATURES = {
     "svg_kmeans_xsq": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_kmeans_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
     "svg_kmeans_iter": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
+    "svg_kmeans_assign": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
+    "svg_kmeans_update": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_kmeans_loop_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
     "svg_kmeans_loop": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _SZ, _VP]),
     "svg_identify_dynamic_map": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, _I32, _VP]),
@@ -620,6 +622,40 @@ def kmeans_iter(x: torch.Tensor, xsq: Optional[torch.Tensor], c_in: torch.Tensor
                              buf.counts.data_ptr(), buf.sorted_idx.data_ptr(), buf.shift.data_ptr(), B, N, K, D,
                              _dtype_code(x), buf.ws.data_ptr(), buf.ws.numel(), _stream())
     _check(rc, "svg_kmeans_iter")
+
+
+def kmeans_assign(x: torch.Tensor, centroids: torch.Tensor) -> torch.Tensor:
+    """labels int32 [B, N] of the nearest centroid (lowest index on ties): the assignment half of kmeans_iter (svg_kmeans_assign)"""
+    lib = load()
+    _dev(x, centroids)
+    B, N, D = x.shape
+    K = centroids.shape[1]
+    assert centroids.shape == (B, K, D) and centroids.dtype == x.dtype and x.is_contiguous() and centroids.is_contiguous()
+    labels = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    ws = torch.empty(lib.svg_kmeans_workspace_bytes(B, N, K, D), dtype=torch.uint8, device=x.device)
+    _check(lib.svg_kmeans_assign(x.data_ptr(), centroids.data_ptr(), labels.data_ptr(), B, N, K, D, _dtype_code(x), ws.data_ptr(),
+                                 ws.numel(), _stream()), "svg_kmeans_assign")
+    return labels
+
+
+def kmeans_update(x: torch.Tensor, labels: torch.Tensor, centroids_in: torch.Tensor):
+    """The update half on given labels (svg_kmeans_update) -> (centroids [B, K, D] of x.dtype, counts int32 [B, K], sorted_idx int32
+    [B, N], shift float32 [B]); empty clusters keep centroids_in."""
+    lib = load()
+    _dev(x, labels, centroids_in)
+    B, N, D = x.shape
+    K = centroids_in.shape[1]
+    assert labels.dtype == torch.int32 and labels.shape == (B, N) and labels.is_contiguous()
+    assert centroids_in.shape == (B, K, D) and centroids_in.dtype == x.dtype and x.is_contiguous() and centroids_in.is_contiguous()
+    cent = torch.empty_like(centroids_in)
+    counts = torch.empty((B, K), dtype=torch.int32, device=x.device)
+    sorted_idx = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    shift = torch.empty((B,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.svg_kmeans_workspace_bytes(B, N, K, D), dtype=torch.uint8, device=x.device)
+    _check(lib.svg_kmeans_update(x.data_ptr(), labels.data_ptr(), centroids_in.data_ptr(), cent.data_ptr(), counts.data_ptr(),
+                                 sorted_idx.data_ptr(), shift.data_ptr(), B, N, K, D, _dtype_code(x), ws.data_ptr(), ws.numel(), _stream()),
+           "svg_kmeans_update")
+    return cent, counts, sorted_idx, shift
 
 
 def kmeans_loop(x: torch.Tensor, xsq: Optional[torch.Tensor], c_init: torch.Tensor, max_iters: int, tol: float, work=None):

@@ -230,3 +230,30 @@ def dynamic_block_sparse_fwd_triton(q, k, v, dynamic_map, qc_size, kc_size):
     kernel as `dynamic_block_sparse_fwd_flashinfer` (tests/test_gpu_triton_golden.py compares that kernel with the OUTPUT of the
     reference's Triton kernel)."""
     return dynamic_block_sparse_fwd_flashinfer(q, k, v, dynamic_map, qc_size, kc_size, is_cpu=False)
+
+
+# ---- the two halves of a Euclidean iteration under the reference's names (ref svg/kmeans_utils.py:562-627, 375-421, 208-255) ----
+# (host plumbing added at the end of round 3 on the kernels batch_kmeans_Euclid runs; GPU test: tests/test_gpu_experimental.py)
+def euclid_assign_triton(x, centroids, x_sq=None, out=None, *, BLOCK_N: int = 128, BLOCK_K: int = 128):
+    """-> cluster ids int64 [B, N] (ref :562-627).  `x_sq` and the tile sizes are accepted and not needed: the HIP kernel takes
+    argmax_k (<x, c_k> - |c_k|^2 / 2), with fp32 centroid norms (the Triton kernel reduces them in the input type)."""
+    assert x.is_cuda and centroids.is_cuda, "All tensors must be on CUDA"
+    assert centroids.dtype == x.dtype, "centroids dtype mismatch"
+    ids = _native.kmeans_assign(x.contiguous(), centroids.contiguous()).to(torch.int64)
+    if out is not None:
+        out.copy_(ids)
+        return out
+    return ids
+
+
+def triton_centroid_update_sorted_euclid(x, cluster_ids, old_centroids, *, BLOCK_N: int = 256):
+    """-> (centroids [B, K, D] of x.dtype, counts int32 [B, K]) (ref :375-421): fp32 means in a fixed order (bit-reproducible, unlike
+    the reference's atomics), empty clusters keep the old centroid."""
+    assert x.is_cuda and cluster_ids.is_cuda, "Inputs must be on CUDA device"
+    cent, counts, _, _ = _native.kmeans_update(x.contiguous(), cluster_ids.to(torch.int32).contiguous(), old_centroids.to(x.dtype).contiguous())
+    return cent, counts
+
+
+def triton_centroid_update_euclid(x, cluster_ids, old_centroids):
+    """ref :208-255 (the unsorted, one-atomic-per-token kernel): the same result as the sorted form -> centroids only"""
+    return triton_centroid_update_sorted_euclid(x, cluster_ids, old_centroids)[0]

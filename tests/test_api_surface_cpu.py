@@ -65,8 +65,6 @@ OUT_OF_SCOPE_NAMES = {
         # other clustering back-ends the processors never call (cuVS, cosine / dot k-means) and their kernels' wrappers
         "pairwise_distance", "kmeans_predict", "kmeans_rapidai", "batch_kmeans_rapidai", "batch_kmeans_Cosine", "batch_kmeans_Dot",
         "triton_centroid_update_cosine", "torch_loop_centroid_update_cosine", "triton_centroid_update_sorted_cosine",
-        # the two halves of one Euclidean iteration as separate calls: here one launch sequence (svg_kmeans_iter / svg_kmeans_loop)
-        "triton_centroid_update_euclid", "triton_centroid_update_sorted_euclid", "euclid_assign_triton",
     },
     "svg.kernels.ops.attention_ops_wan": {"visualize_attention_mask"},          # matplotlib figure of the mask
     "svg.models.utils": {"pseudo_quantize_absmax_perhead"},                     # an unused quantisation experiment

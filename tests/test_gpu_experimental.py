@@ -50,3 +50,44 @@ def test_varblock_mixed_precision_body(nat, dt, Hq, Hkv):
     print(f"[mixed body {dt} Hq={Hq} Hkv={Hkv}] rel L2 vs fp32 oracle: 16-bit {e_16:.2e}, mixed {e_pv:.2e}, all-e4m3 {e_f8:.2e}")
     assert torch.isfinite(o_pv).all() and rows.numel() == S
     assert e_16 < 5e-3 and e_pv < 4.5e-2 and e_pv < e_f8
+
+
+@pytest.mark.parametrize("tag", ["as_c", "as_d"])
+def test_euclid_assign_under_the_references_name(nat, tag):
+    """svg.kmeans_utils.euclid_assign_triton (svg_kmeans_assign) against the fixture the reference's Triton kernel produced — the same
+    check as tests/test_gpu_triton_golden.py makes on svg_kmeans_iter's labels"""
+    import numpy as np
+
+    from svg.kmeans_utils import euclid_assign_triton
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+    x, c, ids = (torch.from_numpy(g[tag + s]) for s in ("_x", "_c", "_ids"))
+    lab = euclid_assign_triton(x.cuda(), c.cuda(), None).cpu()
+    assert lab.dtype == torch.int64
+    d = O.kmeans_distances(x, O.kmeans_xsq(x), c)
+    mine = d.argmin(-1)
+    dif = lab != mine
+    assert dif.float().mean().item() < 0.01
+    assert ((d.gather(2, lab[..., None]) - d.gather(2, mine[..., None]))[..., 0][dif].abs() <= 1e-3 * d.abs().max()).all()
+    assert (lab != ids.long()).float().mean().item() < 0.2          # the Triton kernel's fp16 norms re-label near-ties
+    buf = nat.KmeansBuffers(*x.shape[:2], c.shape[1], x.shape[2], "cuda")
+    nat.kmeans_iter(x.cuda(), None, c.cuda(), torch.empty_like(c).cuda(), buf)
+    assert torch.equal(buf.labels.cpu().long(), lab), "the half is the whole iteration's assignment"
+
+
+def test_centroid_update_under_the_references_name(nat):
+    """svg.kmeans_utils.triton_centroid_update_sorted_euclid (svg_kmeans_update) against the fixture the reference's kernel produced"""
+    import numpy as np
+
+    from svg.kmeans_utils import triton_centroid_update_euclid, triton_centroid_update_sorted_euclid
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+    x, ids, old = (torch.from_numpy(g["up_b" + s]) for s in ("_x", "_ids", "_old"))       # fp16, D = 128, K = 40, one empty cluster
+    ref, cnt = torch.from_numpy(g["up_b_cent"]), torch.from_numpy(g["up_b_cnt"])
+    cent, counts = triton_centroid_update_sorted_euclid(x.cuda(), ids.long().cuda(), old.cuda())
+    assert torch.equal(counts.cpu(), cnt) and cent.dtype == x.dtype
+    ulp = torch.finfo(x.dtype).eps * ref.float().abs().clamp_min(2.0 ** -14)
+    assert ((cent.float().cpu() - ref.float()).abs() <= ulp).all()
+    empty = cnt == 0
+    assert empty.any() and torch.equal(cent.cpu()[empty], old[empty])
+    assert torch.equal(triton_centroid_update_euclid(x.cuda(), ids.long().cuda(), old.cuda()), cent)
