@@ -425,6 +425,91 @@ def main():
     m_ = seen["mse"].float()
     print(f"call_wan: Wan SVG processor __call__ S={S}: best_mask_idx {best.tolist()}, MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, out {tuple(o.shape)}")
 
+    # ---------------- 12. the whole `__call__` of the reference's Hunyuan SVG processor: double-stream and single-stream block ----------------
+    # Hunyuan_SVGAttn_Processor2_0.__call__ (hyvideo/attention.py:328-374) with the reference's own fall-backs for the CUDA extension that is
+    # not built here (:196-224: the norm modules' forward, diffusers' apply_rotary_emb on the video rows).  diffusers is absent (a dependency
+    # of the reference, not vendored): for its `apply_rotary_emb(x, (cos, sin))` the REFERENCE'S OWN statement of that function is loaded from
+    # the reference's kernel test (ref_host_apply_rope, svg/kernels/test/test_apply_rope.py:24-37, "Ref: diffusers/models/embeddings.py").
+    # Everything else is the reference's code as it is: projections, per-head RMSNorm, RoPE on the video rows only, the text stream's own
+    # projections and norms (double) or the concatenated sequence (single), attention_core_logic as in section 9, the split and the output
+    # projections.
+    import importlib.util
+
+    if "_kernels" not in sys.modules:
+        MG._stub("_kernels")         # the test module imports the CUDA extension at the top; only its host reference is used (stubbed AFTER
+                                     # the processors were imported: they took their fall-back branch, ENABLE_FAST_KERNEL False)
+    spec = importlib.util.spec_from_file_location("ref_test_apply_rope", Path(MG.REF) / "svg/kernels/test/test_apply_rope.py")
+    ref_rope = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_rope)
+    hy_attn.apply_rotary_emb = lambda x, freqs_cis: ref_rope.ref_host_apply_rope(x, freqs_cis[0], freqs_cis[1])
+    heads, hd, F_, P_, ctx, L, mul = 2, 64, 4, 128, 32, 20, 1.4
+    dim, V = heads * hd, F_ * P_
+    S = V + ctx
+    for tag, single in (("call_hyd", False), ("call_hys", True)):
+        g = torch.Generator().manual_seed(321 + single)
+        attn = standins.Attention(dim, heads, qk_norm="rms", added_kv=not single, dtype=torch.float32)
+
+        def h16(*shape, s=1.0):
+            return (torch.randn(*shape, generator=g) * s).half().float()
+
+        with torch.no_grad():
+            for lin in (attn.to_q, attn.to_k):
+                lin.weight.copy_(torch.eye(dim))
+                lin.bias.zero_()
+            attn.to_v.weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_v.bias.copy_(h16(dim, s=0.1))
+            chan_w = torch.cat([torch.full((48,), 1.6), torch.full((16,), 0.03)])
+            attn.norm_q.weight.copy_((chan_w * (1 + 0.1 * torch.randn(hd, generator=g))).half().float())
+            attn.norm_k.weight.copy_((chan_w * (1 + 0.1 * torch.randn(hd, generator=g))).half().float())
+            if single:
+                attn.to_out = None                               # HunyuanVideo's single-stream blocks are `pre_only`: no output projection
+            else:
+                attn.to_out[0].weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_out[0].bias.copy_(h16(dim, s=0.1))
+                for lin in (attn.add_q_proj, attn.add_k_proj, attn.add_v_proj, attn.to_add_out):
+                    lin.weight.copy_(h16(dim, dim, s=dim ** -0.5)), lin.bias.copy_(h16(dim, s=0.1))
+                attn.norm_added_q.weight.copy_((1 + 0.1 * torch.randn(hd, generator=g)).half().float())
+                attn.norm_added_k.weight.copy_((1 + 0.1 * torch.randn(hd, generator=g)).half().float())
+        i = torch.arange(V)
+        pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}
+        freqs = torch.arange(1, 25).float()
+        feats = []
+        for kind in (0, 1):
+            ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * V)
+            feats.append(torch.cat([torch.cos(ang) * 2.2, torch.sin(ang) * 2.2, 1.5 * torch.randn(V, 16, generator=g)], 1))
+        hidden = (torch.cat(feats, 1)[None] + 0.05 * torch.randn(1, V, dim, generator=g)).half().float()
+        enc = h16(1, ctx, dim)
+        rope_ang = 0.03 * torch.rand(V, hd // 2, generator=g)
+        rope = (rope_ang.cos().repeat_interleave(2, -1), rope_ang.sin().repeat_interleave(2, -1))    # [V, hd], pair (2i, 2i+1) shares an angle
+        amask = torch.zeros(S, dtype=torch.bool)
+        amask[:V + L] = True
+        cls = hy_attn.Hunyuan_SVGAttn_Processor2_0
+        cls.context_length, cls.num_frame, cls.frame_size, cls.num_sampled_rows, cls.sample_mse_max_row = ctx, F_, P_, 32, V
+        cls.prompt_length, cls.first_layers_fp, cls.first_times_fp = L, 0, 1.0
+        cls.attention_masks = [hy_u.get_attention_mask("spatial", V, ctx, F_, P_), hy_u.get_attention_mask("temporal", V, ctx, F_, P_, device="cpu")]
+        cls.block_mask = create_block_mask(hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), None, None, S, S, device="cpu")
+        proc = cls(0)
+        seen = {}
+        orig_mse = proc.sample_mse
+        proc.sample_mse = lambda a, b, c, _o=orig_mse, _s=seen: _s.setdefault("mse", _o(a, b, c))
+        torch.manual_seed(5)
+        with torch.no_grad():
+            o_h, o_e = proc(attn, hidden, encoder_hidden_states=enc, attention_mask=amask, image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+        m_ = seen["mse"].float()
+        best = m_.argmin(0)
+        out[f"{tag}_hidden"], out[f"{tag}_enc"] = hidden.half().numpy(), enc.half().numpy()
+        out[f"{tag}_o_h"], out[f"{tag}_o_e"], out[f"{tag}_best"] = o_h.half().numpy(), o_e.half().numpy(), best.numpy()
+        out[f"{tag}_rope_ang"] = rope_ang.numpy()
+        names = [("wv", attn.to_v.weight), ("bv", attn.to_v.bias), ("nq", attn.norm_q.weight), ("nk", attn.norm_k.weight)]
+        if not single:
+            names += [("wo", attn.to_out[0].weight), ("bo", attn.to_out[0].bias), ("naq", attn.norm_added_q.weight), ("nak", attn.norm_added_k.weight)]
+            for n, lin in (("aq", attn.add_q_proj), ("ak", attn.add_k_proj), ("av", attn.add_v_proj), ("ao", attn.to_add_out)):
+                names += [("w" + n, lin.weight), ("b" + n, lin.bias)]
+        for n, t in names:
+            out[f"{tag}_{n}"] = t.detach().half().numpy()
+        out[f"{tag}_geo"] = np.array([heads, hd, F_, P_, ctx, L], dtype=np.int64)
+        out[f"{tag}_mul"] = np.float64(mul)
+        print(f"{tag}: Hunyuan SVG processor __call__ ({'single' if single else 'double'}-stream) S={S}: best_mask_idx {best.tolist()}, "
+              f"MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, out {tuple(o_h.shape)} + {tuple(o_e.shape)}")
+
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)
     print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")

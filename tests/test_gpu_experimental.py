@@ -91,3 +91,71 @@ def test_centroid_update_under_the_references_name(nat):
     empty = cnt == 0
     assert empty.any() and torch.equal(cent.cpu()[empty], old[empty])
     assert torch.equal(triton_centroid_update_euclid(x.cuda(), ids.long().cuda(), old.cuda()), cent)
+
+
+@pytest.mark.parametrize("tag", ["call_hyd", "call_hys"])
+def test_hunyuan_processor_call_equals_the_references_call(nat, tag):
+    """NOT experimental code — a parity test written when the round's GPU budget was spent, parked here until it has run once (then it
+    moves to tests/test_gpu_triton_golden.py).  The product's Hunyuan_SVGAttn_Processor2_0.__call__ on a duck-typed attention module
+    (fp16 weights and inputs, HIP path) against the OUTPUT of the reference's processor `__call__` executed in fp32 on the same
+    fp16-representable weights and inputs (tests/golden/make_golden_triton.py section 12): double-stream block (text stream with its own
+    projections / norms / output projection) and single-stream block (concatenated sequence, no output projection).  Same profiler
+    decisions, both outputs equal to 16-bit accuracy."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from standins import Attention
+    from svg.models.hyvideo.attention import Hunyuan_SVGAttn_Processor2_0 as cls
+    from svg.models.hyvideo.utils import generate_temporal_head_mask_mod
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+
+    def T(name):
+        return torch.from_numpy(g[f"{tag}_{name}"])
+
+    single = tag == "call_hys"
+    heads, hd, F_, P_, ctx, L = (int(x) for x in g[tag + "_geo"])
+    mul, best = float(g[tag + "_mul"]), T("best")
+    dim, V = heads * hd, F_ * P_
+    S = V + ctx
+    dt = torch.float16
+    attn = Attention(dim, heads, qk_norm="rms", added_kv=not single, dtype=dt)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(T("wv")), attn.to_v.bias.copy_(T("bv"))
+        attn.norm_q.weight.copy_(T("nq")), attn.norm_k.weight.copy_(T("nk"))
+        if single:
+            attn.to_out = None
+        else:
+            attn.to_out[0].weight.copy_(T("wo")), attn.to_out[0].bias.copy_(T("bo"))
+            attn.norm_added_q.weight.copy_(T("naq")), attn.norm_added_k.weight.copy_(T("nak"))
+            for n, lin in (("aq", attn.add_q_proj), ("ak", attn.add_k_proj), ("av", attn.add_v_proj), ("ao", attn.to_add_out)):
+                lin.weight.copy_(T("w" + n)), lin.bias.copy_(T("b" + n))
+    attn.cuda()
+    names = ("context_length", "num_frame", "frame_size", "num_sampled_rows", "sample_mse_max_row", "prompt_length", "first_layers_fp",
+             "first_times_fp", "block_mask")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (ctx, F_, P_, 32, V, L, 0, 1.0, generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul))):
+            setattr(cls, n, val)
+        attn.set_processor(cls(0))
+        ang = T("rope_ang").float().cuda()
+        rope = (ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1))
+        amask = torch.zeros(S, dtype=torch.bool, device="cuda")
+        amask[:V + L] = True
+        with torch.no_grad():
+            o_h, o_e = attn(T("hidden").cuda(), encoder_hidden_states=T("enc").cuda(), attention_mask=amask, image_rotary_emb=rope,
+                            timestep=torch.tensor([0.5]))
+        torch.cuda.synchronize()
+        assert torch.equal(attn.processor.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
+        for got, name in ((o_h, "o_h"), (o_e, "o_e")):
+            ref = T(name).float()
+            e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+            assert e < 5e-3, (name, e)
+            torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)

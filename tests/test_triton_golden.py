@@ -323,3 +323,43 @@ def test_wan_processor_call_end_to_end(g):
     out = o.transpose(1, 2).flatten(2, 3) @ t["wo"].T + t["bo"]
     torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
     assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["call_hyd", "call_hys"])
+def test_hunyuan_processor_call_end_to_end(g, tag):
+    """Fixture: the whole `__call__` of the reference's Hunyuan_SVGAttn_Processor2_0 (hyvideo/attention.py:328-374) on a duck-typed attention
+    module, as a double-stream block (the text stream has its own projections and norms, both streams have an output projection) and as
+    a single-stream block (one concatenated sequence, no output projection): per-head RMSNorm, RoPE on the video rows only (the reference's
+    own statement of diffusers' apply_rotary_emb), attention_core_logic, the split.  The oracle's statement of the same call."""
+    single = tag == "call_hys"
+    heads, hd, F_, P_, ctx, L = (int(x) for x in g[tag + "_geo"])
+    mul, best = float(g[tag + "_mul"]), T(g[tag + "_best"])
+    t = {n[len(tag) + 1:]: T(g[n]).float() for n in g.files if n.startswith(tag + "_") and n.split("_")[-1] not in ("geo", "mul", "best")}
+    V = F_ * P_
+    S = V + ctx
+    assert best.tolist() == [[0, 1]]
+
+    def rms(y, w):                                   # the norm module's forward (fall-back branch :198-203); fp32 here: no rounding
+        return y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+
+    def split(y):
+        return y.unflatten(2, (heads, -1)).transpose(1, 2)
+
+    x = torch.cat([t["hidden"], t["enc"]], 1) if single else t["hidden"]
+    q, k, v = split(x), split(x), split(x @ t["wv"].T + t["bv"])              # to_q / to_k are the identity in the fixture
+    q, k = rms(q, t["nq"]), rms(k, t["nk"])
+    cos, sin = (f(t["rope_ang"]).repeat_interleave(2, -1) for f in (torch.cos, torch.sin))
+    q, k = O.apply_qk_rope(q, k, cos, sin, ctx if single else 0, "txtlast")
+    if not single:
+        e = t["enc"]
+        eq, ek, ev = (split(e @ t["w" + n].T + t["b" + n]) for n in ("aq", "ak", "av"))
+        q, k, v = torch.cat([q, rms(eq, t["naq"])], 2), torch.cat([k, rms(ek, t["nak"])], 2), torch.cat([v, ev], 2)
+    qp, kp, vp = (O.head_placement(y, best, ctx, F_, P_) for y in (q, k, v))
+    o = O.head_placement(O.masked_attention(qp, kp, vp, O.hy_mask(S, ctx, L, F_, P_, mul)), best, ctx, F_, P_, inverse=True)
+    o = o.transpose(1, 2).flatten(2, 3)
+    o_h, o_e = o[:, :V], o[:, V:]
+    if not single:
+        o_h, o_e = o_h @ t["wo"].T + t["bo"], o_e @ t["wao"].T + t["bao"]
+    for got, want in ((o_h, t["o_h"]), (o_e, t["o_e"])):
+        torch.testing.assert_close(got, want, atol=3e-3, rtol=3e-3)
+        assert ((got - want).norm() / want.norm()).item() < 1e-3
