@@ -510,6 +510,76 @@ def main():
         print(f"{tag}: Hunyuan SVG processor __call__ ({'single' if single else 'double'}-stream) S={S}: best_mask_idx {best.tolist()}, "
               f"MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, out {tuple(o_h.shape)} + {tuple(o_e.shape)}")
 
+    # ---------------- 13. the whole `__call__` of the reference's CogVideoX SVG processor ----------------
+    # CogVideoX_SparseAttn_Processor2_0.__call__ (cog/attention.py:199-224) with its own fall-backs (:40-50: the LayerNorm modules' forward over
+    # head_dim, apply_rotary_emb — the reference's ref_host_apply_rope again — on the video rows, which come AFTER the text).  Two calls on the
+    # same module: one under a seed whose 32 profiler rows are all video rows (the structure of the heads decides: spatial, temporal), one
+    # under a seed that draws a text row (NaN under the temporal profiling mask -> argmin sends EVERY head temporal; the quirk of section 9,
+    # here through the whole call).  `sample_mse` draws with the CPU generator right after the seed, so a caller that seeds the same way
+    # profiles the same rows.
+    cog_attn.apply_rotary_emb = hy_attn.apply_rotary_emb
+    heads, hd, F_, P_, ctx, mul = 2, 64, 6, 128, 32, 1.4
+    dim, V = heads * hd, F_ * P_
+    S = V + ctx
+    g = torch.Generator().manual_seed(4321)
+    attn = standins.Attention(dim, heads, qk_norm="layer", dtype=torch.float32)
+
+    def h16(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).half().float()
+
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_v.bias.copy_(h16(dim, s=0.1))
+        attn.to_out[0].weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_out[0].bias.copy_(h16(dim, s=0.1))
+        chan_w = torch.cat([torch.full((48,), 1.6), torch.full((16,), 0.03)])
+        for nm in (attn.norm_q, attn.norm_k):
+            nm.weight.copy_((chan_w * (1 + 0.1 * torch.randn(hd, generator=g))).half().float())
+            nm.bias.copy_(h16(hd, s=0.02))
+    i = torch.arange(V)
+    pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}
+    freqs = torch.arange(1, 25).float()
+    feats = []
+    for kind in (0, 1):
+        ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * V)
+        feats.append(torch.cat([torch.cos(ang) * 2.2, torch.sin(ang) * 2.2, 1.5 * torch.randn(V, 16, generator=g)], 1))
+    hidden = (torch.cat(feats, 1)[None] + 0.05 * torch.randn(1, V, dim, generator=g)).half().float()
+    enc = h16(1, ctx, dim)
+    rope_ang = 0.03 * torch.rand(V, hd // 2, generator=g)
+    rope = (rope_ang.cos().repeat_interleave(2, -1), rope_ang.sin().repeat_interleave(2, -1))
+    cls = cog_attn.CogVideoX_SparseAttn_Processor2_0
+    cls.context_length, cls.num_frame, cls.frame_size, cls.num_sampled_rows, cls.first_layers_fp, cls.first_times_fp = ctx, F_, P_, 32, 0, 0.0
+    cls.attention_masks = [cog_u.get_attention_mask("spatial", ctx, F_, P_), cog_u.get_attention_mask("temporal", ctx, F_, P_)]
+    cls.block_mask = create_block_mask(cog_u.generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul), None, None, S, S, device="cpu")
+
+    def drawn(seed):
+        torch.manual_seed(seed)
+        return torch.randint(low=0, high=S, size=(32,))
+
+    seed_video = next(sd for sd in range(1000) if int((drawn(sd) < ctx).sum()) == 0)
+    seed_text = next(sd for sd in range(1000) if int((drawn(sd) < ctx).sum()) > 0)
+    for nm, seed in (("v", seed_video), ("t", seed_text)):
+        proc = cls(0)
+        seen = {}
+        orig_mse = proc.sample_mse
+        proc.sample_mse = lambda a, b, c, _o=orig_mse, _s=seen: _s.setdefault("mse", _o(a, b, c))
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            o_h, o_e = proc(attn, hidden.clone(), enc.clone(), image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+        m_ = seen["mse"].float()
+        best = m_.argmin(0)
+        out[f"call_cog_{nm}_o_h"], out[f"call_cog_{nm}_o_e"], out[f"call_cog_{nm}_best"] = o_h.half().numpy(), o_e.half().numpy(), best.numpy()
+        out[f"call_cog_{nm}_seed"] = np.int64(seed)
+        print(f"call_cog[{nm}]: CogVideoX SVG processor __call__ S={S}, seed {seed} ({int((drawn(seed) < ctx).sum())} text rows drawn): best_mask_idx "
+              f"{best.tolist()}, MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, out {tuple(o_h.shape)} + {tuple(o_e.shape)}")
+    out["call_cog_hidden"], out["call_cog_enc"], out["call_cog_rope_ang"] = hidden.half().numpy(), enc.half().numpy(), rope_ang.numpy()
+    for n, t in (("wv", attn.to_v.weight), ("bv", attn.to_v.bias), ("wo", attn.to_out[0].weight), ("bo", attn.to_out[0].bias),
+                 ("nq", attn.norm_q.weight), ("nqb", attn.norm_q.bias), ("nk", attn.norm_k.weight), ("nkb", attn.norm_k.bias)):
+        out[f"call_cog_{n}"] = t.detach().half().numpy()
+    out["call_cog_geo"] = np.array([heads, hd, F_, P_, ctx], dtype=np.int64)
+    out["call_cog_mul"] = np.float64(mul)
+
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)
     print(f"wrote {p} ({p.stat().st_size / 1024:.0f} KB)")

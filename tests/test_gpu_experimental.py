@@ -159,3 +159,60 @@ def test_hunyuan_processor_call_equals_the_references_call(nat, tag):
     finally:
         for n, val in saved.items():
             setattr(cls, n, val)
+
+
+@pytest.mark.parametrize("which", ["v", "t"])
+def test_cog_processor_call_equals_the_references_call(nat, which):
+    """Parked like the Hunyuan test above (a parity test, not experimental code).  The product's CogVideoX_SparseAttn_Processor2_0.__call__
+    (fp16, HIP path: LayerNorm over head_dim, RoPE on the video rows with the softmax scale folded in, profiler, band attention with
+    fused layout transformation) against the reference's processor `__call__` executed in fp32 (make_golden_triton.py section 13).  The
+    profiler draws its rows from the CPU generator like the reference, so seeding the same way profiles the same rows: `v` = video rows
+    only (the heads' structure decides), `t` = a text row among them (NaN -> every head temporal; reference quirk, reproduced)."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from standins import Attention
+    from svg.models.cog.attention import CogVideoX_SparseAttn_Processor2_0 as cls
+    from svg.models.cog.utils import generate_temporal_head_mask_mod
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+
+    def T(name):
+        return torch.from_numpy(g["call_cog_" + name])
+
+    heads, hd, F_, P_, ctx = (int(x) for x in g["call_cog_geo"])
+    mul, best = float(g["call_cog_mul"]), T(which + "_best")
+    dim = heads * hd
+    dt = torch.float16
+    attn = Attention(dim, heads, qk_norm="layer", dtype=dt)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(T("wv")), attn.to_v.bias.copy_(T("bv"))
+        attn.to_out[0].weight.copy_(T("wo")), attn.to_out[0].bias.copy_(T("bo"))
+        attn.norm_q.weight.copy_(T("nq")), attn.norm_q.bias.copy_(T("nqb"))
+        attn.norm_k.weight.copy_(T("nk")), attn.norm_k.bias.copy_(T("nkb"))
+    attn.cuda()
+    names = ("context_length", "num_frame", "frame_size", "num_sampled_rows", "first_layers_fp", "first_times_fp", "block_mask")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (ctx, F_, P_, 32, 0, 0.0, generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul))):
+            setattr(cls, n, val)
+        attn.set_processor(cls(0))
+        ang = T("rope_ang").float().cuda()
+        rope = (ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1))
+        torch.manual_seed(int(g[f"call_cog_{which}_seed"]))
+        with torch.no_grad():
+            o_h, o_e = attn(T("hidden").cuda(), encoder_hidden_states=T("enc").cuda(), image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+        torch.cuda.synchronize()
+        assert torch.equal(attn.processor.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
+        for got, name in ((o_h, "o_h"), (o_e, "o_e")):
+            ref = T(f"{which}_{name}").float()
+            e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+            assert e < 5e-3, (name, e)
+            torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)

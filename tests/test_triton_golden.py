@@ -363,3 +363,36 @@ def test_hunyuan_processor_call_end_to_end(g, tag):
     for got, want in ((o_h, t["o_h"]), (o_e, t["o_e"])):
         torch.testing.assert_close(got, want, atol=3e-3, rtol=3e-3)
         assert ((got - want).norm() / want.norm()).item() < 1e-3
+
+
+@pytest.mark.parametrize("which,expect", [("v", [[0, 1]]), ("t", [[1, 1]])])
+def test_cog_processor_call_end_to_end(g, which, expect):
+    """Fixture: the whole `__call__` of the reference's CogVideoX_SparseAttn_Processor2_0 (cog/attention.py:199-224) on a duck-typed attention
+    module — text FIRST, LayerNorm over head_dim (module forward), RoPE on the video rows, attention_core_logic, ONE output projection over
+    the whole sequence, the split.  `v`: a seed whose profiler rows are all video rows (the heads' structure decides); `t`: a seed that
+    draws a text row (NaN under the temporal profiling mask, argmin sends every head temporal).  The oracle's statement of the call under the
+    recorded decisions."""
+    heads, hd, F_, P_, ctx = (int(x) for x in g["call_cog_geo"])
+    mul, best = float(g["call_cog_mul"]), T(g[f"call_cog_{which}_best"])
+    t = {n: T(g["call_cog_" + n]).float() for n in ("hidden", "enc", "wv", "bv", "wo", "bo", "nq", "nqb", "nk", "nkb", "rope_ang")}
+    V = F_ * P_
+    S = V + ctx
+    assert best.tolist() == expect
+    torch.manual_seed(int(g[f"call_cog_{which}_seed"]))
+    n_text = int((torch.randint(low=0, high=S, size=(32,)) < ctx).sum())      # what sample_mse drew (cog/attention.py:126)
+    assert (n_text > 0) == (which == "t")
+
+    def split(y):
+        return y.unflatten(2, (heads, -1)).transpose(1, 2)
+
+    x = torch.cat([t["enc"], t["hidden"]], 1)
+    q, k, v = split(x), split(x), split(x @ t["wv"].T + t["bv"])              # to_q / to_k are the identity in the fixture
+    q, k = O.layer_norm(q, t["nq"], t["nqb"]), O.layer_norm(k, t["nk"], t["nkb"])
+    cos, sin = (f(t["rope_ang"]).repeat_interleave(2, -1) for f in (torch.cos, torch.sin))
+    q, k = O.apply_qk_rope(q, k, cos, sin, ctx, "cossin")
+    qp, kp, vp = (O.head_placement(y, best, ctx, F_, P_, text_first=True) for y in (q, k, v))
+    o = O.head_placement(O.masked_attention(qp, kp, vp, O.cog_mask(S, ctx, F_, P_, mul)), best, ctx, F_, P_, text_first=True, inverse=True)
+    o = o.transpose(1, 2).flatten(2, 3) @ t["wo"].T + t["bo"]
+    for got, want in ((o[:, ctx:], T(g[f"call_cog_{which}_o_h"]).float()), (o[:, :ctx], T(g[f"call_cog_{which}_o_e"]).float())):
+        torch.testing.assert_close(got, want, atol=3e-3, rtol=3e-3)
+        assert ((got - want).norm() / want.norm()).item() < 1e-3
