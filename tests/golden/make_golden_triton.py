@@ -220,7 +220,15 @@ def main():
     import json
     import tempfile
 
-    MG._stub("diffusers.models.normalization", RMSNorm=type("RMSNorm", (), {}))     # (wan/attention.py:11 imports it; unused on this path)
+    class FP32LayerNorm(torch.nn.LayerNorm):
+        """diffusers.models.normalization.FP32LayerNorm by its published definition (diffusers is absent): layer_norm of the input cast to
+        fp32 with fp32 parameters, cast back.  Only the torch fall-back branch of the Wan block (section 14) calls it."""
+
+        def forward(self, inputs):
+            return torch.nn.functional.layer_norm(inputs.float(), self.normalized_shape, None if self.weight is None else self.weight.float(),
+                                                  None if self.bias is None else self.bias.float(), self.eps).to(inputs.dtype)
+
+    MG._stub("diffusers.models.normalization", RMSNorm=type("RMSNorm", (), {}), FP32LayerNorm=FP32LayerNorm)   # (wan/attention.py:11, wan/custom_models.py:5)
     import svg.models.hyvideo.attention as hy_attn
     import svg.models.wan.attention as wan_attn
 
@@ -581,6 +589,57 @@ def main():
         out[f"call_cog_{n}"] = t.detach().half().numpy()
     out["call_cog_geo"] = np.array([heads, hd, F_, P_, ctx], dtype=np.int64)
     out["call_cog_mul"] = np.float64(mul)
+
+    # ---------------- 14. the reference's Wan transformer BLOCK forward, both branches ----------------
+    # WanTransformerBlock_Sparse.forward (wan/custom_models.py:23-111) called as a plain function on a duck-typed block (scale_shift_table,
+    # norm1/2/3, attn1/attn2/ffn): once with ENABLE_FAST_KERNEL (its Triton LayerNorm / modulate-shift / gate-residual kernels, interpreted)
+    # and once on its torch fall-back.  Hidden size 192 — not a power of two, rows with a non-zero mean — so the two branches DIFFER: the
+    # Triton LayerNorm counts its zero padding (to 256) in the variance (section 7's finding), the fall-back is FP32LayerNorm.  attn1 /
+    # attn2 / ffn are fixed linear stand-ins (what they compute is not the block's business); diffusers' base classes are empty stubs.
+    MG._stub("diffusers.models.modeling_outputs", Transformer2DModelOutput=object)
+    MG._stub("diffusers.models.transformers")
+    MG._stub("diffusers.models.transformers.transformer_wan", WanTransformer3DModel=type("WanTransformer3DModel", (), {}),
+             WanTransformerBlock=type("WanTransformerBlock", (), {}))
+    MG._stub("diffusers.utils", USE_PEFT_BACKEND=False, scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None)
+    import svg.models.wan.custom_models as wan_cm
+
+    # Batch 1: the reference's modulate kernels load ONE scale / shift / gate vector (`tl.load(SCALE + cols)`, kernels/triton/modulate.py:35-36,113)
+    # — with a [B, 1, C] modulation they apply batch 0's to every batch (the fast path is a batch-1 path, which is how the Wan pipeline calls it).
+    C, S_, B_ = 192, 64, 1     # B_ * S_ a multiple of 32: for hidden sizes <= 512 the reference's kernels take 32 rows per program WITHOUT a row
+                               # mask (layernorm.py:27-35,60-61,78-81) and would read and WRITE past the last row otherwise
+    g = torch.Generator().manual_seed(99)
+
+    def h16(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).half().float()
+
+    lin = {n: (h16(C, C, s=C ** -0.5), h16(C, s=0.1)) for n in ("attn1", "attn2", "ffn")}
+    blk = types.SimpleNamespace(
+        scale_shift_table=h16(1, 6, C, s=C ** -0.5),
+        norm1=FP32LayerNorm(C, eps=1e-6, elementwise_affine=False), norm3=FP32LayerNorm(C, eps=1e-6, elementwise_affine=False),
+        norm2=FP32LayerNorm(C, eps=1e-6, elementwise_affine=True),
+        attn1=lambda hidden_states, rotary_emb=None, timestep=None: torch.roll(hidden_states, 1, 1) @ lin["attn1"][0].T + lin["attn1"][1],
+        attn2=lambda hidden_states, encoder_hidden_states=None: hidden_states @ lin["attn2"][0].T + lin["attn2"][1] + encoder_hidden_states.mean(1, keepdim=True),
+        ffn=lambda x: torch.tanh(x @ lin["ffn"][0].T + lin["ffn"][1]))
+    # The affine Triton kernel loads W and B WITHOUT a mask over the padded width (`tl.load(W + cols)`, kernels/triton/layernorm.py:52-53):
+    # for a hidden size that is not a power of two it reads past both vectors (the values only reach masked-off columns).  On a GPU that
+    # goes unnoticed; the interpreter segfaults on it.  Here the two vectors are views into 256-element buffers, so the reads stay in bounds.
+    pad_w, pad_b = torch.zeros(256), torch.zeros(256)
+    blk.norm2.weight, blk.norm2.bias = torch.nn.Parameter(pad_w[:C]), torch.nn.Parameter(pad_b[:C])
+    with torch.no_grad():
+        blk.norm2.weight.copy_((1 + h16(C, s=0.2)).half().float()), blk.norm2.bias.copy_(h16(C, s=0.1))
+    hidden = (h16(B_, S_, C, s=1.3) + 0.9 * torch.randn(B_, S_, 1, generator=g)).half().float()      # per-row mean offset
+    enc, temb = h16(B_, 5, C), h16(B_, 6, C, s=0.3)
+    fwd = wan_cm.WanTransformerBlock_Sparse.forward
+    with torch.no_grad():
+        for name, fast in (("fast", True), ("torch", False)):
+            wan_cm.ENABLE_FAST_KERNEL = fast
+            out[f"blk_{name}_out"] = fwd(blk, hidden.clone(), enc, temb, None, timestep=0).numpy()
+    d = np.abs(out["blk_fast_out"] - out["blk_torch_out"])
+    out["blk_hidden"], out["blk_enc"], out["blk_temb"], out["blk_table"] = hidden.half().numpy(), enc.half().numpy(), temb.half().numpy(), blk.scale_shift_table.half().numpy()
+    out["blk_n2w"], out["blk_n2b"] = blk.norm2.weight.detach().half().numpy(), blk.norm2.bias.detach().half().numpy()
+    for n, (w_, b_) in lin.items():
+        out[f"blk_{n}_w"], out[f"blk_{n}_b"] = w_.half().numpy(), b_.half().numpy()
+    print(f"blk: Wan block forward C={C}: Triton branch vs torch branch differ by up to {d.max():.3f} (mean {d.mean():.4f}) — the padded variance")
 
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)

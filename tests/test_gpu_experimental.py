@@ -216,3 +216,48 @@ def test_cog_processor_call_equals_the_references_call(nat, which):
     finally:
         for n, val in saved.items():
             setattr(cls, n, val)
+
+
+@pytest.mark.parametrize("branch", ["fast", "torch"])
+def test_wan_block_forward_equals_the_references_block(nat, branch):
+    """Parked like the two tests above.  The product's wan_block_forward (HIP glue: fused LayerNorm + modulate, gate-residual; fp16) against
+    the reference's WanTransformerBlock_Sparse.forward executed in fp32 (make_golden_triton.py section 14) on the same fp16-representable
+    block: `fast` = the reference on its Triton kernels — the product with svg.kernels.triton.layernorm.REFERENCE_PADDING on reproduces its
+    padded variance; `torch` = the reference's fall-back (FP32LayerNorm), the product's default.  Hidden size 192 with a row mean: the two
+    references differ by up to 0.6, so each switch position can only match its own."""
+    import types
+
+    import numpy as np
+    from svg.kernels.triton import layernorm as ln_mod
+    from svg.models.wan.custom_models import wan_block_forward
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+    dt = torch.float16
+    t = {n[4:]: torch.from_numpy(g[n]).cuda() for n in g.files if n.startswith("blk_")}
+    C = t["hidden"].shape[-1]
+
+    def lin(name, x):
+        return torch.nn.functional.linear(x, t[name + "_w"].to(dt), t[name + "_b"].to(dt))
+
+    n1, n3 = (torch.nn.LayerNorm(C, eps=1e-6, elementwise_affine=False) for _ in range(2))
+    n2 = torch.nn.LayerNorm(C, eps=1e-6, elementwise_affine=True).cuda()
+    with torch.no_grad():
+        n2.weight.copy_(t["n2w"]), n2.bias.copy_(t["n2b"])
+    blk = types.SimpleNamespace(
+        scale_shift_table=t["table"].float(), norm1=n1, norm2=n2, norm3=n3,
+        attn1=lambda hidden_states, rotary_emb=None, timestep=None: lin("attn1", torch.roll(hidden_states, 1, 1)),
+        attn2=lambda hidden_states, encoder_hidden_states=None: lin("attn2", hidden_states) + encoder_hidden_states.mean(1, keepdim=True),
+        ffn=lambda x: torch.tanh(lin("ffn", x)))
+    saved = ln_mod.REFERENCE_PADDING
+    try:
+        ln_mod.REFERENCE_PADDING = branch == "fast"
+        with torch.no_grad():
+            out = wan_block_forward(blk, t["hidden"].to(dt), t["enc"].to(dt), t["temb"].float(), None, timestep=0)
+    finally:
+        ln_mod.REFERENCE_PADDING = saved
+    torch.cuda.synchronize()
+    ref, other = t[branch + "_out"].float(), t[("torch" if branch == "fast" else "fast") + "_out"].float()
+    e = ((out.float() - ref).norm() / ref.norm()).item()
+    e_other = ((out.float() - other).norm() / other.norm()).item()
+    assert e < 5e-3 and e_other > 5 * e, (e, e_other)
+    torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=2e-2)
