@@ -13,7 +13,7 @@ What that pins that the loop-level fixtures (make_golden_kmeans.py: launches REP
   * head placement           `*_sparse_head_placement_kernel`, `*_hidden_states_placement_kernel`  svg/models/{hyvideo,wan,cog}/placement.py
   * token permutation        `_permute_kernel`, `_inverse_permute_kernel`   svg/kernels/triton/permute.py
   * block glue               RMSNorm / LayerNorm / modulate kernels         svg/kernels/triton/{rmsnorm,layernorm,modulate}.py
-and, on top of the kernels, the reference's PROCESSORS as they are (sections 8-13): `attention_core_logic` of the SAP and SVG1 processors, the
+and, on top of the kernels, the reference's PROCESSORS and its Wan block forward as they are (sections 8-14): `attention_core_logic` of the SAP and SVG1 processors, the
 Wan uniform-block mask generator, and the whole `__call__` of the Wan / Hunyuan (double-, single-stream) / CogVideoX SVG processors.
 Limits, stated: the interpreter of the Triton in this image (3.6.0) mis-handles bfloat16 (numpy has no such type; a 16 x 16
 bf16 `tl.dot` returns garbage), so the fixtures are float32 and float16 — the dtype-independent structure of every kernel is pinned,
