@@ -30,6 +30,41 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in _native.build_info()
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/svg_attn.h against the ctypes signature the Python side binds it with (svg/_native.py SIGNATURES):
+    same number of parameters, same class per parameter (pointer / int32 / int64 / size_t / float / double) and same return class —
+    a mismatch here is a corrupted argument on the GPU box, found without one."""
+    from svg import _native
+
+    src = (ROOT / "include" / "svg_attn.h").read_text()
+    src = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", src, flags=re.S))
+    protos = re.findall(r"\b([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(svg_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    assert {n for _, n, _ in protos} == set(_native.SIGNATURES)
+
+    def c_class(t):
+        t = t.strip()
+        for pat, c in ((r"\*", "ptr"), (r"\bsize_t\b", "size"), (r"\b(int64_t|long long)\b", "i64"), (r"\b(int32_t|uint32_t|int|unsigned)\b", "i32"),
+                       (r"\bfloat\b", "f32"), (r"\bdouble\b", "f64"), (r"^void$", "void")):
+            if re.search(pat, t):
+                return c
+        return "?" + t
+
+    def py_class(a):
+        if a is None:
+            return "void"
+        if a in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(a, type) and issubclass(a, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_size_t: "size", ctypes.c_int64: "i64", ctypes.c_longlong: "i64", ctypes.c_int32: "i32", ctypes.c_int: "i32",
+                ctypes.c_uint32: "i32", ctypes.c_float: "f32", ctypes.c_double: "f64"}.get(a, "?" + repr(a))
+
+    for ret, name, params in protos:
+        ps = [x.strip() for x in params.split(",") if x.strip() and x.strip() != "void"]
+        want = [c_class(x if x.endswith("*") else re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*(\[[^\]]*\])?$", "", x)) for x in ps]
+        res, args = _native.SIGNATURES[name]
+        assert [py_class(a) for a in args] == want, (name, want, [py_class(a) for a in args])
+        assert py_class(res) == c_class(ret), (name, ret, res)
+
+
 def test_struct_layouts():
     from svg import _native
 
