@@ -65,6 +65,24 @@ def test_ctypes_signatures_match_the_header_prototypes():
         assert py_class(res) == c_class(ret), (name, ret, res)
 
 
+def test_every_call_site_passes_as_many_arguments_as_the_signature_has():
+    """Static check of svg/_native.py: each `lib.svg_*(...)` call passes exactly the number of positional arguments its ctypes
+    signature declares (ctypes would raise only when the call runs — on the GPU box)."""
+    import ast
+
+    from svg import _native
+
+    tree = ast.parse((ROOT / "sparse-videogen_amd" / "svg" / "_native.py").read_text())
+    checked = 0
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr in _native.SIGNATURES:
+            if any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            assert not node.keywords and len(node.args) == len(_native.SIGNATURES[node.func.attr][1]), (node.func.attr, node.lineno)
+            checked += 1
+    assert checked >= 45
+
+
 def test_struct_layouts():
     from svg import _native
 
