@@ -10,6 +10,9 @@ Pinning status (see tests/golden/make_golden.py, which imports the reference its
       placement (hy/cog ref fns), torch permute / inverse, weighted_softmax, identify_dynamic_map,
       dynamic_block_sparse_fwd_torch, density_calculation, sparsity_to_width, get_attention_mask (hy/wan/cog) and
       sample_mse (Hunyuan processor method).
+      Beyond the committed geometries: tools/fuzz_oracle_vs_reference.py draws random ones (frame counts, ragged frame sizes, text lengths,
+      multipliers, cluster counts with empty clusters, top-p / min_kc_ratio) and compares these functions with the reference's on each —
+      all equal (profiles/r03zt_fuzz_oracle_vs_reference.txt).
   pinned at loop level: flash-kmeans — tests/golden/make_golden_kmeans.py runs the reference's own batch_kmeans_Euclid /
       _euclid_iter / host half of triton_centroid_update_sorted_euclid on CPU with only the two Triton kernel LAUNCHES replaced
       (svg/kmeans_utils.py:258-554; their bodies are restated here from the Triton source and the commented torch form :631-635).

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of oracle/svg_oracle.py against the reference's OWN torch functions, imported from /root/reference (build
+container only: the reference does not travel to the GPU box).  The committed fixtures (tests/golden/make_golden.py) pin each function
+on one or two geometries; this draws many random ones — frame counts, ragged frame sizes, text lengths, band multipliers, cluster
+counts with empty clusters, top-p / min_kc_ratio — and demands equality:
+
+  mask_mod predicates (hy / wan / cog) on the full index grid      bit-exact
+  get_attention_mask profiling masks (hy / wan / cog)              bit-exact
+  sparsity_to_width (hy / wan / cog)                               exact (same float expression)
+  ref_*_sparse_head_placement / ref_*_hidden_states_placement      bit-exact
+  weighted_softmax                                                 1e-6
+  identify_dynamic_map (fp32 and bf16 centroids)                   bit-exact off exact ties of two probabilities (torch.sort is not stable: the
+                                                                   reference's own result is undefined there; such rows are counted and reported)
+  density_calculation                                              exact
+  dynamic_block_sparse_fwd_torch (ragged + empty clusters)         1e-5
+  sample_mse of the Hunyuan / Wan / Cog processors                 1e-6 (fp32 inputs; NaN positions equal for Cog)
+  Wan BSR op: get_factor / ref_gen_temporal_mask                   bit-exact against the PRODUCT's host-side generator (svg.kernels.ops)
+
+    python tools/fuzz_oracle_vs_reference.py [--trials 40] > profiles/<round>_fuzz_oracle_vs_reference.txt"""
+import argparse
+import sys
+import types
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+import make_golden as MG  # noqa: E402
+
+from oracle import svg_oracle as O  # noqa: E402
+
+
+def grid_mask(mask_mod, S):
+    q = torch.arange(S)[:, None].expand(S, S)
+    k = torch.arange(S)[None, :].expand(S, S)
+    return mask_mod(0, 0, q, k)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=2026)
+    args = ap.parse_args()
+
+    MG.install_stubs()
+    MG._stub("diffusers.models.normalization", RMSNorm=type("RMSNorm", (), {}))
+    if "matplotlib" not in sys.modules:
+        try:
+            import matplotlib  # noqa: F401
+        except ImportError:
+            MG._stub("matplotlib", pyplot=types.SimpleNamespace())
+            MG._stub("matplotlib.pyplot")
+    sys.path.insert(0, MG.REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import svg.kernels.ops.attention_ops_wan as ref_ops_wan
+    import svg.kmeans_utils as KU
+    import svg.models.cog.attention as cog_attn
+    import svg.models.cog.placement as cog_pl
+    import svg.models.cog.utils as cog_u
+    import svg.models.hyvideo.attention as hy_attn
+    import svg.models.hyvideo.placement as hy_pl
+    import svg.models.hyvideo.utils as hy_u
+    import svg.models.wan.attention as wan_attn
+    import svg.models.wan.utils as wan_u
+
+    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+    from svg.kernels.ops import attention_ops_wan as own_ops_wan   # product host code (pure CPU part)
+
+    gen = torch.Generator().manual_seed(args.seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=gen))
+
+    def rf(lo, hi):
+        return lo + (hi - lo) * float(torch.rand(1, generator=gen))
+
+    counts = {}
+
+    def ok(name, cond, detail=""):
+        c = counts.setdefault(name, [0, 0])
+        c[0] += 1
+        if not cond:
+            c[1] += 1
+            print(f"MISMATCH {name}: {detail}")
+
+    ties = 0
+    for trial in range(args.trials):
+        F_, P_, ctx = ri(2, 6), ri(20, 170), ri(1, 40)
+        L, mul = ri(1, ctx), rf(0.3, 3.0)
+        V = F_ * P_
+        S = V + ctx
+        # ---- mask_mod predicates ----
+        ok("mask_mod hy", torch.equal(grid_mask(hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), S), O.hy_mask(S, ctx, L, F_, P_, mul)), (F_, P_, ctx, L, mul))
+        ok("mask_mod wan", torch.equal(grid_mask(wan_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul), V), O.wan_mask(V, F_, P_, mul)), (F_, P_, mul))
+        for sink in (False, True):
+            ok("mask_mod cog", torch.equal(grid_mask(cog_u.generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul, attn_sink=sink), S),
+                                           O.cog_mask(S, ctx, F_, P_, mul, attn_sink=sink)), (F_, P_, ctx, mul, sink))
+        # ---- the band descriptor of the C ABI states the same predicate ----
+        ok("band desc hy", torch.equal(O.band_mask(S, **O.hy_band_params(S, ctx, L, F_, P_, mul)), O.hy_mask(S, ctx, L, F_, P_, mul)))
+        ok("band desc wan", torch.equal(O.band_mask(V, **O.wan_band_params(V, F_, P_, mul)), O.wan_mask(V, F_, P_, mul)))
+        ok("band desc cog", torch.equal(O.band_mask(S, **O.cog_band_params(S, ctx, F_, P_, mul)), O.cog_mask(S, ctx, F_, P_, mul)))
+        # ---- profiling masks ----
+        for which, idx in (("spatial", 0), ("temporal", 1)):
+            ok("profile mask hy", torch.equal(hy_u.get_attention_mask(which, V, ctx, F_, P_, device="cpu").float(), O.profile_masks("hy", ctx, F_, P_)[idx][:V]), (which, F_, P_, ctx))      # (the first sample_mse_max_row rows)
+            ok("profile mask wan", torch.equal(wan_u.get_attention_mask(which, V, 0, F_, P_).float(), O.profile_masks("wan", 0, F_, P_)[idx][:V]), (which, F_, P_))
+            ok("profile mask cog", torch.equal(cog_u.get_attention_mask(which, ctx, F_, P_).float(), O.profile_masks("cog", ctx, F_, P_)[idx]), (which, F_, P_, ctx))
+        # ---- sparsity -> width ----
+        sp = rf(0.1, 0.6)
+        for mod in (hy_u, wan_u, cog_u):
+            try:
+                want = mod.sparsity_to_width(sp, ctx, F_, P_)
+            except ValueError:      # sqrt of a negative number: the sparsity does not leave room for the text rows / columns
+                continue
+            ok("sparsity_to_width", want == O.sparsity_to_width(sp, ctx, F_, P_), (sp, ctx, F_, P_))
+        # ---- placement ----
+        cfg, H, D = ri(1, 2), ri(1, 3), 8 * ri(1, 4)
+        x = [torch.randn(cfg, H, S, D, generator=gen).to(torch.bfloat16) for _ in range(3)]
+        best = torch.randint(0, 2, (cfg, H), generator=gen)
+        for name, fwd, inv, tf in (("hy", hy_pl.ref_hunyuan_sparse_head_placement, hy_pl.ref_hunyuan_hidden_states_placement, False),
+                                   ("cog", cog_pl.ref_sparse_head_placement, cog_pl.ref_hidden_states_placement, True)):
+            got = fwd(x[0], x[1], x[2], best, ctx, F_, P_)
+            ok(f"placement {name} fwd", all(torch.equal(a, O.head_placement(b, best, ctx, F_, P_, text_first=tf)) for a, b in zip(got, x)))
+            out = torch.zeros_like(x[0])
+            inv(x[0], out, best, ctx, F_, P_)
+            ok(f"placement {name} inv", torch.equal(out, O.head_placement(x[0], best, ctx, F_, P_, text_first=tf, inverse=True)))
+        # ---- weighted softmax, dynamic map, density, variable-block attention ----
+        B, Hh, QC, KC, Dd = 1, ri(1, 3), ri(2, 12), ri(2, 16), 16 * ri(1, 4)
+        qc, kc = torch.randn(B, Hh, QC, Dd, generator=gen) * 2, torch.randn(B, Hh, KC, Dd, generator=gen) * 2
+        N = ri(40, 200)
+
+        def sizes(n):
+            cut = torch.sort(torch.randint(0, N + 1, (B, Hh, n - 1), generator=gen), dim=-1)[0]
+            edges = torch.cat([torch.zeros(B, Hh, 1, dtype=torch.long), cut, torch.full((B, Hh, 1), N)], -1)
+            return (edges[..., 1:] - edges[..., :-1]).to(torch.int32)       # sums to N, zeros allowed (empty clusters)
+
+        qsz, ksz = sizes(QC), sizes(KC)
+        scores = torch.randn(B, Hh, QC, KC, generator=gen) * 3
+        ok("weighted_softmax", torch.allclose(KU.weighted_softmax(scores, ksz.unsqueeze(-2).float()), O.weighted_softmax(scores, ksz.unsqueeze(-2).float()), atol=1e-6, rtol=1e-6))
+        p_, r_ = rf(0.3, 0.99), (0.0 if ri(0, 1) else rf(0.0, 0.5))
+        for dt in (torch.float32, torch.bfloat16):
+            want = KU.identify_dynamic_map(qc.to(dt), kc.to(dt), qsz, ksz, p_, r_)
+            got = O.identify_dynamic_map(qc.to(dt), kc.to(dt), qsz, ksz, p_, r_)
+            if not torch.equal(want, got):
+                # rows with two exactly equal probabilities: torch.sort (unstable) may order them either way
+                sc = torch.matmul(qc.to(dt), kc.to(dt).transpose(-2, -1)) / (Dd ** 0.5)
+                pr = KU.weighted_softmax(sc, ksz.unsqueeze(-2).float())
+                srt = torch.sort(pr.float(), dim=-1)[0]
+                tie_rows = (srt[..., 1:] == srt[..., :-1]).any(-1)
+                bad_rows = (want != got).any(-1)
+                if bool((bad_rows & ~tie_rows).any()):
+                    ok("identify_dynamic_map", False, (dt, QC, KC, p_, r_))
+                else:
+                    ties += int(bad_rows.sum())
+                    ok("identify_dynamic_map", True)
+            else:
+                ok("identify_dynamic_map", True)
+        dmap = KU.identify_dynamic_map(qc, kc, qsz, ksz, p_, r_)
+        ok("density_calculation", torch.equal(KU.density_calculation(dmap, qsz, ksz), O.density_calculation(dmap, qsz, ksz)))
+        q3, k3, v3 = (torch.randn(B, Hh, N, Dd, generator=gen) for _ in range(3))
+        dm2 = dmap.clone()
+        dm2[..., 0] |= ~dm2.any(-1)                       # (rows without any block: the reference divides 0 / 0 there)
+        first_nonempty = (ksz > 0).float().argmax(-1)     # make sure every q block sees a key block WITH rows
+        dm2.scatter_(-1, first_nonempty[:, :, None, None].expand(B, Hh, QC, 1), True)
+        want = KU.dynamic_block_sparse_fwd_torch(q3, k3, v3, dm2, qsz, ksz)
+        got = O.dynamic_block_sparse_fwd(q3, k3, v3, dm2, qsz, ksz)
+        ok("dynamic_block_sparse_fwd_torch", torch.allclose(want.float(), got, atol=1e-5, rtol=1e-5), float((want.float() - got).abs().max()))
+        # ---- online profiler of the three processors (fp32 inputs) ----
+        Hs, Ds = ri(1, 3), 16 * ri(1, 4)
+        n_rows = 8
+        for name, cls, ctx_m, mod, model in (("hy", hy_attn.Hunyuan_SVGAttn_Processor2_0, ctx, hy_u, "hy"), ("wan", wan_attn.WanAttn_SVGAttn_Processor2_0, 0, wan_u, "wan"),
+                                             ("cog", cog_attn.CogVideoX_SparseAttn_Processor2_0, ctx, cog_u, "cog")):
+            Sm = V + ctx_m
+            q, k, v = (torch.randn(1, Hs, Sm, Ds, generator=gen) for _ in range(3))
+            if model == "cog":
+                cls.attention_masks = [mod.get_attention_mask("spatial", ctx_m, F_, P_), mod.get_attention_mask("temporal", ctx_m, F_, P_)]
+            elif model == "hy":
+                cls.attention_masks = [mod.get_attention_mask("spatial", V, ctx_m, F_, P_, device="cpu"), mod.get_attention_mask("temporal", V, ctx_m, F_, P_, device="cpu")]
+            else:
+                cls.attention_masks = [mod.get_attention_mask("spatial", V, 0, F_, P_), mod.get_attention_mask("temporal", V, 0, F_, P_)]
+            cls.num_sampled_rows = n_rows
+            if model != "cog":
+                cls.sample_mse_max_row = V
+            seed = ri(0, 10 ** 6)
+            torch.manual_seed(seed)
+            want = cls(0).sample_mse(q, k, v)
+            torch.manual_seed(seed)
+            rows = torch.randint(low=0, high=Sm if model == "cog" else V, size=(n_rows,))
+            got = O.sample_mse(q, k, v, rows, O.profile_masks(model, ctx_m, F_, P_))
+            same_nan = torch.equal(torch.isnan(want), torch.isnan(got))
+            ok(f"sample_mse {name}", same_nan and torch.allclose(torch.nan_to_num(want), torch.nan_to_num(got), atol=1e-6, rtol=1e-5),
+               (seed, float((torch.nan_to_num(want) - torch.nan_to_num(got)).abs().max())))
+        # ---- Wan uniform-block op: the product's host-side generator against the reference's ----
+        Fw, Pw, mw = ri(2, 8), ri(30, 600), rf(0.2, 2.5)
+        ok("wan bsr get_factor", ref_ops_wan.get_factor(Fw, Pw) == own_ops_wan.get_factor(Fw, Pw), (Fw, Pw))
+        ok("wan bsr ref_gen_temporal_mask", torch.equal(torch.as_tensor(ref_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw)), torch.as_tensor(own_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw))), (Fw, Pw, mw))
+
+    print(f"# fuzz of oracle/svg_oracle.py (and the product's Wan BSR mask generator) against the reference's own torch functions: {args.trials} random geometries, seed {args.seed}")
+    print("| function | comparisons | mismatches |\n|---|---|---|")
+    total_bad = 0
+    for name, (n, bad) in counts.items():
+        print(f"| {name} | {n} | {bad} |")
+        total_bad += bad
+    print(f"\nidentify_dynamic_map: {ties} rows differed only where two probabilities are exactly equal (torch.sort is unstable: undefined in the reference too)")
+    print("RESULT:", "all equal" if total_bad == 0 else f"{total_bad} MISMATCHES")
+    return 1 if total_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
