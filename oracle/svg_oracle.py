@@ -12,7 +12,8 @@ Pinning status (see tests/golden/make_golden.py, which imports the reference its
       sample_mse (Hunyuan processor method).
       Beyond the committed geometries: tools/fuzz_oracle_vs_reference.py draws random ones (frame counts, ragged frame sizes, text lengths,
       multipliers, cluster counts with empty clusters, top-p / min_kc_ratio) and compares these functions with the reference's on each —
-      all equal (profiles/r03zt_fuzz_oracle_vs_reference.txt).
+      all equal (profiles/r03zt_fuzz_oracle_vs_reference.txt); tools/fuzz_oracle_vs_triton.py does the same against the interpreted Triton
+      kernels in float32 (profiles/r03zu_fuzz_oracle_vs_triton.txt: equal; k-means labels differ only on fp32 near-ties, counted there).
   pinned at loop level: flash-kmeans — tests/golden/make_golden_kmeans.py runs the reference's own batch_kmeans_Euclid /
       _euclid_iter / host half of triton_centroid_update_sorted_euclid on CPU with only the two Triton kernel LAUNCHES replaced
       (svg/kmeans_utils.py:258-554; their bodies are restated here from the Triton source and the commented torch form :631-635).

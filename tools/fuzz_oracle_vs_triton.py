@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of oracle/svg_oracle.py against the reference's own TRITON kernels, executed by Triton's interpreter in the
+build container (TRITON_INTERPRET=1; see tests/golden/make_golden_triton.py for what that can and cannot run: float32 here — every
+result is then bit-defined up to the order of fp32 sums).  The committed fixtures pin each kernel on two to four shapes; this draws
+random ones:
+
+  _euclid_assign_kernel        random (B, N, D, K) and a random tile configuration of the reference's autotune list     labels equal off near-ties
+                               (two candidate distances closer than the fp32 rounding bound of |x|^2 + |c|^2 - 2 x.c: counted, reported)
+  centroid update (sorted)     random labels incl. empty clusters, random chunk size                                   counts equal, centres 2e-6
+  batch_kmeans_Euclid          both kernels, random K / iteration cap                                                  labels, sizes, n_iters equal
+  variable-block attention     `_dynamic_block_sparse_fwd_kernel`, ragged and EMPTY clusters                           1e-5
+  head placement kernels       hy / wan / cog, random geometry and head flags                                          bit-exact
+  permutation kernels          random labels, stable order                                                             bit-exact
+  LayerNorm / modulate / RMSNorm kernels at random hidden sizes (the padded-variance form restated)                     1e-5
+
+    python tools/fuzz_oracle_vs_triton.py [--trials 12] > profiles/<round>_fuzz_oracle_vs_triton.txt"""
+import argparse
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+import make_golden_triton as MT  # noqa: E402  (sets TRITON_INTERPRET=1 before triton is imported)
+
+import torch  # noqa: E402
+
+from oracle import svg_oracle as O  # noqa: E402
+
+MG = MT.MG
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=950)
+    args = ap.parse_args()
+    MG.install_stubs()
+    sys.path.insert(0, MG.REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.is_cuda = property(lambda self: True)
+    import svg.kernels.triton.permute as TP
+    import svg.kmeans_utils as KU
+    import svg.models.cog.placement as cog_pl
+    import svg.models.hyvideo.placement as hy_pl
+    import svg.models.wan.placement as wan_pl
+    from svg.kernels.triton.layernorm import triton_layernorm_forward
+    from svg.kernels.triton.modulate import triton_modulate_gate_residual_forward, triton_modulate_shift_forward
+    from svg.kernels.triton.rmsnorm import triton_rmsnorm_forward
+
+    auto = KU._euclid_assign_kernel
+    tile_cfgs = sorted({(c.kwargs["BLOCK_N"], c.kwargs["BLOCK_K"]) for c in auto.configs})
+    KU._euclid_iter_compiled = KU._euclid_iter
+    gen = torch.Generator().manual_seed(args.seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=gen))
+
+    counts = {}
+
+    def ok(name, cond, detail=""):
+        c = counts.setdefault(name, [0, 0])
+        c[0] += 1
+        if not cond:
+            c[1] += 1
+            print(f"MISMATCH {name}: {detail}")
+
+    near = {"points": 0, "loop": 0}
+
+    def labels_agree(x, c, a, b):
+        """equal, or different only on points whose two candidate distances (fp64) are closer than the rounding error bound of the fp32
+        form |x|^2 + |c|^2 - 2 x.c that both sides evaluate — in different summation orders (D * 2^-23 * (|x|^2 + |c|^2))"""
+        bad = a != b
+        if not bad.any():
+            return True
+        d64 = ((x.double()[:, :, None, :] - c.double()[:, None, :, :]) ** 2).sum(-1)
+        gap = (d64.gather(2, a[..., None]) - d64.gather(2, b[..., None]))[..., 0].abs()
+        bound = x.shape[-1] * 2.0 ** -23 * ((x.double() ** 2).sum(-1) + (c.double() ** 2).sum(-1).max(-1)[0][:, None])
+        if bool((gap[bad] <= bound[bad]).all()):
+            near["points"] += int(bad.sum())
+            return True
+        return False
+
+    for trial in range(args.trials):
+        # ---- k-means ----
+        B, N, D, K = ri(1, 2), ri(50, 400), (32, 64, 128)[ri(0, 2)], ri(2, 60)     # (the kernels take a power-of-two head size)
+        x = MT.clustered(B, N, D, ri(2, 9), gen)
+        c = x[:, torch.randperm(N, generator=gen)[:K]].clone() if K <= N else torch.randn(B, K, D, generator=gen)
+        bn, bk = tile_cfgs[ri(0, len(tile_cfgs) - 1)]
+        KU._euclid_assign_kernel = MT.ExplicitConfig(auto, BLOCK_N=bn, BLOCK_K=bk)
+        ids = KU.euclid_assign_triton(x, c, (x ** 2).sum(-1))
+        ok("assign kernel", labels_agree(x, c, ids, O.kmeans_assign(x, O.kmeans_xsq(x), c)), (B, N, D, K, bn, bk))
+        lab = torch.randint(0, K, (B, N), generator=gen)
+        if K > 2:
+            lab[lab == 1] = 0                                # an empty cluster
+        old = torch.randn(B, K, D, generator=gen)
+        cent, cnt = KU.triton_centroid_update_sorted_euclid(x, lab, old, BLOCK_N=(32, 64, 128, 256)[ri(0, 3)])
+        oc, ocnt = O.kmeans_update(x, lab, old)
+        ok("update kernel", torch.equal(cnt, ocnt) and torch.allclose(cent, oc, rtol=1e-6, atol=2e-6), (B, N, D, K))
+        KU._euclid_assign_kernel = MT.ExplicitConfig(auto, BLOCK_N=64, BLOCK_K=64)
+        Kl, iters = ri(2, 12), ri(1, 12)
+        init = x[:, :Kl].clone()
+        r_ids, r_c, r_sz, r_n = KU.batch_kmeans_Euclid(x, Kl, max_iters=iters, tol=1e-4, init_centroids=init.clone())
+        o_ids, o_c, o_sz, o_n = O.batch_kmeans_euclid(x, Kl, max_iters=iters, tol=1e-4, init_centroids=init.clone())
+        same = int(r_n) == int(o_n) and torch.equal(r_ids, o_ids) and torch.equal(r_sz.to(o_sz.dtype), o_sz) and torch.allclose(r_c, o_c, rtol=1e-5, atol=1e-5)
+        if not same:
+            # Did a near-tie flip a label somewhere along the way?  Step the loop on the reference's kernels and compare each assignment.
+            cc, flipped = init.clone(), False
+            for _ in range(int(r_n)):
+                a_ref, a_or = KU.euclid_assign_triton(x, cc, (x ** 2).sum(-1)), O.kmeans_assign(x, O.kmeans_xsq(x), cc)
+                if not torch.equal(a_ref, a_or):
+                    flipped = labels_agree(x, cc, a_ref, a_or)       # True: only near-ties differ (counted); False: a real disagreement
+                    break
+                cc = KU.triton_centroid_update_sorted_euclid(x, a_ref, cc)[0]
+            near["loop"] += int(flipped)
+            same = flipped
+        ok("k-means loop", same, (B, N, D, Kl, iters, int(r_n), int(o_n)))
+        # ---- variable-block attention (Triton statement) ----
+        H, Dv, nq, nk = ri(1, 2), (32, 64)[ri(0, 1)], ri(2, 6), ri(2, 7)
+        S = ri(64, 300)      # (below 64 the wrapper sets BLOCK = S, which Triton refuses unless S is a power of two)
+
+        def sizes(n):
+            cut = torch.sort(torch.randint(0, S + 1, (n - 1,), generator=gen))[0]
+            e = torch.cat([torch.zeros(1, dtype=torch.long), cut, torch.tensor([S])])
+            return (e[1:] - e[:-1]).tolist()
+
+        qsz, ksz = sizes(nq), sizes(nk)
+        q, k, v = (torch.randn(1, H, S, Dv, generator=gen) for _ in range(3))
+        qc, kc = torch.tensor(qsz).expand(1, H, -1).contiguous(), torch.tensor(ksz).expand(1, H, -1).contiguous()
+        dmap = torch.rand(1, H, nq, nk, generator=gen) < 0.5
+        big = max(range(nk), key=lambda j: ksz[j])
+        dmap[..., big] |= ~(dmap & (kc[:, :, None, :] > 0)).any(-1)        # every q block sees a key block with rows
+        o = KU.dynamic_block_sparse_fwd_triton(q, k, v, dmap, qc, kc)
+        ok("variable-block attention kernel", torch.allclose(o, O.dynamic_block_sparse_fwd(q, k, v, dmap, qc, kc), atol=1e-5, rtol=1e-5), (H, Dv, qsz, ksz))
+        # ---- placement kernels ----
+        F_, P_, ctx = ri(2, 6), ri(10, 90), ri(1, 30)
+        cfg, Hp, Dp = ri(1, 2), ri(1, 3), 16
+        for name, mod, fwd, inv, c_len, tf in (("hy", hy_pl, "hunyuan_sparse_head_placement", "hunyuan_hidden_states_placement", ctx, False),
+                                                ("wan", wan_pl, "wan_sparse_head_placement", "wan_hidden_states_placement", 0, False),
+                                                ("cog", cog_pl, "sparse_head_placement", "hidden_states_placement", ctx, True)):
+            Sp = c_len + F_ * P_
+            t = [torch.randn(cfg, Hp, Sp, Dp, generator=gen).half() for _ in range(3)]
+            best = torch.randint(0, 2, (cfg, Hp), generator=gen).to(torch.int32)
+            outs = [torch.zeros_like(t[0]) for _ in range(3)]
+            getattr(mod, fwd)(t[0], t[1], t[2], outs[0], outs[1], outs[2], best, c_len, F_, P_)
+            ok(f"placement kernel {name}", all(torch.equal(a, O.head_placement(b, best, c_len, F_, P_, text_first=tf)) for a, b in zip(outs, t)), (F_, P_, c_len))
+            back = torch.zeros_like(t[0])
+            getattr(mod, inv)(t[0], back, best, c_len, F_, P_)
+            ok(f"inverse placement kernel {name}", torch.equal(back, O.head_placement(t[0], best, c_len, F_, P_, text_first=tf, inverse=True)), (F_, P_, c_len))
+        # ---- permutation kernels ----
+        Hm, Sm, Dm, nl = ri(1, 3), ri(30, 250), 32, ri(2, 12)
+        xm = torch.randn(1, Hm, Sm, Dm, generator=gen).half()
+        labels = torch.randint(0, nl, (1, Hm, Sm), generator=gen)
+        sidx = torch.stack([O.stable_argsort(labels[0, h]) for h in range(Hm)])[None]
+        xp, sout = TP.permute_tensor_by_labels_triton(xm, None, 2, sorted_indices=sidx)
+        want = O.permute_by_labels(xm, labels.reshape(Hm, Sm))[0]
+        ok("permute kernel", torch.equal(xp, want))
+        ok("inverse permute kernel", torch.equal(TP.apply_inverse_permutation_triton(xp, sout.reshape(1, Hm, Sm), 2), xm))
+        # ---- block glue kernels (hidden size > 512: one row per program, like production) ----
+        M, Nn = ri(1, 6), 8 * ri(65, 200)
+        N2 = 1 << (Nn - 1).bit_length()
+        xg = torch.randn(1, M, Nn, generator=gen) * 1.5 + 0.4
+        w, b = torch.randn(Nn, generator=gen) * 0.2 + 1, torch.randn(Nn, generator=gen) * 0.1
+        wp, bp = torch.zeros(N2), torch.zeros(N2)          # (the kernels read W / B over the padded width without a mask: keep the reads in bounds)
+        wp[:Nn], bp[:Nn] = w, b
+
+        def ln_padded(xx, ww=None, bb=None):
+            mean = xx.mean(-1, keepdim=True)
+            var = (xx - mean).pow(2).mean(-1, keepdim=True) + (N2 - Nn) / Nn * mean * mean
+            y = (xx - mean) / torch.sqrt(var + 1e-6)
+            return y if ww is None else y * ww + bb
+
+        ok("layernorm kernel (affine)", torch.allclose(triton_layernorm_forward(xg, wp[:Nn], bp[:Nn], 1e-6, True), ln_padded(xg, w, b), atol=1e-5, rtol=1e-5), Nn)
+        ok("layernorm kernel (no affine)", torch.allclose(triton_layernorm_forward(xg, None, None, 1e-6, False), ln_padded(xg), atol=1e-5, rtol=1e-5), Nn)
+        mod_buf = torch.zeros(3, N2)
+        mod_buf[:, :Nn] = torch.randn(3, Nn, generator=gen) * 0.3
+        sc, sh, gt = (mod_buf[i, :Nn].reshape(1, 1, Nn) for i in range(3))
+        ok("modulate-shift kernel", torch.allclose(triton_modulate_shift_forward(xg, sc, sh, output_dtype=torch.float32), O.modulate_shift(xg, sc, sh, torch.float32), atol=1e-6, rtol=1e-6), Nn)
+        att = torch.randn(1, M, Nn, generator=gen)
+        ok("gate-residual kernel", torch.allclose(triton_modulate_gate_residual_forward(xg, att, gt, output_dtype=torch.float32), O.modulate_gate_residual(xg, att, gt, torch.float32),
+                                                  atol=1e-6, rtol=1e-6), Nn)
+        rms = triton_rmsnorm_forward(xg.reshape(M, Nn).contiguous(), wp[:Nn], 1e-6)
+        rms = rms[0] if isinstance(rms, (tuple, list)) else rms
+        x2 = xg.reshape(M, Nn)
+        ok("rmsnorm kernel", torch.allclose(rms, x2 * torch.rsqrt(x2.pow(2).mean(-1, keepdim=True) + 1e-6) * w, atol=1e-5, rtol=1e-5), Nn)
+
+    print(f"# fuzz of oracle/svg_oracle.py against the reference's Triton kernels run by Triton's interpreter (float32): {args.trials} random shapes, seed {args.seed}")
+    print("| kernel | comparisons | mismatches |\n|---|---|---|")
+    bad_total = 0
+    for name, (n, bad) in counts.items():
+        print(f"| {name} | {n} | {bad} |")
+        bad_total += bad
+    print(f"\nassign kernel: {near['points']} points took another label than the oracle where the two distances are closer than the fp32 rounding bound of the distance form; "
+          f"{near['loop']} whole loops diverged behind such a point (the summation order of the dot product is implementation-chosen: numpy's in the interpreter, the matrix unit's on a GPU)")
+    print("RESULT:", "all equal" if bad_total == 0 else f"{bad_total} MISMATCHES")
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
