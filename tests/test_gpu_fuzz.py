@@ -1,0 +1,196 @@
+"""Opt-in GPU fuzz of the HIP kernels against the oracle on RANDOM geometries (SVG_FUZZ=<trials>, e.g. `SVG_FUZZ=40 pytest
+tests/test_gpu_fuzz.py -m gpu`; the default `-m gpu` run skips it).  The parity suite fixes its geometries in the parametrisation;
+this draws them — frame count, ragged frame size, text / prompt length, band multiplier, heads, head size, dtype, schedule; cluster
+counts with EMPTY clusters, GQA ratios, block-map densities — with the same tolerances as tests/test_gpu_kernels.py.  The CPU side of the
+same idea (oracle against the EXECUTED reference on random geometries) is tools/fuzz_*_vs_reference.py, logs under profiles/.
+Written at the end of round 3 when the GPU budget was spent: first run is round 4's (tools/r04_first_call.sh)."""
+import os
+
+import pytest
+import torch
+
+from oracle import svg_oracle as O
+
+TRIALS = int(os.environ.get("SVG_FUZZ", "0") or 0)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(TRIALS <= 0, reason="set SVG_FUZZ=<trials>")]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from svg import _native
+
+    _native.load()
+    assert torch.cuda.is_available()
+    return _native
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp(min=1e-20)).item()
+
+
+def check_attn(o, ref, dtype, what):
+    o = o.float().cpu()
+    torch.testing.assert_close(o, ref, atol=1e-2, rtol=1e-2, msg=lambda m: f"{what}: {m}")
+    e = rel_l2(o, ref)
+    assert e <= (3e-3 if dtype == torch.bfloat16 else 1e-3), (what, e)
+
+
+class Rng:
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+
+    def ri(self, lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=self.g))
+
+    def rf(self, lo, hi):
+        return lo + (hi - lo) * float(torch.rand(1, generator=self.g))
+
+    def pick(self, seq):
+        return seq[self.ri(0, len(seq) - 1)]
+
+    def randn(self, *shape):
+        return torch.randn(*shape, generator=self.g)
+
+
+def _band_case(model, F_, P_, ctx, L, mul):
+    V = F_ * P_
+    if model == "hy":
+        S = V + ctx
+        return S, O.hy_band_params(S, ctx, L, F_, P_, mul), O.hy_mask(S, ctx, L, F_, P_, mul), 0, ctx, False
+    if model == "wan":
+        return V, O.wan_band_params(V, F_, P_, mul), O.wan_mask(V, F_, P_, mul), 0, 0, False
+    S = V + ctx
+    return S, O.cog_band_params(S, ctx, F_, P_, mul), O.cog_mask(S, ctx, F_, P_, mul), ctx, ctx, True
+
+
+@pytest.mark.parametrize("trial", range(max(TRIALS, 1)))
+def test_fuzz_band_attention(nat, trial):
+    """svg_band_attention under the three models' masks, random geometry / schedule / dtype, with and without the fused layout
+    transformation (head_perm_flag), against dense attention under the mask_mod predicate (placement -> attention -> inverse placement)."""
+    r = Rng(1000 + trial)
+    model = r.pick(("hy", "wan", "cog"))
+    F_, P_, ctx = r.ri(2, 7), r.ri(17, 260), r.ri(1, 60)
+    L, mul = r.ri(1, ctx), r.rf(0.3, 3.0)
+    D, dtype, variant = r.pick((64, 128)), r.pick((torch.bfloat16, torch.float16)), r.pick((0, 1, 2, 3))
+    H = r.ri(1, 4)
+    S, prm, mask, vid0, c_len, tf = _band_case(model, F_, P_, ctx, L, mul)
+    q, k, v = (r.randn(1, H, S, D).to(dtype) for _ in range(3))
+    what = f"band {model} F={F_} P={P_} ctx={ctx} L={L} mul={mul:.3f} D={D} {dtype} variant={variant} H={H}"
+    o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), variant=variant)
+    check_attn(o, O.masked_attention(q, k, v, mask), dtype, what)
+    best = torch.randint(0, 2, (1, H), generator=r.g)
+    o = nat.band_attention(dev(q), dev(k), dev(v), nat.BandMask(**prm), head_perm_flag=dev(best), vid0=vid0, num_frame=F_, frame_size=P_)
+    qp, kp, vp = (O.head_placement(t, best, c_len, F_, P_, text_first=tf) for t in (q, k, v))
+    ref = O.head_placement(O.masked_attention(qp, kp, vp, mask), best, c_len, F_, P_, text_first=tf, inverse=True)
+    check_attn(o, ref, dtype, what + f" fused placement {best.tolist()}")
+
+
+@pytest.mark.parametrize("trial", range(max(TRIALS, 1)))
+def test_fuzz_varblock_attention(nat, trial):
+    """svg_varblock_attention: random ragged partitions WITH empty clusters on both sides, GQA, density, schedule, dtype"""
+    r = Rng(2000 + trial)
+    hkv = r.pick((1, 2, 4))
+    hq = hkv * r.pick((1, 2, 4))
+    D, dtype, variant = r.pick((64, 128)), r.pick((torch.bfloat16, torch.float16)), r.pick((0, 1, 2, 3, 4))
+    S, MB, NB = r.ri(64, 3000), r.ri(1, 24), r.ri(1, 60)
+
+    def sizes(n):
+        cut = torch.sort(torch.randint(0, S + 1, (hkv, n - 1), generator=r.g), dim=-1)[0]
+        e = torch.cat([torch.zeros(hkv, 1, dtype=torch.long), cut, torch.full((hkv, 1), S)], -1)
+        return (e[:, 1:] - e[:, :-1]).to(torch.int32)          # sums to S, zeros allowed
+
+    rsz, csz = sizes(MB), sizes(NB)
+    bmap = torch.rand(hkv, MB, NB, generator=r.g) < r.rf(0.1, 0.95)
+    first = (csz > 0).float().argmax(-1)                        # every q block sees a key block with rows (an all-masked row is 0 / 0 in the reference)
+    bmap.scatter_(-1, first[:, None, None].expand(hkv, MB, 1), True)
+    q = r.randn(hq, S, D).to(dtype)
+    k, v = r.randn(hkv, S, D).to(dtype), r.randn(hkv, S, D).to(dtype)
+    o = nat.varblock_attention(dev(q), dev(k), dev(v), dev(bmap), dev(rsz), dev(csz), variant=variant).float().cpu()
+    g = hq // hkv
+    for h in range(hkv):
+        em = O.block_mask_to_element_mask(bmap[h], rsz[h], csz[h])
+        check_attn(o[h * g:(h + 1) * g], O.masked_attention(q[h * g:(h + 1) * g], k[h:h + 1], v[h:h + 1], em), dtype,
+                   f"varblock hq={hq} hkv={hkv} D={D} S={S} MB={MB} NB={NB} {dtype} variant={variant} head {h}")
+
+
+@pytest.mark.parametrize("trial", range(max(TRIALS, 1)))
+def test_fuzz_placement_permutation_argsort(nat, trial):
+    """bit-exact kernels: head placement (both directions, both text positions), argsort of labels, row permutation and its inverse"""
+    r = Rng(3000 + trial)
+    cfg, H, F_, P_, D = r.ri(1, 2), r.ri(1, 4), r.ri(1, 7), r.ri(1, 200), r.pick((64, 128))
+    tf = bool(r.ri(0, 1))
+    ctx = r.ri(0, 50) if not tf else r.ri(1, 50)
+    dtype = r.pick((torch.bfloat16, torch.float16))
+    S = ctx + F_ * P_
+    xs = [r.randn(cfg, H, S, D).to(dtype) for _ in range(3)]
+    best = torch.randint(0, 2, (cfg, H), generator=r.g)
+    for inverse in (False, True):
+        outs = [torch.full_like(x, float("nan")).cuda() for x in xs]
+        nat.head_placement([dev(x) for x in xs], outs, dev(best), ctx, F_, P_, tf, inverse)
+        for x, o in zip(xs, outs):
+            assert torch.equal(o.cpu(), O.head_placement(x, best, ctx, F_, P_, text_first=tf, inverse=inverse)), (cfg, H, F_, P_, ctx, tf, inverse)
+    BH, N, K = r.ri(1, 4), r.ri(1, 9000), r.ri(1, 1200)
+    labels = torch.randint(0, K, (BH, N), generator=r.g, dtype=torch.int32)
+    sidx, counts = nat.argsort_labels(dev(labels), K)
+    ref_idx = O.stable_argsort(labels.long()).to(torch.int32)
+    assert torch.equal(sidx.cpu(), ref_idx), (BH, N, K)
+    assert torch.equal(counts.cpu(), torch.stack([torch.bincount(l.long(), minlength=K) for l in labels]).int())
+    x = r.randn(BH, N, D).to(dtype)
+    y = nat.permute_rows(dev(x), sidx)
+    assert torch.equal(y.cpu(), torch.gather(x, 1, ref_idx.long()[..., None].expand(-1, -1, D)))
+    assert torch.equal(nat.permute_rows(y, sidx, inverse=True).cpu(), x)
+
+
+@pytest.mark.parametrize("trial", range(max(TRIALS, 1)))
+def test_fuzz_kmeans_iter(nat, trial):
+    """one Lloyd iteration (svg_kmeans_iter): labels equal the oracle's argmin or differ on rounding-level near-ties only; sorted
+    indices, counts, empty clusters and centres exact / to bf16 rounding given the labels"""
+    r = Rng(4000 + trial)
+    B, N, K, D = r.ri(1, 3), r.ri(64, 6000), r.ri(1, 400), r.pick((64, 128))
+    dtype = r.pick((torch.bfloat16, torch.float16))
+    modes = r.ri(1, 40)
+    centers = r.randn(B, modes, D) * 2
+    x = torch.gather(centers, 1, torch.randint(0, modes, (B, N), generator=r.g)[..., None].expand(-1, -1, D)) + 0.5 * r.randn(B, N, D)
+    x = x.to(dtype)
+    c0 = x[:, torch.randint(0, N, (K,), generator=r.g)].clone()
+    if K > 1:
+        c0[:, -1] = 100.0                                    # an empty cluster: keeps its old centre
+    xd = dev(x)
+    xsq = nat.kmeans_xsq(xd)
+    buf = nat.KmeansBuffers(B, N, K, D, xd.device)
+    c_out = torch.empty_like(dev(c0))
+    nat.kmeans_iter(xd, xsq, dev(c0), c_out, buf)
+    dist = O.kmeans_distances(x, xsq.cpu(), c0)
+    lab = buf.labels.cpu().long()
+    mism = lab != dist.argmin(-1)
+    d_got, d_ref = torch.gather(dist, 2, lab[..., None])[..., 0], dist.min(-1).values
+    what = (B, N, K, D, dtype, modes)
+    assert mism.float().mean() < 2e-2 and torch.all((d_got - d_ref)[mism] <= 1e-2 * d_ref[mism].clamp(min=1.0)), what
+    assert torch.equal(buf.sorted_idx.cpu(), O.stable_argsort(lab).to(torch.int32)), what
+    c_ref, cnt_ref = O.kmeans_update(x, lab, c0)
+    assert torch.equal(buf.counts.cpu(), cnt_ref), what
+    torch.testing.assert_close(c_out.float().cpu(), c_ref.float(), rtol=1e-2, atol=1e-2)
+    empty = cnt_ref == 0
+    assert torch.equal(c_out.cpu()[empty], c0[empty]), what
+
+
+@pytest.mark.parametrize("trial", range(max(TRIALS, 1)))
+def test_fuzz_dynamic_map(nat, trial):
+    """svg_identify_dynamic_map against the oracle's exact statement (bit-exact: csrc/dynmap.hip reproduces exact=True), empty clusters
+    and min_kc_ratio included"""
+    r = Rng(5000 + trial)
+    BH, QC, KC, D = r.ri(1, 6), r.ri(1, 120), r.ri(1, 600), r.pick((64, 128))
+    dtype = r.pick((torch.bfloat16, torch.float16))
+    qc, kc = (r.randn(BH, QC, D) * 1.5).to(dtype), (r.randn(BH, KC, D) * 1.5).to(dtype)
+    ksz = torch.randint(0, 500, (BH, KC), generator=r.g, dtype=torch.int32)
+    ksz[torch.rand(BH, KC, generator=r.g) < 0.2] = 0         # empty clusters: weight zero
+    ksz[:, 0] = ksz[:, 0].clamp(min=1)
+    p, ratio = r.rf(0.2, 0.99), (0.0 if r.ri(0, 1) else r.rf(0.0, 0.5))
+    got = nat.identify_dynamic_map(dev(qc), dev(kc), dev(ksz), p, int(ratio * KC)).cpu()
+    ref = O.identify_dynamic_map(qc[None], kc[None], None, ksz[None], p, ratio, exact=True)[0]
+    assert torch.equal(got.bool(), ref), (BH, QC, KC, D, dtype, p, ratio, int((got.bool() != ref).sum()))
