@@ -13,7 +13,7 @@ What that pins that the loop-level fixtures (make_golden_kmeans.py: launches REP
   * head placement           `*_sparse_head_placement_kernel`, `*_hidden_states_placement_kernel`  svg/models/{hyvideo,wan,cog}/placement.py
   * token permutation        `_permute_kernel`, `_inverse_permute_kernel`   svg/kernels/triton/permute.py
   * block glue               RMSNorm / LayerNorm / modulate kernels         svg/kernels/triton/{rmsnorm,layernorm,modulate}.py
-and, on top of the kernels, the reference's PROCESSORS and its Wan block forward as they are (sections 8-14): `attention_core_logic` of the SAP and SVG1 processors, the
+and, on top of the kernels, the reference's PROCESSORS and its Wan block forward as they are (sections 8-15): `attention_core_logic` of the SAP and SVG1 processors, the
 Wan uniform-block mask generator, and the whole `__call__` of the Wan / Hunyuan (double-, single-stream) / CogVideoX SVG processors.
 Limits, stated: the interpreter of the Triton in this image (3.6.0) mis-handles bfloat16 (numpy has no such type; a 16 x 16
 bf16 `tl.dot` returns garbage), so the fixtures are float32 and float16 — the dtype-independent structure of every kernel is pinned,
@@ -640,6 +640,78 @@ def main():
     for n, (w_, b_) in lin.items():
         out[f"blk_{n}_w"], out[f"blk_{n}_b"] = w_.half().numpy(), b_.half().numpy()
     print(f"blk: Wan block forward C={C}: Triton branch vs torch branch differ by up to {d.max():.3f} (mean {d.mean():.4f}) — the padded variance")
+
+    # ---------------- 15. the whole `__call__` of the reference's Cosmos SVG processor: self attention (sparse) and cross attention ----------------
+    # Cosmos_SVG_AttnProcessor2_0.__call__ (cosmos/attention.py:73-124): projections, head split, per-head norm modules, diffusers' apply_rotary_emb
+    # in its HALF-SPLIT form (use_real_unbind_dim=-2: the channel halves are the real / imaginary parts), attention_core_logic (the Wan one:
+    # cosmos/utils.py is wan/utils.py), output projection; with `timestep=None` and encoder states it is the block's cross attention (torch
+    # SDPA, no RoPE given).  diffusers is absent and the reference has no statement of its own for the -2 form (its kernel tests cover -1):
+    # restated here from diffusers' published definition — x_real, x_imag = x.reshape(..., 2, D/2).unbind(-2); rot = cat(-x_imag, x_real).
+    import svg.models.cosmos.attention as cos_attn
+    import svg.models.cosmos.utils as cos_u
+
+    def diffusers_rope(x, freqs_cis, use_real=True, use_real_unbind_dim=-1):
+        assert use_real and use_real_unbind_dim == -2
+        cos, sin = freqs_cis
+        cos, sin = cos[None, None], sin[None, None]
+        x_real, x_imag = x.reshape(*x.shape[:-1], 2, -1).unbind(-2)
+        x_rot = torch.cat([-x_imag, x_real], dim=-1)
+        return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
+
+    cos_attn.apply_rotary_emb = diffusers_rope
+    heads, hd, F_, P_, mul = 2, 64, 4, 128, 0.9
+    dim, S = heads * hd, F_ * P_
+    g = torch.Generator().manual_seed(777)
+    attn = standins.Attention(dim, heads, qk_norm="rms", dtype=torch.float32)
+
+    def h16(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).half().float()
+
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_v.bias.copy_(h16(dim, s=0.1))
+        attn.to_out[0].weight.copy_(h16(dim, dim, s=dim ** -0.5)), attn.to_out[0].bias.copy_(h16(dim, s=0.1))
+        # channel layout of a head for the half-split RoPE: [24 cos | 8 noise | 24 sin | 8 noise] — pair (c, c + 32) rotates together
+        chan_w = torch.cat([torch.full((24,), 1.6), torch.full((8,), 0.03)]).repeat(2)
+        attn.norm_q.weight.copy_((chan_w * (1 + 0.1 * torch.randn(hd, generator=g))).half().float())
+        attn.norm_k.weight.copy_((chan_w * (1 + 0.1 * torch.randn(hd, generator=g))).half().float())
+    i = torch.arange(S)
+    pos = {0: i.float(), 1: ((i % P_) * F_ + i // P_).float()}
+    freqs = torch.arange(1, 25).float()
+    feats = []
+    for kind in (0, 1):
+        ang = 2 * math.pi * pos[kind][:, None] * freqs[None, :] / (4.0 * S)
+        feats.append(torch.cat([torch.cos(ang) * 2.2, 1.5 * torch.randn(S, 8, generator=g), torch.sin(ang) * 2.2, 1.5 * torch.randn(S, 8, generator=g)], 1))
+    hidden = (torch.cat(feats, 1)[None] + 0.05 * torch.randn(1, S, dim, generator=g)).half().float()
+    rope_ang = 0.03 * torch.rand(S, hd // 2, generator=g)
+    rope = (torch.cat([rope_ang.cos()] * 2, -1), torch.cat([rope_ang.sin()] * 2, -1))            # [S, hd]: both halves share the angles
+    cls = cos_attn.Cosmos_SVG_AttnProcessor2_0
+    cls.context_length, cls.num_frame, cls.frame_size, cls.num_sampled_rows, cls.sample_mse_max_row = 0, F_, P_, 32, S
+    cls.first_layers_fp, cls.first_times_fp = 0, 1.0
+    cls.attention_masks = [cos_u.get_attention_mask("spatial", S, 0, F_, P_), cos_u.get_attention_mask("temporal", S, 0, F_, P_)]
+    cls.block_mask = create_block_mask(cos_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul), None, None, S, S, device="cpu")
+    proc = cls(0)
+    seen = {}
+    orig_mse = proc.sample_mse
+    proc.sample_mse = lambda a, b, c: seen.setdefault("mse", orig_mse(a, b, c))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        o = proc(attn, hidden, image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+        enc = h16(1, 40, dim)
+        o_cross = proc(attn, hidden, encoder_hidden_states=enc)                                  # timestep None: cross attention
+    m_ = seen["mse"].float()
+    best = m_.argmin(0)
+    out["call_cos_hidden"], out["call_cos_o"], out["call_cos_best"], out["call_cos_rope_ang"] = hidden.half().numpy(), o.half().numpy(), best.numpy(), rope_ang.numpy()
+    out["call_cos_enc"], out["call_cos_o_cross"] = enc.half().numpy(), o_cross.half().numpy()
+    for n, t in (("wv", attn.to_v.weight), ("bv", attn.to_v.bias), ("wo", attn.to_out[0].weight), ("bo", attn.to_out[0].bias),
+                 ("nq", attn.norm_q.weight), ("nk", attn.norm_k.weight)):
+        out[f"call_cos_{n}"] = t.detach().half().numpy()
+    out["call_cos_geo"] = np.array([heads, hd, F_, P_], dtype=np.int64)
+    out["call_cos_mul"] = np.float64(mul)
+    print(f"call_cos: Cosmos SVG processor __call__ S={S}: best_mask_idx {best.tolist()}, MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, "
+          f"out {tuple(o.shape)}; cross attention out {tuple(o_cross.shape)}")
 
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)

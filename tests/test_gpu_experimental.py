@@ -261,3 +261,57 @@ def test_wan_block_forward_equals_the_references_block(nat, branch):
     e_other = ((out.float() - other).norm() / other.norm()).item()
     assert e < 5e-3 and e_other > 5 * e, (e, e_other)
     torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=2e-2)
+
+
+def test_cosmos_processor_call_equals_the_references_call(nat):
+    """Parked like the tests above.  The product's Cosmos_SVG_AttnProcessor2_0.__call__ (fp16: per-head RMSNorm on the HIP path, half-split
+    RoPE, the Wan sparse core) and the same processor as cross attention against the reference's executed `__call__`
+    (make_golden_triton.py section 15)."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from standins import Attention
+    from svg.models.cosmos.attention import Cosmos_SVG_AttnProcessor2_0 as cls
+    from svg.models.wan.utils import generate_temporal_head_mask_mod
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+
+    def T(name):
+        return torch.from_numpy(g["call_cos_" + name])
+
+    heads, hd, F_, P_ = (int(x) for x in g["call_cos_geo"])
+    mul, best = float(g["call_cos_mul"]), T("best")
+    dim, S = heads * hd, F_ * P_
+    dt = torch.float16
+    attn = Attention(dim, heads, qk_norm="rms", dtype=dt)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim))
+            lin.bias.zero_()
+        attn.to_v.weight.copy_(T("wv")), attn.to_v.bias.copy_(T("bv"))
+        attn.to_out[0].weight.copy_(T("wo")), attn.to_out[0].bias.copy_(T("bo"))
+        attn.norm_q.weight.copy_(T("nq")), attn.norm_k.weight.copy_(T("nk"))
+    attn.cuda()
+    names = ("context_length", "num_frame", "frame_size", "num_sampled_rows", "sample_mse_max_row", "first_layers_fp", "first_times_fp",
+             "block_mask")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (0, F_, P_, 32, S, 0, 1.0, generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul))):
+            setattr(cls, n, val)
+        attn.set_processor(cls(0))
+        ang = T("rope_ang").float().cuda()
+        rope = (torch.cat([ang.cos()] * 2, -1), torch.cat([ang.sin()] * 2, -1))
+        with torch.no_grad():
+            out = attn(T("hidden").cuda(), image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+            oc = attn(T("hidden").cuda(), encoder_hidden_states=T("enc").cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(attn.processor.last_best_mask_idx.cpu().reshape(best.shape).long(), best.long())
+        for got, name in ((out, "o"), (oc, "o_cross")):
+            ref = T(name).float()
+            e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+            assert e < 5e-3, (name, e)
+            torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)

@@ -594,3 +594,78 @@ def test_product_wan_call_plumbing_on_cpu(g):
             setattr(cls, n, val)
     torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
     assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
+
+
+def _cosmos_inputs(g):
+    heads, hd, F_, P_ = (int(x) for x in g["call_cos_geo"])
+    t = {n: T(g["call_cos_" + n]).float() for n in ("hidden", "o", "enc", "o_cross", "wv", "bv", "wo", "bo", "nq", "nk", "rope_ang")}
+    return heads, hd, F_, P_, float(g["call_cos_mul"]), T(g["call_cos_best"]), t
+
+
+def _rope_half(x, ang):
+    """diffusers apply_rotary_emb(use_real_unbind_dim=-2): channel c and c + D/2 rotate together by ang[..., c]"""
+    cos, sin = torch.cat([ang.cos()] * 2, -1), torch.cat([ang.sin()] * 2, -1)
+    xr, xi = x.reshape(*x.shape[:-1], 2, -1).unbind(-2)
+    return x * cos + torch.cat([-xi, xr], -1) * sin
+
+
+def test_cosmos_processor_call_end_to_end(g):
+    """Fixture: `__call__` of the reference's Cosmos_SVG_AttnProcessor2_0 (cosmos/attention.py:73-124) — per-head norm modules, half-split
+    RoPE, the Wan attention core, output projection — and the same processor as the block's cross attention (`timestep=None`, encoder
+    states, torch SDPA).  The oracle's statement of both calls."""
+    heads, hd, F_, P_, mul, best, t = _cosmos_inputs(g)
+    S = F_ * P_
+    assert best.tolist() == [[0, 1]]
+
+    def rms(y, w):
+        return y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+
+    def split(y):
+        return y.unflatten(2, (heads, -1)).transpose(1, 2)
+
+    x = t["hidden"]
+    q, k, v = rms(split(x), t["nq"]), rms(split(x), t["nk"]), split(x @ t["wv"].T + t["bv"])
+    q, k = _rope_half(q, t["rope_ang"]), _rope_half(k, t["rope_ang"])
+    qp, kp, vp = (O.head_placement(y, best, 0, F_, P_) for y in (q, k, v))
+    o = O.head_placement(O.masked_attention(qp, kp, vp, O.wan_mask(S, F_, P_, mul)), best, 0, F_, P_, inverse=True)
+    out = o.transpose(1, 2).flatten(2, 3) @ t["wo"].T + t["bo"]
+    torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
+    assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
+    e = t["enc"]
+    q, k, v = rms(split(x), t["nq"]), rms(split(e), t["nk"]), split(e @ t["wv"].T + t["bv"])
+    oc = O.masked_attention(q, k, v, None).transpose(1, 2).flatten(2, 3) @ t["wo"].T + t["bo"]
+    torch.testing.assert_close(oc, t["o_cross"], atol=3e-3, rtol=3e-3)
+
+
+def test_product_cosmos_call_plumbing_on_cpu(g):
+    _product_path()
+    from standins import Attention
+    from svg.models.cosmos.attention import Cosmos_SVG_AttnProcessor2_0 as cls
+
+    heads, hd, F_, P_, mul, best, t = _cosmos_inputs(g)
+    dim, S = heads * hd, F_ * P_
+    attn = Attention(dim, heads, qk_norm="rms", dtype=torch.float32)
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k):
+            lin.weight.copy_(torch.eye(dim)), lin.bias.zero_()
+        attn.to_v.weight.copy_(t["wv"]), attn.to_v.bias.copy_(t["bv"])
+        attn.to_out[0].weight.copy_(t["wo"]), attn.to_out[0].bias.copy_(t["bo"])
+        attn.norm_q.weight.copy_(t["nq"]), attn.norm_k.weight.copy_(t["nk"])
+    names = ("context_length", "num_frame", "frame_size")
+    saved = {n: getattr(cls, n) for n in names}
+    try:
+        for n, val in zip(names, (0, F_, P_)):
+            setattr(cls, n, val)
+        proc = cls(0)
+        proc.attention_core_logic = _oracle_core(best, 0, F_, P_, O.wan_mask(S, F_, P_, mul))
+        ang = t["rope_ang"]
+        rope = (torch.cat([ang.cos()] * 2, -1), torch.cat([ang.sin()] * 2, -1))
+        with torch.no_grad():
+            out = proc(attn, t["hidden"], image_rotary_emb=rope, timestep=torch.tensor([0.5]))
+            oc = proc(attn, t["hidden"], encoder_hidden_states=t["enc"])       # cross attention: torch SDPA, nothing HIP-only
+    finally:
+        for n, val in saved.items():
+            setattr(cls, n, val)
+    torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
+    assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
+    torch.testing.assert_close(oc, t["o_cross"], atol=3e-3, rtol=3e-3)
