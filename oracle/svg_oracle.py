@@ -25,7 +25,7 @@ Pinning status (see tests/golden/make_golden.py, which imports the reference its
       head-placement and permutation kernels of the three models, the LayerNorm / RMSNorm / modulate kernels of the Wan block.
       Found that way: the LayerNorm kernels count the zero padding up to the next power of two in the VARIANCE (a reference quirk for
       hidden sizes such as 1536 / 5120; `fp32_layernorm` below states FP32LayerNorm, the specification — see its docstring).
-  pinned at PROCESSOR level by executing the reference's processors (same generator, sections 8-15; section 14 is the Wan block forward on both of its branches, held against the glue functions below): `attention_core_logic` of the SVG1
+  pinned at PROCESSOR level by executing the reference's processors (same generator, sections 8-16; section 14 is the Wan block forward on both of its branches, held against the glue functions below): `attention_core_logic` of the SVG1
       processors (Hunyuan, Wan, CogVideoX) and of the SAP processors (Hunyuan, Wan), and the whole `__call__` of the Wan, Hunyuan (double-
       and single-stream) and CogVideoX SVG processors on a duck-typed attention module — the composition of the functions below that the
       tests use as the checker for the product's processors is itself held to the reference's output (1e-3, fp32).

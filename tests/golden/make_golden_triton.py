@@ -13,7 +13,7 @@ What that pins that the loop-level fixtures (make_golden_kmeans.py: launches REP
   * head placement           `*_sparse_head_placement_kernel`, `*_hidden_states_placement_kernel`  svg/models/{hyvideo,wan,cog}/placement.py
   * token permutation        `_permute_kernel`, `_inverse_permute_kernel`   svg/kernels/triton/permute.py
   * block glue               RMSNorm / LayerNorm / modulate kernels         svg/kernels/triton/{rmsnorm,layernorm,modulate}.py
-and, on top of the kernels, the reference's PROCESSORS and its Wan block forward as they are (sections 8-15): `attention_core_logic` of the SAP and SVG1 processors, the
+and, on top of the kernels, the reference's PROCESSORS and its Wan block forward as they are (sections 8-16): `attention_core_logic` of the SAP and SVG1 processors, the
 Wan uniform-block mask generator, and the whole `__call__` of the Wan / Hunyuan (double-, single-stream) / CogVideoX SVG processors.
 Limits, stated: the interpreter of the Triton in this image (3.6.0) mis-handles bfloat16 (numpy has no such type; a 16 x 16
 bf16 `tl.dot` returns garbage), so the fixtures are float32 and float16 — the dtype-independent structure of every kernel is pinned,
@@ -712,6 +712,40 @@ def main():
     out["call_cos_mul"] = np.float64(mul)
     print(f"call_cos: Cosmos SVG processor __call__ S={S}: best_mask_idx {best.tolist()}, MSE ratio {(m_.max(0).values / m_.min(0).values).min().item():.1f}x, "
           f"out {tuple(o.shape)}; cross attention out {tuple(o_cross.shape)}")
+
+    # ---------------- 16. the reference's Wan processor as CROSS attention: text (T2V) and text + CLIP image tokens (I2V) ----------------
+    # WanAttn_SVGAttn_Processor2_0.__call__ with encoder states and `timestep=None` (wan/attention.py:151-208): q from the video tokens, k / v from
+    # the encoder tokens, the Triton RMSNorm across heads on q and k (interpreted), torch SDPA; with `add_k_proj` (I2V) the first 257 encoder
+    # tokens are the image branch — its own k / v projections, `norm_added_k` by the MODULE's forward, a second SDPA with the same q, the two
+    # results added before the output projection.
+    heads, hd = 2, 64
+    dim, S_v, n_txt = heads * hd, 96, 64      # (row counts in multiples of 32: below 513 columns the Triton RMSNorm takes 32 rows per program without a row mask)
+    g = torch.Generator().manual_seed(2468)
+
+    def h16(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g) * s).half().float()
+
+    for tag, i2v in (("xwan_t2v", False), ("xwan_i2v", True)):
+        attn = standins.Attention(dim, heads, qk_norm="rms", across_heads=True, added_kv=i2v, dtype=torch.float32)
+        mods = [("q", attn.to_q), ("k", attn.to_k), ("v", attn.to_v), ("o", attn.to_out[0])]
+        if i2v:
+            attn.norm_added_k = standins.RMSNorm(dim)                     # Wan: across heads, like norm_k
+            mods += [("ak", attn.add_k_proj), ("av", attn.add_v_proj)]
+        with torch.no_grad():
+            for n, lin in mods:
+                lin.weight.copy_(h16(dim, dim, s=dim ** -0.5)), lin.bias.copy_(h16(dim, s=0.1))
+                out[f"{tag}_w{n}"], out[f"{tag}_b{n}"] = lin.weight.detach().half().numpy(), lin.bias.detach().half().numpy()
+            norms = [("nq", attn.norm_q), ("nk", attn.norm_k)] + ([("nak", attn.norm_added_k)] if i2v else [])
+            for n, nm in norms:
+                nm.weight.copy_((1 + h16(dim, s=0.2)).half().float())
+                out[f"{tag}_{n}"] = nm.weight.detach().half().numpy()
+        hidden, enc = h16(1, S_v, dim), h16(1, n_txt + (257 if i2v else 0), dim)
+        proc = wan_attn.WanAttn_SVGAttn_Processor2_0(0)
+        with torch.no_grad():
+            o = proc(attn, hidden, encoder_hidden_states=enc)
+        out[f"{tag}_hidden"], out[f"{tag}_enc"], out[f"{tag}_o"] = hidden.half().numpy(), enc.half().numpy(), o.half().numpy()
+        out[f"{tag}_geo"] = np.array([heads, hd], dtype=np.int64)
+        print(f"{tag}: Wan cross attention ({'I2V: 257 image tokens + ' if i2v else ''}{n_txt} text tokens): out {tuple(o.shape)}, finite {bool(torch.isfinite(o).all())}")
 
     p = HERE / "triton_golden.npz"
     np.savez_compressed(p, **out)

@@ -315,3 +315,40 @@ def test_cosmos_processor_call_equals_the_references_call(nat):
     finally:
         for n, val in saved.items():
             setattr(cls, n, val)
+
+
+@pytest.mark.parametrize("tag", ["xwan_t2v", "xwan_i2v"])
+def test_wan_cross_attention_and_i2v_equal_the_references_call(nat, tag):
+    """Parked like the tests above.  The product's Wan processor as cross attention (fp16 on the GPU: RMSNorm across heads through
+    svg_rmsnorm_forward, torch SDPA), text only and with the I2V image branch, against the reference's executed call
+    (make_golden_triton.py section 16)."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from standins import RMSNorm, Attention
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as cls
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "triton_golden.npz")
+    t = {n[len(tag) + 1:]: torch.from_numpy(g[n]) for n in g.files if n.startswith(tag + "_") and not n.endswith("_geo")}
+    heads, hd = (int(x) for x in g[tag + "_geo"])
+    i2v, dim, dt = tag == "xwan_i2v", heads * hd, torch.float16
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, added_kv=i2v, dtype=dt)
+    mods = [("q", attn.to_q), ("k", attn.to_k), ("v", attn.to_v), ("o", attn.to_out[0])]
+    if i2v:
+        attn.norm_added_k = RMSNorm(dim).to(dt)
+        mods += [("ak", attn.add_k_proj), ("av", attn.add_v_proj)]
+    with torch.no_grad():
+        for n, m in mods:
+            m.weight.copy_(t["w" + n]), m.bias.copy_(t["b" + n])
+        attn.norm_q.weight.copy_(t["nq"]), attn.norm_k.weight.copy_(t["nk"])
+        if i2v:
+            attn.norm_added_k.weight.copy_(t["nak"])
+    attn.cuda()
+    with torch.no_grad():
+        got = cls(0)(attn, t["hidden"].cuda(), encoder_hidden_states=t["enc"].cuda())
+    torch.cuda.synchronize()
+    ref = t["o"].float()
+    e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
+    assert e < 5e-3, e
+    torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)

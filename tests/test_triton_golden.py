@@ -669,3 +669,57 @@ def test_product_cosmos_call_plumbing_on_cpu(g):
     torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
     assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
     torch.testing.assert_close(oc, t["o_cross"], atol=3e-3, rtol=3e-3)
+
+
+def _xwan(g, tag):
+    t = {n[len(tag) + 1:]: T(g[n]).float() for n in g.files if n.startswith(tag + "_") and not n.endswith("_geo")}
+    heads, hd = (int(x) for x in g[tag + "_geo"])
+    return heads, hd, t
+
+
+@pytest.mark.parametrize("tag", ["xwan_t2v", "xwan_i2v"])
+def test_wan_cross_attention_and_i2v_branch(g, tag):
+    """Fixture: the reference's Wan processor called as the block's CROSS attention (wan/attention.py:151-208, `timestep=None`): text only
+    (T2V) and CLIP image tokens + text (I2V: the first 257 encoder tokens go through add_k_proj / norm_added_k / add_v_proj and a second
+    SDPA with the same q; the results are added before the output projection).  The oracle's statement — and the PRODUCT's processor on
+    CPU tensors, which is plain torch on this path and must return the same."""
+    heads, hd, t = _xwan(g, tag)
+    i2v = tag == "xwan_i2v"
+
+    def rms(y, w):
+        return y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+
+    def split(y):
+        return y.unflatten(2, (heads, -1)).transpose(1, 2)
+
+    def lin(n, x):
+        return x @ t["w" + n].T + t["b" + n]
+
+    x, enc = t["hidden"], t["enc"]
+    img, txt = (enc[:, :257], enc[:, 257:]) if i2v else (None, enc)
+    q, k, v = split(rms(lin("q", x), t["nq"])), split(rms(lin("k", txt), t["nk"])), split(lin("v", txt))
+    o = O.masked_attention(q, k, v, None)
+    if i2v:
+        o = o + O.masked_attention(q, split(rms(lin("ak", img), t["nak"])), split(lin("av", img)), None)
+    out = lin("o", o.transpose(1, 2).flatten(2, 3))
+    torch.testing.assert_close(out, t["o"], atol=3e-3, rtol=3e-3)
+    assert ((out - t["o"]).norm() / t["o"].norm()).item() < 1e-3
+
+    _product_path()
+    from standins import RMSNorm, Attention
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as cls
+    dim = heads * hd
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, added_kv=i2v, dtype=torch.float32)
+    mods = [("q", attn.to_q), ("k", attn.to_k), ("v", attn.to_v), ("o", attn.to_out[0])]
+    if i2v:
+        attn.norm_added_k = RMSNorm(dim)
+        mods += [("ak", attn.add_k_proj), ("av", attn.add_v_proj)]
+    with torch.no_grad():
+        for n, m in mods:
+            m.weight.copy_(t["w" + n]), m.bias.copy_(t["b" + n])
+        attn.norm_q.weight.copy_(t["nq"]), attn.norm_k.weight.copy_(t["nk"])
+        if i2v:
+            attn.norm_added_k.weight.copy_(t["nak"])
+        got = cls(0)(attn, x, encoder_hidden_states=enc)
+    torch.testing.assert_close(got, t["o"], atol=3e-3, rtol=3e-3)
+    assert ((got - t["o"]).norm() / t["o"].norm()).item() < 1e-3
