@@ -229,3 +229,103 @@ def test_wan_bsr_backend_helpers_layout(monkeypatch):
     n_active = int(blk.sum())
     assert indptr.tolist() == [0] + np.cumsum(blk.sum(1).numpy()).tolist() and cols.numel() == n_active + 256
     assert cols[:n_active].tolist() == blk.nonzero()[:, 1].tolist()
+
+
+# ---- the install hooks against what the reference's hooks computed (tests/golden/make_golden_install.py executes them) ----------------
+def _install_golden():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).resolve().parent / "golden" / "install_golden.json").read_text())
+
+
+def _mask_fields(m):
+    return {n: int(getattr(m, n)) for n in ("real_len", "band", "colfull_lo", "colfull_hi", "rowfull_lo", "rowfull_hi")}
+
+
+_CONFIG_KEYS = ("context_length", "num_frame", "frame_size", "prompt_length", "num_sampled_rows", "sample_mse_max_row", "first_layers_fp",
+                "first_times_fp", "sparsity", "version", "num_q_centroids", "num_k_centroids", "top_p_kmeans", "min_kc_ratio",
+                "kmeans_iter_init", "kmeans_iter_step", "zero_step_kmeans_init")
+
+
+def _check_config(cls, ref_cfg, tag):
+    checked = 0
+    for k in _CONFIG_KEYS:
+        if k in ref_cfg and hasattr(cls, k):
+            assert getattr(cls, k) == ref_cfg[k], (tag, k, getattr(cls, k), ref_cfg[k])
+            checked += 1
+    assert checked >= 6, (tag, checked)
+
+
+@pytest.mark.parametrize("tag", ["hy_720p_svg", "hy_480p_svg", "hy_odd_svg", "hy_720p_sap"])
+def test_hunyuan_install_hook_equals_the_references(tag):
+    """replace_hyvideo_attention with the arguments of the reference's scripts: every scalar class attribute the reference's hook set,
+    the band mask that follows from the multiplier IT handed to prepare_flexattention, and the processor class / layer index per block."""
+    from svg.models.hyvideo.inference import replace_hyvideo_attention, replace_hyvideo_flashattention
+
+    gold = _install_golden()
+    ref = gold[tag]
+    n = len(ref["blocks"])
+    blocks = [Block(Attention(256, 2, added_kv=(i < 3)), "attn") for i in range(n)]
+    tr = Transformer(blocks[:3], "transformer_blocks")
+    tr.single_transformer_blocks = torch.nn.ModuleList(blocks[3:])
+    call = dict(ref["call"])
+    cls = replace_hyvideo_attention(Pipe(tr), call.pop("height"), call.pop("width"), call.pop("num_frames"), call.pop("prompt_length"),
+                                    call.pop("first_layers_fp"), call.pop("first_times_fp"), **call)
+    _check_config(cls, ref["config"], tag)
+    assert [[type(b.attn.processor).__name__, b.attn.processor.layer_idx] for b in blocks] == [b[:2] for b in ref["blocks"]]
+    if ref["call"]["pattern"] == "SVG":
+        (flex,) = ref["recorded"]["prepare_flexattention"]
+        ctx, L, F_, P_ = flex["args"][5:9]
+        assert flex["kwargs"]["diag_width"] == flex["kwargs"]["multiplier"]
+        assert _mask_fields(cls.block_mask) == O.hy_band_params(F_ * P_ + ctx, ctx, L, F_, P_, flex["kwargs"]["multiplier"])
+        # the profiling masks were asked for with the same geometry
+        assert ref["recorded"]["get_attention_mask"][0][1:5] == [cls.sample_mse_max_row, cls.context_length, cls.num_frame, cls.frame_size]
+    if tag == "hy_720p_svg":
+        replace_hyvideo_flashattention(Pipe(tr))
+        dense = gold["hy_dense"]["blocks"]
+        assert [[type(b.attn.processor).__name__, b.attn.processor.layer_idx] for b in blocks[:len(dense)]] == [[d[0], i] for i, d in enumerate(dense)]
+
+
+@pytest.mark.parametrize("tag", ["wan_720p_svg", "wan_480p_svg", "wan_odd_svg", "wan_720p_sap"])
+def test_wan_install_hook_equals_the_references(tag):
+    from svg.models.wan.inference import replace_wan_attention
+
+    ref = _install_golden()[tag]
+
+    class WanCfg:
+        patch_size = (1, 2, 2)
+
+    blocks = [Block(Attention(256, 2, across_heads=True), "attn1") for _ in ref["blocks"]]
+    tr = Transformer(blocks, "blocks")
+    tr.config, tr.num_attention_heads, tr.attention_head_dim = WanCfg(), 40, 128
+    pipe = Pipe(tr)
+    pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, 8
+    call = dict(ref["call"])
+    cls = replace_wan_attention(pipe, call.pop("height"), call.pop("width"), call.pop("num_frames"), call.pop("first_layers_fp"),
+                                call.pop("first_times_fp"), **call)
+    _check_config(cls, ref["config"], tag)
+    got = [[type(b.attn1.processor).__name__, b.attn1.processor.layer_idx, getattr(b.attn1.processor, "num_layers", None)] for b in blocks]
+    assert got == ref["blocks"]
+    if ref["call"]["pattern"] == "SVG":
+        (flex,) = ref["recorded"]["prepare_flexattention"]
+        F_, P_, diag, mult = flex["args"][7:11]
+        assert diag == mult and flex["args"][5:7] == [0, 0]
+        assert _mask_fields(cls.block_mask) == O.wan_band_params(F_ * P_, F_, P_, mult)
+
+
+@pytest.mark.parametrize("tag", ["cog_v1", "cog_v15"])
+def test_cog_install_hook_equals_the_references(tag):
+    from svg.models.cog.inference import replace_cog_attention
+
+    ref = _install_golden()[tag]
+    pipe = make_cog(heads=2, head_dim=64, layers=len(ref["blocks"]))
+    c = ref["call"]
+    cls = replace_cog_attention(pipe, c["version"], c["num_sampled_rows"], c["sparsity"], c["first_layers_fp"], c["first_times_fp"])
+    _check_config(cls, ref["config"], tag)
+    got = [[type(b.attn1.processor).__name__, b.attn1.processor.layer_idx, getattr(b.attn1.processor, "num_layers", None)]
+           for b in pipe.transformer.transformer_blocks]
+    assert got == ref["blocks"]
+    (flex,) = ref["recorded"]["prepare_flexattention"]
+    ctx, F_, P_, diag, mult = flex["args"][5:10]
+    assert diag == mult
+    assert _mask_fields(cls.block_mask) == O.cog_band_params(F_ * P_ + ctx, ctx, F_, P_, mult)
