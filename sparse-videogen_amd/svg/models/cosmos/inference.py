@@ -7,7 +7,7 @@ import os
 import torch
 
 from ...logger import logger
-from .attention import Cosmos_SAPAttn_Processor, Cosmos_SVG_AttnProcessor2_0, prepare_flexattention
+from .attention import Cosmos_SAPAttn_Processor, Cosmos_SVG_AttnProcessor2_0, prepare_flashinfer_attention, prepare_flexattention
 from .custom_models import register_transformer, replace_sparse_forward
 from .utils import get_attention_mask, sparsity_to_width
 
@@ -60,6 +60,9 @@ def replace_cosmos_attention(
             raise ValueError(f"Attention backend {attention_backend} not supported")
         AttnModule.block_mask = prepare_flexattention(1, None, None, torch.bfloat16, None, context_length, context_length,
                                                       num_frame_patches, frame_patches_one_frame, diag_width, multiplier)
+        if attention_backend == "flashinfer":   # ref :92-117: the uniform-block (BSR) statement of the same mask, kept for callers that read it
+            AttnModule.temporal_mask_metadata = prepare_flashinfer_attention(1, None, None, torch.bfloat16, None, context_length, context_length,
+                                                                             num_frame_patches, frame_patches_one_frame, diag_width, multiplier)
         logger.info(f"SVG: sparsity {sparsity} -> width {multiplier:.4f} frames -> band {AttnModule.block_mask.band - 1} tokens")
     elif pattern == "SAP":
         logger.info(f"Configuring KMEANS_BLOCK attention with QC: {num_q_centroids}, KC: {num_k_centroids}, "

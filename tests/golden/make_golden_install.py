@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pins the class-level configuration the reference's INSTALL HOOKS compute — `replace_hyvideo_attention`, `replace_wan_attention`,
-`replace_cog_attention` (svg/models/{hyvideo,wan,cog}/inference.py) — by EXECUTING them in the build container on duck-typed pipelines at
+`replace_cog_attention`, `replace_cosmos_attention` (svg/models/{hyvideo,wan,cog,cosmos}/inference.py) — by EXECUTING them in the build container on duck-typed pipelines at
 the geometries of the reference's own scripts (scripts/{hyvideo,wan,cog}/*.sh) and a few odd ones.  Three names inside each hook's module
 are replaced by recorders, because what they do is out of reach here and not what is being pinned: `get_attention_mask` (a [10000, S]
 fp32 tensor built through a 56 GB host tensor at 720p), `prepare_flexattention` (compiles flex_attention on "cuda") and
@@ -71,10 +71,11 @@ def main():
     MG._stub("diffusers.models.transformers")
     for name, classes in (("transformer_wan", ("WanTransformer3DModel", "WanTransformerBlock")),
                           ("transformer_hunyuan_video", ("HunyuanVideoTransformer3DModel", "HunyuanVideoTransformerBlock", "HunyuanVideoSingleTransformerBlock")),
-                          ("cogvideox_transformer_3d", ("CogVideoXTransformer3DModel", "CogVideoXBlock"))):
+                          ("cogvideox_transformer_3d", ("CogVideoXTransformer3DModel", "CogVideoXBlock")),
+                          ("transformer_cosmos", ("CosmosTransformer3DModel", "CosmosTransformerBlock", "Transformer2DModelOutput"))):
         MG._stub("diffusers.models.transformers." + name, **{c: type(c, (), {}) for c in classes})
     MG._stub("diffusers.utils", USE_PEFT_BACKEND=False, scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None,
-             is_torch_version=lambda *a, **k: True, export_to_video=None, load_image=None, logging=types.SimpleNamespace(get_logger=lambda *a, **k: types.SimpleNamespace(warning=print, info=print)))
+             is_torch_version=lambda *a, **k: True, export_to_video=None, load_image=None, is_torchvision_available=lambda: False, logging=types.SimpleNamespace(get_logger=lambda *a, **k: types.SimpleNamespace(warning=print, info=print)))
     if "matplotlib" not in sys.modules:
         try:
             import matplotlib  # noqa: F401
@@ -86,7 +87,7 @@ def main():
     import importlib
 
     mods = {}
-    for m in ("hyvideo", "wan", "cog"):
+    for m in ("hyvideo", "wan", "cog", "cosmos"):
         try:
             mods[m] = importlib.import_module(f"svg.models.{m}.inference")
         except Exception as e:      # a diffusers name the stubs above do not cover
@@ -104,14 +105,16 @@ def main():
 
         def pfa(*a, **k):
             rec["prepare_flexattention"].append({"args": [x if isinstance(x, SCALARS) else str(x) for x in a], "kwargs": {kk: (vv if isinstance(vv, SCALARS) else str(vv)) for kk, vv in k.items()}})
-            return "BLOCK_MASK"
+            return types.SimpleNamespace(to_string=lambda **k: "BLOCK_MASK")
 
         def rsf(*a, **k):
             rec["replace_sparse_forward"] += 1
 
         mod.get_attention_mask, mod.prepare_flexattention, mod.replace_sparse_forward = gam, pfa, rsf
         if hasattr(mod, "prepare_flashinfer_attention"):
-            mod.prepare_flashinfer_attention = lambda *a, **k: "BSR_METADATA"
+            rec["prepare_flashinfer_attention"] = []
+            mod.prepare_flashinfer_attention = lambda *a, **k: (rec["prepare_flashinfer_attention"].append([x if isinstance(x, SCALARS) else str(x) for x in a]), ("indptr", "indices", "bsz"))[1]
+            mod.visualize_sparse_bsr = lambda *a, **k: "(bsr picture)"
         return rec
 
     out = {}
@@ -160,6 +163,30 @@ def main():
         cls = wan.WanAttn_SVGAttn_Processor2_0 if kw["pattern"] == "SVG" else wan.WanAttn_SAPAttn_Processor
         out[tag] = {"call": dict(height=h, width=w, num_frames=nf, first_layers_fp=lfp, first_times_fp=tfp, **kw),
                     "config": class_config(cls), "blocks": blocks_of(pipe, "wan"), "recorded": rec}
+
+    rec = recorders(wan, "wan_720p_svg_flashinfer")
+    pipe = wan_pipe(3)
+    kw = dict(pattern="SVG", attention_backend="flashinfer", num_sampled_rows=64, sparsity=0.3)
+    wan.replace_wan_attention(pipe, 720, 1280, 81, 1, 901.0, **kw)
+    out["wan_720p_svg_flashinfer"] = {"call": dict(height=720, width=1280, num_frames=81, first_layers_fp=1, first_times_fp=901.0, **kw),
+                                      "config": class_config(wan.WanAttn_SVGAttn_Processor2_0), "blocks": blocks_of(pipe, "wan"), "recorded": rec}
+
+    # ---- Cosmos: scripts/cosmos/cosmos_t2v_{svg,sap}.sh (704 x 1280, 121 frames) ----
+    cos = mods["cosmos"]
+    for tag, (h, w, nf, lfp, tfp, kw) in {
+        "cosmos_svg": (704, 1280, 121, 1, 700.0, dict(pattern="SVG", num_sampled_rows=64, sparsity=0.25)),
+        "cosmos_sap": (704, 1280, 121, 1, 700.0, dict(pattern="SAP", num_q_centroids=200, num_k_centroids=800, top_p_kmeans=0.9, min_kc_ratio=0.1,
+                                                      kmeans_iter_init=50, kmeans_iter_step=2, zero_step_kmeans_init=True)),
+    }.items():
+        rec = recorders(cos, tag)
+        blocks = [types.SimpleNamespace(attn1=Attn(), attn2=Attn()) for _ in range(4)]
+        tr = types.SimpleNamespace(transformer_blocks=blocks, config=types.SimpleNamespace(patch_size=(1, 2, 2)), num_attention_heads=40, attention_head_dim=128)
+        pipe = types.SimpleNamespace(transformer=tr, vae_scale_factor_temporal=8, vae_scale_factor_spatial=8, device="cpu")
+        cos.replace_cosmos_attention(pipe, h, w, nf, lfp, tfp, **kw)
+        cls = cos.Cosmos_SVG_AttnProcessor2_0 if kw["pattern"] == "SVG" else cos.Cosmos_SAPAttn_Processor
+        out[tag] = {"call": dict(height=h, width=w, num_frames=nf, first_layers_fp=lfp, first_times_fp=tfp, **kw), "config": class_config(cls),
+                    "blocks": [[type(b.attn1.processor).__name__, getattr(b.attn1.processor, "layer_idx", None), getattr(b.attn1.processor, "num_layers", None)] for b in blocks],
+                    "recorded": rec}
 
     # ---- CogVideoX: scripts/cog/cog_inference.sh (v1 and v1.5) ----
     cog = mods["cog"]

@@ -247,10 +247,15 @@ _CONFIG_KEYS = ("context_length", "num_frame", "frame_size", "prompt_length", "n
                 "kmeans_iter_init", "kmeans_iter_step", "zero_step_kmeans_init")
 
 
+_SVG_ONLY = ("num_sampled_rows", "sample_mse_max_row", "sparsity")          # what only the SVG branch of a hook sets: on the SAP class (a
+_SAP_ONLY = _CONFIG_KEYS[10:]                                               # subclass) they are whatever an earlier SVG install left behind
+
+
 def _check_config(cls, ref_cfg, tag):
     checked = 0
+    skip = _SVG_ONLY if tag.endswith("_sap") else _SAP_ONLY
     for k in _CONFIG_KEYS:
-        if k in ref_cfg and hasattr(cls, k):
+        if k in ref_cfg and hasattr(cls, k) and k not in skip:
             assert getattr(cls, k) == ref_cfg[k], (tag, k, getattr(cls, k), ref_cfg[k])
             checked += 1
     assert checked >= 6, (tag, checked)
@@ -329,3 +334,56 @@ def test_cog_install_hook_equals_the_references(tag):
     ctx, F_, P_, diag, mult = flex["args"][5:10]
     assert diag == mult
     assert _mask_fields(cls.block_mask) == O.cog_band_params(F_ * P_ + ctx, ctx, F_, P_, mult)
+
+
+@pytest.mark.parametrize("tag", ["cosmos_svg", "cosmos_sap"])
+def test_cosmos_install_hook_equals_the_references(tag):
+    from svg.models.cosmos.inference import replace_cosmos_attention
+
+    ref = _install_golden()[tag]
+
+    class Cfg:
+        patch_size = (1, 2, 2)
+
+    blocks = [Block(Attention(256, 2), "attn1") for _ in ref["blocks"]]
+    tr = Transformer(blocks, "transformer_blocks")
+    tr.config, tr.num_attention_heads, tr.attention_head_dim = Cfg(), 40, 128
+    pipe = Pipe(tr)
+    pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 8, 8
+    call = dict(ref["call"])
+    cls = replace_cosmos_attention(pipe, call.pop("height"), call.pop("width"), call.pop("num_frames"), call.pop("first_layers_fp"),
+                                   call.pop("first_times_fp"), **call)
+    _check_config(cls, ref["config"], tag)
+    got = [[type(b.attn1.processor).__name__, b.attn1.processor.layer_idx, getattr(b.attn1.processor, "num_layers", None)] for b in blocks]
+    assert got == ref["blocks"]
+    if ref["call"]["pattern"] == "SVG":
+        (flex,) = ref["recorded"]["prepare_flexattention"]
+        F_, P_, diag, mult = flex["args"][7:11]
+        assert diag == mult
+        assert _mask_fields(cls.block_mask) == O.wan_band_params(F_ * P_, F_, P_, mult)     # (cosmos/utils.py is wan/utils.py)
+
+
+def test_wan_install_hook_flashinfer_backend_equals_the_references():
+    """attention_backend="flashinfer": the reference prepares BSR metadata instead of a flex BlockMask (wan/inference.py:92-117); same
+    class configuration, same per-block processors, and the product's metadata is the uniform-block statement of the same mask."""
+    from svg.models.wan.inference import replace_wan_attention
+
+    ref = _install_golden()["wan_720p_svg_flashinfer"]
+
+    class WanCfg:
+        patch_size = (1, 2, 2)
+
+    blocks = [Block(Attention(256, 2, across_heads=True), "attn1") for _ in ref["blocks"]]
+    tr = Transformer(blocks, "blocks")
+    tr.config, tr.num_attention_heads, tr.attention_head_dim = WanCfg(), 40, 128
+    pipe = Pipe(tr)
+    pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, 8
+    call = dict(ref["call"])
+    cls = replace_wan_attention(pipe, call.pop("height"), call.pop("width"), call.pop("num_frames"), call.pop("first_layers_fp"),
+                                call.pop("first_times_fp"), **call)
+    _check_config(cls, ref["config"], "wan_720p_svg_flashinfer")
+    got = [[type(b.attn1.processor).__name__, b.attn1.processor.layer_idx, getattr(b.attn1.processor, "num_layers", None)] for b in blocks]
+    assert got == ref["blocks"]
+    (fi,) = ref["recorded"]["prepare_flashinfer_attention"]
+    assert fi[5:9] == [0, 0, cls.num_frame, cls.frame_size] and fi[9] == fi[10]
+    assert cls.temporal_mask_metadata is not None
