@@ -422,6 +422,18 @@ int svg_varblock_attention_fp8pv(const void* q, const void* k, const void* v, vo
                                  const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx,
                                  const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* EXPERIMENTAL (written at the end of round 3; compiled, NOT yet run on a GPU; nothing in the package calls it by default).
+ * svg_varblock_attention's default schedule (two-phase body, 256-row q tiles, longest-first order with remainder packing) in the
+ * pre-scaled form of svg_band_attention_prescaled: a pre-pass writes q * sm_scale * log2(e), rounded to the input type, into the
+ * workspace (k-means and the block map keep the plain q), the score accumulators start at minus the row's reference and the MFMAs
+ * deliver the exponent argument — no scale-and-shift FMA per score.  Same arguments as svg_varblock_attention without `variant`;
+ * head_dim 64 / 128.  workspace: svg_varblock_attention_pre_workspace_bytes(...) bytes (the plan + Hq * Sq * D * 2). */
+size_t svg_varblock_attention_pre_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t D);
+int svg_varblock_attention_pre(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq, int32_t Skv,
+                               int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map, const int32_t* q_sizes,
+                               const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exchange overlapped with ONE launch (multi-GPU, SURVEY §8 e).  svg_band_attention_notify = svg_band_attention (variant 0) that
  * also counts completions: every wave adds 1 to done_per_head[h] (int32 [2 * BH], zeroed by the caller; the second half is
  * scratch of the library) after its last store of head h, so done_per_head[h] == svg_band_attention_notify_target(S, mask)

@@ -127,6 +127,9 @@ SIGNATURES = {
     "svg_varblock_attention_fp8pv_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "svg_varblock_attention_fp8pv": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
                                                _VP, _VP, _VP, _SZ, _VP]),
+    "svg_varblock_attention_pre_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32]),
+    "svg_varblock_attention_pre": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
+                                             _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
     "svg_band_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_stage": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _I32, _VP]),
@@ -454,6 +457,7 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
     """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB].
     fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only).
     fp8="pv": EXPERIMENTAL mixed form, 16-bit QK^T + e4m3 PV (svg_varblock_attention_fp8pv).
+    variant="pre": EXPERIMENTAL pre-scaled form of the default 16-bit schedule (svg_varblock_attention_pre).
     workspace: optional uint8 GPU tensor of svg_varblock_workspace_bytes(...) bytes for the 16-bit call (tests read the launch
     order back from it; see varblock_launch_order)."""
     lib = load()
@@ -469,6 +473,17 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
         assert kv_row_idx.dtype == torch.int32 and kv_row_idx.shape == (Hkv, Skv)
     o = torch.zeros_like(q) if q_row_idx is None else torch.zeros_like(q)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    if variant == "pre":   # EXPERIMENTAL: q copy carrying the softmax scale + the PRE form of the two-phase body (not yet validated on a GPU)
+        assert not fp8
+        need = int(lib.svg_varblock_attention_pre_workspace_bytes(Hq, Hkv, QB, KB, Sq, D))
+        if need == 0:
+            raise RuntimeError(f"svg_varblock_attention_pre: unsupported shape (D = {D})")
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        rc = lib.svg_varblock_attention_pre(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D, _dtype_code(q),
+                                            scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(), QB, KB,
+                                            _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), _stream())
+        _check(rc, "svg_varblock_attention_pre")
+        return o
     if fp8 == "pv":   # EXPERIMENTAL: 16-bit QK^T, e4m3 PV (svg_varblock_attention_fp8pv; not yet validated on a GPU)
         need = int(lib.svg_varblock_attention_fp8pv_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
         if need == 0:

@@ -352,3 +352,76 @@ def test_wan_cross_attention_and_i2v_equal_the_references_call(nat, tag):
     e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
     assert e < 5e-3, e
     torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 2, 2), (64, 4, 2)])
+def test_varblock_prescaled_body(nat, dt, D, Hq, Hkv):
+    """svg_varblock_attention_pre (EXPERIMENTAL: a copy of q carrying the softmax scale + the PRE form of the two-phase body) against the
+    fp32 oracle under the element mask with the tolerances of the shipped kernel, and against the shipped kernel itself: ragged and EMPTY
+    clusters, GQA, partial tiles, with and without the fused permutation."""
+    gen = torch.Generator().manual_seed(11)
+    q_sizes = torch.tensor([[300, 1, 0, 129, 70, 524]] * Hkv, dtype=torch.int32)
+    k_sizes = torch.tensor([[64, 0, 200, 333, 1, 426]] * Hkv, dtype=torch.int32)
+    S = int(q_sizes[0].sum())
+    q = torch.randn(Hq, S, D, generator=gen).to(dt)
+    k, v = torch.randn(Hkv, S, D, generator=gen).to(dt), torch.randn(Hkv, S, D, generator=gen).to(dt)
+    bmap = torch.rand(Hkv, 6, 6, generator=gen) < 0.6
+    bmap[:, torch.arange(6), torch.tensor([5, 3, 2, 0, 3, 5])] = True       # every q block sees a key block with rows
+    args = (q.cuda(), k.cuda(), v.cuda(), bmap.cuda(), q_sizes.cuda(), k_sizes.cuda())
+    o = nat.varblock_attention(*args, variant="pre").float().cpu()
+    base = nat.varblock_attention(*args, variant=3).float().cpu()
+    g = Hq // Hkv
+    for h in range(Hkv):
+        em = O.block_mask_to_element_mask(bmap[h], q_sizes[h], k_sizes[h])
+        ref = O.masked_attention(q[h * g:(h + 1) * g], k[h:h + 1], v[h:h + 1], em)
+        torch.testing.assert_close(o[h * g:(h + 1) * g], ref, atol=1e-2, rtol=1e-2)
+        e = ((o[h * g:(h + 1) * g] - ref).norm() / ref.norm()).item()
+        assert e <= (3e-3 if dt == torch.bfloat16 else 1e-3), e
+    assert ((o - base).norm() / base.norm()).item() < (4e-3 if dt == torch.bfloat16 else 1e-3)
+    # fused permutation: rows of q / k / v in a shuffled physical order, the kernel gathers through the index arrays
+    perm_q = torch.stack([torch.randperm(S, generator=gen) for _ in range(Hq)]).int()
+    perm_k = torch.stack([torch.randperm(S, generator=gen) for _ in range(Hkv)]).int()
+    q_phys, k_phys, v_phys = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    for h in range(Hq):
+        q_phys[h, perm_q[h].long()] = q[h]
+    for h in range(Hkv):
+        k_phys[h, perm_k[h].long()] = k[h]
+        v_phys[h, perm_k[h].long()] = v[h]
+    o2 = nat.varblock_attention(q_phys.cuda(), k_phys.cuda(), v_phys.cuda(), bmap.cuda(), q_sizes.cuda(), k_sizes.cuda(),
+                                q_row_idx=perm_q.cuda(), kv_row_idx=perm_k.cuda(), variant="pre").float().cpu()
+    back = torch.stack([o2[h, perm_q[h].long()] for h in range(Hq)])
+    assert torch.equal(back, o), "the fused permutation changes where rows live, not what is computed"
+
+
+def test_varblock_prescaled_body_time_at_production_shape(nat):
+    """prints the time of the shipped SVG2 kernel and of the pre-scaled form on a Wan-720p-like layer slice (8 of 40 heads, 75600 tokens,
+    300 x 1000 ragged clusters, ~25 % of the blocks active); no assertion on the ratio — round 4 decides on `bench_svg2.py`."""
+    gen = torch.Generator().manual_seed(3)
+    H, S, D, QC, KC = 8, 75600, 128, 300, 1000
+
+    def sizes(n):
+        w = torch.rand(H, n, generator=gen) + 0.2
+        s = torch.floor(w / w.sum(-1, keepdim=True) * S).int()
+        s[:, 0] += S - s.sum(-1).int()
+        return s
+
+    qs, ks = sizes(QC), sizes(KC)
+    q, k, v = (torch.randn(H, S, D, generator=gen).to(torch.bfloat16).cuda() for _ in range(3))
+    bmap = (torch.rand(H, QC, KC, generator=gen) < 0.25).cuda()
+    args = (q, k, v, bmap, qs.cuda(), ks.cuda())
+    out = {}
+    for name, var in (("shipped", 3), ("pre-scaled", "pre"), ("shipped", 3), ("pre-scaled", "pre")):
+        nat.varblock_attention(*args, variant=var)
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(5):
+            o = nat.varblock_attention(*args, variant=var)
+        t1.record()
+        torch.cuda.synchronize()
+        out.setdefault(name, []).append(t0.elapsed_time(t1) / 5)
+        out[name + "_o"] = o
+    e = ((out["pre-scaled_o"].float() - out["shipped_o"].float()).norm() / out["shipped_o"].float().norm()).item()
+    print(f"\n[varblock pre-scaled] shipped {out['shipped']} ms, pre-scaled (incl. the q copy) {out['pre-scaled']} ms, rel. L2 between them {e:.2e}")
+    assert e < 4e-3

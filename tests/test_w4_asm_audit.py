@@ -96,9 +96,10 @@ def test_first_step_mfmas_have_no_hazards(f8_listings, capsys):
         for l in kernels:
             assert "2 asm MFMAs, 0 hazards" in l, l
     assert seen == 6, seen
-    rc, out, kernels = _audit(audit, capsys, "pp2q", f8_listings[0])   # pre-scaled band kernels: {plain, switch} x dtype x head_dim
+    # pre-scaled kernels: band {plain, switch} x dtype x head_dim, and the (experimental) variable-block form x dtype x head_dim
+    rc, out, kernels = _audit(audit, capsys, "pp2q", f8_listings[0])
     assert rc == 0, out
     assert not any("trace" in l for l in kernels), "the kept listing is the PRODUCT build's (an -DSVG_ABLATIONS build has the trace kernels)"
-    assert len(kernels) == 8, out
+    assert len(kernels) == 12 and sum("varblock" in l for l in kernels) == 4, out
     for l in kernels:
         assert (" 8 asm MFMAs, 0 hazards" if "switch" in l else " 4 asm MFMAs, 0 hazards") in l, l
