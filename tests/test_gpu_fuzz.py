@@ -3,7 +3,7 @@ tests/test_gpu_fuzz.py -m gpu`; the default `-m gpu` run skips it).  The parity 
 this draws them — frame count, ragged frame size, text / prompt length, band multiplier, heads, head size, dtype, schedule; cluster
 counts with EMPTY clusters, GQA ratios, block-map densities — with the same tolerances as tests/test_gpu_kernels.py.  The CPU side of the
 same idea (oracle against the EXECUTED reference on random geometries) is tools/fuzz_*_vs_reference.py, logs under profiles/.
-Written at the end of round 3 when the GPU budget was spent: first run is round 4's (tools/r04_first_call.sh)."""
+Written at the end of round 3 when the GPU budget was spent: first run is round 4's (tools/r04_second_call.sh)."""
 import os
 
 import pytest

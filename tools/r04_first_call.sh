@@ -20,9 +20,3 @@ for t in cur ms64 cur ms64; do
   echo "== $t"; SVG_ATTN_LIB=$L/$f timeout 200 python tools/svg1_models.py pre 2>>$O/err.txt | grep -i "cog"
 done 2>&1 | tee $O/ab_cog_mfmasum.txt
 SVG_ATTN_LIB=$L/libsvgattn_ms64.so timeout 400 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_prescaled.py tests/test_gpu_fullsize.py -q -k "64 or cog" 2>&1 | tail -3 | tee $O/pytest_d64_mfmasum.txt
-# 4. the mixed-precision SVG2 body (csrc/attn_f8pv.h): first run ever
-SVG_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_experimental.py -q -s 2>&1 | grep -v amdgpu.ids | tail -60 | tee $O/pytest_experimental.txt
-#    (the same file also holds three parity tests written after round 3's GPU budget was spent — the product's Hunyuan / CogVideoX
-#     processor __call__ and Wan block forward against the reference's executed ones: once green they move to tests/test_gpu_triton_golden.py)
-# 5. random-geometry fuzz of the HIP kernels against the oracle (tests/test_gpu_fuzz.py, opt-in): first run ever
-SVG_FUZZ=25 timeout 600 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | tail -8 | tee $O/pytest_fuzz.txt
