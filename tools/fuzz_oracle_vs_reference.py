@@ -15,6 +15,8 @@ counts with empty clusters, top-p / min_kc_ratio — and demands equality:
   dynamic_block_sparse_fwd_torch (ragged + empty clusters)         1e-5
   sample_mse of the Hunyuan / Wan / Cog processors                 1e-6 (fp32 inputs; NaN positions equal for Cog)
   Wan BSR op: get_factor / ref_gen_temporal_mask                   bit-exact against the PRODUCT's host-side generator (svg.kernels.ops)
+  the PRODUCT's mask descriptors (host code of svg.models.*.utils): profile_desc expanded as the device reads it == get_attention_mask;
+      generate_temporal_head_mask_mod (svg_band_mask_t) expanded == the reference's mask_mod on the full grid             bit-exact
 
     python tools/fuzz_oracle_vs_reference.py [--trials 40] > profiles/<round>_fuzz_oracle_vs_reference.txt"""
 import argparse
@@ -36,6 +38,31 @@ def grid_mask(mask_mod, S):
     q = torch.arange(S)[:, None].expand(S, S)
     k = torch.arange(S)[None, :].expand(S, S)
     return mask_mod(0, 0, q, k)
+
+
+def expand_profile_variant(pv, vid0, F_, P_, S, rows=None):
+    """svg_profile_variant_t as the device reads it (csrc/profiler.hip `ProfilePolicy::allowed`, documented in include/svg_attn.h) -> the
+    float mask it stands for: rows `rows` (default all) x all S keys"""
+    V = F_ * P_
+    idx = torch.arange(S)
+
+    def coord(t):
+        if pv.coord != 1:
+            return t
+        v = t - vid0
+        inside = (v >= 0) & (v < V)
+        tm = vid0 + (v % P_) * F_ + v // P_
+        return torch.where(inside, tm, t)
+
+    q = idx if rows is None else torch.as_tensor(rows)
+    x, y = (coord(q) - pv.origin)[:, None], (coord(idx) - pv.origin)[None, :]
+    qtext = ((q >= pv.text_lo) & (q < pv.text_hi))[:, None]
+    ktext = ((idx >= pv.text_lo) & (idx < pv.text_hi))[None, :]
+    dom = (x >= 0) & (x < pv.span) & (y >= 0) & (y < pv.span)
+    db = torch.div(x, 128, rounding_mode="floor") - torch.div(y, 128, rounding_mode="floor")
+    band = (db < pv.band_blocks) & (-db < pv.band_blocks)
+    sink = y < pv.sink_cols
+    return (qtext | ktext | (dom & (band | sink))).float()
 
 
 def main():
@@ -65,8 +92,22 @@ def main():
     import svg.models.wan.attention as wan_attn
     import svg.models.wan.utils as wan_u
 
-    sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
-    from svg.kernels.ops import attention_ops_wan as own_ops_wan   # product host code (pure CPU part)
+    # The product's package is called `svg` like the reference's, which is imported above: load it under another top-level name (its
+    # modules import each other relatively).  Host code only — mask generators and descriptors; nothing here touches the GPU.
+    import importlib
+    import importlib.util
+
+    pkg_dir = ROOT / "sparse-videogen_amd" / "svg"
+    spec = importlib.util.spec_from_file_location("svg_amd", pkg_dir / "__init__.py", submodule_search_locations=[str(pkg_dir)])
+    svg_amd = importlib.util.module_from_spec(spec)
+    sys.modules["svg_amd"] = svg_amd
+    spec.loader.exec_module(svg_amd)
+    own_ops_wan = importlib.import_module("svg_amd.kernels.ops.attention_ops_wan")
+    own_cog_u = importlib.import_module("svg_amd.models.cog.utils")
+    own_hy_u = importlib.import_module("svg_amd.models.hyvideo.utils")
+    own_wan_u = importlib.import_module("svg_amd.models.wan.utils")
+    for m in (own_ops_wan, own_cog_u, own_hy_u, own_wan_u):
+        assert str(pkg_dir) in m.__file__ and "/root/reference" not in m.__file__, m.__file__
 
     gen = torch.Generator().manual_seed(args.seed)
 
@@ -106,6 +147,20 @@ def main():
             ok("profile mask hy", torch.equal(hy_u.get_attention_mask(which, V, ctx, F_, P_, device="cpu").float(), O.profile_masks("hy", ctx, F_, P_)[idx][:V]), (which, F_, P_, ctx))      # (the first sample_mse_max_row rows)
             ok("profile mask wan", torch.equal(wan_u.get_attention_mask(which, V, 0, F_, P_).float(), O.profile_masks("wan", 0, F_, P_)[idx][:V]), (which, F_, P_))
             ok("profile mask cog", torch.equal(cog_u.get_attention_mask(which, ctx, F_, P_).float(), O.profile_masks("cog", ctx, F_, P_)[idx]), (which, F_, P_, ctx))
+        # ---- the PRODUCT's analytic profile descriptors (host code: svg.models.*.utils.profile_desc), expanded as the device reads them ----
+        for model, mod_own, ref_masks, c_len in (("hy", own_hy_u, [hy_u.get_attention_mask(w, V, ctx, F_, P_, device="cpu").float() for w in ("spatial", "temporal")], ctx),
+                                                 ("wan", own_wan_u, [wan_u.get_attention_mask(w, V, 0, F_, P_).float() for w in ("spatial", "temporal")], 0),
+                                                 ("cog", own_cog_u, [cog_u.get_attention_mask(w, ctx, F_, P_).float() for w in ("spatial", "temporal")], ctx)):
+            d = mod_own.profile_desc(c_len, F_, P_)
+            for i in range(2):
+                mine = expand_profile_variant(d.variant[i], d.vid0, F_, P_, V + c_len)
+                ok(f"product profile descriptor {model}", torch.equal(mine[:ref_masks[i].shape[0]], ref_masks[i]), (model, i, F_, P_, c_len))
+        # ---- the PRODUCT's band-mask descriptors (generate_temporal_head_mask_mod -> svg_band_mask_t) against the reference's mask_mod ----
+        for name, desc, ref_mm, Sx in (("hy", own_hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), hy_u.generate_temporal_head_mask_mod(ctx, L, F_, P_, mul=mul), S),
+                                       ("wan", own_wan_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul), wan_u.generate_temporal_head_mask_mod(0, 0, F_, P_, mul=mul), V),
+                                       ("cog", own_cog_u.generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul), cog_u.generate_temporal_head_mask_mod(ctx, F_, P_, mul=mul), S)):
+            fields = {n: int(getattr(desc, n)) for n in ("real_len", "band", "colfull_lo", "colfull_hi", "rowfull_lo", "rowfull_hi")}
+            ok(f"product band descriptor {name}", torch.equal(O.band_mask(Sx, **fields), grid_mask(ref_mm, Sx)), (name, F_, P_, ctx, L, mul))
         # ---- sparsity -> width ----
         sp = rf(0.1, 0.6)
         for mod in (hy_u, wan_u, cog_u):
@@ -196,7 +251,7 @@ def main():
         ok("wan bsr get_factor", ref_ops_wan.get_factor(Fw, Pw) == own_ops_wan.get_factor(Fw, Pw), (Fw, Pw))
         ok("wan bsr ref_gen_temporal_mask", torch.equal(torch.as_tensor(ref_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw)), torch.as_tensor(own_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw))), (Fw, Pw, mw))
 
-    print(f"# fuzz of oracle/svg_oracle.py (and the product's Wan BSR mask generator) against the reference's own torch functions: {args.trials} random geometries, seed {args.seed}")
+    print(f"# fuzz of oracle/svg_oracle.py (and of the product's host-side mask descriptors and BSR generator, loaded under the name svg_amd) against the reference's own torch functions: {args.trials} random geometries, seed {args.seed}")
     print("| function | comparisons | mismatches |\n|---|---|---|")
     total_bad = 0
     for name, (n, bad) in counts.items():
