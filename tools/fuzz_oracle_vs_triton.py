@@ -105,13 +105,15 @@ def main():
         same = int(r_n) == int(o_n) and torch.equal(r_ids, o_ids) and torch.equal(r_sz.to(o_sz.dtype), o_sz) and torch.allclose(r_c, o_c, rtol=1e-5, atol=1e-5)
         if not same:
             # Did a near-tie flip a label somewhere along the way?  Step the loop on the reference's kernels and compare each assignment.
-            cc, flipped = init.clone(), False
-            for _ in range(int(r_n)):
-                a_ref, a_or = KU.euclid_assign_triton(x, cc, (x ** 2).sum(-1)), O.kmeans_assign(x, O.kmeans_xsq(x), cc)
+            # Each side steps with ITS OWN centroids: the two updates add in different orders, the centres differ in the last bits
+            # (~1e-6), and that alone moves a point whose two distances are closer than that.
+            cr, co, flipped = init.clone(), init.clone(), False
+            for _ in range(max(int(r_n), int(o_n))):
+                a_ref, a_or = KU.euclid_assign_triton(x, cr, (x ** 2).sum(-1)), O.kmeans_assign(x, O.kmeans_xsq(x), co)
                 if not torch.equal(a_ref, a_or):
-                    flipped = labels_agree(x, cc, a_ref, a_or)       # True: only near-ties differ (counted); False: a real disagreement
+                    flipped = labels_agree(x, cr, a_ref, a_or)       # True: only near-ties differ (counted); False: a real disagreement
                     break
-                cc = KU.triton_centroid_update_sorted_euclid(x, a_ref, cc)[0]
+                cr, co = KU.triton_centroid_update_sorted_euclid(x, a_ref, cr)[0], O.kmeans_update(x, a_or, co)[0]
             near["loop"] += int(flipped)
             same = flipped
         ok("k-means loop", same, (B, N, D, Kl, iters, int(r_n), int(o_n)))
@@ -191,7 +193,7 @@ def main():
         print(f"| {name} | {n} | {bad} |")
         bad_total += bad
     print(f"\nassign kernel: {near['points']} points took another label than the oracle where the two distances are closer than the fp32 rounding bound of the distance form; "
-          f"{near['loop']} whole loops diverged behind such a point (the summation order of the dot product is implementation-chosen: numpy's in the interpreter, the matrix unit's on a GPU)")
+          f"{near['loop']} whole loops diverged behind such a point (the summation order of the dot product is implementation-chosen: numpy's in the interpreter, the matrix unit's on a GPU; the two centroid updates also add in different orders, ~1e-6)")
     print("RESULT:", "all equal" if bad_total == 0 else f"{bad_total} MISMATCHES")
     return 1 if bad_total else 0
 
