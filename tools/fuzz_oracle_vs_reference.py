@@ -15,6 +15,7 @@ counts with empty clusters, top-p / min_kc_ratio — and demands equality:
   dynamic_block_sparse_fwd_torch (ragged + empty clusters)         1e-5
   sample_mse of the Hunyuan / Wan / Cog processors                 1e-6 (fp32 inputs; NaN positions equal for Cog)
   Wan BSR op: get_factor / ref_gen_temporal_mask                   bit-exact against the PRODUCT's host-side generator (svg.kernels.ops)
+  Hunyuan BSR op: _gen_temporal_mask / _gen_spatial_mask           bit-exact against the PRODUCT's (row pointer, padded column indices, block size)
   the PRODUCT's mask descriptors (host code of svg.models.*.utils): profile_desc expanded as the device reads it == get_attention_mask;
       generate_temporal_head_mask_mod (svg_band_mask_t) expanded == the reference's mask_mod on the full grid             bit-exact
 
@@ -81,6 +82,7 @@ def main():
             MG._stub("matplotlib.pyplot")
     sys.path.insert(0, MG.REF)
     torch.Tensor.cuda = lambda self, *a, **k: self
+    import svg.kernels.ops.attention_ops as ref_ops_hy
     import svg.kernels.ops.attention_ops_wan as ref_ops_wan
     import svg.kmeans_utils as KU
     import svg.models.cog.attention as cog_attn
@@ -103,10 +105,11 @@ def main():
     sys.modules["svg_amd"] = svg_amd
     spec.loader.exec_module(svg_amd)
     own_ops_wan = importlib.import_module("svg_amd.kernels.ops.attention_ops_wan")
+    own_ops_hy = importlib.import_module("svg_amd.kernels.ops.attention_ops")
     own_cog_u = importlib.import_module("svg_amd.models.cog.utils")
     own_hy_u = importlib.import_module("svg_amd.models.hyvideo.utils")
     own_wan_u = importlib.import_module("svg_amd.models.wan.utils")
-    for m in (own_ops_wan, own_cog_u, own_hy_u, own_wan_u):
+    for m in (own_ops_wan, own_ops_hy, own_cog_u, own_hy_u, own_wan_u):
         assert str(pkg_dir) in m.__file__ and "/root/reference" not in m.__file__, m.__file__
 
     gen = torch.Generator().manual_seed(args.seed)
@@ -248,6 +251,16 @@ def main():
                (seed, float((torch.nan_to_num(want) - torch.nan_to_num(got)).abs().max())))
         # ---- Wan uniform-block op: the product's host-side generator against the reference's ----
         Fw, Pw, mw = ri(2, 8), ri(30, 600), rf(0.2, 2.5)
+        # ---- Hunyuan uniform-block op (svg/kernels/ops/attention_ops.py): BSR row pointer, column indices (with the reference's padding) and block size ----
+        Fh, Ph, mh = ri(1, 9), 10 * ri(1, 40), rf(0.1, 3.0)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):                       # (the reference prints the whole mask)
+            ref_t, ref_s = ref_ops_hy._gen_temporal_mask(Fh, Ph, mh), ref_ops_hy._gen_spatial_mask(Fh, Ph, int(mh))
+        own_t, own_s = own_ops_hy._gen_temporal_mask(Fh, Ph, mh), own_ops_hy._gen_spatial_mask(Fh, Ph, int(mh))
+        for nm, a, b in (("temporal", ref_t, own_t), ("spatial", ref_s, own_s)):
+            ok(f"hunyuan bsr _gen_{nm}_mask", torch.equal(a[0].cpu(), b[0].cpu()) and torch.equal(a[1].cpu(), b[1].cpu()) and tuple(a[2]) == tuple(b[2]) and a[0].dtype == b[0].dtype and a[1].dtype == b[1].dtype,
+               (Fh, Ph, mh))
         ok("wan bsr get_factor", ref_ops_wan.get_factor(Fw, Pw) == own_ops_wan.get_factor(Fw, Pw), (Fw, Pw))
         ok("wan bsr ref_gen_temporal_mask", torch.equal(torch.as_tensor(ref_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw)), torch.as_tensor(own_ops_wan.ref_gen_temporal_mask(Fw, Pw, mw))), (Fw, Pw, mw))
 
