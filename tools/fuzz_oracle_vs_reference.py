@@ -16,6 +16,7 @@ counts with empty clusters, top-p / min_kc_ratio — and demands equality:
   sample_mse of the Hunyuan / Wan / Cog processors                 1e-6 (fp32 inputs; NaN positions equal for Cog)
   Wan BSR op: get_factor / ref_gen_temporal_mask                   bit-exact against the PRODUCT's host-side generator (svg.kernels.ops)
   Hunyuan BSR op: _gen_temporal_mask / _gen_spatial_mask           bit-exact against the PRODUCT's (row pointer, padded column indices, block size)
+  the PRODUCT's torch-level placement helpers (ref_* functions, in-place token reorders) and sparsity_to_width             bit-exact
   the PRODUCT's mask descriptors (host code of svg.models.*.utils): profile_desc expanded as the device reads it == get_attention_mask;
       generate_temporal_head_mask_mod (svg_band_mask_t) expanded == the reference's mask_mod on the full grid             bit-exact
 
@@ -106,6 +107,8 @@ def main():
     spec.loader.exec_module(svg_amd)
     own_ops_wan = importlib.import_module("svg_amd.kernels.ops.attention_ops_wan")
     own_ops_hy = importlib.import_module("svg_amd.kernels.ops.attention_ops")
+    own_hy_pl = importlib.import_module("svg_amd.models.hyvideo.placement")
+    own_cog_pl = importlib.import_module("svg_amd.models.cog.placement")
     own_cog_u = importlib.import_module("svg_amd.models.cog.utils")
     own_hy_u = importlib.import_module("svg_amd.models.hyvideo.utils")
     own_wan_u = importlib.import_module("svg_amd.models.wan.utils")
@@ -183,6 +186,26 @@ def main():
             out = torch.zeros_like(x[0])
             inv(x[0], out, best, ctx, F_, P_)
             ok(f"placement {name} inv", torch.equal(out, O.head_placement(x[0], best, ctx, F_, P_, text_first=tf, inverse=True)))
+        # ---- the PRODUCT's torch-level placement helpers (CPU tensors: the `ref_*` functions and the in-place token reorders) ----
+        for name, r_mod, o_mod, fwd, inv, tm, fm in (
+                ("hy", hy_pl, own_hy_pl, "ref_hunyuan_sparse_head_placement", "ref_hunyuan_hidden_states_placement", "hunyuan_token_reorder_to_token_major", "hunyuan_token_reorder_to_frame_major"),
+                ("cog", cog_pl, own_cog_pl, "ref_sparse_head_placement", "ref_hidden_states_placement", "token_reorder_to_token_major", "token_reorder_to_frame_major")):
+            a, b = getattr(r_mod, fwd)(x[0], x[1], x[2], best, ctx, F_, P_), getattr(o_mod, fwd)(x[0], x[1], x[2], best, ctx, F_, P_)
+            ok(f"product placement {name} fwd", all(torch.equal(u, w) for u, w in zip(a, b)))
+            oa, ob = torch.zeros_like(x[0]), torch.zeros_like(x[0])
+            getattr(r_mod, inv)(x[0], oa, best, ctx, F_, P_)
+            getattr(o_mod, inv)(x[0], ob, best, ctx, F_, P_)
+            ok(f"product placement {name} inv", torch.equal(oa, ob))
+            for fn in (tm, fm):
+                ta, tb = x[1].clone(), x[1].clone()
+                ra, rb = getattr(r_mod, fn)(ta, ctx, V, F_, P_), getattr(o_mod, fn)(tb, ctx, V, F_, P_)
+                ok(f"product token reorder {name}", torch.equal(ra, rb) and torch.equal(ta, tb))
+        for mod_r, mod_o in ((hy_u, own_hy_u), (wan_u, own_wan_u), (cog_u, own_cog_u)):
+            try:
+                want = mod_r.sparsity_to_width(sp, ctx, F_, P_)
+            except ValueError:
+                continue
+            ok("product sparsity_to_width", want == mod_o.sparsity_to_width(sp, ctx, F_, P_))
         # ---- weighted softmax, dynamic map, density, variable-block attention ----
         B, Hh, QC, KC, Dd = 1, ri(1, 3), ri(2, 12), ri(2, 16), 16 * ri(1, 4)
         qc, kc = torch.randn(B, Hh, QC, Dd, generator=gen) * 2, torch.randn(B, Hh, KC, Dd, generator=gen) * 2
