@@ -8,3 +8,7 @@ O=gpurun_out/r04b; mkdir -p $O
 SVG_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_experimental.py -q -s 2>&1 | grep -v amdgpu.ids | tail -60 | tee $O/pytest_experimental.txt
 # 2. random-geometry fuzz of the HIP kernels against the oracle (tests/test_gpu_fuzz.py, opt-in): first run ever
 SVG_FUZZ=25 timeout 600 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | tail -8 | tee $O/pytest_fuzz.txt
+# 3. the pre-scaled SVG2 path in the layer-call bench (Wan 720p): default, --pre, default, --pre
+for m in "" "--pre" "" "--pre"; do
+  timeout 200 python bench_svg2.py $m --steps 4 --warmup 2 2>>$O/err.txt | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('svg2 16-bit [$m]', d['ms'], 'spot rows', d.get('spot_rows_rel_l2_vs_torch_fp32'))"
+done 2>&1 | tee $O/ab_svg2_pre.txt
