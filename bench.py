@@ -208,11 +208,14 @@ def main():
     ap.add_argument("--no-step", action="store_true", help="skip the measured 60-layer denoise step (bench_step.measure)")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
     ap.add_argument("--no-ab", action="store_true", help="skip the same-box A/B block (frozen reference schedule and the other schedules timed beside the default)")
-    ap.add_argument("--no-prescaled", action="store_true", help="plain q and svg_band_attention (scale applied per score inside the kernel). "
-                    "Default at N = 1, bf16, default schedule: q carries sm_scale * log2(e) — what the fused prologue of "
-                    "Hunyuan_SVGAttn_Processor2_0 hands its attention core (svg_qk_norm_rope_transpose_qscale; here multiplied and "
-                    "rounded once before the timed region) — and the step runs svg_sample_mse / svg_band_attention_prescaled on it")
+    ap.add_argument("--prescaled", action="store_true", help="opt-in pre-scaled path (flex_attention's PRESCALE_QK trade-off; the processors' "
+                    "prescale_q = True): q carries sm_scale * log2(e) — what the fused prologue hands the attention core then "
+                    "(svg_qk_norm_rope_transpose_qscale; here multiplied and rounded once before the timed region) — and the step runs "
+                    "svg_sample_mse / svg_band_attention_prescaled on it.  Default since round 4: plain q, the softmax scale applied to the fp32 "
+                    "scores inside the kernel (the reference's formulation, svg/models/hyvideo/attention.py:401-403)")
     ap.add_argument("--heads", default="alt", choices=["alt", "spatial", "temporal"], help="best_mask_idx pattern")
+    ap.add_argument("--extras", default="auto", choices=["auto", "small"], help="auto: the SVG2 / denoise-step extras blocks at full size beside the "
+                    "hy720p headline workload and nowhere else; small: the same blocks on reduced geometries beside ANY workload (contract tests)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,9 +267,11 @@ def main():
     Hl = len(my_heads)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     if world > 1:
-        # token-sharded inputs: ALL heads (ordered owner by owner, as the fused prologue would write them) of this rank's frames
+        # token-sharded inputs: ALL heads (ordered owner by owner, as the fused prologue would write them) of this rank's tokens
+        # (shards in units of 128 tokens like bench_step.StepGeo.unit: largest / mean 1.006 at N = 8 where whole frames give 1.21)
+        TOKEN_UNIT = 128 if S >= 8 * 128 * world else 8
         head_lists = [chunked_head_layout(H, r, world, max_chunks=24)[2] for r in range(world)]
-        ta, tb = token_range(S, rank, world, unit=P_)
+        ta, tb = token_range(S, rank, world, unit=TOKEN_UNIT)
         q_tok, k_tok, v_tok = (torch.randn(H, tb - ta, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
         q, k, v = (torch.empty(1, Hl, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
         seen = torch.ones(1, device=dev)
@@ -317,7 +322,7 @@ def main():
         assert world == 1, "--dtype fp8 is a single-GPU line"
         a.no_step = True
     q_att = q
-    a.prescaled = not fp8 and a.variant == 0 and D == 128 and not a.no_prescaled
+    a.prescaled = a.prescaled and not fp8 and a.variant == 0 and D == 128
     if a.prescaled and world == 1:
         q_att = (q.float() * nat.softmax_q_scale(D)).to(q.dtype)   # outside the timed region: the prologue's job (svg_qk_norm_rope* q_scale)
     if a.prescaled and world > 1:   # token shards as the token-sharded prologue would write them: pre-scaled q
@@ -329,9 +334,9 @@ def main():
         if world > 1:   # inbound exchange: token shards -> this rank's heads over the full sequence
             for x_tok, x in ((q_tok, q), (k_tok, k), (v_tok, v)):
                 if smoke:   # gloo: stage through host memory (the smoke run checks control flow and placement, not speed)
-                    x[0].copy_(tokens_to_heads(x_tok.cpu(), S, unit=P_, head_lists=head_lists, presorted=True))
+                    x[0].copy_(tokens_to_heads(x_tok.cpu(), S, unit=TOKEN_UNIT, head_lists=head_lists, presorted=True))
                 else:
-                    tokens_to_heads(x_tok, S, unit=P_, head_lists=head_lists, presorted=True, out=x[0])
+                    tokens_to_heads(x_tok, S, unit=TOKEN_UNIT, head_lists=head_lists, presorted=True, out=x[0])
         if not a.no_profiler:
             mse = nat.sample_mse(q_att[0], k[0], v[0], rows, prof, sm_scale=LN2 if a.prescaled else None)
             _ = mse.argmin(0)  # best_mask_idx (kept on device; the bench uses the fixed alternating pattern)
@@ -538,7 +543,7 @@ def main():
             "clock": clock_info,   # sustained shader clock during the timed steps (the 2.5 PFLOP/s peak is quoted at 2.4 GHz)
         }
         if a.prescaled:
-            out["config"]["q_prescaled"] = "q carries sm_scale * log2(e), as the fused prologue of the SVG1 processor writes it (--no-prescaled: plain q)"
+            out["config"]["q_prescaled"] = "--prescaled: q carries sm_scale * log2(e), as the fused prologue writes it under prescale_q = True (opt-in; default: plain q)"
             ob = nat.band_attention(q[:, :2].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), mask,
                                     head_perm_flag=best[:, :2].contiguous(), vid0=0, num_frame=F_, frame_size=P_).float()
             out["prescaled_rel_l2_vs_default_kernel"] = round(((o[:, :2].float() - ob).norm() / ob.norm()).item(), 6)
@@ -563,18 +568,25 @@ def main():
         ab = {}
         try:
             qs = q_att if a.prescaled else (q.float() * nat.softmax_q_scale(D)).to(q.dtype)
-            ab["default_ms"] = round(time_attn(lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)), 3)
+            plain = lambda: nat.band_attention(q, k, v, mask, **pk)                          # noqa: E731  (the default path of the processors)
+            pre = lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)        # noqa: E731  (opt-in, prescale_q = True)
+            ab["default_ms"] = round(time_attn(plain), 3)
             ab["frozen_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=6, **pk)), 3)
-            ab["plain_q_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, **pk)), 3)
+            ab["prescaled_q_ms"] = round(time_attn(pre), 3)
+            os.environ["SVG_BAND_ROTATE"] = "0"      # (read per launch, csrc/band_policy.h: every q-tile sweeps from its own first key, as until round 3)
+            ab["default_no_cyclic_start_ms"] = round(time_attn(plain), 3)
+            ab["prescaled_q_no_cyclic_start_ms"] = round(time_attn(pre), 3)
+            os.environ.pop("SVG_BAND_ROTATE", None)
             ab["variant_3_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=3, **pk)), 3)
             ab["variant_1_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=1, **pk), n=2), 3)
-            ab["default_ms_again"] = round(time_attn(lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)), 3)   # (drift over the block)
+            ab["default_ms_again"] = round(time_attn(plain), 3)   # (drift over the block)
             ab["default_over_frozen"] = round(ab["default_ms"] / ab["frozen_ms"], 4)
-            ab["plain_q_over_frozen"] = round(ab["plain_q_ms"] / ab["frozen_ms"], 4)
-            ab["what"] = ("attention kernel ms, same process / box / inputs: default = svg_band_attention_prescaled (two-phase body, "
-                          "max-free softmax, carried operands, score accumulators started at minus the reference; q pre-scaled by the "
-                          "prologue), frozen = variant 6 (two-phase body with the round-1 softmax and operand fetch, plain q), plain_q = "
-                          "svg_band_attention variant 0 on the plain q, 3 = one wave per SIMD, 1 = lock-step 4 waves")
+            ab["prescaled_q_over_frozen"] = round(ab["prescaled_q_ms"] / ab["frozen_ms"], 4)
+            ab["what"] = ("attention kernel ms, same process / box / inputs: default = svg_band_attention variant 0 on the plain q (two-phase body, "
+                          "max-free softmax, carried operands, cyclic sweep start; softmax scale on the fp32 scores — the reference's formulation), "
+                          "prescaled_q = svg_band_attention_prescaled (opt-in: score accumulators started at minus the reference, q pre-scaled by the "
+                          "prologue — flex_attention's PRESCALE_QK trade-off), frozen = variant 6 (two-phase body with the round-1 softmax and operand "
+                          "fetch, plain q), *_no_cyclic_start = SVG_BAND_ROTATE=0, 3 = one wave per SIMD, 1 = lock-step 4 waves")
             del qs
         except Exception as e:  # noqa: BLE001
             ab["error"] = f"{type(e).__name__}: {str(e)[:300]}"
@@ -706,28 +718,38 @@ def main():
             out["dense_same_gpu"]["speedup_sparse_vs_torch_sdpa"] = round(sms / ms_step, 3)
         except Exception as e:  # noqa: BLE001
             out["dense_same_gpu"]["torch_sdpa_error"] = str(e)[:200]
-    if world == 1 and not a.no_svg2 and a.workload == "hy720p":
+    extras_full = a.workload == "hy720p" and a.extras == "auto"
+    extras_small = a.extras == "small"
+    failed_extras = []          # an extras block that raises is reported in the line AND fails the run (exit code 3 after the line is printed)
+    if world == 1 and not a.no_svg2 and (extras_full or extras_small):
         # BASELINE.json configs[2]: one SVG2 / SAP layer-call of Wan 2.1 720p (k-means, block map, variable-block attention)
         del q, k, v, o
         torch.cuda.empty_cache()
-        try:
-            import bench_svg2
+        svg2_wl, svg2_steps = ("wan720p", 3) if extras_full else ("small", 1)
+        for key, f8 in (("svg2_wan720p", fp8),) + ((("svg2_wan720p_fp8", True),) if not fp8 else ()):   # fp8: BASELINE.json configs[4]
+            try:
+                import bench_svg2
 
-            out["svg2_wan720p"] = bench_svg2.measure("wan720p", steps=3, warmup=1, fp8=fp8)   # fp8: BASELINE.json configs[4] as named
-            if not fp8:   # ... and configs[4] beside it in the default run
-                out["svg2_wan720p_fp8"] = bench_svg2.measure("wan720p", steps=3, warmup=1, fp8=True)
-        except Exception as e:  # noqa: BLE001
-            out["svg2_wan720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-    if world == 1 and not a.no_step and a.workload == "hy720p":
+                if os.environ.get("SVG_BENCH_TEST_BREAK_EXTRAS"):    # test hook (tests/test_gpu_bench_contract.py): the failure path below
+                    raise RuntimeError("SVG_BENCH_TEST_BREAK_EXTRAS")
+                out[key] = bench_svg2.measure(svg2_wl, steps=svg2_steps, warmup=1, fp8=f8)
+            except Exception as e:  # noqa: BLE001
+                out[key] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                failed_extras.append(key)
+    if world == 1 and not a.no_step and (extras_full or extras_small):
         # BASELINE.json configs[3] at N = 1: a measured denoise step of the synthetic 60-block HunyuanVideo stack (GEMMs + glue +
         # attention), sparse and dense; `denoise_steps_per_s` here is measured, unlike attention_only_steps_per_s above
         torch.cuda.empty_cache()
         try:
             import bench_step
 
-            out["denoise_step_hy720p"] = bench_step.measure(steps=3, warmup=1)
+            if extras_full:
+                out["denoise_step_hy720p"] = bench_step.measure(steps=3, warmup=1)
+            else:
+                out["denoise_step_hy720p"] = bench_step.measure(steps=1, warmup=0, n_double=1, n_single=1)
         except Exception as e:  # noqa: BLE001
             out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            failed_extras.append("denoise_step_hy720p")
         torch.cuda.empty_cache()
     if world > 1 and not a.no_step and not fp8:
         # BASELINE.json configs[3] at N > 1: the denoise step token-sharded over the ranks (bench_step.py: tokens/N for norms, GEMMs,
@@ -754,9 +776,12 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if failed_extras:
+        print(f"bench.py: extras block(s) failed: {failed_extras} (their 'error' strings are in the line above)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,8 @@ the first `first_layers_fp` * 60 = 1 layer, sparse (online profiler + band atten
 a warm-up step (the first `first_times_fp` * 50 = 5 of 50 steps, scripts/hyvideo/hyvideo_t2v_720p_svg.sh:4-7) is dense in all layers.
 
 N > 1 (the shape of the hooks: svg/models/wan_orig/distributed/xdit_context_parallel.py:120,129): hidden states live
-TOKEN-sharded by whole frames (`svg.distributed.token_range`, the 256 text tokens on the last rank), so norms, projections, the
+TOKEN-sharded in units of 128 tokens (`svg.distributed.token_range(unit=StepGeo.unit)`: 14976 / 14848 tokens per rank at N = 8, largest /
+mean = 1.006 — whole frames would be 5 / 4 frames, 1.21; the text tokens are simply the tail of the last rank's range), so norms, projections, the
 fused prologue, output projection, MLP and glue run on the local tokens only; around the attention of every layer the q, k, v of the
 local tokens are exchanged for this rank's heads over the full sequence (`tokens_to_heads`: 3 x all_to_all_single, every peer to every
 peer directly over xGMI), the head-sharded SVG1 attention runs unchanged, and `heads_to_tokens` brings the output back to token
@@ -57,6 +58,7 @@ class StepGeo:
     heads: int = 24
     hd: int = 128
     mlp: int = 12288
+    unit: int = 128      # granularity of the token shards at N > 1 (svg.distributed.token_range): S = 119056 over 8 ranks -> 14976 / 14848 (+16) tokens
 
     @property
     def V(self):
@@ -123,7 +125,10 @@ class HipOps:
         self.prof = nat.ProfileDesc(0, geo.F, geo.P, 1)
         self.prof.variant[0] = nat.ProfileVariant(0, 0, Vv, bb, 0, Vv, geo.S)
         self.prof.variant[1] = nat.ProfileVariant(1, 0, Vv, bb, 0, Vv, geo.S)
-        self.q_scale = nat.softmax_q_scale(geo.hd)   # like Hunyuan_SVGAttn_Processor2_0: q leaves the prologue carrying the softmax scale
+        # like Hunyuan_SVGAttn_Processor2_0 (prescale_q False by default since round 4: the reference's formulation — scale applied to the
+        # fp32 scores; SVG_STEP_PRESCALE=1: the opt-in pre-scaled path, q leaves the prologue carrying the softmax scale)
+        self.prescale = bool(int(os.environ.get("SVG_STEP_PRESCALE", "0") or 0)) and geo.hd == 128
+        self.q_scale = nat.softmax_q_scale(geo.hd) if self.prescale else 1.0
 
     def ln_mod(self, x, scale, shift):
         return self.nat.layernorm_modulate_forward(x, scale=scale, shift=shift, eps=1e-6)
@@ -145,8 +150,8 @@ class HipOps:
         """q, k, v [1, H_local, S, hd] -> o [1, H_local, S, hd]"""
         g = self.geo
         if sparse:
-            return self.core.svg1_sparse_attention(q, k, v, self.cgeo, self.mask, self.prof, 64, min(10000, g.V), q_prescaled=True)[0]
-        return self.core.dense_attention(q, k, v, valid_len=g.V + g.L, q_prescaled=True)
+            return self.core.svg1_sparse_attention(q, k, v, self.cgeo, self.mask, self.prof, 64, min(10000, g.V), q_prescaled=self.prescale)[0]
+        return self.core.dense_attention(q, k, v, valid_len=g.V + g.L, q_prescaled=self.prescale)
 
     def gelu(self, x):
         return torch.nn.functional.gelu(x, approximate="tanh")
@@ -159,14 +164,16 @@ class Sharding:
         from svg import distributed as D
 
         self.D, self.geo, self.rank, self.world, self.group = D, geo, rank, world, group
-        self.a, self.b = D.token_range(geo.S, rank, world, unit=geo.P) if world > 1 else (0, geo.S)
+        self.a, self.b = D.token_range(geo.S, rank, world, unit=geo.unit) if world > 1 else (0, geo.S)
         self.nv = max(0, min(self.b, geo.V) - self.a)     # local video tokens: positions a .. a + nv
-        self.nt = (self.b - self.a) - self.nv             # local text tokens
+        self.nt = (self.b - self.a) - self.nv             # local text tokens: text positions t0 .. t0 + nt
+        self.t0 = max(self.a, geo.V) - geo.V
+        self.ranges = [D.token_range(geo.S, r, world, unit=geo.unit) for r in range(world)] if world > 1 else [(0, geo.S)]
         self.host_staged = host_staged                    # gloo smoke run on one GPU: the exchanges go through host memory
         self.buf = None
         if world > 1:
             assert geo.heads % world == 0, f"{geo.heads} heads over {world} ranks"
-            self.buf = D.ExchangeBuffers(geo.heads, geo.S, geo.hd, dtype, torch.device("cpu") if host_staged else dev, group, unit=geo.P)
+            self.buf = D.ExchangeBuffers(geo.heads, geo.S, geo.hd, dtype, torch.device("cpu") if host_staged else dev, group, unit=geo.unit)
         self.dev = dev
 
     def to_heads(self, x, which):   # [H, S_r, hd] -> [H_local, S, hd]
@@ -183,7 +190,7 @@ class Sharding:
         """the per-step all-gather of the final hidden states [S_r, hid] -> [S, hid] (ragged token shards: padded to the largest)"""
         import torch.distributed as dist
 
-        tr = [self.D.token_range(self.geo.S, r, self.world, unit=self.geo.P) for r in range(self.world)]
+        tr = [self.D.token_range(self.geo.S, r, self.world, unit=self.geo.unit) for r in range(self.world)]
         mx = max(b - a for a, b in tr)
         src = x.cpu() if self.host_staged else x
         pad = torch.zeros((mx, x.shape[1]), dtype=x.dtype, device=src.device)
@@ -280,7 +287,7 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
     img_all = (torch.randn(geo.V, geo.hid, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     txt_all = (torch.randn(geo.ctx, geo.hid, device=dev, generator=g) * 0.5).to(torch.bfloat16)
     img = img_all[sh.a: sh.a + sh.nv].contiguous()
-    txt = txt_all[geo.ctx - sh.nt:].contiguous() if sh.nt else txt_all[:0]
+    txt = txt_all[sh.t0: sh.t0 + sh.nt].contiguous()
     del img_all, txt_all
     res = {}
     for kind in kinds:
@@ -333,12 +340,12 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
         "workload": f"synthetic HunyuanVideo-style transformer forward: {n_double} double + {n_single} single blocks, hidden {geo.hid}, "
                     f"{geo.heads} x {geo.hd} heads, MLP {geo.mlp}, S = {geo.S} ({geo.V} video + {geo.ctx} text tokens, prompt {geo.L}), bf16, "
                     f"random weights; sparse step = {first_layers_fp} dense + {n_layers - first_layers_fp} SVG1 layers (sparsity 0.25, band "
-                    f"{ops.band}); q pre-scaled by the fused prologue",
+                    f"{ops.band}); " + ("q pre-scaled by the fused prologue (SVG_STEP_PRESCALE=1)" if ops.prescale else "plain q, softmax scale on the fp32 scores (the reference's formulation)"),
         "steps": steps, "warmup": warmup, "n_gpus": world,
         "not_modelled": "patch / time / text embedders, final layer, scheduler, text encoder, VAE",
     }
     if world > 1:
-        out["parallelism"] = (f"tokens/{world} (whole frames; text tokens on the last rank) for norms / GEMMs / prologue / glue, heads/{world} for the "
+        out["parallelism"] = (f"tokens/{world} (units of {geo.unit} tokens, largest / mean shard {max(b - a for a, b in sh.ranges) * world / geo.S:.4f}) for norms / GEMMs / prologue / glue, heads/{world} for the "
                               f"attention; per layer 3 x all_to_all in + 1 x all_to_all out, one all-gather of the hidden states per step; "
                               f"this rank: tokens [{sh.a}, {sh.b})")
         out["exchange_backend"] = "gloo through host memory (SVG_BENCH_SMOKE: control-flow run on one GPU, not a measurement)" if host_staged else "RCCL"

@@ -129,7 +129,7 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         else:
             o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
                                        q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=("pre" if a.pre else a.variant), fp8=a.fp8)
+                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8)
         t[3].record()
         torch.cuda.synchronize()
         if it >= a.warmup:
@@ -189,7 +189,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variant", type=int, default=-1, help="svg_varblock_attention variant (-1: auto, 0: 4 waves, 1: 8 waves, 2: mixed, 3: two-phase longest-first, 4: two-phase block-row order, 7: two-phase similarity order)")
     ap.add_argument("--fp8", action="store_true", help="e4m3 QK^T / PV in the attention (BASELINE.json configs[4])")
-    ap.add_argument("--pre", action="store_true", help="EXPERIMENTAL: svg_varblock_attention_pre (pre-scaled q copy + PRE body) instead of the default 16-bit schedule")
     ap.add_argument("--materialize", action="store_true", help="permute q,k,v / inverse-permute o with separate kernels "
                     "(the reference's pipeline) instead of the fused row-index gather")
     a = ap.parse_args()

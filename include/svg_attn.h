@@ -32,6 +32,12 @@ extern "C" {
 #define SVG_ERR_WORKSPACE (-3)     /* caller-provided workspace too small                          */
 #define SVG_ERR_LAUNCH (-4)        /* hipLaunchKernel / attribute call failed (see svg_last_hip_error) */
 
+/* ABI version of this header: bumped whenever an existing entry point's signature or a struct layout changes (new entry points do
+ * not bump it).  A binding compares svg_abi_version() of the library it loaded with the SVG_ABI_VERSION it was written against and
+ * refuses to call into a mismatch (svg/_native.py load()).  4: round 4 (svg_band_attention_notify* carry `done_words`). */
+#define SVG_ABI_VERSION 4
+int svg_abi_version(void);
+
 const char* svg_strerror(int code);
 int svg_last_hip_error(void);          /* raw hipError_t of the last failing launch in this thread */
 const char* svg_build_info(void);      /* "libsvgattn gfx950 <date> ..."                           */
@@ -408,28 +414,6 @@ int svg_band_attention_fp8_stage(const void* q, const void* k, const void* v, vo
  * fragments come from ds_read_b64_tr_b8.  workspace: svg_varblock_attention_fp8_workspace_bytes(...) bytes. */
 size_t svg_varblock_attention_fp8_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv, int32_t D);
 int svg_varblock_attention_fp8(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq, int32_t Skv,
-                               int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map, const int32_t* q_sizes,
-                               const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx,
-                               void* workspace, size_t workspace_bytes, void* stream);
-
-/* EXPERIMENTAL (written at the end of round 3; compiled, NOT yet run on a GPU; nothing in the package calls it by default).
- * svg_varblock_attention with 16-bit QK^T and e4m3 PV (csrc/attn_f8pv.h): the scores keep their accuracy — on the clustered SVG2
- * data the error of the all-e4m3 kernel is the scores' (8.6 % all e4m3, 3.6 % with 16-bit QK^T: tools/fp8_precision_study.py) —
- * while V and the probabilities are e4m3.  Same arguments as svg_varblock_attention_fp8; head_dim 128. */
-size_t svg_varblock_attention_fp8pv_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv, int32_t D);
-int svg_varblock_attention_fp8pv(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
-                                 int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
-                                 const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx,
-                                 const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes, void* stream);
-
-/* EXPERIMENTAL (written at the end of round 3; compiled, NOT yet run on a GPU; nothing in the package calls it by default).
- * svg_varblock_attention's default schedule (two-phase body, 256-row q tiles, longest-first order with remainder packing) in the
- * pre-scaled form of svg_band_attention_prescaled: a pre-pass writes q * sm_scale * log2(e), rounded to the input type, into the
- * workspace (k-means and the block map keep the plain q), the score accumulators start at minus the row's reference and the MFMAs
- * deliver the exponent argument — no scale-and-shift FMA per score.  Same arguments as svg_varblock_attention without `variant`;
- * head_dim 64 / 128.  workspace: svg_varblock_attention_pre_workspace_bytes(...) bytes (the plan + Hq * Sq * D * 2). */
-size_t svg_varblock_attention_pre_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t D);
-int svg_varblock_attention_pre(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq, int32_t Skv,
                                int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map, const int32_t* q_sizes,
                                const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx,
                                void* workspace, size_t workspace_bytes, void* stream);

@@ -5,7 +5,6 @@
 
 #include "attn_core.h"
 #include "attn_f8.h"
-#include "attn_f8pv.h"
 #include "band_policy.h"
 
 namespace svg {
@@ -314,28 +313,6 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_pp2_kernel(typename Varb
     attn_body_pp2<T, D, VarblockPolicy<T, D, 8>>(prm, smem, smem + attn_pp2_lds_bytes<D>());
 }
 
-// EXPERIMENTAL (svg_varblock_attention_pre; compiled at the end of round 3, not yet run): the same kernel on a q that a pre-pass has
-// multiplied by sm_scale * log2(e) — the body's PRE form: the S^T accumulators start at minus the row's reference, the MFMAs deliver the
-// exponent argument, no scale-and-shift FMA per score (what svg_band_attention_prescaled does for SVG1; there the prologue scales q, here
-// k-means and the block map need the plain q, so a copy is scaled: 1.5 GB of traffic at Wan 720p against 32 FMAs per lane and tile)
-template <typename T, int D>
-__global__ __launch_bounds__(512, 2) void varblock_attn_pp2q_kernel(typename VarblockPolicy<T, D, 8>::Params prm) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_pp2<T, D, VarblockPolicy<T, D, 8>, false, 0, true>(prm, smem, smem + attn_pp2_lds_bytes<D>());
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void varblock_scale_q_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n8, float s) {
-    using V8 = typename Elt<T>::v8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-        const V8 a = ((const V8*)x)[i];
-        V8 b;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = Elt<T>::from_float(Elt<T>::to_float(a[j]) * s);
-        ((V8*)y)[i] = b;
-    }
-}
-
 #ifdef SVG_ABLATIONS
 // the same kernel with the launch timeline of svg_debug_wg_trace (variant 5, diagnostics build only)
 template <typename T, int D>
@@ -358,14 +335,6 @@ __global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8_kernel(ty
                                                                               F8GArgs fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_f8g<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8_lds_bytes<128, kVbF8Waves>());
-}
-
-// mixed form (EXPERIMENTAL, attn_f8pv.h): 16-bit QK^T, e4m3 PV; the same tiling as the fp8 kernel
-template <typename T>
-__global__ __launch_bounds__(kVbF8Waves * 64, 2) void varblock_attn_f8pv_kernel(typename VarblockPolicy<T, 128, kVbF8Waves>::Params prm,
-                                                                                F8PVArgs fa) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_f8pv<T, VarblockPolicy<T, 128, kVbF8Waves>, kVbF8Waves>(prm, fa, smem, smem + attn_f8pv_lds_bytes<kVbF8Waves>());
 }
 
 static inline int vb_policy_lds(int kb_cap) { return (2 * (kb_cap + 2) + 32) * (int)sizeof(int32_t); }
@@ -1074,13 +1043,13 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0, const F8PVArgs* pv = nullptr) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0) {
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
     int32_t* tile_off2 = k_off + (size_t)Hkv * (KB + 1);
     hipLaunchKernelGGL(varblock_plan_kernel, dim3(Hkv), dim3(256), 0, st, q_sizes, k_sizes, q_off, k_off, tile_off, tile_off2, QB,
-                       KB, ((NW == -9 || NW == -10) ? kVbF8Waves : NW < 0 ? 8 : NW) * 32);
+                       KB, (NW == -9 ? kVbF8Waves : NW < 0 ? 8 : NW) * 32);
     auto launch = [&](auto nw_c, int mode, const int32_t* toff, int max_tiles) -> int {
         constexpr int W = decltype(nw_c)::value;
         using Pol = VarblockPolicy<T, D, W>;
@@ -1094,7 +1063,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
         p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
         p.order = nullptr;
-        if constexpr (NW == -8 || NW == -9 || NW == -10 || NW == -11) {
+        if constexpr (NW == -8 || NW == -9) {
             const int group = Hq / Hkv;
             if (!block_row_order && QB < 32768 && Sq / 256 + 1 < 65536) {   // packing of (block-row, sub-tile) in one word
                 int32_t* work = tile_off2 + (size_t)Hkv * (QB + 1);          // [2 * Hkv * QB]
@@ -1134,16 +1103,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                                        pack ? partner : nullptr, work, hist, order, Hkv, QB, group, BMo);
                 }
                 p.order = order;
-                if constexpr (NW == -10) {
-                    if constexpr (D == 128) {
-                        auto kern = varblock_attn_f8pv_kernel<T>;
-                        const int lds = attn_f8pv_lds_bytes<kVbF8Waves>() + vb_policy_lds(p.kb_cap);
-                        if (const int rc = configure_lds((const void*)kern, lds); rc != SVG_OK) return rc;
-                        hipLaunchKernelGGL(kern, dim3(p.max_tiles * Hq), dim3(kVbF8Waves * 64), lds, st, p, *pv);
-                        return launch_status();
-                    }
-                    return SVG_ERR_UNSUPPORTED;
-                } else if constexpr (NW == -9) {
+                if constexpr (NW == -9) {
                     if constexpr (D == 128) {
                         auto kern = varblock_attn_f8_kernel<T>;
                         const int lds = attn_f8_lds_bytes<128, kVbF8Waves>() + vb_policy_lds(p.kb_cap);
@@ -1161,16 +1121,12 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                     }
 #endif
                     if (trace) return SVG_ERR_UNSUPPORTED;   // diagnostics builds only (-DSVG_ABLATIONS)
-                    if constexpr (NW == -11)
-                        return launch_attn(varblock_attn_pp2q_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
-                                           attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
-                    else
-                        return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
-                                           attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+                    return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
+                                       attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
                 }
             }
-            if constexpr (NW == -9 || NW == -10 || NW == -11)
-                return SVG_ERR_UNSUPPORTED;   // (the fp8 and the pre-scaled kernels take the ordered 1-D launch only)
+            if constexpr (NW == -9)
+                return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
             else
                 return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
                                    attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
@@ -1183,9 +1139,9 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         if (Sq >= kVbFull) rc = launch(std::integral_constant<int, 8>{}, 1, tile_off, Sq / kVbFull);
         if (rc != SVG_OK) return rc;
         return launch(std::integral_constant<int, 4>{}, 2, tile_off2, 2 * QB);
-    } else if constexpr (NW == -9 || NW == -10) {   // fp8 bodies
+    } else if constexpr (NW == -9) {   // fp8 body
         return launch(std::integral_constant<int, kVbF8Waves>{}, 0, tile_off, Sq / (kVbF8Waves * 32) + QB);
-    } else if constexpr (NW == -8 || NW == -11) {   // two-phase ping-pong body, 256-row q tiles
+    } else if constexpr (NW == -8) {   // two-phase ping-pong body, 256-row q tiles
         return launch(std::integral_constant<int, 8>{}, 0, tile_off, Sq / 256 + QB);
     } else {
         return launch(std::integral_constant<int, NW>{}, 0, tile_off, Sq / (NW * 32) + QB);
@@ -1267,75 +1223,3 @@ extern "C" int svg_varblock_attention_fp8(const void* q, const void* k, const vo
     return SVG_ERR_UNSUPPORTED;
 }
 
-// EXPERIMENTAL (end of round 3, not yet run on a GPU): variable-block attention with 16-bit QK^T and e4m3 PV (attn_f8pv.h).
-// EXPERIMENTAL: svg_varblock_attention's default schedule (two-phase body, longest-first order with remainder packing) on a copy of q
-// that carries the softmax scale (see varblock_attn_pp2q_kernel).  The workspace holds the plan and the copy.
-extern "C" size_t svg_varblock_attention_pre_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t D) {
-    const size_t plan = svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq);
-    if (plan == 0 || (D != 64 && D != 128)) return 0;
-    return ((plan + 255) & ~(size_t)255) + (size_t)Hq * Sq * D * 2;
-}
-
-extern "C" int svg_varblock_attention_pre(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
-                                          int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
-                                          const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB, const int32_t* q_row_idx,
-                                          const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
-    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
-    if ((D != 64 && D != 128) || KB > kVbMaxKB || QB >= 32768 || Sq / 256 + 1 >= 65536) return SVG_ERR_UNSUPPORTED;
-    if ((int64_t)Skv * D * 2 >= (1ll << 32) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
-    if (workspace_bytes < svg_varblock_attention_pre_workspace_bytes(Hq, Hkv, QB, KB, Sq, D)) return SVG_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t plan = (svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq) + 255) & ~(size_t)255;
-    void* qs = (char*)workspace + plan;
-    const size_t n8 = (size_t)Hq * Sq * D / 8;
-    const float c = sm_scale * 1.4426950408889634f;
-#define SVG_VBQ(T, DD)                                                                                                          \
-    do {                                                                                                                         \
-        hipLaunchKernelGGL(varblock_scale_q_kernel<T>, dim3(2048), dim3(256), 0, st, (const T*)q, (T*)qs, n8, c);               \
-        return run_varblock<T, DD, -11>(qs, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, \
-                                       kv_row_idx, workspace, false, false, st);                                                \
-    } while (0)
-    if (dtype == SVG_DTYPE_BF16) {
-        if (D == 128) SVG_VBQ(__bf16, 128);
-        SVG_VBQ(__bf16, 64);
-    }
-    if (dtype == SVG_DTYPE_F16) {
-        if (D == 128) SVG_VBQ(_Float16, 128);
-        SVG_VBQ(_Float16, 64);
-    }
-#undef SVG_VBQ
-    return SVG_ERR_UNSUPPORTED;
-}
-
-extern "C" size_t svg_varblock_attention_fp8pv_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv,
-                                                               int32_t D) {
-    if (D != 128) return 0;
-    const size_t plan = svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq);
-    if (plan == 0 || Skv <= 0) return 0;
-    return ((plan + 255) & ~(size_t)255) + f8pv_ws_bytes(Hq, Hkv, Sq, Skv);
-}
-
-extern "C" int svg_varblock_attention_fp8pv(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
-                                            int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
-                                            const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
-                                            const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace, size_t workspace_bytes,
-                                            void* stream) {
-    if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
-    if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
-    if (D != 128 || KB > kVbMaxKB || QB >= 32768 || Sq / 256 + 1 >= 65536) return SVG_ERR_UNSUPPORTED;
-    if ((int64_t)Skv * D * 2 >= (1ll << 32) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
-    if (workspace_bytes < svg_varblock_attention_fp8pv_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D)) return SVG_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t plan = (svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq) + 255) & ~(size_t)255;
-    F8PVArgs fa;
-    int rc = f8pv_prepare(q, v, Hq, Hkv, Sq, Skv, dtype, sm_scale, (char*)workspace + plan, &fa, st);
-    if (rc != SVG_OK) return rc;
-    if (dtype == SVG_DTYPE_BF16)
-        return run_varblock<__bf16, 128, -10>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
-                                             kv_row_idx, workspace, false, false, st, nullptr, 0, &fa);
-    if (dtype == SVG_DTYPE_F16)
-        return run_varblock<_Float16, 128, -10>(q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx,
-                                               kv_row_idx, workspace, false, false, st, nullptr, 0, &fa);
-    return SVG_ERR_UNSUPPORTED;
-}

@@ -1,7 +1,6 @@
 // fp8 (e4m3) SVG1 band / dense attention: quantise + placement pre-pass, kernel on attn_body_f8, C entry points.
 // BASELINE.json configs[4]; no reference implementation exists (README.md:117), see attn_f8.h.
 #include "attn_f8.h"
-#include "attn_f8pv.h"
 #include "band_policy.h"
 
 namespace svg {
@@ -16,10 +15,7 @@ template <typename T>
 __global__ __launch_bounds__(512, 2) void band_attn_f8_kernel(typename BandF8<T>::Params prm, F8Args fa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #if SVG_F8_PINGPONG
-#ifndef SVG_F8_MFMA_ROWSUM
-#define SVG_F8_MFMA_ROWSUM 0
-#endif
-    attn_body_f8pp<T, BandF8<T>, SVG_F8_MFMA_ROWSUM != 0>(prm, fa, smem);
+    attn_body_f8pp<T, BandF8<T>>(prm, fa, smem);
 #else
     attn_body_f8<T, BandF8<T>>(prm, fa, smem);
 #endif
@@ -228,49 +224,6 @@ int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, i
                  F8GArgs* fa, hipStream_t st) {
     if (dtype == SVG_DTYPE_BF16) return f8g_quantize_t<__bf16>(q, k, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
     if (dtype == SVG_DTYPE_F16) return f8g_quantize_t<_Float16>(q, k, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
-    return SVG_ERR_UNSUPPORTED;
-}
-
-// ---- pre-pass of the mixed body (attn_f8pv.h, EXPERIMENTAL): q16 = T(q * sm_scale * log2 e), v8 = e4m3(v * 448 / amax_head) ----
-template <typename T>
-__global__ __launch_bounds__(256) void f8pv_scale_q_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n8, float s) {
-    using V8 = typename Elt<T>::v8;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-        const V8 a = ((const V8*)x)[i];
-        V8 b;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = Elt<T>::from_float((float)a[j] * s);
-        ((V8*)y)[i] = b;
-    }
-}
-
-size_t f8pv_ws_bytes(int Hq, int Hkv, int Sq, int Skv) {
-    return (size_t)Hq * Sq * 128 * 2 + (size_t)Hkv * Skv * 128 + (size_t)Hkv * (sizeof(unsigned) + sizeof(float)) + 512;
-}
-
-template <typename T>
-static int f8pv_prepare_t(const void* q, const void* v, int Hq, int Hkv, int Sq, int Skv, float sm_scale, void* ws, F8PVArgs* fa,
-                          hipStream_t st) {
-    constexpr int D = 128;
-    T* q16 = (T*)ws;
-    uint8_t* v8 = (uint8_t*)(q16 + (size_t)Hq * Sq * D);
-    unsigned* amax = (unsigned*)(((uintptr_t)(v8 + (size_t)Hkv * Skv * D) + 63) & ~(uintptr_t)63);   // [Hkv]
-    float* v_inv = (float*)(amax + Hkv);
-    if (hipMemsetAsync(amax, 0, (size_t)Hkv * sizeof(unsigned), st) != hipSuccess) return SVG_ERR_LAUNCH;
-    const size_t phk = (size_t)Skv * D;
-    hipLaunchKernelGGL(f8pv_scale_q_kernel<T>, dim3(1024), dim3(256), 0, st, (const T*)q, q16, (size_t)Hq * Sq * D / 8,
-                       sm_scale * 1.4426950408889634f);
-    hipLaunchKernelGGL(f8_amax1_kernel<T>, dim3(64, Hkv), dim3(256), 0, st, (const T*)v, amax, phk);
-    const unsigned* no_k = nullptr;
-    hipLaunchKernelGGL(f8_quantize1_kernel<T>, dim3(256, Hkv), dim3(256), 0, st, (const T*)v, v8, amax, v_inv, 1, phk, 0, no_k, 1, 0.f);
-    fa->q16 = q16, fa->v8 = v8, fa->v_inv = v_inv;
-    return launch_status();
-}
-
-int f8pv_prepare(const void* q, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws, F8PVArgs* fa,
-                 hipStream_t st) {
-    if (dtype == SVG_DTYPE_BF16) return f8pv_prepare_t<__bf16>(q, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
-    if (dtype == SVG_DTYPE_F16) return f8pv_prepare_t<_Float16>(q, v, Hq, Hkv, Sq, Skv, sm_scale, ws, fa, st);
     return SVG_ERR_UNSUPPORTED;
 }
 

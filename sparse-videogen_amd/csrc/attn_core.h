@@ -566,21 +566,6 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // in LDS since the barrier in front of M(t)) and carried through the vector phase in registers: the phase opens with MFMAs
     // instead of with an LDS round trip.
     constexpr int kCarry = (ABL == 0) ? SVG_PP2_CARRY : 0;
-#ifndef SVG_PP2_DOTSUM
-#define SVG_PP2_DOTSUM 0
-#endif
-    constexpr bool kDotSum = SVG_PP2_DOTSUM != 0 && kMaxFree;   // (the max-free softmax computes whole 8-key steps: always pairs)
-#ifndef SVG_PP2_MFMASUM
-#define SVG_PP2_MFMASUM 0
-#endif
-    // SVG_PP2_MFMASUM (experiment prepared at the end of round 3, NOT measured yet — default off, the default binaries are unchanged;
-    // head_dim 64 only): the softmax denominator on the MATRIX pipe.  At head_dim 64 the kernel is bound by the vector pipe and the
-    // matrix pipe idles half of the time (tools/clock_by_variant.py: 0.376 of the matrix rate at the full 2.4 GHz), so the 32 v_add of
-    // a tile's row sum move there: one more MFMA per 16-key step, A = a fragment of ones — D[d][q] = the sum of the ROUNDED
-    // probabilities of the step's 16 keys in every row, i.e. the whole row sum in every lane of column q (no cross-lane add at the
-    // end; the normaliser is the sum of exactly what the PV MFMAs multiply).  The "reference still good" test runs on the exponent
-    // arguments (v_max3 chain: 16 instead of 32 VALU).  Changes numerics (normaliser): error and time to be measured before it ships.
-    constexpr bool kMfmaSum = SVG_PP2_MFMASUM != 0 && kMaxFree && ABL == 0 && D == 64 && !kDotSum && !P::kPartialOut;
 #ifndef SVG_PP2_ONEBAR
 #define SVG_PP2_ONEBAR -1   // -1: as the policy says (P::kOneBarrier); 0 / 1: force (A/B builds)
 #endif
@@ -773,11 +758,6 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     f32x16 sc[2];          // scores: S(t) until the PV steps of the matrix phase have consumed it, then S(t+1) accumulates here
     V8 pf[2][2];           // probabilities: [32-key block][16-key half]
     float m_use = 0.f, psum = 0.f;
-    f32x16 acc_l = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // kMfmaSum: the row sums (every register, every lane of a column)
-    V8 ones_frag;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones_frag[j] = E::from_float(1.f);
-    float arg_thr = -INFINITY;    // kMfmaSum: 11 (= log2 2048) once every row of the wave has a finite reference
     float psum_thr = -1.f;        // (wave-uniform) max-free softmax: 2048 once every row of the wave has a finite reference; until
                                   // then no sum passes the check and every tile takes the exact path
 
@@ -805,15 +785,9 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 if constexpr (PRE && shifted) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r] + pre_shift);
                 else if constexpr (PRE) p = __builtin_amdgcn_exp2f(sc[kk >> 1][8 * (kk & 1) + r]);   // the MFMAs delivered the exponent argument
                 else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kk >> 1][8 * (kk & 1) + r], c_log2, -m_use));
-                if constexpr (!kDotSum && !kMfmaSum) psum += p;
+                psum += p;
                 pf[kk >> 1][kk & 1][r] = E::from_float(p);
             }
-        }
-        if constexpr (kDotSum && ABL != 4) {
-            // row sum from the ROUNDED probabilities, two per instruction (v_dot2c_f32_{bf16,f16} against (1, 1)): half the adds of the
-            // fp32 sum, and the normaliser is the sum of exactly what the PV MFMAs multiply
-#pragma unroll
-            for (int r = lo; r < hi; r += 2) psum = E::add_pair(pf[kk >> 1][kk & 1][r], pf[kk >> 1][kk & 1][r + 1], psum);
         }
     };
     auto probs = [&](int kk, int lo, int hi) { probs_impl(kk, lo, hi, std::false_type{}); };
@@ -892,23 +866,11 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
             // (a wave takes the exact path until every one of its rows has a reference taken from a finite score — a row maximum
             //  instead of the pseudo-reference 0, under which scores below -126 in log2 units would underflow to nothing)
             float mx = sc[0][0];
-            bool exact;
-            if constexpr (kMfmaSum) {
-                // the largest exponent argument of the lane's 32 scores (PRE: sc holds the arguments; else score * c_log2 - m_use)
+            const bool exact = !__all(psum <= psum_thr);
+            if (exact) {      // exact path (rare; also a non-finite sum)
 #pragma unroll
                 for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
                 mx = vmax2(mx, sc[1][15]);
-                const float arg = PRE ? mx : __builtin_fmaf(mx, c_log2, -m_use);
-                exact = !__all(arg <= arg_thr);
-            } else {
-                exact = !__all(psum <= psum_thr);
-            }
-            if (exact) {      // exact path (rare; also a non-finite sum)
-                if constexpr (!kMfmaSum) {
-#pragma unroll
-                    for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
-                    mx = vmax2(mx, sc[1][15]);
-                }
                 const unsigned u = __builtin_bit_cast(unsigned, mx);
                 const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // the other half of the row: lane ^ 32
                 mx = vmax2(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
@@ -921,12 +883,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 asm volatile("s_nop 1" : "+v"(alpha));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
                 m_run = m_new;
                 psum_thr = __all(m_new != -INFINITY) ? 2048.f : -1.f;
-                arg_thr = __all(m_new != -INFINITY) ? 11.f : -INFINITY;
                 l_run *= alpha;
-                if constexpr (kMfmaSum) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc_l[r] *= alpha;
-                }
                 if constexpr (PRE) {
                     pre_shift = m_prev - m_use;
                     // what the next S^T accumulators start from.  Rewritten IN PLACE (tied asm operands): as plain assignments hipcc
@@ -1052,11 +1009,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
                 acc_o[db] = E::mfma(i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)], pf[kk >> 1][kk & 1], acc_o[db]);
                 // probabilities of a later 16-key step in the shadow of this MFMA (one slice per d-block)
                 if (kk + 1 < 4 && kk + 1 >= 4 - kShadow) probs(kk + 1, db * (8 / DB), (db + 1) * (8 / DB));
-                if constexpr (kMfmaSum) {
-                    if (db == DB - 1) acc_l = E::mfma(ones_frag, pf[kk >> 1][kk & 1], acc_l);
-                } else {
-                    if (i == NPV - 1) l_run += psum;
-                }
+                if (i == NPV - 1) l_run += psum;
             } else {
                 const int j = i - NPV, ks = j >> 1, b = j & 1;
                 // (PRE, first step: D = A B + neg_ref with neg_ref left where it is — E::mfma_keep_c.  Its result is read by the next
@@ -1135,7 +1088,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     unsigned long long wg_t2 = 0;
     if constexpr (TRACE) wg_t2 = __builtin_amdgcn_s_memtime();
     // ---------------- epilogue (same as attn_body) ----------------
-    const float l_tot = kMfmaSum ? acc_l[0] : l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     if constexpr (P::kPartialOut) {
         // (max-free softmax: O and l are scaled to the reference m_use, not to the running maximum)
         P::store_partial(prm, ctx, row_in_wg, g, acc_o, kMaxFree ? ((m_run == -INFINITY) ? -INFINITY : m_use) : m_run, l_tot);

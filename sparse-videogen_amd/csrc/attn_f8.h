@@ -292,11 +292,7 @@ __device__ __forceinline__ void attn_body_f8(const typename P::Params& prm, cons
 // (leading waves) / N(w - 3) (lagging waves), and every wave waits at the end of a vector phase for what it requested in the
 // previous one.  Inputs are those of attn_body_f8 (pre-pass images in logical token order: nothing is gathered).
 // =====================================================================================================================
-// RS (experiment prepared at the end of round 3, NOT measured yet; the kernel instantiates RS = false unless built with
-// -DSVG_F8_MFMA_ROWSUM=1): the row sums from one more MFMA per tile (A = e4m3 ones) in the matrix phase and the e4m3 range test of the
-// vector phase on the exponent arguments — see attn_body_f8g.  A TEMPLATE parameter, so that the discarded statements are not even
-// instantiated for RS = false and the product kernel's code stays what it was, byte for byte.
-template <typename T, typename P, bool RS = false>
+template <typename T, typename P>
 __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, const F8Args& fa, char* smem) {
     using E = Elt<T>;
     constexpr int D = 128, DB = D / 32, KS = D / 64, NW = 8, NS = 4;
@@ -398,18 +394,6 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
         return;
     }
 
-    constexpr bool kRowSumMfma = RS;
-    constexpr float kArgMax = 8.75f;          // 2^8.75 = 430 < 448
-    struct RowSum { f32x16 acc; i32x8 ones; float arg_thr; };
-    struct Nothing {};
-    std::conditional_t<RS, RowSum, Nothing> rs;
-    if constexpr (RS) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs.acc[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rs.ones[j] = 0x38383838;      // four e4m3 ones per word
-        rs.arg_thr = -INFINITY;
-    }
     f32x16 sc[2];          // S(t) until the vector phase has turned it into pf, then S(t + 1) accumulates here
     i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // probabilities of tile t (e4m3, slot order of the file header); every word is rewritten
                                            // per tile with its own stale contents as the conversions' "old" operand (see attn_body_f8)
@@ -473,7 +457,7 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 const int e = 4 * w8 + i;
                 if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15] + delta);
                 else p4[i] = __builtin_amdgcn_exp2f(sc[e >> 4][e & 15]);
-                if constexpr (!RS) psum += p4[i];
+                psum += p4[i];
             }
             const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
             pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
@@ -498,26 +482,12 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
                 }
         }
         probs(std::false_type{}, 0.f);
-        bool exact;
-        float mx_args = 0.f;
-        if constexpr (RS) {
-            mx_args = sc[0][0];
-#pragma unroll
-            for (int e = 1; e < 31; e += 2) mx_args = vmax3(mx_args, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
-            mx_args = vmax2(mx_args, sc[1][15]);
-            exact = __any(!(mx_args <= rs.arg_thr));
-        } else {
-            exact = __any(!(psum <= psum_thr));
-        }
+        const bool exact = __any(!(psum <= psum_thr));
         if (exact) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
             float mx = sc[0][0];
-            if constexpr (RS) {
-                mx = mx_args;
-            } else {
 #pragma unroll
-                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
-                mx = vmax2(mx, sc[1][15]);
-            }
+            for (int e = 1; e < 31; e += 2) mx = vmax3(mx, sc[e >> 4][e & 15], sc[(e + 1) >> 4][(e + 1) & 15]);
+            mx = vmax2(mx, sc[1][15]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // (sc holds x = scaled score - m_off: the row maximum of the scaled scores is mx + m_off)
             const float m_prev = m_off + kPShift;
@@ -527,21 +497,16 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             const float delta = m_prev - m_use;       // new exponent argument = x + (m_off_old - m_off_new)
             m_ref = m_new;
             psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
-            if constexpr (RS) rs.arg_thr = __any(m_new == -INFINITY) ? -INFINITY : kArgMax;
             m_off = m_use - kPShift;
             set_cneg(-m_off);
             probs(std::true_type{}, delta);
             l_run *= alpha;
-            if constexpr (RS) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rs.acc[r] *= alpha;
-            }
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
         }
-        if constexpr (!RS) l_run += psum;
+        l_run += psum;
         asm volatile("" : "+v"(pf), "+v"(l_run));      // stays in this phase
         stage_request(t);
     };
@@ -561,9 +526,6 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
             if (i + kPF < NALL) ring[(i + kPF) % (kPF + 1)] = fetch(i + kPF);
             if (i < 4) {
                 acc_o[i] = mfma_f8(ring[i % (kPF + 1)], pf, acc_o[i]);
-                if constexpr (RS) {
-                    if (i == 3) rs.acc = mfma_f8(rs.ones, pf, rs.acc);
-                }
             } else {
                 const int j = i - 4, ks = j >> 1, b = j & 1;
                 if (ks == 0) sc[b] = mfma_qk_first(ring[i % (kPF + 1)], qf[ks]);
@@ -599,7 +561,6 @@ __device__ __forceinline__ void attn_body_f8pp(const typename P::Params& prm, co
 
     // ---------------- epilogue: as attn_body_f8 ----------------
     float l_tot = l_run + __shfl_xor(l_run, 32);
-    if constexpr (RS) l_tot = rs.acc[0];      // (every lane of a column holds the whole row sum)
     constexpr int kEpiStride = D * 2 + 8;
     char* erow = smem + (size_t)(wave * 32) * kEpiStride;
     {
@@ -779,26 +740,6 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
         return d;
     };
     i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};   // (outside the loop: its stale words are the conversions' "old" operand, see attn_body_f8)
-#ifndef SVG_F8_MFMA_ROWSUM
-#define SVG_F8_MFMA_ROWSUM 0
-#endif
-    // SVG_F8_MFMA_ROWSUM (experiment prepared at the end of round 3, NOT measured yet — default off, the default binary is unchanged).
-    // The softmax denominator from the matrix pipe instead of the vector pipe, which is what bounds this kernel:
-    //   * l += one more MFMA per tile, A = a fragment of e4m3 ones: D[d][q] = sum over the tile's 64 keys of the QUANTISED probabilities,
-    //     the same in every row — the whole row sum (both lane halves) lands in every lane of column q: no 32 v_add per tile, no
-    //     cross-lane add at the end, and the normaliser is the sum of exactly what the PV MFMAs multiply (O becomes a true convex
-    //     combination of the quantised weights: the probabilities' rounding no longer biases the scale of the row);
-    //   * the "does every probability fit e4m3" test on the exponent ARGUMENTS (a v_max3 chain: 16 instead of 32 VALU): p <= 448 per
-    //     element is what e4m3 needs, not the sum.
-    // Numerics change (different normaliser, later renormalisation): needs the fp8 tolerances re-measured before it may ship.
-    constexpr bool kRowSumMfma = SVG_F8_MFMA_ROWSUM != 0;
-    f32x16 acc_l;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc_l[r] = 0.f;
-    const int one4 = 0x38383838;              // four e4m3 ones
-    const i32x8 ones8 = {one4, one4, one4, one4, one4, one4, one4, one4};
-    constexpr float kArgMax = 8.75f;          // 2^8.75 = 430 < 448
-    float arg_thr = -INFINITY;                // kArgMax once every row of the wave has a finite reference
     int buf = 0;
     for (int t = 0; t < nT; ++t) {
         const char* kbuf = smem + buf * kStage;
@@ -838,7 +779,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                         const int e = 4 * w8 + i;
                         if constexpr (decltype(shifted_c)::value) p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15] + delta);
                         else p4[i] = __builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]);
-                        if constexpr (!kRowSumMfma) psum += p4[i];
+                        psum += p4[i];
                     }
                     const int w = __builtin_amdgcn_cvt_pk_fp8_f32(p4[0], p4[1], pf[w8], false);   // (old = the word's stale contents: see pf)
                     pf[w8] = __builtin_amdgcn_cvt_pk_fp8_f32(p4[2], p4[3], w, true);
@@ -846,22 +787,12 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
             };
             probs(std::false_type{}, 0.f);
             float mx = s_cur[0][0];
-            bool exact;
-            if constexpr (kRowSumMfma) {
-#pragma unroll
-                for (int e = 1; e < 31; e += 2) mx = vmax3(mx, s_cur[e >> 4][e & 15], s_cur[(e + 1) >> 4][(e + 1) & 15]);
-                mx = vmax2(mx, s_cur[1][15]);
-                exact = __any(!(mx <= arg_thr));
-            } else {
-                exact = __any(!(psum <= psum_thr));
-            }
+            const bool exact = __any(!(psum <= psum_thr));
             if (exact) {      // exact path (rare; always until every row has a finite reference: see attn_body_pp2)
-                if constexpr (!kRowSumMfma) {
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_cur[0][r]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_cur[1][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_prev = m_off + kPShift;
                 const float m_new = fmaxf(m_ref, mx + m_off);      // (s_cur holds x = scaled score - m_off)
@@ -870,22 +801,16 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
                 const float delta = m_prev - m_use;
                 m_ref = m_new;
                 psum_thr = __any(m_new == -INFINITY) ? -1.f : kPSumMax;
-                arg_thr = __any(m_new == -INFINITY) ? -INFINITY : kArgMax;
                 m_off = m_use - kPShift;
                 set_cneg(-m_off);
                 probs(std::true_type{}, delta);
                 l_run *= alpha;
-                if constexpr (kRowSumMfma) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc_l[r] *= alpha;
-                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
             }
-            if constexpr (kRowSumMfma) acc_l = mfma_f8(ones8, pf, acc_l);
-            else l_run += psum;
+            l_run += psum;
             // ---------------- O^T += V^T P^T: 4 MFMAs, V^T through 4 transpose reads each ----------------
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
@@ -906,7 +831,7 @@ __device__ __forceinline__ void attn_body_f8g(const typename P::Params& prm, con
         buf ^= 1;
     }
 
-    const float l_tot = kRowSumMfma ? acc_l[0] : l_run + __shfl_xor(l_run, 32);   // (MFMA row sum: every lane of a column holds the whole sum)
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     constexpr int kEpiStride = D * 2 + 8;
     char* erow = smem + (size_t)(wave * 32) * kEpiStride;
     {

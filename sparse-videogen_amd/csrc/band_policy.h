@@ -3,6 +3,7 @@
 // the launch helper shared by the translation units that instantiate band kernels (attention.hip, attention_w4.hip).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 
 #include "attn_core.h"
 
@@ -52,6 +53,7 @@ struct BandPolicy {
         int sp64, sp128;       // physical-row step of a token-major head: q + r * P (the patch index advances by q, the frame by r)
         int wrap_phys;         // 1 - F * P: correction when the frame index wraps
         int heavy_lo, n_heavy; // q-tiles [heavy_lo, heavy_lo + n_heavy) of every head see ALL keys (text rows): scheduled first
+        int rotate;            // cyclic start of the band sweep at the XCD group's common key tile (init(); 0: every tile from its own first key)
         // Row regions: q-tiles never straddle rowfull_lo / rowfull_hi / real_len, so every q-tile is homogeneous (band rows, full
         // rows or rows behind real_len).  Region r = rows [reg_lo[r], reg_hi[r]), its first q-tile is reg_t0[r].
         int reg_lo[4], reg_hi[4], reg_t0[4];
@@ -93,6 +95,7 @@ struct BandPolicy {
         //    overlap in that XCD's L2 while the whole chip stays within one or two heads (KV working set fits the 256 MiB
         //    Infinity Cache).
         int qt;
+        int qt_last = -1;          // last q-tile of this workgroup's XCD group in the same head (-1: no group: heavy tiles, the launch's tail)
         const int nh = p.BH * p.n_heavy;
         const int b = blockIdx.x;
         if (b >= p.nqt * p.BH) return false;   // (the device-switched launch is sized for the larger of its two masks)
@@ -111,14 +114,22 @@ struct BandPolicy {
             c.head = w2 / nl;
             const int r = w2 - c.head * nl;
             qt = r < p.heavy_lo ? r : r + p.n_heavy;
+            if (b2 < full && p.rotate) {   // the 32 tiles an XCD works on together are w2 & ~31 .. w2 | 31
+                const int r_last = min((w2 | 31) - c.head * nl, nl - 1);
+                qt_last = r_last < p.heavy_lo ? r_last : r_last + p.n_heavy;
+            }
         }
         // (explicit selects: a run-time index into the kernel-argument arrays would go through scratch)
-        const bool r1 = qt >= p.reg_t0[1], r2 = qt >= p.reg_t0[2], r3 = qt >= p.reg_t0[3];
-        const int rlo = r3 ? p.reg_lo[3] : r2 ? p.reg_lo[2] : r1 ? p.reg_lo[1] : p.reg_lo[0];
-        const int rhi = r3 ? p.reg_hi[3] : r2 ? p.reg_hi[2] : r1 ? p.reg_hi[1] : p.reg_hi[0];
-        const int rt0 = r3 ? p.reg_t0[3] : r2 ? p.reg_t0[2] : r1 ? p.reg_t0[1] : 0;
+        auto tile_rows = [&](int t, int& q0, int& rhi_out) {
+            const bool r1 = t >= p.reg_t0[1], r2 = t >= p.reg_t0[2], r3 = t >= p.reg_t0[3];
+            const int rlo = r3 ? p.reg_lo[3] : r2 ? p.reg_lo[2] : r1 ? p.reg_lo[1] : p.reg_lo[0];
+            rhi_out = r3 ? p.reg_hi[3] : r2 ? p.reg_hi[2] : r1 ? p.reg_hi[1] : p.reg_hi[0];
+            const int rt0 = r3 ? p.reg_t0[3] : r2 ? p.reg_t0[2] : r1 ? p.reg_t0[1] : 0;
+            q0 = rlo + (t - rt0) * BM;
+        };
+        int rhi;
         c.qt = qt;
-        c.q0 = rlo + (qt - rt0) * BM;
+        tile_rows(qt, c.q0, rhi);
         c.q_end = min(rhi, c.q0 + BM);
         c.perm = (p.head_flag != nullptr) && (p.head_flag[c.head] != 0);
 
@@ -150,6 +161,27 @@ struct BandPolicy {
             if (blo < BIG && blo <= ahi) ahi = max(ahi, bhi), blo = BIG, bhi = BIG;
         } else if (clo < BIG && clo <= bhi) {
             bhi = max(bhi, chi), clo = BIG, chi = BIG;
+        }
+        // Cyclic start (round 4).  The 32 q-tiles an XCD works on together are neighbours whose band windows are 4 key tiles apart; swept
+        // from their own first key, workgroup j reads key tile base + 4 j + tau at time tau: 32 streams spread over 124 tiles = 4 MiB of K
+        // and V, the size of the XCD's L2 — a tile fetched for the workgroup furthest ahead is evicted before the others reach it (L2 hit
+        // rate 0.77, 37 GB across the fabric per launch for 2.9 GB of tensors: profiles/r03z_pmc_traffic.json).  All 32 windows contain
+        // the window start T0 of the group's LAST tile, so every workgroup starts THERE, runs to the end of its window, takes the other
+        // intervals, and finishes with [own start, T0): at any time the group reads at most two different key tiles (one in the upper
+        // parts, one in the wrapped parts — the wrap position only depends on the time, not on the member), each fetched once per XCD.
+        // The online softmax does not care about the order of the key tiles.  Needs a free interval slot (the third one).
+        if (qt_last >= 0 && clo >= BIG) {
+            int q0_last, rhi_last;
+            tile_rows(qt_last, q0_last, rhi_last);
+            const int t0 = max(0, q0_last - p.band + 1) / kBN;
+            if (t0 > alo && t0 < ahi) {            // [t0, ahi), (b), [alo, t0)
+                if (blo < BIG) clo = alo, chi = t0;
+                else blo = alo, bhi = t0;
+                alo = t0;
+            } else if (blo < BIG && t0 > blo && t0 < bhi) {   // a, [t0, bhi), [blo, t0)   (text-first models: the text columns come first)
+                clo = blo, chi = t0;
+                blo = t0;
+            }
         }
         c.seg_lo[0] = alo, c.seg_n[0] = ahi - alo;
         c.seg_lo[1] = blo, c.seg_n[1] = bhi - blo;
@@ -404,6 +436,12 @@ inline int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
+// SVG_BAND_ROTATE=0 in the environment switches the cyclic sweep start off (same-process A/B: bench.py same_box_ab, tools/ab_rotate.py)
+inline int band_rotate_default() {
+    const char* e = std::getenv("SVG_BAND_ROTATE");
+    return e ? (std::atoi(e) != 0) : 1;
+}
+
 template <typename Pol, typename T>
 inline typename Pol::Params make_band_params(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                                              const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const BandOpts& opts = BandOpts()) {
@@ -423,6 +461,7 @@ inline typename Pol::Params make_band_params(const void* q, const void* k, const
     p.q128 = 2 * kBN / p.F, p.r128 = 2 * kBN % p.F;
     p.sp64 = p.q64 + p.r64 * p.P, p.sp128 = p.q128 + p.r128 * p.P;
     p.wrap_phys = 1 - p.F * p.P;
+    p.rotate = band_rotate_default();
     // row regions (see Params): cut at rowfull_lo, rowfull_hi (inside [0, real_len)) and real_len; unused slots are empty regions
     // behind the last tile.  A q-tile of full rows visits every key tile on the unmasked fast path (with the text rows sharing a
     // tile with band rows or rows behind real_len, all 1861 tiles of it took the per-element masked path: 9.5 ms instead of 3.2).
@@ -458,12 +497,6 @@ struct F8GArgs;
 size_t f8g_ws_bytes(int Hq, int Hkv, int Sq, int Skv);
 int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws,
                  F8GArgs* fa, hipStream_t st);
-
-// mixed body (attn_f8pv.h, EXPERIMENTAL): pre-pass in attention_f8.hip — q * sm_scale * log2(e) rounded to T, v quantised to e4m3
-struct F8PVArgs;
-size_t f8pv_ws_bytes(int Hq, int Hkv, int Sq, int Skv);
-int f8pv_prepare(const void* q, const void* v, int Hq, int Hkv, int Sq, int Skv, int dtype, float sm_scale, void* ws, F8PVArgs* fa,
-                 hipStream_t st);
 
 // 4 waves x 64 rows, one wave per SIMD (attn_body_w4, attention_w4.hip)
 int run_band_w4(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,

@@ -145,47 +145,8 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s[bb][rq * 4 + j] = h4[j];
             }
-#ifndef SVG_KMEANS_V2
-#define SVG_KMEANS_V2 0
-#endif
-        // SVG_KMEANS_V2 (experiment prepared at the end of round 3, NOT measured yet — default off, the default binary is unchanged):
-        //   * the centroid operands of the 2 KS MFMAs are kept kPF reads ahead in a register ring, steps fenced with sched_barrier
-        //     (as compiled, every MFMA of the loop below waits for a read issued one MFMA earlier: `s_waitcnt lgkmcnt(1)` in front of each);
-        //   * the arg-max runs as TWO independent chains, one per 32-centroid block, merged at the end (shorter dependence chain; the
-        //     instruction count stays 3 VALU per score: compare to an SGPR pair + two selects, and hipcc still serialises the two chains
-        //     on one SGPR pair with its two wait states — an explicit 4-chain form would drop those).  Same result: every index of
-        //     block 0 is lower than every index of block 1, so "block 1 wins only if strictly greater" is the lowest-index tie rule.
         float tb;
         int ti;
-        if constexpr (SVG_KMEANS_V2 != 0) {
-            constexpr int NOP = 2 * KS, kPF = 4;
-            auto frag = [&](int i) -> V8 {      // operand i: contraction step i >> 1, centroid block i & 1
-                const int cch = ((2 * (i >> 1) + g) ^ ksw0) << 4;
-                return *(const V8*)(kbuf + (32 * (i & 1) + ql) * L::kRowBytes + cch);
-            };
-            V8 ring[kPF + 1];
-#pragma unroll
-            for (int i = 0; i < kPF; ++i) ring[i] = frag(i);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < NOP; ++i) {
-                if (i + kPF < NOP) ring[(i + kPF) % (kPF + 1)] = frag(i + kPF);
-                s[i & 1] = E::mfma(ring[i % (kPF + 1)], xf[i >> 1], s[i & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            float b0 = s[0][0], b1 = s[1][0];
-            int i0 = 0, i1 = 32;
-#pragma unroll
-            for (int r = 1; r < 16; ++r) {
-                const int c = 8 * (r >> 2) + (r & 3);
-                const bool u0 = s[0][r] > b0, u1 = s[1][r] > b1;
-                b0 = u0 ? s[0][r] : b0, i0 = u0 ? c : i0;
-                b1 = u1 ? s[1][r] : b1, i1 = u1 ? 32 + c : i1;
-            }
-            const bool u = b1 > b0;
-            tb = u ? b1 : b0;
-            ti = (u ? i1 : i0) + 4 * g;
-        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cch = ((2 * ks + g) ^ ksw0) << 4;
@@ -206,7 +167,6 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
                 tb = upd ? s[bb][r] : tb;
                 ti = upd ? c + 4 * g : ti;
             }
-        }
         const bool upd = tb > best;
         best = upd ? tb : best;
         best_idx = upd ? t * kBN + ti : best_idx;
@@ -347,10 +307,16 @@ __global__ __launch_bounds__(256) void kmeans_commit_kernel(const int32_t* __res
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         float mx = 0.f;
-        for (int b = threadIdx.x; b < B; b += 64) mx = fmaxf(mx, shift[b]);
+        bool nan = false;   // fmaxf drops a NaN operand; the reference's `shift.max()` propagates it, and `NaN < tol` is False (:723)
+        for (int b = threadIdx.x; b < B; b += 64) {
+            const float sft = shift[b];
+            nan |= sft != sft;
+            mx = fmaxf(mx, sft);
+        }
         mx = wave_max(mx);
+        nan = __builtin_amdgcn_ballot_w64(nan) != 0ull;
         if (threadIdx.x == 0) {
-            const bool conv = mx < tol;   // `center_shift < tol` (:723) — NaN compares false like the reference's `.item() < tol`
+            const bool conv = !nan && mx < tol;   // `center_shift < tol` (:723): a NaN shift never converges, the loop runs to max_iters
             if (!stopped) {
                 state[2] += 1;
                 state[3] = conv ? sel_cur : sel_out;   // converged: the OLD centroids are returned; otherwise the new ones become current

@@ -107,6 +107,8 @@ extern "C" const char* svg_strerror(int code) {
 
 extern "C" int svg_last_hip_error(void) { return svg::g_last_hip_error; }
 
+extern "C" int svg_abi_version(void) { return SVG_ABI_VERSION; }
+
 extern "C" const char* svg_build_info(void) { return "libsvgattn gfx950 wave64 mfma32x32x16 built " __DATE__ " " __TIME__; }
 
 extern "C" int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out,

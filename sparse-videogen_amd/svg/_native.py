@@ -77,6 +77,7 @@ _I32, _I64, _F32, _VP, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_si
 
 # name -> (restype, argtypes); must list every symbol include/svg_attn.h declares (tests check this)
 SIGNATURES = {
+    "svg_abi_version": (C.c_int, []),
     "svg_strerror": (C.c_char_p, [C.c_int]),
     "svg_last_hip_error": (C.c_int, []),
     "svg_build_info": (C.c_char_p, []),
@@ -124,12 +125,6 @@ SIGNATURES = {
     "svg_varblock_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "svg_varblock_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
                                              _VP, _VP, _VP, _SZ, _VP]),
-    "svg_varblock_attention_fp8pv_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32, _I32]),
-    "svg_varblock_attention_fp8pv": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
-                                               _VP, _VP, _VP, _SZ, _VP]),
-    "svg_varblock_attention_pre_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32, _I32, _I32]),
-    "svg_varblock_attention_pre": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _I32, _I32,
-                                             _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
     "svg_band_attention_fp8": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _VP]),
     "svg_band_attention_fp8_stage": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP, _SZ, _I32, _VP]),
@@ -160,6 +155,9 @@ SIGNATURES = {
 }
 
 
+SVG_ABI_VERSION = 4   # include/svg_attn.h
+
+
 def lib_path() -> Path:
     return Path(os.environ.get("SVG_ATTN_LIB", str(_LIB_PATH)))
 
@@ -176,8 +174,11 @@ def load(strict: bool = True) -> Optional[C.CDLL]:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = int(lib.svg_abi_version())
+        if got != SVG_ABI_VERSION:   # a library built from another revision of include/svg_attn.h: its entry points may take other arguments
+            raise OSError(f"ABI version {got}, this binding was written against {SVG_ABI_VERSION} (rebuild: python sparse-videogen_amd/build.py)")
         _lib = lib
-    except (OSError, AttributeError) as e:  # missing .so or missing symbol
+    except (OSError, AttributeError) as e:  # missing .so, missing symbol or ABI mismatch
         _load_error = f"{p}: {e}"
         if strict:
             raise RuntimeError(
@@ -334,7 +335,41 @@ def softmax_q_scale(D: int, sm_scale: Optional[float] = None) -> float:
     return (float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)) * 1.4426950408889634
 
 
-_F8_WS = {}
+class WorkspaceCache:
+    """Scratch tensors the wrappers keep between calls, keyed by (shape..., device, stream): two calls of one shape on different
+    streams never share a buffer, and at most `capacity` entries stay alive (least recently used goes first), so transient streams
+    cannot pile up multi-GB workspaces.  One policy for the fp8 workspaces and the k-means loop scratch."""
+
+    def __init__(self, capacity: int = 8):
+        from collections import OrderedDict
+
+        self.capacity, self._d = capacity, OrderedDict()
+
+    @staticmethod
+    def key(*shape, device):
+        return tuple(shape) + (device, _stream())
+
+    def get(self, key):
+        v = self._d.get(key)
+        if v is not None:
+            self._d.move_to_end(key)
+        return v
+
+    def __setitem__(self, key, value):
+        self._d[key] = value
+        self._d.move_to_end(key)
+        while len(self._d) > self.capacity:
+            self._d.popitem(last=False)
+
+    def __len__(self):
+        return len(self._d)
+
+    def clear(self):
+        self._d.clear()
+
+
+_F8_WS = WorkspaceCache()
+_KMEANS_WS = WorkspaceCache()
 
 
 def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
@@ -361,7 +396,7 @@ def band_attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: 
     if need == 0:
         raise RuntimeError(f"svg_band_attention_fp8: unsupported shape (D = {D}; only 128)")
     if workspace is None:
-        key = (BH, S, q.device, _stream())   # (per stream: two calls of one shape on different streams must not share the buffer)
+        key = WorkspaceCache.key("band", BH, S, device=q.device)
         workspace = _F8_WS.get(key)
         if workspace is None or workspace.numel() < need:
             workspace = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -456,8 +491,6 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
                        workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB].
     fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only).
-    fp8="pv": EXPERIMENTAL mixed form, 16-bit QK^T + e4m3 PV (svg_varblock_attention_fp8pv).
-    variant="pre": EXPERIMENTAL pre-scaled form of the default 16-bit schedule (svg_varblock_attention_pre).
     workspace: optional uint8 GPU tensor of svg_varblock_workspace_bytes(...) bytes for the 16-bit call (tests read the launch
     order back from it; see varblock_launch_order)."""
     lib = load()
@@ -473,32 +506,11 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
         assert kv_row_idx.dtype == torch.int32 and kv_row_idx.shape == (Hkv, Skv)
     o = torch.zeros_like(q) if q_row_idx is None else torch.zeros_like(q)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
-    if variant == "pre":   # EXPERIMENTAL: q copy carrying the softmax scale + the PRE form of the two-phase body (not yet validated on a GPU)
-        assert not fp8
-        need = int(lib.svg_varblock_attention_pre_workspace_bytes(Hq, Hkv, QB, KB, Sq, D))
-        if need == 0:
-            raise RuntimeError(f"svg_varblock_attention_pre: unsupported shape (D = {D})")
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-        rc = lib.svg_varblock_attention_pre(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D, _dtype_code(q),
-                                            scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(), QB, KB,
-                                            _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), _stream())
-        _check(rc, "svg_varblock_attention_pre")
-        return o
-    if fp8 == "pv":   # EXPERIMENTAL: 16-bit QK^T, e4m3 PV (svg_varblock_attention_fp8pv; not yet validated on a GPU)
-        need = int(lib.svg_varblock_attention_fp8pv_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
-        if need == 0:
-            raise RuntimeError(f"svg_varblock_attention_fp8pv: unsupported shape (D = {D}; only 128)")
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-        rc = lib.svg_varblock_attention_fp8pv(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), Hq, Hkv, Sq, Skv, D, _dtype_code(q),
-                                              scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(), QB, KB,
-                                              _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), _stream())
-        _check(rc, "svg_varblock_attention_fp8pv")
-        return o
     if fp8:
         need = int(lib.svg_varblock_attention_fp8_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
         if need == 0:
             raise RuntimeError(f"svg_varblock_attention_fp8: unsupported shape (D = {D}; only 128)")
-        key = ("vb", Hq, Hkv, Sq, Skv, QB, KB, q.device, _stream())
+        key = WorkspaceCache.key("vb", Hq, Hkv, Sq, Skv, QB, KB, device=q.device)
         ws = _F8_WS.get(key)
         if ws is None or ws.numel() < need:
             ws = _F8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
@@ -576,8 +588,10 @@ class ClockProbe:
 
 
 def clear_workspace_cache() -> None:
-    """Drop the cached fp8 workspaces (band_attention_fp8 / varblock_attention(fp8=True) keep one per shape, device and stream)."""
+    """Drop the cached workspaces (band_attention_fp8 / varblock_attention(fp8=True) / kmeans_loop keep one per shape, device and stream,
+    at most WorkspaceCache.capacity of each kind)."""
     _F8_WS.clear()
+    _KMEANS_WS.clear()
 
 
 def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,
@@ -675,14 +689,14 @@ def kmeans_update(x: torch.Tensor, labels: torch.Tensor, centroids_in: torch.Ten
 
 def kmeans_loop(x: torch.Tensor, xsq: Optional[torch.Tensor], c_init: torch.Tensor, max_iters: int, tol: float, work=None):
     """The whole Lloyd loop as one library call without host synchronisation (svg_kmeans_loop) -> (labels int32 [B, N], centroids
-    [B, K, D], counts int32 [B, K], n_iters int32 [] on the device, sorted_idx int32 [B, N]).  `work`: optional dict that keeps the
-    scratch tensors of a (B, N, K, D) shape between calls."""
+    [B, K, D], counts int32 [B, K], n_iters int32 [] on the device, sorted_idx int32 [B, N]).  `work`: a WorkspaceCache (or None: fresh
+    scratch per call) that keeps the scratch tensors of a (B, N, K, D) shape per device AND stream between calls."""
     lib = load()
     _dev(x, xsq, c_init)
     B, N, D = x.shape
     K = c_init.shape[1]
     assert c_init.shape == (B, K, D) and c_init.dtype == x.dtype and c_init.is_contiguous() and x.is_contiguous()
-    key = (B, N, K, D, x.dtype, x.device)
+    key = WorkspaceCache.key("kmeans", B, N, K, D, x.dtype, device=x.device)
     w = None if work is None else work.get(key)
     if w is None:
         w = dict(ca=torch.empty_like(c_init), cb=torch.empty_like(c_init),

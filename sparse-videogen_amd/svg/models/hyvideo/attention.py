@@ -61,9 +61,14 @@ class _HunyuanProcessorBase:
     (ref: hyvideo/attention.py:252-373)."""
 
     fused_prologue = True   # QK-norm + RoPE in one HIP pass (False: two stages, as in the reference)
-    # True (the SVG1 processor): the fused prologue folds sm_scale * log2(e) into its last rounding of q, and the attention /
-    # profiler kernels run their pre-scaled forms (svg_band_attention_prescaled: one FMA per score less on the vector pipe).  Only
-    # when the fused HIP prologue applies (GPU tensors, head_dim 128); q never leaves the processor, so nothing outside sees it.
+    # prescale_q = what flex_attention calls its PRESCALE_QK kernel option ("pre-scale QK by 1/sqrt(d) and change of base. Has about
+    # 20% more numerical error, but slightly faster", torch/_inductor/kernel/flex/templates/flex_attention.py.jinja; default False,
+    # which is what the reference runs: it passes no kernel_options, svg/models/hyvideo/attention.py:401-403).  True: the fused
+    # prologue folds sm_scale * log2(e) into its last rounding of q and the attention / profiler kernels run their pre-scaled forms
+    # (svg_band_attention_prescaled: one FMA per score less, -4 % kernel time) — the scores then come from round(c * q) instead of
+    # c * round(q): against the reference's formulation the bf16 output moves by 3e-3 (scores of O(1)) to 6e-3 rel. L2 (|score| 50 - 80),
+    # tests/test_gpu_prescaled.py::test_prescaled_vs_reference_formulation_on_large_logits.  OFF by default since round 4 (parity first);
+    # only when the fused HIP prologue applies (GPU tensors, head_dim 128); q never leaves the processor, so nothing outside sees it.
     prescale_q = False
     _valid_len_cache: dict = {}
 
@@ -229,7 +234,7 @@ class Hunyuan_SVGAttn_Processor2_0(_HunyuanProcessorBase):
     block_mask = None      # svg_band_mask_t descriptor (what the reference's flex BlockMask encodes)
     fused_placement = True  # fold both layout transformations into the attention kernel (bit-identical result)
     device_switch = True    # dense / sparse decision on the device when the timestep is a GPU tensor (no read-back per forward)
-    prescale_q = True       # q leaves the fused prologue carrying the softmax scale (see _HunyuanProcessorBase.prescale_q)
+    prescale_q = False      # opt-in (flex_attention's PRESCALE_QK trade-off, see _HunyuanProcessorBase.prescale_q): q leaves the fused prologue carrying the softmax scale
 
     def __init__(self, layer_idx):
         super().__init__(layer_idx)

@@ -15,19 +15,22 @@ from .._core import CentroidStore, Geometry
 from .utils import dense_mask, generate_temporal_head_mask_mod, profile_desc
 
 
-def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs, q_scale: float = 1.0):
+def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs, q_scale: float = 1.0, scaled: Optional[list] = None):
     """ref: wan/attention.py:40-66.  `freqs` is either the complex tensor [1, 1, S, D/2] of diffusers or the
     (real, imag) fp32 pair [S, D/2] the reference's patched model forward produces for its CUDA kernel.
-    q_scale != 1 (HIP path only; the caller checks the returned flag): folded into the last rounding of q."""
+    q_scale != 1: folded into the last rounding of q IF the HIP pass takes the call — `scaled` (a list) receives True / False, and when the
+    pass declines (its own acceptance rules decide, nobody re-states them) the torch RoPE below runs on the plain q."""
     # HIP fast path (ref: `_kernels.apply_qk_rope_inplace_cossin_complex(query, key, freqs_real, freqs_imag, 0)`, :45-48)
     S = query.shape[2]
     if isinstance(freqs, (tuple, list)):
         fr, fi = freqs
     else:
         fr, fi = freqs.real, freqs.imag
-    if _core.qk_rope_inplace(query, key, fr, fi, 0, S, complex_pairs=True, q_scale=q_scale):
+    took = bool(_core.qk_rope_inplace(query, key, fr, fi, 0, S, complex_pairs=True, q_scale=q_scale))
+    if scaled is not None:
+        scaled.append(took and q_scale != 1.0)
+    if took:
         return query, key
-    assert q_scale == 1.0, "a pre-scaled q needs the HIP RoPE pass"
     if isinstance(freqs, (tuple, list)):
         freqs = torch.complex(fr.double(), fi.double())[None, None]
 
@@ -58,14 +61,16 @@ class WanAttn_SVGAttn_Processor2_0:
     block_mask = None
     temporal_mask_metadata = None
     fused_placement = True
-    # self attention: the HIP RoPE pass folds sm_scale * log2(e) into its (last) rounding of q and the attention core runs its
-    # pre-scaled kernels (see Hunyuan's processor); not for the cross attention and the I2V image branch, whose q feeds torch SDPA
-    prescale_q = True
+    # opt-in, the PRESCALE_QK trade-off of flex_attention (see Hunyuan's processor; off by default since round 4: parity with the
+    # reference's formulation first).  True, self attention only: the HIP RoPE pass folds sm_scale * log2(e) into its (last) rounding
+    # of q and the attention core runs its pre-scaled kernels; never for the cross attention and the I2V image branch (torch SDPA)
+    prescale_q = False
 
     def __init__(self, layer_idx):
         self.layer_idx = layer_idx
         self.last_best_mask_idx = None
         self._q_prescaled = False
+        self._rope_scaled = False
 
     @classmethod
     def geometry(cls) -> Geometry:
@@ -80,10 +85,19 @@ class WanAttn_SVGAttn_Processor2_0:
         # Wan normalises across all heads, before the head split, and the reference does it with its Triton RMSNorm kernel whatever the
         # module is (ref :105-120: `triton_rmsnorm_forward(query, attn.norm_q.weight, attn.norm_q.eps)` — fp32, one rounding), not with
         # the module's forward (diffusers rounds before the weight): same here on the GPU; other tensors take the module
+        def is_rms(mod):
+            # the reference takes torch.nn.RMSNorm or diffusers' RMSNorm and raises on anything else (:107-119); diffusers is not a
+            # dependency here, so its class is recognised by name, and a module with a bias (LayerNorm) is never an RMSNorm
+            if isinstance(mod, torch.nn.RMSNorm):
+                return True
+            return type(mod).__name__ == "RMSNorm" and getattr(mod, "bias", None) is None and getattr(mod, "weight", None) is not None
+
         def norm(mod, x):
-            w = getattr(mod, "weight", None)
-            if (x.is_cuda and w is not None and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
-                    and w.shape == (x.shape[-1],) and hasattr(mod, "eps") and mod.eps is not None):
+            if not is_rms(mod):
+                raise ValueError(f"Unsupported norm type: {type(mod)}")
+            w = mod.weight
+            if (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
+                    and w.shape == (x.shape[-1],) and getattr(mod, "eps", None) is not None):
                 return triton_rmsnorm_forward(x.contiguous(), w, mod.eps)
             return mod(x)
 
@@ -99,8 +113,11 @@ class WanAttn_SVGAttn_Processor2_0:
 
     @time_logging_decorator("Level 2 - rotary_emb")
     def get_rotary_emb(self, query, key, rotary_emb, q_scale: float = 1.0):
+        self._rope_scaled = False       # set by the RoPE pass itself: True only when the HIP pass folded q_scale into q
         if rotary_emb is not None:
-            query, key = apply_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
+            flag = []
+            query, key = apply_rotary_emb(query, key, rotary_emb, q_scale=q_scale, scaled=flag)
+            self._rope_scaled = bool(flag and flag[0])
         return query, key
 
     @time_logging_decorator("Level 2 - output")
@@ -127,11 +144,8 @@ class WanAttn_SVGAttn_Processor2_0:
         query, key = self.get_qk_norm(attn, query, key)
         query, key, value = self.get_transpose_qkv(attn, query, key, value)
         q_scale = 1.0
-        if (self.prescale_q and not cross and timestep is not None and rotary_emb is not None and _core.prescale_supported(query)
-                and _core._fast_ok(query, key)):
-            fr = rotary_emb[0] if isinstance(rotary_emb, (tuple, list)) else rotary_emb
-            if fr.shape[-2] == query.shape[2] and fr.shape[-1] == query.shape[-1] // 2:   # the HIP RoPE pass will take it
-                q_scale = _core._native.softmax_q_scale(query.shape[-1])
+        if self.prescale_q and not cross and timestep is not None and rotary_emb is not None and _core.prescale_supported(query):
+            q_scale = _core._native.softmax_q_scale(query.shape[-1])     # a request: the RoPE pass reports whether it folded it in
         query, key = self.get_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
         hidden_states_img = None
         if encoder_hidden_states_img is not None:  # I2V: CLIP image tokens, small dense cross attention (ref :174-188)
@@ -146,7 +160,7 @@ class WanAttn_SVGAttn_Processor2_0:
             hidden_states = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=0.0,
                                                            is_causal=False)
         else:
-            self._q_prescaled = q_scale != 1.0
+            self._q_prescaled = self._rope_scaled
             try:
                 hidden_states = self.attention_core_logic(query, key, value, timestep)
             finally:

@@ -25,6 +25,8 @@ class TorchOps:
         g = self.geo
         q, k, v = (b.unflatten(2, (g.heads, -1)).transpose(1, 2).contiguous() for b in (q_buf, k_buf, v_buf))
         q, k = O.rms_norm(q, st.qn, 1e-6), O.rms_norm(k, st.kn, 1e-6)
+        if n_rot == 0:      # a rank whose token range holds text tokens only (the 8-rank test geometry; never at production sizes)
+            return q, k, v
         cos, sin = st.cos[pos0:pos0 + n_rot], st.sin[pos0:pos0 + n_rot]
         q = torch.cat([O.rope_cossin(q[:, :, :n_rot], cos, sin), q[:, :, n_rot:]], dim=2)
         k = torch.cat([O.rope_cossin(k[:, :, :n_rot], cos, sin), k[:, :, n_rot:]], dim=2)

@@ -104,11 +104,6 @@ def test_argument_validation_returns_error_codes():
     assert lib.svg_argsort_workspace_bytes(2, 5000, 100) == 2 * 5 * 100 * 4
     assert lib.svg_varblock_workspace_bytes(4, 4, 10, 20, 1000) > 0
     assert lib.svg_kmeans_workspace_bytes(2, 5000, 100, 128) >= lib.svg_argsort_workspace_bytes(2, 5000, 100)
-    # the experimental pre-scaled SVG2 entry: plan + a copy of q; rejects null pointers and unsupported head sizes before any launch
-    plan = lib.svg_varblock_workspace_bytes(4, 4, 10, 20, 1000)
-    assert lib.svg_varblock_attention_pre_workspace_bytes(4, 4, 10, 20, 1000, 128) == (plan + 255) // 256 * 256 + 4 * 1000 * 128 * 2
-    assert lib.svg_varblock_attention_pre_workspace_bytes(4, 4, 10, 20, 1000, 96) == 0
-    assert lib.svg_varblock_attention_pre(None, None, None, None, 4, 4, 1000, 1000, 128, 0, 1.0, None, None, None, 10, 20, None, None, None, 0, None) == -1
 
 
 def test_native_ops_refuse_cpu_tensors():

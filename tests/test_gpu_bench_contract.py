@@ -102,3 +102,55 @@ def test_bench_step_two_rank_smoke():
     for kind in ("sparse_step", "dense_step"):
         assert d[kind]["ms"] > 0 and d[kind]["rccl_bytes_received_per_step_this_rank"] > 0
     assert d["denoise_steps_per_s"] > 0
+
+
+def _error_keys(node, path=""):
+    """every path in a bench line's JSON at which an "error"-like key sits (an extras block that raised)."""
+    found = []
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if "error" in str(k).lower():
+                found.append(f"{path}/{k}")
+            found += _error_keys(v, f"{path}/{k}")
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            found += _error_keys(v, f"{path}[{i}]")
+    return found
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_bench_svg2_measure_small(fp8):
+    """bench_svg2.measure() is what bench.py embeds as svg2_wan720p / svg2_wan720p_fp8 (BASELINE.json configs[2] / [4]): called the way
+    bench.py calls it, on the reduced geometry.  (Round 3's driver line lost both blocks to an AttributeError inside measure().)"""
+    sys.path.insert(0, str(ROOT))
+    import bench_svg2
+
+    d = bench_svg2.measure("small", steps=1, warmup=0, fp8=fp8)
+    assert not _error_keys(d), _error_keys(d)
+    assert d["ms"]["total"] > 0 and d["ms"]["attention"] > 0 and 0 < d["density_mean"] <= 1
+    assert d["spot_rows_rel_l2_vs_torch_fp32"] < (0.15 if fp8 else 4e-3)
+    if fp8:
+        assert "rel_l2_vs_16bit_kernel" in d
+
+
+def test_bench_line_with_extras_has_no_error_key():
+    """bench.py with every extras block switched on (reduced geometries): exit code 0 and no "error" key anywhere in the line."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu",
+                        "--extras", "small"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-1500:])
+    d = _last_json(r.stdout)
+    assert not _error_keys(d), _error_keys(d)
+    for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p"):
+        assert key in d, sorted(d)
+    assert d["svg2_wan720p"]["ms"]["total"] > 0 and d["svg2_wan720p_fp8"]["ms"]["total"] > 0
+    assert d["denoise_step_hy720p"]["denoise_steps_per_s"] > 0
+
+
+def test_bench_exits_nonzero_when_an_extras_block_raises():
+    """a failing extras block must not vanish silently: the line still carries the error string, and the exit code is 3."""
+    env = dict(os.environ, SVG_BENCH_TEST_BREAK_EXTRAS="1")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu",
+                        "--extras", "small", "--no-step"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    d = _last_json(r.stdout)
+    assert "error" in d["svg2_wan720p"] and d["value"] > 0

@@ -1,9 +1,10 @@
-"""Opt-in GPU fuzz of the HIP kernels against the oracle on RANDOM geometries (SVG_FUZZ=<trials>, e.g. `SVG_FUZZ=40 pytest
-tests/test_gpu_fuzz.py -m gpu`; the default `-m gpu` run skips it).  The parity suite fixes its geometries in the parametrisation;
+"""GPU fuzz of the HIP kernels against the oracle on RANDOM (seeded) geometries: 4 trials per kernel family in the default `-m gpu` run,
+`SVG_FUZZ=40 pytest tests/test_gpu_fuzz.py -m gpu` for more (first run round 4: 124 of 125 green at SVG_FUZZ=25, the one red case a
+test-side tie rule, see test_fuzz_kmeans_iter).  The parity suite fixes its geometries in the parametrisation;
 this draws them — frame count, ragged frame size, text / prompt length, band multiplier, heads, head size, dtype, schedule; cluster
 counts with EMPTY clusters, GQA ratios, block-map densities — with the same tolerances as tests/test_gpu_kernels.py.  The CPU side of the
 same idea (oracle against the EXECUTED reference on random geometries) is tools/fuzz_*_vs_reference.py, logs under profiles/.
-Written at the end of round 3 when the GPU budget was spent: first run is round 4's (tools/r04_second_call.sh)."""
+"""
 import os
 
 import pytest
@@ -11,8 +12,8 @@ import torch
 
 from oracle import svg_oracle as O
 
-TRIALS = int(os.environ.get("SVG_FUZZ", "0") or 0)
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(TRIALS <= 0, reason="set SVG_FUZZ=<trials>")]
+TRIALS = int(os.environ.get("SVG_FUZZ", "4") or 4)     # default run: 4 seeded trials per kernel family; SVG_FUZZ=<n> for more
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")

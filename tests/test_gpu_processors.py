@@ -125,8 +125,8 @@ def test_hunyuan_svg_processor_end_to_end():
 
 
 def test_hunyuan_svg_processor_prescaled_q_equals_plain_path():
-    """prescale_q (default of the SVG1 processor: the fused prologue folds sm_scale * log2(e) into its last rounding of q and the
-    kernels run their pre-scaled forms) against prescale_q = False (plain q, scale applied inside the kernel): the same processor
+    """prescale_q = True (opt-in since round 4, flex_attention's PRESCALE_QK trade-off: the fused prologue folds sm_scale * log2(e) into
+    its last rounding of q and the kernels run their pre-scaled forms) against the default (plain q, scale applied inside the kernel): the same processor
     output up to the rounding of q — sparse step, dense warm-up step and the device-switched path, double- and single-stream block."""
     from svg.models import _core
     from svg.models.hyvideo.inference import replace_hyvideo_attention
@@ -142,7 +142,7 @@ def test_hunyuan_svg_processor_prescaled_q_equals_plain_path():
     L = 21
     cls = replace_hyvideo_attention(pipe, 160, 320, 17, L, first_layers_fp=0, first_times_fp=900.0, pattern="SVG",
                                     num_sampled_rows=32, sparsity=0.45)
-    assert cls.prescale_q
+    assert not cls.prescale_q      # the default is the reference's formulation
     ctx, F_, P_ = cls.context_length, cls.num_frame, cls.frame_size
     cls.sample_mse_max_row = F_ * P_
     V = F_ * P_
@@ -167,7 +167,7 @@ def test_hunyuan_svg_processor_prescaled_q_equals_plain_path():
                     e = ((a.float() - b.float()).norm() / b.float().norm()).item()
                     assert e < 6e-3, e
     finally:
-        cls.prescale_q = True
+        cls.prescale_q = False
 
 
 def _clustered(H, N, D, modes, gen):
@@ -300,8 +300,8 @@ def test_wan_and_cog_svg_processors_run_and_match():
 
 @pytest.mark.parametrize("hd", [64, 128])
 def test_wan_and_cog_prescaled_q_equals_plain_path(hd):
-    """Wan / Cog SVG1 processors: prescale_q (default — the HIP RoPE pass folds the softmax scale into its rounding of q, pre-scaled
-    kernels downstream, at head_dim 64 and 128) against prescale_q = False: the same processor output up to the rounding of q, on
+    """Wan / Cog SVG1 processors: prescale_q = True (opt-in — the HIP RoPE pass folds the softmax scale into its rounding of q, pre-scaled
+    kernels downstream, at head_dim 64 and 128) against the default prescale_q = False: the same processor output up to the rounding of q, on
     sparse and dense steps, host- and device-switched.  Cross attention (Wan) never pre-scales: its q feeds torch SDPA."""
     from svg.models import _core
     from svg.models.cog.attention import CogVideoX_SparseAttn_Processor2_0 as CogP
@@ -323,7 +323,7 @@ def test_wan_and_cog_prescaled_q_equals_plain_path(hd):
                 with torch.no_grad():
                     outs.append(run())
         finally:
-            cls.prescale_q = True
+            cls.prescale_q = False
         for a, b in zip(*outs):
             torch.testing.assert_close(a.float(), b.float(), atol=2e-2, rtol=2e-2)
             assert ((a.float() - b.float()).norm() / b.float().norm()).item() < 6e-3

@@ -1,7 +1,9 @@
-"""GPU tests of EXPERIMENTAL entry points — code that compiles and has not been validated on hardware yet.  They run only with
-SVG_EXPERIMENTAL=1 (the first thing round 4 does); the default `-m gpu` run skips them, so an unvalidated kernel cannot turn the
-parity suite red."""
-import os
+"""The product's processors and k-means halves against what the EXECUTED reference produced (tests/golden/triton_golden.npz,
+tests/golden/make_golden_triton.py: the reference's processors' `__call__`, Wan block forward and Triton k-means kernels run in the build
+container): Hunyuan double / single stream, CogVideoX (both profiler outcomes), Cosmos, Wan cross attention + I2V image branch, Wan block
+forward (fast and torch branch), euclid_assign_triton / triton_centroid_update_sorted_euclid under the reference's names.
+Written at the end of round 3 (opt-in then, tests/test_gpu_experimental.py); first run on a GPU in round 4 — all green
+(profiles/r04a_pytest_parked.txt) — and part of the default `-m gpu` run since."""
 from pathlib import Path
 
 import pytest
@@ -9,7 +11,7 @@ import torch
 
 from oracle import svg_oracle as O
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SVG_EXPERIMENTAL") != "1", reason="set SVG_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
@@ -19,37 +21,6 @@ def nat():
     from svg import _native
     _native.load()
     return _native
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("Hq,Hkv", [(2, 2), (4, 2)])
-def test_varblock_mixed_precision_body(nat, dt, Hq, Hkv):
-    """svg_varblock_attention_fp8pv (16-bit QK^T, e4m3 PV) against the fp32 oracle under the element mask: ragged and EMPTY clusters,
-    GQA, partial tiles.  Expected error: the e4m3 rounding of P and V only (~2.5 - 3.7 % rel. L2, tools/fp8_precision_study.py) —
-    well below the all-e4m3 kernel's on the same inputs."""
-    gen = torch.Generator().manual_seed(7)
-    D = 128
-    q_sizes = torch.tensor([[300, 1, 0, 129, 70, 524]] * Hkv, dtype=torch.int32)
-    k_sizes = torch.tensor([[64, 0, 200, 333, 1, 426]] * Hkv, dtype=torch.int32)
-    S = int(q_sizes[0].sum())
-    assert S == int(k_sizes[0].sum())
-    q = torch.randn(Hq, S, D, generator=gen).to(dt)
-    k, v = torch.randn(Hkv, S, D, generator=gen).to(dt), torch.randn(Hkv, S, D, generator=gen).to(dt)
-    bmap = torch.rand(Hkv, 6, 6, generator=gen) < 0.6
-    bmap[:, torch.arange(6), torch.tensor([5, 3, 2, 0, 3, 5])] = True       # every q block sees a key block with rows
-    args = (q.cuda(), k.cuda(), v.cuda(), bmap.cuda(), q_sizes.cuda(), k_sizes.cuda())
-    o_pv = nat.varblock_attention(*args, fp8="pv").float().cpu()
-    o_f8 = nat.varblock_attention(*args, fp8=True).float().cpu()
-    o_16 = nat.varblock_attention(*args).float().cpu()
-    g = Hq // Hkv
-    ref = torch.stack([O.masked_attention(q[h].float(), k[h // g].float(), v[h // g].float(),
-                                          O.block_mask_to_element_mask(bmap[h // g], q_sizes[h // g], k_sizes[h // g])) for h in range(Hq)])
-    rows = torch.repeat_interleave(torch.arange(6), q_sizes[0].long())       # rows of empty q clusters do not exist
-    err = lambda o: ((o - ref).norm() / ref.norm()).item()      # noqa: E731
-    e_pv, e_f8, e_16 = err(o_pv), err(o_f8), err(o_16)
-    print(f"[mixed body {dt} Hq={Hq} Hkv={Hkv}] rel L2 vs fp32 oracle: 16-bit {e_16:.2e}, mixed {e_pv:.2e}, all-e4m3 {e_f8:.2e}")
-    assert torch.isfinite(o_pv).all() and rows.numel() == S
-    assert e_16 < 5e-3 and e_pv < 4.5e-2 and e_pv < e_f8
 
 
 @pytest.mark.parametrize("tag", ["as_c", "as_d"])
@@ -95,8 +66,7 @@ def test_centroid_update_under_the_references_name(nat):
 
 @pytest.mark.parametrize("tag", ["call_hyd", "call_hys"])
 def test_hunyuan_processor_call_equals_the_references_call(nat, tag):
-    """NOT experimental code — a parity test written when the round's GPU budget was spent, parked here until it has run once (then it
-    moves to tests/test_gpu_triton_golden.py).  The product's Hunyuan_SVGAttn_Processor2_0.__call__ on a duck-typed attention module
+    """The product's Hunyuan_SVGAttn_Processor2_0.__call__ on a duck-typed attention module
     (fp16 weights and inputs, HIP path) against the OUTPUT of the reference's processor `__call__` executed in fp32 on the same
     fp16-representable weights and inputs (tests/golden/make_golden_triton.py section 12): double-stream block (text stream with its own
     projections / norms / output projection) and single-stream block (concatenated sequence, no output projection).  Same profiler
@@ -163,7 +133,7 @@ def test_hunyuan_processor_call_equals_the_references_call(nat, tag):
 
 @pytest.mark.parametrize("which", ["v", "t"])
 def test_cog_processor_call_equals_the_references_call(nat, which):
-    """Parked like the Hunyuan test above (a parity test, not experimental code).  The product's CogVideoX_SparseAttn_Processor2_0.__call__
+    """The product's CogVideoX_SparseAttn_Processor2_0.__call__
     (fp16, HIP path: LayerNorm over head_dim, RoPE on the video rows with the softmax scale folded in, profiler, band attention with
     fused layout transformation) against the reference's processor `__call__` executed in fp32 (make_golden_triton.py section 13).  The
     profiler draws its rows from the CPU generator like the reference, so seeding the same way profiles the same rows: `v` = video rows
@@ -220,7 +190,7 @@ def test_cog_processor_call_equals_the_references_call(nat, which):
 
 @pytest.mark.parametrize("branch", ["fast", "torch"])
 def test_wan_block_forward_equals_the_references_block(nat, branch):
-    """Parked like the two tests above.  The product's wan_block_forward (HIP glue: fused LayerNorm + modulate, gate-residual; fp16) against
+    """The product's wan_block_forward (HIP glue: fused LayerNorm + modulate, gate-residual; fp16) against
     the reference's WanTransformerBlock_Sparse.forward executed in fp32 (make_golden_triton.py section 14) on the same fp16-representable
     block: `fast` = the reference on its Triton kernels — the product with svg.kernels.triton.layernorm.REFERENCE_PADDING on reproduces its
     padded variance; `torch` = the reference's fall-back (FP32LayerNorm), the product's default.  Hidden size 192 with a row mean: the two
@@ -264,7 +234,7 @@ def test_wan_block_forward_equals_the_references_block(nat, branch):
 
 
 def test_cosmos_processor_call_equals_the_references_call(nat):
-    """Parked like the tests above.  The product's Cosmos_SVG_AttnProcessor2_0.__call__ (fp16: per-head RMSNorm on the HIP path, half-split
+    """The product's Cosmos_SVG_AttnProcessor2_0.__call__ (fp16: per-head RMSNorm on the HIP path, half-split
     RoPE, the Wan sparse core) and the same processor as cross attention against the reference's executed `__call__`
     (make_golden_triton.py section 15)."""
     import sys
@@ -319,7 +289,7 @@ def test_cosmos_processor_call_equals_the_references_call(nat):
 
 @pytest.mark.parametrize("tag", ["xwan_t2v", "xwan_i2v"])
 def test_wan_cross_attention_and_i2v_equal_the_references_call(nat, tag):
-    """Parked like the tests above.  The product's Wan processor as cross attention (fp16 on the GPU: RMSNorm across heads through
+    """The product's Wan processor as cross attention (fp16 on the GPU: RMSNorm across heads through
     svg_rmsnorm_forward, torch SDPA), text only and with the I2V image branch, against the reference's executed call
     (make_golden_triton.py section 16)."""
     import sys
@@ -352,76 +322,3 @@ def test_wan_cross_attention_and_i2v_equal_the_references_call(nat, tag):
     e = ((got.float().cpu() - ref).norm() / ref.norm()).item()
     assert e < 5e-3, e
     torch.testing.assert_close(got.float().cpu(), ref, atol=2e-2, rtol=2e-2)
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("D,Hq,Hkv", [(128, 2, 2), (64, 4, 2)])
-def test_varblock_prescaled_body(nat, dt, D, Hq, Hkv):
-    """svg_varblock_attention_pre (EXPERIMENTAL: a copy of q carrying the softmax scale + the PRE form of the two-phase body) against the
-    fp32 oracle under the element mask with the tolerances of the shipped kernel, and against the shipped kernel itself: ragged and EMPTY
-    clusters, GQA, partial tiles, with and without the fused permutation."""
-    gen = torch.Generator().manual_seed(11)
-    q_sizes = torch.tensor([[300, 1, 0, 129, 70, 524]] * Hkv, dtype=torch.int32)
-    k_sizes = torch.tensor([[64, 0, 200, 333, 1, 426]] * Hkv, dtype=torch.int32)
-    S = int(q_sizes[0].sum())
-    q = torch.randn(Hq, S, D, generator=gen).to(dt)
-    k, v = torch.randn(Hkv, S, D, generator=gen).to(dt), torch.randn(Hkv, S, D, generator=gen).to(dt)
-    bmap = torch.rand(Hkv, 6, 6, generator=gen) < 0.6
-    bmap[:, torch.arange(6), torch.tensor([5, 3, 2, 0, 3, 5])] = True       # every q block sees a key block with rows
-    args = (q.cuda(), k.cuda(), v.cuda(), bmap.cuda(), q_sizes.cuda(), k_sizes.cuda())
-    o = nat.varblock_attention(*args, variant="pre").float().cpu()
-    base = nat.varblock_attention(*args, variant=3).float().cpu()
-    g = Hq // Hkv
-    for h in range(Hkv):
-        em = O.block_mask_to_element_mask(bmap[h], q_sizes[h], k_sizes[h])
-        ref = O.masked_attention(q[h * g:(h + 1) * g], k[h:h + 1], v[h:h + 1], em)
-        torch.testing.assert_close(o[h * g:(h + 1) * g], ref, atol=1e-2, rtol=1e-2)
-        e = ((o[h * g:(h + 1) * g] - ref).norm() / ref.norm()).item()
-        assert e <= (3e-3 if dt == torch.bfloat16 else 1e-3), e
-    assert ((o - base).norm() / base.norm()).item() < (4e-3 if dt == torch.bfloat16 else 1e-3)
-    # fused permutation: rows of q / k / v in a shuffled physical order, the kernel gathers through the index arrays
-    perm_q = torch.stack([torch.randperm(S, generator=gen) for _ in range(Hq)]).int()
-    perm_k = torch.stack([torch.randperm(S, generator=gen) for _ in range(Hkv)]).int()
-    q_phys, k_phys, v_phys = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    for h in range(Hq):
-        q_phys[h, perm_q[h].long()] = q[h]
-    for h in range(Hkv):
-        k_phys[h, perm_k[h].long()] = k[h]
-        v_phys[h, perm_k[h].long()] = v[h]
-    o2 = nat.varblock_attention(q_phys.cuda(), k_phys.cuda(), v_phys.cuda(), bmap.cuda(), q_sizes.cuda(), k_sizes.cuda(),
-                                q_row_idx=perm_q.cuda(), kv_row_idx=perm_k.cuda(), variant="pre").float().cpu()
-    back = torch.stack([o2[h, perm_q[h].long()] for h in range(Hq)])
-    assert torch.equal(back, o), "the fused permutation changes where rows live, not what is computed"
-
-
-def test_varblock_prescaled_body_time_at_production_shape(nat):
-    """prints the time of the shipped SVG2 kernel and of the pre-scaled form on a Wan-720p-like layer slice (8 of 40 heads, 75600 tokens,
-    300 x 1000 ragged clusters, ~25 % of the blocks active); no assertion on the ratio — round 4 decides on `bench_svg2.py`."""
-    gen = torch.Generator().manual_seed(3)
-    H, S, D, QC, KC = 8, 75600, 128, 300, 1000
-
-    def sizes(n):
-        w = torch.rand(H, n, generator=gen) + 0.2
-        s = torch.floor(w / w.sum(-1, keepdim=True) * S).int()
-        s[:, 0] += S - s.sum(-1).int()
-        return s
-
-    qs, ks = sizes(QC), sizes(KC)
-    q, k, v = (torch.randn(H, S, D, generator=gen).to(torch.bfloat16).cuda() for _ in range(3))
-    bmap = (torch.rand(H, QC, KC, generator=gen) < 0.25).cuda()
-    args = (q, k, v, bmap, qs.cuda(), ks.cuda())
-    out = {}
-    for name, var in (("shipped", 3), ("pre-scaled", "pre"), ("shipped", 3), ("pre-scaled", "pre")):
-        nat.varblock_attention(*args, variant=var)
-        torch.cuda.synchronize()
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record()
-        for _ in range(5):
-            o = nat.varblock_attention(*args, variant=var)
-        t1.record()
-        torch.cuda.synchronize()
-        out.setdefault(name, []).append(t0.elapsed_time(t1) / 5)
-        out[name + "_o"] = o
-    e = ((out["pre-scaled_o"].float() - out["shipped_o"].float()).norm() / out["shipped_o"].float().norm()).item()
-    print(f"\n[varblock pre-scaled] shipped {out['shipped']} ms, pre-scaled (incl. the q copy) {out['pre-scaled']} ms, rel. L2 between them {e:.2e}")
-    assert e < 4e-3

@@ -1,6 +1,6 @@
-"""The N-rank denoise step of bench_step.py (BASELINE.json configs[3]: hidden states token-sharded by whole frames, attention
+"""The N-rank denoise step of bench_step.py (BASELINE.json configs[3]: hidden states token-sharded in units of tokens, attention
 head-sharded, tokens_to_heads / heads_to_tokens around every attention, one all-gather of the hidden states per step) against the
-single-process step on the same stack: 2 and 3 processes over gloo on CPU with a torch statement of the op table
+single-process step on the same stack: 2, 3 and 8 processes (24 heads) over gloo on CPU with a torch statement of the op table
 (tests/step_ops_torch.py) — what is under test is the sharding: token ranges, RoPE table slices, the text stream living on the last
 rank, head shards, exchange layouts, the final gather.  The HIP ops themselves are tested in tests/test_gpu_*.py."""
 import os
@@ -25,7 +25,7 @@ def _geo(heads):
     _setup_paths()
     import bench_step
 
-    return bench_step.StepGeo(F=5, P=40, ctx=24, L=7, hid=heads * 32, heads=heads, hd=32, mlp=96)
+    return bench_step.StepGeo(F=5, P=40, ctx=24, L=7, hid=heads * 32, heads=heads, hd=32, mlp=96, unit=8)
 
 
 def _single(heads, sparse):
@@ -53,7 +53,7 @@ def _worker(rank, world, port, heads, sparse, ret):
     ref, img, txt = _single(heads, sparse)
     st = bench_step.Stack(1, 1, torch.device("cpu"), geo, dtype=torch.float32)
     sh = bench_step.Sharding(geo, rank, world, torch.device("cpu"), torch.float32)
-    x = bench_step.run_step(st, img[sh.a: sh.a + sh.nv].contiguous(), txt[geo.ctx - sh.nt:].contiguous() if sh.nt else txt[:0], sparse, 1,
+    x = bench_step.run_step(st, img[sh.a: sh.a + sh.nv].contiguous(), txt[sh.t0: sh.t0 + sh.nt].contiguous(), sparse, 1,
                             [], TorchOps(geo), sh, events=False)
     full, nbytes = sh.gather_tokens(x)
     ok = (tuple(x.shape) == (sh.b - sh.a, geo.hid) and torch.allclose(x, ref[sh.a:sh.b], atol=2e-5, rtol=2e-5)
@@ -63,16 +63,34 @@ def _worker(rank, world, port, heads, sparse, ret):
     want_in = 2 * 3 * Hl * (geo.S - (sh.b - sh.a)) * geo.hd * 4
     want_out = 2 * (geo.heads - Hl) * (sh.b - sh.a) * geo.hd * 4
     ok = ok and sh.buf.bytes_in == want_in and sh.buf.bytes_out == want_out and nbytes > 0
-    # the text tokens live on the last rank only
-    ok = ok and (sh.nt == (geo.ctx if rank == world - 1 else 0))
+    # the text tokens are the tail of the sequence: whichever ranks' ranges reach past V hold them, in order
+    ok = ok and sh.nt == max(0, sh.b - max(sh.a, geo.V)) and sh.t0 == max(sh.a, geo.V) - geo.V
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,heads,sparse", [(2, 4, True), (2, 4, False), (3, 6, True)])
+@pytest.mark.parametrize("world,heads,sparse", [(2, 4, True), (2, 4, False), (3, 6, True), (8, 24, True)])
 def test_token_sharded_step_equals_single_process(world, heads, sparse):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29650 + world * 7 + heads + int(sparse)
     mp.spawn(_worker, args=(world, port, heads, sparse, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_production_token_shards_are_balanced():
+    """HunyuanVideo 720p over 8 ranks: the shards the step bench uses differ by at most 1 % from the mean
+    (whole frames: 5 / 4 frames, 21 % over), cover the sequence exactly once, and every boundary but the last sits on a unit."""
+    _setup_paths()
+    import bench_step
+    from svg import distributed as D
+
+    geo = bench_step.HY720P
+    for world in (2, 4, 8):
+        tr = [D.token_range(geo.S, r, world, unit=geo.unit) for r in range(world)]
+        assert tr[0][0] == 0 and tr[-1][1] == geo.S and all(tr[i][1] == tr[i + 1][0] for i in range(world - 1))
+        assert all(a % geo.unit == 0 for a, _ in tr)
+        sizes = [b - a for a, b in tr]
+        assert max(sizes) * world / geo.S <= 1.01, (world, sizes)
+    frames = [b - a for a, b in (D.token_range(geo.S, r, 8, unit=geo.P) for r in range(8))]
+    assert max(frames) * 8 / geo.S > 1.2      # what the frame-granular split cost

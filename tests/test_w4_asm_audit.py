@@ -89,17 +89,17 @@ def test_first_step_mfmas_have_no_hazards(f8_listings, capsys):
     for f in f8_listings:
         assert f.exists(), f"build.py keeps the assembly of {f.name}"
     seen = 0
-    for f in f8_listings:                                    # {band, varblock, varblock mixed (attn_f8pv.h)} x {bf16, f16}: 2 asm MFMAs each
+    for f in f8_listings:                                    # {band, varblock} x {bf16, f16}: 2 asm MFMAs each
         rc, out, kernels = _audit(audit, capsys, "attn_f8", f)
         seen += len(kernels)
         assert rc == 0, out
         for l in kernels:
             assert "2 asm MFMAs, 0 hazards" in l, l
-    assert seen == 6, seen
-    # pre-scaled kernels: band {plain, switch} x dtype x head_dim, and the (experimental) variable-block form x dtype x head_dim
+    assert seen == 4, seen
+    # pre-scaled kernels: band {plain, switch} x dtype x head_dim
     rc, out, kernels = _audit(audit, capsys, "pp2q", f8_listings[0])
     assert rc == 0, out
     assert not any("trace" in l for l in kernels), "the kept listing is the PRODUCT build's (an -DSVG_ABLATIONS build has the trace kernels)"
-    assert len(kernels) == 12 and sum("varblock" in l for l in kernels) == 4, out
+    assert len(kernels) == 8 and not any("varblock" in l for l in kernels), out
     for l in kernels:
         assert (" 8 asm MFMAs, 0 hazards" if "switch" in l else " 4 asm MFMAs, 0 hazards") in l, l
