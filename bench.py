@@ -13,7 +13,7 @@ metric  = attention TFLOP/s, algorithmic: 4 * D * H * (#unmasked (q,k) pairs) pe
           at L=64) divided by wall time per step; `attention_only_steps_per_s` (60 such layer-calls, nothing else of a
           denoise step — no projections, norms, MLPs) is reported beside it.
 roofline: bound = MFMA (dense bf16 peak 2.5 PFLOP/s); `achieved` = algorithmic FLOPs of the dominant kernel
-          (band_attn_pp2_kernel) / its mean launch duration measured with HIP events on the launch stream.
+          (band_attn_m16_kernel since round 4) / its mean launch duration measured with HIP events on the launch stream.
 cpu_baseline: BASELINE.md §3 — the reference's CPU-capable dense path torch SDPA (ref: svg/models/wan/attention.py:279-281,
           svg/models/hyvideo_orig/modules/attenion.py:488-491) on all host cores, bf16, ONE head at the full sequence length
           (median of 3), or the longest sequence that fits the time bound; plus flex_attention eager on the CPU with the
@@ -88,7 +88,7 @@ def band_pairs(m, S: int) -> int:
     return int((alen + blen).sum())
 
 
-BAND_KERNELS = {0: "band_attn_pp2_kernel<bf16,128>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
+BAND_KERNELS = {0: "band_attn_m16_kernel<bf16>", 8: "band_attn_m16_kernel<bf16>", 3: "band_attn_w4_kernel<bf16,128>", 2: "band_attn_pp2_kernel<bf16,128>",
                 1: "band_attn_kernel<bf16,128,4>"}
 
 
@@ -197,8 +197,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="hy720p", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 2), "
-                    "1 lock-step 4 waves, 2 two-phase ping-pong, 3 one wave per SIMD")
+    ap.add_argument("--variant", type=int, default=0, help="svg_band_attention schedule (include/svg_attn.h): 0 default (= 8 at head_dim 128), "
+                    "1 lock-step 4 waves, 2 two-phase ping-pong on 32x32x16 MFMAs, 3 one wave per SIMD, 8 two-phase on 16x16x32 MFMAs")
     ap.add_argument("--chunks", type=int, default=1, help="N = 1 only: split the launch into this many head chunks on two streams")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: e4m3 QK^T / PV (svg_band_attention_fp8: quantise + "
                     "placement pre-pass and attention kernel, both inside the timed step; BASELINE.json configs[4]); N = 1 only")
@@ -573,20 +573,18 @@ def main():
             ab["default_ms"] = round(time_attn(plain), 3)
             ab["frozen_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=6, **pk)), 3)
             ab["prescaled_q_ms"] = round(time_attn(pre), 3)
-            os.environ["SVG_BAND_ROTATE"] = "0"      # (read per launch, csrc/band_policy.h: every q-tile sweeps from its own first key, as until round 3)
-            ab["default_no_cyclic_start_ms"] = round(time_attn(plain), 3)
-            ab["prescaled_q_no_cyclic_start_ms"] = round(time_attn(pre), 3)
-            os.environ.pop("SVG_BAND_ROTATE", None)
+            ab["variant_2_mfma_32x32x16_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=2, **pk)), 3)
             ab["variant_3_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=3, **pk)), 3)
             ab["variant_1_ms"] = round(time_attn(lambda: nat.band_attention(q, k, v, mask, variant=1, **pk), n=2), 3)
             ab["default_ms_again"] = round(time_attn(plain), 3)   # (drift over the block)
             ab["default_over_frozen"] = round(ab["default_ms"] / ab["frozen_ms"], 4)
             ab["prescaled_q_over_frozen"] = round(ab["prescaled_q_ms"] / ab["frozen_ms"], 4)
-            ab["what"] = ("attention kernel ms, same process / box / inputs: default = svg_band_attention variant 0 on the plain q (two-phase body, "
-                          "max-free softmax, carried operands, cyclic sweep start; softmax scale on the fp32 scores — the reference's formulation), "
+            ab["what"] = ("attention kernel ms, same process / box / inputs: default = svg_band_attention variant 0 on the plain q (= 8: two-phase body on "
+                          "16x16x32 MFMAs, max-free softmax, carried operands, one barrier per tile; softmax scale on the fp32 scores — the reference's "
+                          "formulation), variant_2 = the same schedule on 32x32x16 MFMAs (the default until round 3), "
                           "prescaled_q = svg_band_attention_prescaled (opt-in: score accumulators started at minus the reference, q pre-scaled by the "
                           "prologue — flex_attention's PRESCALE_QK trade-off), frozen = variant 6 (two-phase body with the round-1 softmax and operand "
-                          "fetch, plain q), *_no_cyclic_start = SVG_BAND_ROTATE=0, 3 = one wave per SIMD, 1 = lock-step 4 waves")
+                          "fetch, plain q), 3 = one wave per SIMD, 1 = lock-step 4 waves")
             del qs
         except Exception as e:  # noqa: BLE001
             ab["error"] = f"{type(e).__name__}: {str(e)[:300]}"

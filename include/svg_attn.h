@@ -111,7 +111,7 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = default (= 2).  All schedules produce the same result up to rounding.
+/* variant: 0 = default (= 8 at head_dim 128, = 2 at head_dim 64).  All schedules produce the same result up to rounding.
  *   1 = lock-step, 4 waves x 32 query rows, 128-row q-tiles, two workgroups per CU (register-staged K/V) — the plain schedule
  *       the test-suite uses as the in-library reference;
  *   2 = two-phase ping-pong, 8 waves x 32 rows: the two waves that share a SIMD alternate a matrix phase (PV of tile t + QK^T
@@ -119,6 +119,9 @@ typedef struct svg_perm_desc {
  *       in opposite phases;
  *   3 = one wave per SIMD, 4 waves x 64 rows, O and Q in the AGPR half of the register file, softmax / LDS reads / LDS-DMA
  *       requests software-pipelined into the gaps between the wave's own MFMAs, one barrier per tile (csrc/attn_w4.h).
+ *   8 = the two-phase schedule of 2 on v_mfma_f32_16x16x32 instead of 32x32x16 (head_dim 128 only; csrc/attn_m16.h): the 16-bit
+ *       attention kernels run at the chip's power limit, and the 16x16x32 shape does the same FLOPs with half the accumulator
+ *       traffic — the matrix pipe alone is granted 2.15 GHz instead of 1.75 on changing operands (profiles/r04c_energy_table.txt).
  *   6 = frozen reference schedule (bf16, D = 128 only): the two-phase body with the round-1 softmax (running maximum, deferred
  *       rescale) and operand fetch, kept so that a bench run can time it beside the default on the same box.
  * Any other value: SVG_ERR_BAD_ARG.  Builds with -DSVG_ABLATIONS (diagnostics, never the product library) additionally accept
@@ -165,6 +168,8 @@ int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, con
  * matching on the map's bitmap rows) run as ONE tile that walks the common key blocks once — exact: a row sees its own block-row's
  * keys only (two key intervals per row); 6 = variant 3 without the packing (the default of round 2);
  * 4 = the same kernel in block-row order (A/B measurements); 5 = variant 3 recording the launch timeline (svg_debug_wg_trace);
+ * at head_dim 128 the two-phase body of 3 .. 7 runs on 16x16x32 MFMAs (csrc/attn_m16.h) — 8 = 3 naming that body, 9 = 3 forcing the
+ * 32x32x16 body (A/B);
  * 7 = similarity order: block-rows with (nearly) the same active key blocks are neighbours of a device-built nearest-neighbour
  * chain and consecutive workgroups go to the same XCD so that they meet in its L2 (maps whose bitmap does not fit the chain
  * kernel's 64 KiB of LDS — QB * (KB / 32 + 4) words — fall back to 3).  Measured at Wan 2.1 720p (profiles/r03b_pmc_svg2_*):

@@ -5,6 +5,7 @@
 
 #include "attn_core.h"
 #include "attn_f8.h"
+#include "attn_m16.h"
 #include "band_policy.h"
 
 namespace svg {
@@ -42,6 +43,23 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_frozen_kernel(typename B
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<__bf16, 128, BandPolicy<__bf16, 128, 8, false>, false, 8>(prm, smem, nullptr);
 }
+// the two-phase schedule on v_mfma_f32_16x16x32 (attn_m16.h): head_dim 128; variant 8
+// (issue priority in the matrix phase, ONE barrier per tile: 32.55 ms against 33.1 with two — profiles/r04g_ab_m16_cfg.txt; the 32x32x16
+//  body gained nothing from the single barrier because the clock took it back, this one runs ~300 MHz further from the power limit)
+template <typename T, int PRIO = 1, int ONEBAR = 1>
+__global__ __launch_bounds__(512, 2) void band_attn_m16_kernel(typename BandPolicy<T, 128, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, PRIO, ONEBAR>(prm, smem, nullptr);
+}
+// device-side switch between two masks on the 16x16x32 body (svg_band_attention_switch at head_dim 128): `flag[0] != 0` selects prm_alt
+template <typename T>
+__global__ __launch_bounds__(512, 2) void band_attn_m16_switch_kernel(typename BandPolicy<T, 128, 8, false>::Params prm,
+                                                                      typename BandPolicy<T, 128, 8, false>::Params prm_alt,
+                                                                      const int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (flag[0] != 0) attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1>(prm_alt, smem, nullptr);
+    else attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1>(prm, smem, nullptr);
+}
 // the same for q that carries sm_scale * log2(e) (svg_band_attention_prescaled): no scale-and-shift per score
 template <typename T, int D>
 __global__ __launch_bounds__(512, 2) void band_attn_pp2q_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
@@ -55,6 +73,11 @@ template <typename T, int D, int ABL>
 __global__ __launch_bounds__(512, 2) void band_attn_pp2_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, true, ABL>(prm, smem, nullptr);
+}
+template <typename T>   // trace code 9: the 16x16x32 body (attn_m16.h) with the cycle trace
+__global__ __launch_bounds__(512, 2) void band_attn_m16_trace_kernel(typename BandPolicy<T, 128, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_m16<T, BandPolicy<T, 128, 8, false>, true>(prm, smem, nullptr);
 }
 template <typename T, int D>   // trace code 3: the pre-scaled-q body (svg_band_attention_prescaled) with the cycle trace
 __global__ __launch_bounds__(512, 2) void band_attn_pp2q_trace_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
@@ -312,6 +335,14 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_pp2_kernel(typename Varb
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, VarblockPolicy<T, D, 8>>(prm, smem, smem + attn_pp2_lds_bytes<D>());
 }
+
+// the two-phase body on 16x16x32 MFMAs (attn_m16.h) for the variable-block policy: head_dim 128; svg_varblock_attention variant 8
+template <typename T>
+__global__ __launch_bounds__(512, 2) void varblock_attn_m16_kernel(typename VarblockPolicy<T, 128, 8>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_m16<T, VarblockPolicy<T, 128, 8>>(prm, smem, smem + attn_m16_lds_bytes());
+}
+static thread_local bool tl_vb_m16 = false;   // set by svg_varblock_attention for variant 8 (the launch below picks the m16 kernel)
 
 #ifdef SVG_ABLATIONS
 // the same kernel with the launch timeline of svg_debug_wg_trace (variant 5, diagnostics build only)
@@ -733,18 +764,21 @@ __global__ __launch_bounds__(kVbChainThreads) void varblock_chain_kernel(const u
 thread_local int g_last_hip_error = 0;
 
 // Schedules of svg_band_attention (`variant`, include/svg_attn.h).
-enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3, kBandFrozen = 6 };
+enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3, kBandFrozen = 6, kBandM16 = 8 };
 // default (variant 0): the two-phase ping-pong body with the max-free softmax for head_dim 128 (round 2, late: 33.7 vs 35.0 ms for the
 // one-wave-per-SIMD body on the same box), the one-wave-per-SIMD body for head_dim 64 (2.60 vs 2.67 ms, 13.6 vs 13.8 ms on the
 // CogVideoX geometries).  Launches that count completions (svg_band_attention_notify*) always run the two-phase body: their targets
 // (svg_band_attention_notify_target / _layout) do not know the head size.
 // Round 3: with the carried operands the two-phase body is the faster one at head_dim 64 too (CogVideoX-v1 2.62 vs 2.73 ms, v1.5
 // 13.80 vs 13.84 ms; pre-scaled 2.45 / 13.03 ms): one default for both head sizes.
-static inline int band_default(int, bool) { return kBandPingPong; }
+// Round 4: head_dim 128 runs the two-phase schedule on 16x16x32 MFMAs (attn_m16.h, variant 8): 32.6 ms against 34.1 - 35.7 for the
+// 32x32x16 body on the plain q, same box (profiles/r04f_ab_m16.txt, r04g_ab_m16_cfg.txt); head_dim 64 and the pre-scaled entry points keep
+// the 32x32x16 body (variant 2).
+static inline int band_default(int D, bool) { return D == 128 ? kBandM16 : kBandPingPong; }
 
 int band_waves_per_tile(int variant) {
     const int v = variant == kBandAuto ? kBandPingPong : variant;
-    return v == kBandW4 ? 4 : (v == kBandPingPong ? 8 : -1);   // waves that report per 256-row q-tile; -1: no counters
+    return v == kBandW4 ? 4 : ((v == kBandPingPong || v == kBandM16) ? 8 : -1);   // waves that report per 256-row q-tile; -1: no counters
 }
 
 template <typename T, int D>
@@ -768,6 +802,7 @@ static int run_band_pp2(const void* q, const void* k, const void* v, void* o, in
             switch (trace_abl) {
                 SVG_PP_TRACE(0) SVG_PP_TRACE(1) SVG_PP_TRACE(2) SVG_PP_TRACE(4) SVG_PP_TRACE(5) SVG_PP_TRACE(6) SVG_PP_TRACE(7) SVG_PP_TRACE(8)
                 case 3: return launch_attn(band_attn_pp2q_trace_kernel<T, D>, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<D>(), st);
+                case 9: return launch_attn(band_attn_m16_trace_kernel<T>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
                 default: return SVG_ERR_UNSUPPORTED;
             }
 #undef SVG_PP_TRACE
@@ -840,7 +875,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         variant = kBandPingPong;
         g_trace_is_w4 = false;
     }
-    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr);
+    if (variant == kBandAuto) variant = opts.prescaled ? kBandPingPong : band_default(D, opts.done != nullptr);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
@@ -857,6 +892,32 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
             using Pol = BandPolicy<__bf16, 128, 8, false>;
             const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
             return launch_attn(band_attn_pp2_frozen_kernel, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<128>(), st);
+        }
+        case kBandM16: {   // two-phase body on 16x16x32 MFMAs (attn_m16.h): head_dim 128, plain q
+            if (D != 128 || opts.prescaled) return SVG_ERR_UNSUPPORTED;
+            if (dtype == SVG_DTYPE_BF16) {
+                using Pol = BandPolicy<__bf16, 128, 8, false>;
+                const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+#ifdef SVG_M16_EXPERIMENTS     // A/B builds: issue priority x barriers per tile, selected by SVG_M16_CFG (prio * 2 + onebar)
+                {
+                    const char* e = std::getenv("SVG_M16_CFG");
+                    const int cfg = e ? std::atoi(e) : 3;
+#define SVG_M16_CASE(C, PR, OB) case C: return launch_attn(band_attn_m16_kernel<__bf16, PR, OB>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
+                    switch (cfg) {
+                        SVG_M16_CASE(0, 0, 0) SVG_M16_CASE(1, 0, 1) SVG_M16_CASE(2, 1, 0) SVG_M16_CASE(3, 1, 1) SVG_M16_CASE(4, 2, 0) SVG_M16_CASE(5, 2, 1)
+                        default: return SVG_ERR_BAD_ARG;
+                    }
+#undef SVG_M16_CASE
+                }
+#endif
+                return launch_attn(band_attn_m16_kernel<__bf16>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
+            }
+            if (dtype == SVG_DTYPE_F16) {
+                using Pol = BandPolicy<_Float16, 128, 8, false>;
+                const typename Pol::Params p = make_band_params<Pol, _Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+                return launch_attn(band_attn_m16_kernel<_Float16>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
+            }
+            return SVG_ERR_UNSUPPORTED;
         }
         default: return SVG_ERR_BAD_ARG;
     }
@@ -964,6 +1025,19 @@ extern "C" int svg_band_attention_switch(const void* q, const void* k, const voi
     int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
     if (rc == SVG_OK) rc = band_check_args(q, k, v, o, BH, S, D, alt_mask, nullptr);
     if (rc != SVG_OK) return rc;
+    if (D == 128 && (dtype == SVG_DTYPE_BF16 || dtype == SVG_DTYPE_F16)) {   // the default schedule of this head size (attn_m16.h)
+        auto go = [&](auto t_c) -> int {
+            using T = decltype(t_c);
+            using Pol = BandPolicy<T, 128, 8, false>;
+            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
+            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
+            auto kern = band_attn_m16_switch_kernel<T>;
+            if (const int r2 = configure_lds((const void*)kern, attn_m16_lds_bytes()); r2 != SVG_OK) return r2;
+            hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_m16_lds_bytes(), (hipStream_t)stream, a, b, use_alt_flag);
+            return launch_status();
+        };
+        return dtype == SVG_DTYPE_BF16 ? go(__bf16{}) : go(_Float16{});
+    }
     return run_band_w4_switch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, alt_mask, use_alt_flag, (hipStream_t)stream);
 }
 
@@ -1121,6 +1195,11 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                     }
 #endif
                     if (trace) return SVG_ERR_UNSUPPORTED;   // diagnostics builds only (-DSVG_ABLATIONS)
+                    if constexpr (D == 128) {
+                        if (tl_vb_m16)
+                            return launch_attn(varblock_attn_m16_kernel<T>, p, dim3(p.max_tiles * Hq), 512,
+                                               attn_m16_lds_bytes() + vb_policy_lds(p.kb_cap), st);
+                    }
                     return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles * Hq), 512,
                                        attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
                 }
@@ -1163,6 +1242,10 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
     // (6 = 3: the longest-first order is the default again — the similarity order, variant 7, raised the L2 hit rate from 31 % to 48 %
     //  and cut the L2 <-> fabric traffic by a quarter but not the kernel time, and its chain kernel costs 0.7 - 1.0 ms per call)
+    // two-phase body (variant >= 3): on 16x16x32 MFMAs at head_dim 128 (attn_m16.h: 28.3 vs 29.1 ms at Wan 720p, profiles/r04d_ab_svg2_m16_first.txt);
+    // 8 = 3 with that body named explicitly, 9 = 3 on the 32x32x16 body (A/B)
+    const bool force_pp2 = (variant == 9);
+    if (variant == 8 || variant == 9) variant = 3;
     const bool block_row_order = (variant == 4), trace = (variant == 5);
     const int order_mode = variant == 7 ? 2 : (variant == 6 ? 1 : 0);   // 0: longest-first + remainder packing, 1: longest-first, 2: similarity order
 #define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode
@@ -1181,6 +1264,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
+    tl_vb_m16 = (variant >= 3 && D == 128 && !force_pp2);
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {

@@ -95,6 +95,7 @@ struct BandPolicy {
         //    overlap in that XCD's L2 while the whole chip stays within one or two heads (KV working set fits the 256 MiB
         //    Infinity Cache).
         int qt;
+        int rot_back = 0;
         int qt_last = -1;          // last q-tile of this workgroup's XCD group in the same head (-1: no group: heavy tiles, the launch's tail)
         const int nh = p.BH * p.n_heavy;
         const int b = blockIdx.x;
@@ -117,6 +118,7 @@ struct BandPolicy {
             if (b2 < full && p.rotate) {   // the 32 tiles an XCD works on together are w2 & ~31 .. w2 | 31
                 const int r_last = min((w2 | 31) - c.head * nl, nl - 1);
                 qt_last = r_last < p.heavy_lo ? r_last : r_last + p.n_heavy;
+                rot_back = (r_last - r) * (p.rotate - 1);      // stagger: member j starts (31 - j) * (rotate - 1) key tiles below the common tile
             }
         }
         // (explicit selects: a run-time index into the kernel-argument arrays would go through scratch)
@@ -173,7 +175,7 @@ struct BandPolicy {
         if (qt_last >= 0 && clo >= BIG) {
             int q0_last, rhi_last;
             tile_rows(qt_last, q0_last, rhi_last);
-            const int t0 = max(0, q0_last - p.band + 1) / kBN;
+            const int t0 = max(0, q0_last - p.band + 1) / kBN - rot_back;
             if (t0 > alo && t0 < ahi) {            // [t0, ahi), (b), [alo, t0)
                 if (blo < BIG) clo = alo, chi = t0;
                 else blo = alo, bhi = t0;
@@ -436,10 +438,12 @@ inline int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-// SVG_BAND_ROTATE=0 in the environment switches the cyclic sweep start off (same-process A/B: bench.py same_box_ab, tools/ab_rotate.py)
+// SVG_BAND_ROTATE=n in the environment: cyclic sweep start (BandPolicy::init) with a stagger of n - 1 key tiles between neighbouring
+// members of an XCD group; 0 / unset: off — every q-tile sweeps from its own first key (natural stagger: 4 tiles).  Measured round 4
+// (profiles/r04b_ab_rotate.txt): n = 1 (all 32 workgroups of an XCD on the SAME key tile) is 1 - 4.5 % SLOWER than off.
 inline int band_rotate_default() {
     const char* e = std::getenv("SVG_BAND_ROTATE");
-    return e ? (std::atoi(e) != 0) : 1;
+    return e ? std::max(0, std::atoi(e)) : 0;
 }
 
 template <typename Pol, typename T>

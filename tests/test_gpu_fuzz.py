@@ -1,6 +1,6 @@
 """GPU fuzz of the HIP kernels against the oracle on RANDOM (seeded) geometries: 4 trials per kernel family in the default `-m gpu` run,
-`SVG_FUZZ=40 pytest tests/test_gpu_fuzz.py -m gpu` for more (first run round 4: 124 of 125 green at SVG_FUZZ=25, the one red case a
-test-side tie rule, see test_fuzz_kmeans_iter).  The parity suite fixes its geometries in the parametrisation;
+`SVG_FUZZ=40 pytest tests/test_gpu_fuzz.py -m gpu` for more (first run round 4: 124 of 125 green at SVG_FUZZ=25; the red one was the oracle's
+einsum rounding bit-identical duplicate centres differently — see test_fuzz_kmeans_iter).  The parity suite fixes its geometries in the parametrisation;
 this draws them — frame count, ragged frame size, text / prompt length, band multiplier, heads, head size, dtype, schedule; cluster
 counts with EMPTY clusters, GQA ratios, block-map densities — with the same tolerances as tests/test_gpu_kernels.py.  The CPU side of the
 same idea (oracle against the EXECUTED reference on random geometries) is tools/fuzz_*_vs_reference.py, logs under profiles/.
@@ -168,9 +168,17 @@ def test_fuzz_kmeans_iter(nat, trial):
     nat.kmeans_iter(xd, xsq, dev(c0), c_out, buf)
     dist = O.kmeans_distances(x, xsq.cpu(), c0)
     lab = buf.labels.cpu().long()
-    mism = lab != dist.argmin(-1)
+    ref_lab = dist.argmin(-1)
+    mism = lab != ref_lab
     d_got, d_ref = torch.gather(dist, 2, lab[..., None])[..., 0], dist.min(-1).values
     what = (B, N, K, D, dtype, modes)
+    # K > N draws duplicate centres: bit-identical copies tie exactly in the kernel (lowest index wins, like the reference's argmin),
+    # while the oracle's fp32 einsum rounds identical COLUMNS differently by 1e-4 (first run, trial 6: 9 such labels of 225,
+    # profiles/r04b_diag_kmeans_fuzz.txt) — a label that names a copy of the oracle's centre with a lower index is not a mismatch
+    b_i, n_i = mism.nonzero(as_tuple=True)
+    same_centre = torch.zeros_like(mism)
+    same_centre[b_i, n_i] = (c0[b_i, lab[b_i, n_i]] == c0[b_i, ref_lab[b_i, n_i]]).all(-1) & (lab[b_i, n_i] < ref_lab[b_i, n_i])
+    mism = mism & ~same_centre
     assert mism.float().mean() < 2e-2 and torch.all((d_got - d_ref)[mism] <= 1e-2 * d_ref[mism].clamp(min=1.0)), what
     assert torch.equal(buf.sorted_idx.cpu(), O.stable_argsort(lab).to(torch.int32)), what
     c_ref, cnt_ref = O.kmeans_update(x, lab, c0)

@@ -14,6 +14,9 @@ from svg.models.hyvideo import utils as hy  # noqa: E402
 from svg.models.hyvideo.utils import sparsity_to_width  # noqa: E402
 
 
+ROTS = tuple(os.environ.get("SVG_AB_ROTS", "0,1,2,3").split(","))   # 0: off; n: cyclic start, n - 1 key tiles of stagger between members
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     dev = torch.device("cuda", 0)
@@ -29,7 +32,7 @@ def main():
     for name, fn in (("plain q (default)", lambda o: nat.band_attention(q, k, v, mask, head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_, out=o)),
                      ("pre-scaled q", lambda o: nat.band_attention(qs, k, v, mask, q_prescaled=True, head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_, out=o))):
         for rnd in range(2):
-            for rot in ("0", "1"):
+            for rot in ROTS:
                 os.environ["SVG_BAND_ROTATE"] = rot
                 o = torch.empty_like(q)
                 fn(o)
@@ -45,7 +48,7 @@ def main():
                 mhz = probe.result()
                 print(f"{name:18s} rotate {rot} round {rnd}: {e0.elapsed_time(e1) / n:7.3f} ms / launch, sustained {mhz} MHz", flush=True)
                 outs[(name, rot)] = o
-        a, b = outs[(name, "0")].float(), outs[(name, "1")].float()
+        a, b = outs[(name, ROTS[0])].float(), outs[(name, ROTS[-1])].float()
         print(f"{name:18s} rel L2 between the two sweep orders: {((a - b).norm() / a.norm()).item():.3e}, max abs {(a - b).abs().max().item():.3e}", flush=True)
     os.environ.pop("SVG_BAND_ROTATE", None)
 

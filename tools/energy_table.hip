@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short i16x4 __attribute__((ext_vector_type(4)));
 typedef short i16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -37,7 +38,7 @@ constexpr int kStages = 4;
 
 // LDSR: LDS operand reads per 32 MFMAs in units of 1/4 of the real kernel's 48 (0, 2 = half, 4 = all).  NV: VALU per tile in units of
 // 1/4 of 112 (0, 2, 4).  DMA: 0 none, 1 all requests hit a 1 MiB window (L2), 2 one request in four streams fresh lines.
-template <int LDSR, int NV, int DMA>
+template <int LDSR, int NV, int DMA, int SHAPE = 0>
 __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, unsigned long long stream_bytes, int tiles, int pad,
                                                    unsigned long long* __restrict__ ticks, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
     __syncthreads();
     float a0 = threadIdx.x * 0.001f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = 0;
     f32x16 c[4] = {{0}, {0}, {0}, {0}};
+    f32x4m d16[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
     bf16x8 Bq[4], Areg[4];
     for (int j = 0; j < 4; ++j)
         for (int e = 0; e < 8; ++e) {
@@ -96,13 +98,21 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
         }
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if (LDSR == 4) {
+            if (LDSR == 4 && SHAPE == 1) {
+                // the same 32 operand fragments per tile, each feeding TWO 16x16x32 MFMAs (the two 16-row blocks of a wave's 32 rows)
+                if (i + PF < 32) fetch(i + PF, stage, (i + PF) % (PF + 1));
+                d16[(2 * i) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i % (PF + 1)], Bq[i & 3], d16[(2 * i) & 7], 0, 0, 0);
+                d16[(2 * i + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i % (PF + 1)], Bq[(i + 1) & 3], d16[(2 * i + 1) & 7], 0, 0, 0);
+            } else if (LDSR == 4) {
                 if (i + PF < 32) fetch(i + PF, stage, (i + PF) % (PF + 1));
                 c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[i % (PF + 1)], Bq[i & 3], c[i & 3], 0, 0, 0);
             } else if (LDSR == 2) {
                 const int j = i >> 1;
                 if ((i & 1) == 0 && j + PF < 16) fetch(2 * (j + PF), stage, (j + PF) % (PF + 1));
                 c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[j % (PF + 1)], Bq[i & 3], c[i & 3], 0, 0, 0);
+            } else if (SHAPE == 1) {
+                d16[(2 * i) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Areg[(i >> 2) & 3], Bq[i & 3], d16[(2 * i) & 7], 0, 0, 0);
+                d16[(2 * i + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Areg[(i >> 1) & 3], Bq[(i + 1) & 3], d16[(2 * i + 1) & 7], 0, 0, 0);
             } else {
                 c[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[(i >> 2) & 3], Bq[i & 3], c[i & 3], 0, 0, 0);
             }
@@ -155,7 +165,9 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
         ticks[blockIdx.x * 2 + 0] = t1 - t0;
         ticks[blockIdx.x * 2 + 1] = w1 - w0;
     }
-    sink[blockIdx.x * 512 + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3] + a0 + a1 + a2 + a3 + a4;
+    float acc16 = 0.f;
+    for (int j = 0; j < 8; ++j) acc16 += d16[j][0] + d16[j][3];
+    sink[blockIdx.x * 512 + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3] + a0 + a1 + a2 + a3 + a4 + acc16;
 }
 
 // duty 1.0 reference: both waves of a SIMD issue MFMAs back to back, nothing else.  SHAPE 0: 32x32x16 (32 per tile and wave), 1: 16x16x32
@@ -237,14 +249,14 @@ struct Power {
 
 struct Result { double mhz, duty, ms, watts; };
 
-template <int LDSR, int NV, int DMA>
+template <int LDSR, int NV, int DMA, int SHAPE = 0>
 Result launch(const char* src, unsigned long long stream_bytes, int tiles, int pad, unsigned long long* ticks, float* sink, Power* pw) {
-    CHECK(hipFuncSetAttribute((const void*)mix_kernel<LDSR, NV, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, kStage * kStages));
+    CHECK(hipFuncSetAttribute((const void*)mix_kernel<LDSR, NV, DMA, SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, kStage * kStages));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     if (pw) pw->start();
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((mix_kernel<LDSR, NV, DMA>), dim3(256), dim3(512), kStage * kStages, 0, src, stream_bytes, tiles, pad, ticks, sink);
+    hipLaunchKernelGGL((mix_kernel<LDSR, NV, DMA, SHAPE>), dim3(256), dim3(512), kStage * kStages, 0, src, stream_bytes, tiles, pad, ticks, sink);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     const double watts = pw ? pw->stop() : 0;
@@ -264,21 +276,21 @@ Result launch(const char* src, unsigned long long stream_bytes, int tiles, int p
     return r;
 }
 
-template <int LDSR, int NV, int DMA>
+template <int LDSR, int NV, int DMA, int SHAPE = 0>
 void row(const char* name, double target, int tiles, const char* src, unsigned long long stream_bytes, unsigned long long* ticks, float* sink, Power* pw) {
     // bisection on the pad for the target duty (short runs), then one warm launch and the measured one
     int lo = 0, hi = 160, pad = 0;
-    Result r0 = launch<LDSR, NV, DMA>(src, stream_bytes, 3000, 0, ticks, sink, nullptr);
+    Result r0 = launch<LDSR, NV, DMA, SHAPE>(src, stream_bytes, 3000, 0, ticks, sink, nullptr);
     if (r0.duty > target) {
         for (int it = 0; it < 8 && lo < hi; ++it) {
             const int mid = (lo + hi) / 2;
-            Result r = launch<LDSR, NV, DMA>(src, stream_bytes, 3000, mid, ticks, sink, nullptr);
+            Result r = launch<LDSR, NV, DMA, SHAPE>(src, stream_bytes, 3000, mid, ticks, sink, nullptr);
             if (r.duty > target) lo = mid + 1; else hi = mid;
         }
         pad = lo;
     }
-    launch<LDSR, NV, DMA>(src, stream_bytes, tiles, pad, ticks, sink, nullptr);
-    Result r = launch<LDSR, NV, DMA>(src, stream_bytes, tiles, pad, ticks, sink, pw);
+    launch<LDSR, NV, DMA, SHAPE>(src, stream_bytes, tiles, pad, ticks, sink, nullptr);
+    Result r = launch<LDSR, NV, DMA, SHAPE>(src, stream_bytes, tiles, pad, ticks, sink, pw);
     printf("| %-58s | %3d | %.3f | %.3f | %4.0f | %.4f | %6.1f | %5.0f |\n", name, pad, r0.duty, r.duty, r.mhz, r.duty * r.mhz / 2400.0, r.ms, r.watts);
     fflush(stdout);
 }
@@ -332,5 +344,12 @@ int main(int argc, char** argv) {
     row<4, 2, 2>("  the kernel with half the VALU", target, tiles, src, stream_bytes, ticks, sink, &pw);
     row<4, 4, 1>("  the kernel with no L2 misses (repeat of the L2-hit row)", target, tiles, src, stream_bytes, ticks, sink, &pw);
     row<2, 2, 1>("  half LDS, half VALU, no misses", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    printf("| the same with v_mfma_f32_16x16x32_bf16 (64 per tile and wave, every operand fragment feeds two) | | | | | | | |\n");
+    row<0, 0, 0, 1>("16x16x32: MFMA at the target duty (pad only)", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    row<4, 0, 0, 1>("16x16x32: + 48 LDS operand reads", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    row<4, 4, 0, 1>("16x16x32: + 48 LDS + 112 VALU", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    row<4, 4, 1, 1>("16x16x32: + 48 LDS + 112 VALU + DMA (L2 hits)", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    row<4, 4, 2, 1>("16x16x32: + 48 LDS + 112 VALU + DMA (1/4 misses)", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    row<4, 4, 1, 0>("32x32x16 again: + 48 LDS + 112 VALU + DMA (L2 hits)", target, tiles, src, stream_bytes, ticks, sink, &pw);
     return 0;
 }

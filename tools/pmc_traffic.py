@@ -24,13 +24,14 @@ for line in txt.splitlines():
 # (the 16-bit headline kernel when it is there: the bench's fp8 extras block launches band_attn_f8_kernel in the same run)
 want = sys.argv[3] if len(sys.argv) > 3 else None      # optional: substring of the kernel to report (e.g. band_attn_f8)
 cands = [(k, v) for k, v in blocks.items() if want and want in k] or \
+        [(k, v) for k, v in blocks.items() if "band_attn_m16" in k] or \
         [(k, v) for k, v in blocks.items() if "band_attn_pp2q" in k] or \
         [(k, v) for k, v in blocks.items() if "band_attn_pp2" in k or "band_attn_w4" in k] or [(k, v) for k, v in blocks.items() if "band_attn" in k]
 name, c = max(cands, key=lambda kv: kv[1].get("SQ_WAVE_CYCLES", 0.0))
 g = c.get
 out = {
     "kernel": "band_attn_f8_kernel<bf16>" if "band_attn_f8" in name else
-              next((f"{k}<bf16,128>" for k in ("band_attn_pp2q_kernel", "band_attn_w4_kernel", "band_attn_pp2_kernel", "band_attn_kernel") if k in name), name),
+              ("band_attn_m16_kernel<bf16>" if "band_attn_m16" in name else None) or next((f"{k}<bf16,128>" for k in ("band_attn_pp2q_kernel", "band_attn_w4_kernel", "band_attn_pp2_kernel", "band_attn_kernel") if k in name), name),
     "kernel_symbol": name,
     "source": f"tools/gpu_pmc.sh {tag}: separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-profiler`, one launch each",
     "FETCH_SIZE_KB": g("FETCH_SIZE"),
