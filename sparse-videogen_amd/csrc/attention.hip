@@ -1206,9 +1206,15 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
             }
             if constexpr (NW == -9)
                 return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
-            else
+            else {
+                if constexpr (D == 128) {
+                    if (tl_vb_m16)
+                        return launch_attn(varblock_attn_m16_kernel<T>, p, dim3(p.max_tiles, Hq), 512,
+                                           attn_m16_lds_bytes() + vb_policy_lds(p.kb_cap), st);
+                }
                 return launch_attn(varblock_attn_pp2_kernel<T, D>, p, dim3(p.max_tiles, Hq), 512,
                                    attn_pp2_lds_bytes<D>() + vb_policy_lds(p.kb_cap), st);
+            }
         } else
             return launch_attn(varblock_attn_kernel<T, D, W>, p, dim3(p.max_tiles, Hq), W * 64,
                                attn_lds_bytes<D, W>() + vb_policy_lds(p.kb_cap), st);

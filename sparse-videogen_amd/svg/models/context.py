@@ -60,3 +60,22 @@ def install_timestep_hook(transformer) -> None:
 
     transformer.forward = forward
     transformer._svg_timestep_hook = True
+
+
+class TransformerRegistry:
+    """What every model's `custom_models.py` needs: the install hook (`replace_*_attention`) registers the pipeline's transformer, and
+    the reference-named, zero-argument `replace_sparse_forward()` makes `timestep` reach the processors of every registered
+    transformer (plus, for Wan, rebinds the block forward: `also`).  One registry per model module."""
+
+    def __init__(self, also=None):
+        self._transformers, self._also = [], also
+
+    def register_transformer(self, transformer) -> None:
+        if transformer not in self._transformers:
+            self._transformers.append(transformer)
+
+    def replace_sparse_forward(self) -> None:
+        for t in self._transformers:
+            install_timestep_hook(t)
+            if self._also is not None:
+                self._also(t)

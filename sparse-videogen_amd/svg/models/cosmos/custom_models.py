@@ -1,16 +1,11 @@
-"""ref: svg/models/cosmos/custom_models.py — make `timestep` reach every self-attention processor (see wan/custom_models.py)."""
+"""ref: svg/models/cosmos/custom_models.py — make `timestep` reach every self-attention processor.
+
+`replace_sparse_forward()` keeps the reference's name and zero-argument call; it needs the pipeline's transformer, which the install
+hook (`replace_cosmos_attention`) registers through `register_transformer` (svg.models.context.TransformerRegistry)."""
 from __future__ import annotations
 
-from ..context import install_timestep_hook
+from ..context import TransformerRegistry
 
-_TRANSFORMERS = []
-
-
-def register_transformer(transformer) -> None:
-    if transformer not in _TRANSFORMERS:
-        _TRANSFORMERS.append(transformer)
-
-
-def replace_sparse_forward() -> None:
-    for t in _TRANSFORMERS:
-        install_timestep_hook(t)
+_REGISTRY = TransformerRegistry()
+register_transformer = _REGISTRY.register_transformer
+replace_sparse_forward = _REGISTRY.replace_sparse_forward

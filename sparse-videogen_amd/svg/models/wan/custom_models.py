@@ -9,9 +9,8 @@ import types
 import torch
 
 from ... import _native
-from ..context import install_timestep_hook
+from ..context import TransformerRegistry
 
-_TRANSFORMERS = []
 
 
 def wan_block_forward(self, hidden_states, encoder_hidden_states, temb, rotary_emb, timestep=None, **kwargs):
@@ -63,12 +62,6 @@ def install_block_forward(transformer) -> int:
     return n
 
 
-def register_transformer(transformer) -> None:
-    if transformer not in _TRANSFORMERS:
-        _TRANSFORMERS.append(transformer)
-
-
-def replace_sparse_forward() -> None:
-    for t in _TRANSFORMERS:
-        install_timestep_hook(t)
-        install_block_forward(t)
+_REGISTRY = TransformerRegistry(also=install_block_forward)
+register_transformer = _REGISTRY.register_transformer
+replace_sparse_forward = _REGISTRY.replace_sparse_forward
