@@ -53,7 +53,6 @@ struct BandPolicy {
         int sp64, sp128;       // physical-row step of a token-major head: q + r * P (the patch index advances by q, the frame by r)
         int wrap_phys;         // 1 - F * P: correction when the frame index wraps
         int heavy_lo, n_heavy; // q-tiles [heavy_lo, heavy_lo + n_heavy) of every head see ALL keys (text rows): scheduled first
-        int rotate;            // cyclic start of the band sweep at the XCD group's common key tile (init(); 0: every tile from its own first key)
         // Row regions: q-tiles never straddle rowfull_lo / rowfull_hi / real_len, so every q-tile is homogeneous (band rows, full
         // rows or rows behind real_len).  Region r = rows [reg_lo[r], reg_hi[r]), its first q-tile is reg_t0[r].
         int reg_lo[4], reg_hi[4], reg_t0[4];
@@ -95,8 +94,6 @@ struct BandPolicy {
         //    overlap in that XCD's L2 while the whole chip stays within one or two heads (KV working set fits the 256 MiB
         //    Infinity Cache).
         int qt;
-        int rot_back = 0;
-        int qt_last = -1;          // last q-tile of this workgroup's XCD group in the same head (-1: no group: heavy tiles, the launch's tail)
         const int nh = p.BH * p.n_heavy;
         const int b = blockIdx.x;
         if (b >= p.nqt * p.BH) return false;   // (the device-switched launch is sized for the larger of its two masks)
@@ -115,11 +112,6 @@ struct BandPolicy {
             c.head = w2 / nl;
             const int r = w2 - c.head * nl;
             qt = r < p.heavy_lo ? r : r + p.n_heavy;
-            if (b2 < full && p.rotate) {   // the 32 tiles an XCD works on together are w2 & ~31 .. w2 | 31
-                const int r_last = min((w2 | 31) - c.head * nl, nl - 1);
-                qt_last = r_last < p.heavy_lo ? r_last : r_last + p.n_heavy;
-                rot_back = (r_last - r) * (p.rotate - 1);      // stagger: member j starts (31 - j) * (rotate - 1) key tiles below the common tile
-            }
         }
         // (explicit selects: a run-time index into the kernel-argument arrays would go through scratch)
         auto tile_rows = [&](int t, int& q0, int& rhi_out) {
@@ -164,27 +156,10 @@ struct BandPolicy {
         } else if (clo < BIG && clo <= bhi) {
             bhi = max(bhi, chi), clo = BIG, chi = BIG;
         }
-        // Cyclic start (round 4).  The 32 q-tiles an XCD works on together are neighbours whose band windows are 4 key tiles apart; swept
-        // from their own first key, workgroup j reads key tile base + 4 j + tau at time tau: 32 streams spread over 124 tiles = 4 MiB of K
-        // and V, the size of the XCD's L2 — a tile fetched for the workgroup furthest ahead is evicted before the others reach it (L2 hit
-        // rate 0.77, 37 GB across the fabric per launch for 2.9 GB of tensors: profiles/r03z_pmc_traffic.json).  All 32 windows contain
-        // the window start T0 of the group's LAST tile, so every workgroup starts THERE, runs to the end of its window, takes the other
-        // intervals, and finishes with [own start, T0): at any time the group reads at most two different key tiles (one in the upper
-        // parts, one in the wrapped parts — the wrap position only depends on the time, not on the member), each fetched once per XCD.
-        // The online softmax does not care about the order of the key tiles.  Needs a free interval slot (the third one).
-        if (qt_last >= 0 && clo >= BIG) {
-            int q0_last, rhi_last;
-            tile_rows(qt_last, q0_last, rhi_last);
-            const int t0 = max(0, q0_last - p.band + 1) / kBN - rot_back;
-            if (t0 > alo && t0 < ahi) {            // [t0, ahi), (b), [alo, t0)
-                if (blo < BIG) clo = alo, chi = t0;
-                else blo = alo, bhi = t0;
-                alo = t0;
-            } else if (blo < BIG && t0 > blo && t0 < bhi) {   // a, [t0, bhi), [blo, t0)   (text-first models: the text columns come first)
-                clo = blo, chi = t0;
-                blo = t0;
-            }
-        }
+        // (Round 4 tried a cyclic sweep start here — the 32 q-tiles an XCD works on together start at a common key tile and wrap, so that
+        //  the group reads at most two different key tiles at any time — to cut the L2 <-> fabric traffic.  Measured: 87.9 GB per launch
+        //  with all 32 on the same tile, 68.4 GB staggered by one tile, against 32.7 GB for the plain sweep, and 1 - 4.5 % more time: the
+        //  L2 does not merge requests for a line that is still in flight.  Removed; profiles/r04z_rotate_traffic.txt, r04c_ab_rotate_stagger.txt.)
         c.seg_lo[0] = alo, c.seg_n[0] = ahi - alo;
         c.seg_lo[1] = blo, c.seg_n[1] = bhi - blo;
         c.seg_lo[2] = clo, c.seg_n[2] = chi - clo;
@@ -438,14 +413,6 @@ inline int launch_attn(K kernel, const Prm& prm, dim3 grid, int threads, int lds
     return launch_status();
 }
 
-// SVG_BAND_ROTATE=n in the environment: cyclic sweep start (BandPolicy::init) with a stagger of n - 1 key tiles between neighbouring
-// members of an XCD group; 0 / unset: off — every q-tile sweeps from its own first key (natural stagger: 4 tiles).  Measured round 4
-// (profiles/r04b_ab_rotate.txt): n = 1 (all 32 workgroups of an XCD on the SAME key tile) is 1 - 4.5 % SLOWER than off.
-inline int band_rotate_default() {
-    const char* e = std::getenv("SVG_BAND_ROTATE");
-    return e ? std::max(0, std::atoi(e)) : 0;
-}
-
 template <typename Pol, typename T>
 inline typename Pol::Params make_band_params(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
                                              const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const BandOpts& opts = BandOpts()) {
@@ -465,7 +432,6 @@ inline typename Pol::Params make_band_params(const void* q, const void* k, const
     p.q128 = 2 * kBN / p.F, p.r128 = 2 * kBN % p.F;
     p.sp64 = p.q64 + p.r64 * p.P, p.sp128 = p.q128 + p.r128 * p.P;
     p.wrap_phys = 1 - p.F * p.P;
-    p.rotate = band_rotate_default();
     // row regions (see Params): cut at rowfull_lo, rowfull_hi (inside [0, real_len)) and real_len; unused slots are empty regions
     // behind the last tile.  A q-tile of full rows visits every key tile on the unmasked fast path (with the text rows sharing a
     // tile with band rows or rows behind real_len, all 1861 tiles of it took the per-element masked path: 9.5 ms instead of 3.2).

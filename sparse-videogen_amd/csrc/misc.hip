@@ -109,7 +109,7 @@ extern "C" int svg_last_hip_error(void) { return svg::g_last_hip_error; }
 
 extern "C" int svg_abi_version(void) { return SVG_ABI_VERSION; }
 
-extern "C" const char* svg_build_info(void) { return "libsvgattn gfx950 wave64 mfma32x32x16 built " __DATE__ " " __TIME__; }
+extern "C" const char* svg_build_info(void) { return "libsvgattn gfx950 wave64 mfma16x16x32+32x32x16 built " __DATE__ " " __TIME__; }
 
 extern "C" int svg_map_density(const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, float* out,
                                int32_t BH, int32_t QB, int32_t KB, void* stream) {

@@ -16,15 +16,6 @@ bash tools/gpu_pmc.sh $tag --no-svg2 --no-step > $O/pmc.log 2>&1
 cp gpurun_out/pmc_$tag/summary.txt $O/pmc_summary.txt
 python tools/pmc_traffic.py gpurun_out/pmc_$tag/summary.txt $tag > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 bash tools/gpu_pmc_svg2.sh $tag -1 > $O/pmc_traffic_svg2_raw.json 2> $O/pmc_svg2.err
-# cyclic sweep start (SVG_BAND_ROTATE = 1, 2): fabric traffic of the band kernel with the switch on (one pass each; the default above is off)
-for r in 1 2; do
-  SVG_BAND_ROTATE=$r timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/rot$r -o p -- python tools/one_launch.py plain 0 > $O/rot$r.log 2>&1
-  python - <<PY
-import csv, glob
-v=[float(r["Counter_Value"]) for f in glob.glob("$O/rot$r/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f)) if "band_attn" in r.get("Kernel_Name","") and r["Counter_Name"]=="FETCH_SIZE"]
-print("SVG_BAND_ROTATE=$r: FETCH_SIZE x2 =", (2*sum(v)/len(v)*1024/1e9) if v else None, "GB per launch of the band kernel (default off: see pmc_traffic.json)")
-PY
-done > $O/rotate_traffic.txt 2>&1
 timeout 600 python tools/svg1_models.py > $O/svg1_models.md 2>&1
 timeout 300 python bench_svg2.py --workload hy720p > $O/svg2_hy720p.json 2> $O/svg2_hy.err
 SVG_FULL_GRID=1 OMP_NUM_THREADS=8 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k full_reference_grid -n 12 > $O/varblock_fullgrid.txt 2>&1; echo "fullgrid rc=$?" >> $O/varblock_fullgrid.txt; tail -3 $O/varblock_fullgrid.txt
@@ -35,4 +26,4 @@ for k in ("value","ms_per_step","roofline","clock","same_box_ab"): print(k, d.ge
 print("svg2", d.get("svg2_wan720p",{}).get("ms"), d.get("svg2_wan720p_fp8",{}).get("ms"))
 print("step", {k:v for k,v in d.get("denoise_step_hy720p",{}).items() if "per_s" in k})
 PY
-head -4 $O/bench_kernel_trace.txt | cut -c1-180; cat $O/svg1_models.md | tail -12; cat $O/pmc_traffic.json | head -20; cat $O/rotate_traffic.txt
+head -4 $O/bench_kernel_trace.txt | cut -c1-180; cat $O/svg1_models.md | tail -12; cat $O/pmc_traffic.json | head -20

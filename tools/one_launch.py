@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One warm-up + one launch of the band kernel on the headline workload (for rocprofv3 --pmc passes of a single setting):
-python tools/one_launch.py [plain|pre] [variant]   — honours SVG_BAND_ROTATE."""
+python tools/one_launch.py [plain|pre] [variant]"""
 import sys
 from pathlib import Path
 

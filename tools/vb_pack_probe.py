@@ -24,7 +24,7 @@ _core.kmeans_clustering(store, 0, q, k, QC, KC, 50, 2)
 (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = _core.kmeans_clustering(store, 0, q, k, QC, KC, 50, 2)
 dmap = identify_dynamic_map(qc.view(1, H, QC, D), kc.view(1, H, KC, D), qs.view(1, H, QC), ks.view(1, H, KC), 0.9, 0.1)[0].contiguous()
 qs, ks = qs.view(H, QC).contiguous(), ks.view(H, KC).contiguous()
-for variant in (3, 6):
+for variant in tuple(int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("3", "6"))):   # 3: packing (16x16x32 body at head_dim 128), 9: the same on the 32x32x16 body, 6: no packing
     ws = nat.varblock_workspace(H, H, QC, KC, S, dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     nat.varblock_attention(q[0], k[0], v[0], dmap, qs, ks, q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=variant, workspace=ws)
