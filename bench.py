@@ -483,7 +483,7 @@ def main():
     out = None
     if rank == 0:
         value = flops_call / (ms_step * 1e-3) / 1e12
-        kernel_name = "band_attn_pp2q_kernel<bf16,128>" if a.prescaled else BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
+        kernel_name = "band_attn_m16q_kernel<bf16>" if a.prescaled else BAND_KERNELS.get(a.variant, f"band_attn variant {a.variant}")
         peak = PEAK_BF16_TFLOPS
         if fp8:
             kernel_name, peak = "band_attn_f8_kernel<bf16>", PEAK_FP8_TFLOPS

@@ -51,14 +51,21 @@ __global__ __launch_bounds__(512, 2) void band_attn_m16_kernel(typename BandPoli
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, PRIO, ONEBAR>(prm, smem, nullptr);
 }
-// device-side switch between two masks on the 16x16x32 body (svg_band_attention_switch at head_dim 128): `flag[0] != 0` selects prm_alt
-template <typename T>
+// pre-scaled q on the 16x16x32 body (PRE form of attn_body_m16).  QKF16 = true (q and k as fp16 carriers with S^T on the f16 MFMA) was
+// built and measured in round 4 and is not instantiated: see the note at attn_body_m16.
+template <typename T, bool QKF16>
+__global__ __launch_bounds__(512, 2) void band_attn_m16q_kernel(typename BandPolicy<T, 128, 8, false>::Params prm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1, true, QKF16>(prm, smem, nullptr);
+}
+// device-side switch between two masks on the 16x16x32 body (svg_band_attention_switch[_prescaled] at head_dim 128): `flag[0] != 0` selects prm_alt
+template <typename T, bool PRE = false, bool QKF16 = false>
 __global__ __launch_bounds__(512, 2) void band_attn_m16_switch_kernel(typename BandPolicy<T, 128, 8, false>::Params prm,
                                                                       typename BandPolicy<T, 128, 8, false>::Params prm_alt,
                                                                       const int32_t* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (flag[0] != 0) attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1>(prm_alt, smem, nullptr);
-    else attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1>(prm, smem, nullptr);
+    if (flag[0] != 0) attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1, PRE, QKF16>(prm_alt, smem, nullptr);
+    else attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, 1, 1, PRE, QKF16>(prm, smem, nullptr);
 }
 // the same for q that carries sm_scale * log2(e) (svg_band_attention_prescaled): no scale-and-shift per score
 template <typename T, int D>
@@ -875,7 +882,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         variant = kBandPingPong;
         g_trace_is_w4 = false;
     }
-    if (variant == kBandAuto) variant = opts.prescaled ? kBandPingPong : band_default(D, opts.done != nullptr);
+    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
@@ -893,8 +900,21 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
             const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
             return launch_attn(band_attn_pp2_frozen_kernel, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<128>(), st);
         }
-        case kBandM16: {   // two-phase body on 16x16x32 MFMAs (attn_m16.h): head_dim 128, plain q
-            if (D != 128 || opts.prescaled) return SVG_ERR_UNSUPPORTED;
+        case kBandM16: {   // two-phase body on 16x16x32 MFMAs (attn_m16.h): head_dim 128
+            if (D != 128) return SVG_ERR_UNSUPPORTED;
+            if (opts.prescaled) {   // PRE form: q carries the softmax scale
+                if (dtype == SVG_DTYPE_BF16) {
+                    using Pol = BandPolicy<__bf16, 128, 8, false>;
+                    const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+                    return launch_attn(band_attn_m16q_kernel<__bf16, false>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
+                }
+                if (dtype == SVG_DTYPE_F16) {
+                    using Pol = BandPolicy<_Float16, 128, 8, false>;
+                    const typename Pol::Params p = make_band_params<Pol, _Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+                    return launch_attn(band_attn_m16q_kernel<_Float16, false>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
+                }
+                return SVG_ERR_UNSUPPORTED;
+            }
             if (dtype == SVG_DTYPE_BF16) {
                 using Pol = BandPolicy<__bf16, 128, 8, false>;
                 const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
@@ -939,7 +959,8 @@ extern "C" int svg_band_attention_prescaled(const void* q_scaled, const void* k,
     if (rc != SVG_OK) return rc;
     BandOpts opts;
     opts.prescaled = true;
-    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandPingPong, opts, (hipStream_t)stream);
+    // (head_dim 128: the PRE form of the 16x16x32 body — 33.0 - 33.3 ms against 33.6 - 34.2 for the 32x32x16 one, same box, profiles/r04k_ab_m16_prescaled.txt)
+    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandAuto, opts, (hipStream_t)stream);
 }
 
 extern "C" int32_t svg_band_attention_notify_target(int32_t S, const svg_band_mask_t* mask) {
@@ -1001,7 +1022,7 @@ extern "C" int svg_band_attention_prescaled_notify_seg(const void* q_scaled, con
     if ((int64_t)done_words < (int64_t)BH * (nseg + 1)) return SVG_ERR_WORKSPACE;
     BandOpts opts;
     opts.done = done, opts.done_nseg = nseg, opts.prescaled = true;
-    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandPingPong, opts, (hipStream_t)stream);
+    return band_dispatch(q_scaled, k, v, o, BH, S, D, dtype, 1.f, mask, perm, kBandAuto, opts, (hipStream_t)stream);
 }
 
 extern "C" int svg_wait_counters(const int32_t* counters, int32_t n, int32_t target, void* stream) {
@@ -1054,6 +1075,12 @@ extern "C" int svg_band_attention_switch_prescaled(const void* q_scaled, const v
         using Pol = BandPolicy<T, DD, 8, false>;
         const typename Pol::Params a = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, mask, perm);
         const typename Pol::Params b = make_band_params<Pol, T>(q_scaled, k, v, o, BH, S, 1.f, alt_mask, nullptr);
+        if constexpr (DD == 128) {   // the PRE form of the 16x16x32 body, like svg_band_attention_prescaled at this head size
+            auto kern16 = band_attn_m16_switch_kernel<T, true, false>;
+            if (const int r2 = configure_lds((const void*)kern16, attn_m16_lds_bytes()); r2 != SVG_OK) return r2;
+            hipLaunchKernelGGL(kern16, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_m16_lds_bytes(), (hipStream_t)stream, a, b, use_alt_flag);
+            return launch_status();
+        }
         auto kern = band_attn_pp2q_switch_kernel<T, DD>;
         if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<DD>()); r2 != SVG_OK) return r2;
         hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<DD>(), (hipStream_t)stream, a, b,

@@ -41,13 +41,26 @@ namespace svg {
 
 template <typename T>
 struct Mfma16;
+// (mfma_keep_c: D = A B + C with D and C in DIFFERENT registers, as inline asm — for a C that stays live hipcc selects the tied form of
+//  the builtin and copies C first; see Elt::mfma_keep_c in svg_common.h.  The caller owns the hazards: tools/asm_hazards.py audits the
+//  kept listing, tests/test_w4_asm_audit.py.)
 template <>
 struct Mfma16<__bf16> {
     static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma_keep_c(bf16x8 a, bf16x8 b, const f32x4& c) {
+        f32x4 d;
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
 };
 template <>
 struct Mfma16<_Float16> {
     static __device__ __forceinline__ f32x4 mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma_keep_c(f16x8 a, f16x8 b, const f32x4& c) {
+        f32x4 d;
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    }
 };
 
 constexpr int attn_m16_lds_bytes() { return attn_pp2_lds_bytes<128>(); }
@@ -64,11 +77,27 @@ __device__ __forceinline__ float quad_group_sum(float x) {
 
 // PRIO: which phase raises the wave's issue priority (1: matrix phase, as attn_body_pp2; 0: none; 2: vector phase).  ONEBAR: -1 as the
 // policy says, 0 / 1 forced.
-template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1>
+// PRE: q arrives multiplied by sm_scale * log2(e) and the S^T accumulators start at minus the row's reference, so the MFMAs deliver the
+// exponent argument (no scale-and-shift FMA per score; the scheme of attn_body_pp2's PRE form).  QKF16 (with PRE): the q and k pointers
+// hold IEEE fp16 bit patterns whatever T is — q' = fp16(c * q), k16 = fp16(k), written by svg_qk_to_f16 — and S^T runs on the f16 MFMA
+// while P, V and O stay T: for T = bf16 the scale then rides in 11 mantissa bits instead of 8 (2^-12 instead of 2^-9 relative rounding
+// of c * q; a bf16 k converts to fp16 exactly inside fp16's range), which keeps the pre-scaled form inside the plain kernel's distance
+// to the reference's formulation.  MEASURED in round 4 and NOT shipped (an entry point svg_band_attention_f16qk with a conversion pass and a
+// device-side overflow fallback to the plain body was built, tested and removed within the session; what is left are the numbers): parity as intended — 1.95 - 2.33e-3 rel. L2 to the reference's formulation on
+// |score| up to 80, the plain kernel's 1.85 - 2.32e-3, where the bf16 pre-scaled form reaches 6.4e-3 (profiles/r04l_pytest_f16qk.txt) — but
+// no time: the kernel took 33.8 ms where the bf16 PRE form takes 32.8 and the plain body 34.5 under the same profiler run, plus 0.58 ms
+// for the conversion pass (profiles/r04m_f16qk_kernel_trace.txt, r04l_ab_m16_f16qk.txt: 32.9 vs 33.4 ms end to end, -1.4 %).  The f16
+// MFMA's wider multipliers take back in clock what the missing FMAs save — the power limit once more.  The template flag stays (it is
+// four lines of the body); nothing instantiates it.
+template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1, bool PRE = false, bool QKF16 = false>
 __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
-    using M = Mfma16<T>;
+    using M = Mfma16<T>;                                                  // PV
+    using TQ = std::conditional_t<QKF16, _Float16, T>;                    // element type of the q / k bits
+    using MQ = Mfma16<TQ>;                                                // QK^T
     using V8 = typename E::v8;
+    using Q8 = typename Elt<TQ>::v8;
+    static_assert(!QKF16 || PRE, "fp16 q / k carriers exist for the pre-scaled form only");
     constexpr int D = 128;
     constexpr int NW = 8;
     constexpr int KS = D / 32;              // 32-wide contraction steps of S^T
@@ -148,7 +177,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
 
     // ---- Q fragments, mask intervals and softmax state of the lane's two query rows ----
     int q_log[2];
-    V8 qf[2][KS];
+    Q8 qf[2][KS];
     int m_a0[2], m_b0[2];
     unsigned m_alen[2], m_blen[2];
 #pragma unroll
@@ -158,7 +187,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         q_log[rb] = P::q_logical(ctx, row_in_wg);
         const T* qrow = qb + (size_t)(qp >= 0 ? qp : 0) * D + g4 * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const V8*)(qrow + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const Q8*)(qrow + ks * 32);
         P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
     }
 
@@ -199,31 +228,39 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         }
     };
 
+    f32x4 neg_ref[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // PRE: minus the reference of the lane's two rows (what the S^T accumulators start from)
+    float pre_shift[2] = {0.f, 0.f};                                   // PRE, exact path only: old reference minus new reference
     f32x4 sc[4][2];        // scores [16-key block][row block]: S(t) until the PV steps have consumed it, then S(t + 1) accumulates here
     V8 pf[2][2];           // probabilities [32-key chunk][row block]
     float psum_thr = -1.f; // (wave-uniform) 2048 once every row of the wave has a finite reference; until then every tile takes the exact path
 
-    auto kfrag = [&](const char* st, int kblk, int ks) -> V8 { return *(const V8*)(st + k_lane + ks * (kBN * 64) + kblk * 1024); };
-    auto vfrag = [&](const char* st, int kc, int db) -> V8 {
+    // operand fragments travel as raw bits (the ring holds V fragments of type T and K fragments of type TQ)
+    auto kfrag = [&](const char* st, int kblk, int ks) -> i16x8 { return *(const i16x8*)(st + k_lane + ks * (kBN * 64) + kblk * 1024); };
+    auto vfrag = [&](const char* st, int kc, int db) -> i16x8 {
         const char* vbase = st + ((db & 1) ? v_lane1 : v_lane0) + (db >> 1) * (kBN * 64) + (32 * kc) * 64;
         const i16x4 lo = lds_read_tr16(vbase);
         const i16x4 hi = lds_read_tr16(vbase + 16 * 64);
-        i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(V8, both);
+        const i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return both;
     };
     // probabilities of the 32-key chunk kc: the lane's 8 scores per row block (key blocks 2 kc, 2 kc + 1) against the row's reference
-    auto probs = [&](int kc) {
+    auto probs_impl = [&](int kc, auto shifted_c) {
+        constexpr bool shifted = decltype(shifted_c)::value;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * kc + h][rb][r], c_log2, -m_use[rb]));
+                    float p;
+                    if constexpr (PRE && shifted) p = __builtin_amdgcn_exp2f(sc[2 * kc + h][rb][r] + pre_shift[rb]);
+                    else if constexpr (PRE) p = __builtin_amdgcn_exp2f(sc[2 * kc + h][rb][r]);    // the MFMAs delivered the exponent argument
+                    else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * kc + h][rb][r], c_log2, -m_use[rb]));
                     psum[rb] += p;
                     pf[kc][rb][4 * h + r] = E::from_float(p);
                 }
     };
+    auto probs = [&](int kc) { probs_impl(kc, std::false_type{}); };
     auto stage_resolve_next = [&](int t, auto guard_c) {
         take();
         resolve(t + dist + 1, guard_c);
@@ -279,8 +316,10 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 mx = vmax3(mx, sc[2][rb][3], sc[3][rb][0]);
                 mx = vmax3(mx, sc[3][rb][1], sc[3][rb][2]);
                 mx = vmax2(mx, sc[3][rb][3]);
-                mx = quad_group_max(mx) * c_log2;
                 const float m_prev = m_use[rb];
+                mx = quad_group_max(mx);
+                if constexpr (PRE) mx += m_prev;   // scores are relative to the reference they were accumulated under
+                else mx *= c_log2;
                 const float m_new = fmaxf(m_run[rb], mx);
                 m_use[rb] = (m_new == -INFINITY) ? m_prev : m_new;
                 float a = __builtin_amdgcn_exp2f(fminf(m_prev - m_use[rb], 126.f));
@@ -289,6 +328,18 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 m_run[rb] = m_new;
                 all_finite = all_finite && (m_new != -INFINITY);
                 l_run[rb] *= a;
+                if constexpr (PRE) {
+                    pre_shift[rb] = m_prev - m_use[rb];
+                    // what the next S^T accumulators start from.  Rewritten IN PLACE (tied asm operands): as plain assignments hipcc keeps
+                    // the old and the new value in two tuples and copies one into the other on the FAST path of every tile
+                    const float nm = -m_use[rb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float c = neg_ref[rb][r];
+                        asm volatile("v_mov_b32 %0, %1" : "+v"(c) : "v"(nm));
+                        neg_ref[rb][r] = c;
+                    }
+                }
             }
             psum_thr = __all(all_finite) ? 2048.f : -1.f;
 #pragma unroll
@@ -304,7 +355,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
             psum[0] = 0.f, psum[1] = 0.f;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                probs(kc);
+                probs_impl(kc, std::true_type{});
                 asm volatile("" : "+v"(pf[kc][0]), "+v"(pf[kc][1]), "+v"(psum[0]), "+v"(psum[1]));
             }
         }
@@ -314,8 +365,8 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     // Matrix phase: O^T += V(t)^T P(t)^T (16 fragments, 32 MFMAs), then S(t+1)^T = K(t+1) Q^T (16 fragments, 32 MFMAs).  One step =
     // { LDS read of the fragment kPF steps ahead; the fragment's two MFMAs (row blocks 0 and 1) }, fenced with sched_barrier.
     constexpr int NPV = 2 * NDB;
-    V8 ring[kPF + 1];
-    V8 carry[kCarry];
+    i16x8 ring[kPF + 1];
+    i16x8 carry[kCarry];
     auto carry_load = [&](int t, int i) { carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB); };
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
@@ -343,15 +394,22 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
             }
             if (i < NPV) {
                 const int kc = i / NDB, db = i % NDB;
-                const V8 a = i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)];
+                const V8 a = __builtin_bit_cast(V8, i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)]);
                 acc_o[db][0] = M::mfma(a, pf[kc][0], acc_o[db][0]);
                 acc_o[db][1] = M::mfma(a, pf[kc][1], acc_o[db][1]);
                 if (i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
             } else {
                 const int j = i - NPV, ks = j >> 2, b = j & 3;
-                const V8 a = ring[i % (kPF + 1)];
-                sc[b][0] = M::mfma(a, qf[0][ks], ks == 0 ? zero : sc[b][0]);
-                sc[b][1] = M::mfma(a, qf[1][ks], ks == 0 ? zero : sc[b][1]);
+                const Q8 a = __builtin_bit_cast(Q8, ring[i % (kPF + 1)]);
+                // (PRE, first step: D = A B + neg_ref with neg_ref left where it is.  Its result is read by the next step's MFMA of the same
+                //  key block only, as C, same tuple; neg_ref is written on the exact path of a vector phase, a barrier away.)
+                if constexpr (PRE) {
+                    sc[b][0] = ks == 0 ? MQ::mfma_keep_c(a, qf[0][ks], neg_ref[0]) : MQ::mfma(a, qf[0][ks], sc[b][0]);
+                    sc[b][1] = ks == 0 ? MQ::mfma_keep_c(a, qf[1][ks], neg_ref[1]) : MQ::mfma(a, qf[1][ks], sc[b][1]);
+                } else {
+                    sc[b][0] = MQ::mfma(a, qf[0][ks], ks == 0 ? zero : sc[b][0]);
+                    sc[b][1] = MQ::mfma(a, qf[1][ks], ks == 0 ? zero : sc[b][1]);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -381,9 +439,9 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const V8 a = kfrag(smem, b, ks);
-                sc[b][0] = M::mfma(a, qf[0][ks], ks == 0 ? zero : sc[b][0]);
-                sc[b][1] = M::mfma(a, qf[1][ks], ks == 0 ? zero : sc[b][1]);
+                const Q8 a = __builtin_bit_cast(Q8, kfrag(smem, b, ks));
+                sc[b][0] = MQ::mfma(a, qf[0][ks], ks == 0 ? zero : sc[b][0]);   // (reference 0 so far, also for PRE)
+                sc[b][1] = MQ::mfma(a, qf[1][ks], ks == 0 ? zero : sc[b][1]);
             }
 #pragma unroll
         for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(sc[b][0]), "+v"(sc[b][1]));

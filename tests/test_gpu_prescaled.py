@@ -64,7 +64,7 @@ def test_prescaled_vs_oracle(nat, model, D, dtype):
 
 def test_prescaled_fused_placement_and_switch(nat):
     """head_perm_flag path with a pre-scaled q == placement -> attention -> inverse placement of the oracle; the device-switched entry
-    picks mask + placement (flag 0) or the dense alt mask (flag 1), bit-identical to the two plain pre-scaled calls."""
+    picks mask + placement (flag 0) or the dense alt mask (flag 1): the two plain pre-scaled calls up to rounding."""
     torch.manual_seed(3)
     F_, P_, ctx, L, mul, D, H = 6, 130, 24, 7, 1.6, 128, 4
     S = F_ * P_ + ctx
@@ -82,7 +82,10 @@ def test_prescaled_fused_placement_and_switch(nat):
     for flag, want in ((0, o), (1, od)):
         f = torch.tensor([flag], dtype=torch.int32).cuda()
         got = nat.band_attention_switch(qs.cuda(), k.cuda(), v.cuda(), nat.BandMask(**prm), nat.BandMask(**dprm), f, q_prescaled=True, **kw)
-        assert torch.equal(got, want), flag
+        # (another instantiation of the same body — the switch kernel holds it twice: under -ffast-math hipcc may associate the row sums
+        #  differently, so rounding-level, like tests/test_gpu_kernels.py::test_band_attention_device_switch)
+        torch.testing.assert_close(got.float(), want.float(), atol=4e-3, rtol=1e-2)
+        assert (got.float() - want.float()).abs().mean() < 1e-4, flag
 
 
 @pytest.mark.parametrize("spike", [30.0, 120.0, 400.0])

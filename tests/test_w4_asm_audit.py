@@ -103,3 +103,9 @@ def test_first_step_mfmas_have_no_hazards(f8_listings, capsys):
     assert len(kernels) == 8 and not any("varblock" in l for l in kernels), out
     for l in kernels:
         assert (" 8 asm MFMAs, 0 hazards" if "switch" in l else " 4 asm MFMAs, 0 hazards") in l, l
+    # the PRE form of the 16x16x32 body (attn_m16.h, Mfma16::mfma_keep_c): 8 first contraction steps per tile x two copies of the loop;
+    # the switch kernels hold the body twice
+    rc, out, kernels = _audit(audit, capsys, "band_attn_m16", f8_listings[0])
+    assert rc == 0, out
+    assert kernels and all("0 hazards" in l for l in kernels), out
+    assert any(" 16 asm MFMAs" in l for l in kernels) and any(" 32 asm MFMAs" in l for l in kernels), out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B on the headline workload: the two-phase band kernel on 32x32x16 MFMAs (variant 2, plain q; and its pre-scaled form)
-against the same schedule on 16x16x32 MFMAs (variant 8, csrc/attn_m16.h): ms per launch, sustained clock, Mcycles, and the outputs
+against the same schedule on 16x16x32 MFMAs (variant 8, csrc/attn_m16.h) and its pre-scaled form (svg_band_attention_prescaled): ms per launch, sustained clock, Mcycles, and the outputs
 against each other.  usage: python tools/ab_m16.py [launches per leg, default 4] [rounds, default 2]"""
 import sys
 from pathlib import Path
@@ -27,7 +27,7 @@ def main():
     pk = dict(head_perm_flag=best, vid0=0, num_frame=F_, frame_size=P_)
     legs = [("32x32x16 plain q (variant 2)", lambda o: nat.band_attention(q, k, v, mask, variant=2, out=o, **pk)),
             ("16x16x32 plain q (variant 8)", lambda o: nat.band_attention(q, k, v, mask, variant=8, out=o, **pk)),
-            ("32x32x16 pre-scaled q", lambda o: nat.band_attention(qs, k, v, mask, q_prescaled=True, out=o, **pk))]
+            ("16x16x32 pre-scaled q (opt-in)", lambda o: nat.band_attention(qs, k, v, mask, q_prescaled=True, out=o, **pk))]
     outs = {}
     probe = nat.ClockProbe(dev)
     for rnd in range(rounds):
@@ -45,7 +45,7 @@ def main():
             e1.synchronize()
             mhz = probe.result()
             ms = e0.elapsed_time(e1) / n
-            print(f"round {rnd} {name:30s}: {ms:7.3f} ms / launch, sustained {mhz} MHz, {ms * 1e-3 * (mhz or 0):7.2f} Mcycles", flush=True)
+            print(f"round {rnd} {name:42s}: {ms:7.3f} ms / launch, sustained {mhz} MHz, {ms * 1e-3 * (mhz or 0):7.2f} Mcycles", flush=True)
             outs[name] = o
     a, b = outs[legs[0][0]].float(), outs[legs[1][0]].float()
     print(f"rel L2 between variant 2 and variant 8: {((a - b).norm() / a.norm()).item():.3e}, max abs {(a - b).abs().max().item():.3e}; "
