@@ -1,0 +1,80 @@
+"""Host-side helpers added in round 4 (no GPU): the bounded workspace cache of svg._native, the shared registry behind the four
+`custom_models.py` shims, the token shards of the N-rank step, and the Wan QK-norm type gate."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
+
+
+def test_workspace_cache_is_bounded_and_lru():
+    from svg._native import WorkspaceCache
+
+    c = WorkspaceCache(capacity=3)
+    for i in range(3):
+        c[("k", i)] = i
+    assert c.get(("k", 0)) == 0          # touch 0: 1 is now the least recently used
+    c[("k", 3)] = 3
+    assert len(c) == 3 and c.get(("k", 1)) is None and c.get(("k", 0)) == 0 and c.get(("k", 3)) == 3
+    c.clear()
+    assert len(c) == 0
+
+
+def test_transformer_registry_per_model_and_idempotent():
+    from svg.models.cog import custom_models as cog
+    from svg.models.context import TransformerRegistry
+    from svg.models.hyvideo import custom_models as hy
+    from svg.models.wan import custom_models as wan
+
+    assert hy._REGISTRY is not cog._REGISTRY is not wan._REGISTRY        # one registry per model module
+
+    class T(torch.nn.Module):
+        def forward(self, x, timestep=None):
+            from svg.models.context import current_timestep
+
+            return current_timestep()
+
+    calls = []
+    reg = TransformerRegistry(also=lambda t: calls.append(t))
+    t = T()
+    reg.register_transformer(t)
+    reg.register_transformer(t)                                          # registering twice keeps one entry
+    reg.replace_sparse_forward()
+    reg.replace_sparse_forward()                                         # the hook is installed once, `also` runs per call
+    assert calls == [t, t]
+    ts = torch.tensor([7.0])
+    assert t.forward(torch.zeros(1), timestep=ts) is ts                  # the wrapper publishes the timestep during the call
+    from svg.models.context import current_timestep
+
+    assert current_timestep() is None
+
+
+def test_wan_qk_norm_accepts_rms_norm_only():
+    """ref: svg/models/wan/attention.py:105-120 raises ValueError for anything but torch.nn.RMSNorm / diffusers' RMSNorm"""
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as P
+
+    class Attn:
+        pass
+
+    a = Attn()
+    a.norm_q = torch.nn.RMSNorm(16, eps=1e-6)
+    a.norm_k = torch.nn.RMSNorm(16, eps=1e-6)
+    x = torch.randn(1, 5, 16)
+    q, k = P(0).get_qk_norm(a, x, x)
+    torch.testing.assert_close(q, a.norm_q(x))
+    a.norm_q = torch.nn.LayerNorm(16)                                    # has a bias: never an RMSNorm
+    with pytest.raises(ValueError):
+        P(0).get_qk_norm(a, x, x)
+
+
+def test_token_range_units():
+    from svg.distributed import token_range
+
+    S = 119056
+    tr = [token_range(S, r, 8, unit=128) for r in range(8)]
+    assert tr[0] == (0, 14976) and tr[-1][1] == S and all(tr[i][1] == tr[i + 1][0] for i in range(7))
+    assert max(b - a for a, b in tr) * 8 / S < 1.01
+    assert token_range(10, 0, 1) == (0, 10) and token_range(10, 2, 3, unit=4) == (8, 10)   # a trailing partial unit goes to the last rank
