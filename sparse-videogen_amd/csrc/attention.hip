@@ -918,18 +918,6 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
             if (dtype == SVG_DTYPE_BF16) {
                 using Pol = BandPolicy<__bf16, 128, 8, false>;
                 const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
-#ifdef SVG_M16_EXPERIMENTS     // A/B builds: issue priority x barriers per tile, selected by SVG_M16_CFG (prio * 2 + onebar)
-                {
-                    const char* e = std::getenv("SVG_M16_CFG");
-                    const int cfg = e ? std::atoi(e) : 3;
-#define SVG_M16_CASE(C, PR, OB) case C: return launch_attn(band_attn_m16_kernel<__bf16, PR, OB>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
-                    switch (cfg) {
-                        SVG_M16_CASE(0, 0, 0) SVG_M16_CASE(1, 0, 1) SVG_M16_CASE(2, 1, 0) SVG_M16_CASE(3, 1, 1) SVG_M16_CASE(4, 2, 0) SVG_M16_CASE(5, 2, 1)
-                        default: return SVG_ERR_BAD_ARG;
-                    }
-#undef SVG_M16_CASE
-                }
-#endif
                 return launch_attn(band_attn_m16_kernel<__bf16>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes(), st);
             }
             if (dtype == SVG_DTYPE_F16) {
