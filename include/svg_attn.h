@@ -135,9 +135,13 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
 /* svg_band_attention for a q that already carries the softmax scale: q_scaled = q * sm_scale * log2(e), rounded ONCE to the 16-bit
  * type by whoever produced q (svg_qk_norm_rope* with q_scale — the processors' prologue — so no second rounding happens on that
  * path).  The kernel then starts its score accumulators at minus the row's softmax reference and the MFMAs deliver the exponent
- * argument directly: one FMA per score less on the vector pipe (two-phase ping-pong schedule, the default of svg_band_attention at
- * D = 128).  Same mask / perm semantics and the same result as svg_band_attention(q, ..., sm_scale) up to the rounding of
- * q_scaled.  No reference counterpart: flex_attention takes `scale` as an argument (svg/models/hyvideo/attention.py:401-403). */
+ * argument directly: one FMA per score less on the vector pipe (the PRE form of the default two-phase schedule: on 16x16x32 MFMAs at
+ * D = 128, on 32x32x16 at D = 64).  Same mask / perm semantics and the same result as svg_band_attention(q, ..., sm_scale) up to the
+ * rounding of q_scaled — which is the catch: the scores come from round(c * q) instead of c * round(q), a second 2^-9 perturbation on
+ * bf16 (2.8e-3 ... 6.4e-3 rel. L2 to the reference's formulation where svg_band_attention holds 1.9 - 2.3e-3; fp16: 3.5e-4 ... 8e-4 vs
+ * 2.4 - 2.9e-4).  It is what flex_attention calls its PRESCALE_QK kernel option ("about 20% more numerical error, but slightly faster");
+ * the reference runs flex_attention with the default, PRESCALE_QK = False (svg/models/hyvideo/attention.py:401-403), and so do the
+ * processors of this package unless `prescale_q` is switched on. */
 int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                  int32_t dtype, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, void* stream);
 
