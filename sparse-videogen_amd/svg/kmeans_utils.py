@@ -236,7 +236,7 @@ def dynamic_block_sparse_fwd_triton(q, k, v, dynamic_map, qc_size, kc_size):
 
 
 # ---- the two halves of a Euclidean iteration under the reference's names (ref svg/kmeans_utils.py:562-627, 375-421, 208-255) ----
-# (host plumbing added at the end of round 3 on the kernels batch_kmeans_Euclid runs; GPU test: tests/test_gpu_experimental.py)
+# (host plumbing added at the end of round 3 on the kernels batch_kmeans_Euclid runs; GPU test: tests/test_gpu_reference_calls.py)
 def euclid_assign_triton(x, centroids, x_sq=None, out=None, *, BLOCK_N: int = 128, BLOCK_K: int = 128):
     """-> cluster ids int64 [B, N] (ref :562-627).  `x_sq` and the tile sizes are accepted and not needed: the HIP kernel takes
     argmax_k (<x, c_k> - |c_k|^2 / 2), with fp32 centroid norms (the Triton kernel reduces them in the input type)."""

@@ -469,7 +469,7 @@ def test_product_wan_block_forward_on_cpu_tensors_equals_the_references_torch_br
 # expressions); the core itself is HIP-only and refuses them.  With the core replaced — in the test — by the oracle's statement under the
 # fixture's recorded profiler decision, the product's `__call__` must return what the reference's `__call__` returned: projections, norm
 # placement (per head / across heads), which rows RoPE touches, text first or last, the text stream's own projections, the split and
-# the output projections.  (The HIP core under the same call is what tests/test_gpu_triton_golden.py / test_gpu_experimental.py check.)
+# the output projections.  (The HIP core under the same call is what tests/test_gpu_triton_golden.py / test_gpu_reference_calls.py check.)
 def _product_path():
     import sys
     for pth in (Path(__file__).resolve().parent, Path(__file__).resolve().parent.parent / "sparse-videogen_amd"):
