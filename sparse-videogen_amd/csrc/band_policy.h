@@ -3,7 +3,6 @@
 // the launch helper shared by the translation units that instantiate band kernels (attention.hip, attention_w4.hip).
 #pragma once
 #include <algorithm>
-#include <cstdlib>
 
 #include "attn_core.h"
 
@@ -114,16 +113,12 @@ struct BandPolicy {
             qt = r < p.heavy_lo ? r : r + p.n_heavy;
         }
         // (explicit selects: a run-time index into the kernel-argument arrays would go through scratch)
-        auto tile_rows = [&](int t, int& q0, int& rhi_out) {
-            const bool r1 = t >= p.reg_t0[1], r2 = t >= p.reg_t0[2], r3 = t >= p.reg_t0[3];
-            const int rlo = r3 ? p.reg_lo[3] : r2 ? p.reg_lo[2] : r1 ? p.reg_lo[1] : p.reg_lo[0];
-            rhi_out = r3 ? p.reg_hi[3] : r2 ? p.reg_hi[2] : r1 ? p.reg_hi[1] : p.reg_hi[0];
-            const int rt0 = r3 ? p.reg_t0[3] : r2 ? p.reg_t0[2] : r1 ? p.reg_t0[1] : 0;
-            q0 = rlo + (t - rt0) * BM;
-        };
-        int rhi;
+        const bool r1 = qt >= p.reg_t0[1], r2 = qt >= p.reg_t0[2], r3 = qt >= p.reg_t0[3];
+        const int rlo = r3 ? p.reg_lo[3] : r2 ? p.reg_lo[2] : r1 ? p.reg_lo[1] : p.reg_lo[0];
+        const int rhi = r3 ? p.reg_hi[3] : r2 ? p.reg_hi[2] : r1 ? p.reg_hi[1] : p.reg_hi[0];
+        const int rt0 = r3 ? p.reg_t0[3] : r2 ? p.reg_t0[2] : r1 ? p.reg_t0[1] : 0;
         c.qt = qt;
-        tile_rows(qt, c.q0, rhi);
+        c.q0 = rlo + (qt - rt0) * BM;
         c.q_end = min(rhi, c.q0 + BM);
         c.perm = (p.head_flag != nullptr) && (p.head_flag[c.head] != 0);
 
