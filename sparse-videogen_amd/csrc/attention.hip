@@ -781,7 +781,14 @@ enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, 
 // Round 4: head_dim 128 runs the two-phase schedule on 16x16x32 MFMAs (attn_m16.h, variant 8): 32.6 ms against 34.1 - 35.7 for the
 // 32x32x16 body on the plain q, same box (profiles/r04f_ab_m16.txt, r04g_ab_m16_cfg.txt); head_dim 64 and the pre-scaled entry points keep
 // the 32x32x16 body (variant 2).
-static inline int band_default(int D, bool) { return D == 128 ? kBandM16 : kBandPingPong; }
+// head_dim 64 (CogVideoX) on the plain q: the one-wave-per-SIMD body again — 13.6 / 13.9 ms against 14.2 / 14.7 for the two-phase body on two
+// boxes (profiles/r04p_clock_by_variant.txt, r04zx_clock_by_variant.txt; round 3 had measured them equal and the pre-scaled two-phase
+// form, then the default, ahead of both).  Launches that count completions and the pre-scaled entry points keep the two-phase body
+// (8 reporting waves per q-tile; the PRE form exists for it only).
+static inline int band_default(int D, bool with_counters, bool prescaled) {
+    if (D == 128) return kBandM16;
+    return (with_counters || prescaled) ? kBandPingPong : kBandW4;
+}
 
 int band_waves_per_tile(int variant) {
     const int v = variant == kBandAuto ? kBandPingPong : variant;
@@ -882,7 +889,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         variant = kBandPingPong;
         g_trace_is_w4 = false;
     }
-    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr);
+    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr, opts.prescaled);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
