@@ -3,7 +3,7 @@
 roofline.traffic): HBM-side bytes per launch of the dominant attention kernel = 2 x FETCH_SIZE (gfx950 correction of
 MI355X_MICROARCH.md: the counter counts 64-B units of 128-B requests) + WRITE_SIZE, both in KB.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_<tag>/summary.txt <tag>  >  profiles/<tag>_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_<tag>/summary.txt <tag> [kernel substring] [source text]  >  profiles/<tag>_pmc_traffic.json
 """
 import json
 import re
@@ -22,7 +22,7 @@ for line in txt.splitlines():
             cur[m.group(1)] = float(m.group(3))
 # dominant kernel: the band attention kernel with the most wave cycles (or the only one)
 # (the 16-bit headline kernel when it is there: the bench's fp8 extras block launches band_attn_f8_kernel in the same run)
-want = sys.argv[3] if len(sys.argv) > 3 else None      # optional: substring of the kernel to report (e.g. band_attn_f8)
+want = (sys.argv[3] if len(sys.argv) > 3 else None) or None      # optional: substring of the kernel to report (e.g. band_attn_f8)
 cands = [(k, v) for k, v in blocks.items() if want and want in k] or \
         [(k, v) for k, v in blocks.items() if "band_attn_m16" in k] or \
         [(k, v) for k, v in blocks.items() if "band_attn_pp2q" in k] or \
@@ -33,7 +33,8 @@ out = {
     "kernel": "band_attn_f8_kernel<bf16>" if "band_attn_f8" in name else
               ("band_attn_m16_kernel<bf16>" if "band_attn_m16" in name else None) or next((f"{k}<bf16,128>" for k in ("band_attn_pp2q_kernel", "band_attn_w4_kernel", "band_attn_pp2_kernel", "band_attn_kernel") if k in name), name),
     "kernel_symbol": name,
-    "source": f"tools/gpu_pmc.sh {tag}: separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-profiler`, one launch each",
+    "source": sys.argv[4] if len(sys.argv) > 4 else
+              f"tools/gpu_pmc.sh {tag}: separate rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 1 --no-profiler`, one launch each",
     "FETCH_SIZE_KB": g("FETCH_SIZE"),
     "WRITE_SIZE_KB": g("WRITE_SIZE"),
     "traffic_bytes_per_launch": (2.0 * g("FETCH_SIZE", 0.0) + g("WRITE_SIZE", 0.0)) * 1024.0,
