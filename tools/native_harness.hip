@@ -82,6 +82,14 @@ __global__ void fill_normal_kernel(uint16_t* dst, size_t n, uint64_t seed, float
     }
 }
 
+// ---------------------------------------------------------------- order-independent 64-bit checksum of a buffer (bit-exact A/B of two builds)
+__global__ void checksum_kernel(const uint32_t* p, size_t nwords, unsigned long long* out) {
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        h += (unsigned long long)p[i] * (2ull * mix32(i) + 1ull) + mix32(i ^ p[i]);
+    atomicAdd(out, h);
+}
+
 // ---------------------------------------------------------------- fp32 restatement of the masked attention of selected rows
 struct RefGeom {
     int S, D, F, P, V;   // V = F * P video rows (0 when no placement applies)
@@ -250,6 +258,13 @@ int main(int argc, char** argv) {
     double mean = 0;
     for (int i = 0; i < reps; ++i) HIP_OK(hipEventElapsedTime(&ms[i], e0[i], e1[i])), mean += ms[i] / reps;
 
+    unsigned long long* dsum;
+    unsigned long long osum = 0;
+    HIP_OK(hipMalloc(&dsum, 8)), HIP_OK(hipMemsetAsync(dsum, 0, 8, st));
+    checksum_kernel<<<2048, 256, 0, st>>>((const uint32_t*)o, n / 2, dsum);
+    HIP_OK(hipMemcpyAsync(&osum, dsum, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+
     // algorithmic pairs: counted from the predicate, row by row (closed forms: SURVEY §8(d))
     double pairs = 0;
     for (int i = 0; i < S; ++i) {
@@ -303,8 +318,8 @@ int main(int argc, char** argv) {
            lib.c_str(), info ? info() : "?", G->name, H, S, D, dtype.c_str(), m.band, variant, prescaled, flags.c_str());
     for (int i = 0; i < reps; ++i) printf("%s%.3f", i ? ", " : "", ms[i]);
     printf("], \"ms_mean\": %.3f, \"density\": %.4f, \"algorithmic_tflop\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.4f, "
-           "\"spot_rows\": %d, \"rel_l2\": %.3e, \"max_abs\": %.3e}\n",
-           mean, pairs / S / S, flop / 1e12, flop / (mean * 1e-3) / 1e12, flop / (mean * 1e-3) / 2.5e15, nck, rel, maxabs);
+           "\"spot_rows\": %d, \"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\"}\n",
+           mean, pairs / S / S, flop / 1e12, flop / (mean * 1e-3) / 1e12, flop / (mean * 1e-3) / 2.5e15, nck, rel, maxabs, osum);
     const double tol = f16 ? 1e-3 : (prescaled ? 1e-2 : 3e-3);   // the bounds of tests/test_gpu_fullsize.py / test_gpu_prescaled.py, spot rows
     if (nck > 0 && !(rel <= tol)) { fprintf(stderr, "spot rows: rel. L2 %.3e above %.1e\n", rel, tol); return 4; }
     return 0;
