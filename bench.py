@@ -639,7 +639,7 @@ def main():
 
     if world == 1 and not fp8 and a.workload == "hy720p" and not a.no_ab and a.variant == 0:
         # the same kernel on the reference's other SVG1 geometries (production masks of svg/models/{wan,cog}/utils.py, alternating
-        # spatial / temporal heads, pre-scaled q like their processors hand it over): Wan 2.1 720p and CogVideoX-v1.5 (head_dim 64)
+        # spatial / temporal heads, the processors' default path — plain q — unless --prescaled): Wan 2.1 720p and CogVideoX-v1.5 (head_dim 64)
         try:
             from svg.models.cog import utils as cog_u
             from svg.models.wan import utils as wan_u
@@ -654,11 +654,12 @@ def main():
                 mo = mk()
                 go = torch.Generator(device=dev).manual_seed(77)
                 qo_, ko_, vo_ = (torch.randn(1, BHo, So, Do, device=dev, dtype=torch.bfloat16, generator=go) for _ in range(3))
-                qo_ = (qo_.float() * nat.softmax_q_scale(Do)).to(torch.bfloat16)
+                if a.prescaled:
+                    qo_ = (qo_.float() * nat.softmax_q_scale(Do)).to(torch.bfloat16)
                 oo_ = torch.empty_like(qo_)
                 besto = torch.tensor([[h % 2 for h in range(BHo)]], device=dev, dtype=torch.int64)
                 call = lambda: nat.band_attention(qo_, ko_, vo_, mo, head_perm_flag=besto, vid0=ctxo if text_first else 0,  # noqa: E731
-                                                  num_frame=Fo, frame_size=Po, out=oo_, q_prescaled=True)
+                                                  num_frame=Fo, frame_size=Po, out=oo_, q_prescaled=bool(a.prescaled))
                 call()
                 evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                 evs[0].record()

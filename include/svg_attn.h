@@ -111,7 +111,7 @@ typedef struct svg_perm_desc {
     int32_t frame_size;            /* P                                                          */
 } svg_perm_desc_t;
 
-/* variant: 0 = default (= 8 at head_dim 128; at head_dim 64 = 3, or 2 for launches that count completions).  All schedules produce the same result up to rounding.
+/* variant: 0 = default (= 8 at head_dim 128; = 2 at head_dim 64, where the two-phase body runs four waves per SIMD — two workgroups per CU).  All schedules produce the same result up to rounding.
  *   1 = lock-step, 4 waves x 32 query rows, 128-row q-tiles, two workgroups per CU (register-staged K/V) — the plain schedule
  *       the test-suite uses as the in-library reference;
  *   2 = two-phase ping-pong, 8 waves x 32 rows: the two waves that share a SIMD alternate a matrix phase (PV of tile t + QK^T

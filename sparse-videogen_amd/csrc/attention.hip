@@ -19,10 +19,15 @@ __global__ __launch_bounds__(NW * 64, 2) void band_attn_kernel(typename BandPoli
 }
 
 // two-phase ping-pong schedule, 8 waves x 32 rows (attn_body_pp2): variant 2
+// head_dim 64: FOUR waves per SIMD — 128 registers (the LEAN form of the body) and 64 KiB of LDS per workgroup put two workgroups on a
+// CU.  At head_dim 64 a tile is 512 cycles of matrix work beside the same 141 vector instructions per wave as at head_dim 128, and one
+// wave gets a third of what the vector pipe can take (tools/probe_exp.hip): with two waves per SIMD the matrix pipe is 40 % busy, with
+// four 49 % — 18 % fewer cycles per launch; the chip then meets its power limit at head_dim 64 too and gives back part of it: −10.7 % in
+// time on CogVideoX-v1.5, bit-identical output (profiles/r04zr_ab_d64_four_waves.txt, r04zs_*).
 template <typename T, int D>
-__global__ __launch_bounds__(512, 2) void band_attn_pp2_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
+__global__ __launch_bounds__(512, (D == 64 ? 4 : 2)) void band_attn_pp2_kernel(typename BandPolicy<T, D, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>>(prm, smem, nullptr);
+    attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, false, 0, false, D == 64>(prm, smem, nullptr);
 }
 // Device-side switch between two masks on the pre-scaled two-phase body (svg_band_attention_switch_prescaled): `flag[0] != 0`
 // selects prm_alt — the dense warm-up mask without the layout transformation — otherwise prm (see band_attn_w4_switch_kernel)
@@ -786,8 +791,9 @@ enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, 
 // form, then the default, ahead of both).  Launches that count completions and the pre-scaled entry points keep the two-phase body
 // (8 reporting waves per q-tile; the PRE form exists for it only).
 static inline int band_default(int D, bool with_counters, bool prescaled) {
-    if (D == 128) return kBandM16;
-    return (with_counters || prescaled) ? kBandPingPong : kBandW4;
+    // head_dim 64: the two-phase body — since it runs four waves per SIMD there (band_attn_pp2_kernel) it is ahead of the
+    // one-wave-per-SIMD body on the plain q as well (12.7 - 12.9 against 13.7 - 14.3 ms on CogVideoX-v1.5, profiles/r04zr_*, r04zs_*)
+    return D == 128 ? kBandM16 : kBandPingPong;
 }
 
 int band_waves_per_tile(int variant) {

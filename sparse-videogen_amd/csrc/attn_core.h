@@ -536,7 +536,7 @@ constexpr int attn_pp2_lds_bytes() {
     return stages > epi ? stages : epi;
 }
 
-template <typename T, int D, typename P, bool TRACE = false, int ABL = 0, bool PRE = false>
+template <typename T, int D, typename P, bool TRACE = false, int ABL = 0, bool PRE = false, bool LEAN = false>
 __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
     using V8 = typename E::v8;
@@ -565,7 +565,10 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     // V operands of the first kCarry MFMAs of a matrix phase are read in the tail of the PREVIOUS matrix phase (tile t + 1 has been
     // in LDS since the barrier in front of M(t)) and carried through the vector phase in registers: the phase opens with MFMAs
     // instead of with an LDS round trip.
-    constexpr int kCarry = (ABL == 0) ? SVG_PP2_CARRY : 0;
+    // LEAN: the register diet of the instance that runs FOUR waves per SIMD (two workgroups per CU; band_attn_pp2_kernel at head_dim 64,
+    // attention.hip): no carried operands, operand ring 4 instead of 8 fragments ahead — with a second workgroup on the CU the latency the
+    // deep ring hides is hidden by the other workgroup's waves, and 128 registers hold the body without a spill.
+    constexpr int kCarry = (ABL == 0 && !LEAN) ? SVG_PP2_CARRY : 0;
 #ifndef SVG_PP2_ONEBAR
 #define SVG_PP2_ONEBAR -1   // -1: as the policy says (P::kOneBarrier); 0 / 1: force (A/B builds)
 #endif
@@ -963,7 +966,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     //  in front of the barrier, so that the matrix phase opens with an MFMA, measured 1.1 % slower: the 16 reads lengthen the
     //  vector phase by more than the matrix phase gains.  Only the first 2 or 4 operands there, with the barrier waiting for all LDS
     //  reads but those — s_waitcnt lgkmcnt(4 / 8) — measured 0.8 % / 1.5 % slower, same box.)
-    constexpr int kPF = 8;
+    constexpr int kPF = LEAN ? 4 : 8;
     constexpr int NPV = 4 * DB;
     static_assert(kCarry <= kPF && kCarry <= NPV, "carried operands are V operands of the first MFMAs");
     V8 ring[kPF + 1];

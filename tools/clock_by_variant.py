@@ -35,7 +35,7 @@ def run(n, dev, name, BH, D, F_, P_, ctx, vid0, mask, only=None):
     fl = 4.0 * D * BH * pairs(mask, S)
     dfl = 4.0 * D * BH * pairs(dmask, S)
     cases = [
-        ("two-phase on 16x16x32 MFMAs, plain q (default at head_dim 128; = two-phase 32x32x16 at head_dim 64)", fl, PEAK_FLOP_PER_CYCLE,
+        ("two-phase on 16x16x32 MFMAs, plain q (default at head_dim 128; at head_dim 64 the default is the two-phase 32x32x16 body, four waves per SIMD)", fl, PEAK_FLOP_PER_CYCLE,
          lambda: nat.band_attention(q, k, v, mask, **pk)),
         ("two-phase on 32x32x16 MFMAs, plain q (variant 2)", fl, PEAK_FLOP_PER_CYCLE, lambda: nat.band_attention(q, k, v, mask, variant=2, **pk)),
         ("pre-scaled q, opt-in (PRE form of the default body)", fl, PEAK_FLOP_PER_CYCLE, lambda: nat.band_attention(qs, k, v, mask, q_prescaled=True, **pk)),

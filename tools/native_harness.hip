@@ -5,7 +5,7 @@
 // of the product links or loads it, and its numbers are labelled with this file's name wherever they are quoted.
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/native_harness.hip -o tools/native_harness -ldl
-//   tools/native_harness [--lib PATH] [--geom hy720p|wan720p|hy480p|small] [--dtype bf16|f16] [--variant N] [--prescaled]
+//   tools/native_harness [--lib PATH] [--geom hy720p|wan720p|hy480p|small|cog480p|cog15|small64] [--dtype bf16|f16] [--variant N] [--prescaled]
 //                        [--flags half|zero|one] [--heads H] [--warm W] [--reps R] [--check ROWS] [--seed N]
 // Output: one JSON line (ms per launch, algorithmic TFLOP/s, spot-row error against the fp32 restatement below).
 //
@@ -92,7 +92,8 @@ __global__ void checksum_kernel(const uint32_t* p, size_t nwords, unsigned long 
 
 // ---------------------------------------------------------------- fp32 restatement of the masked attention of selected rows
 struct RefGeom {
-    int S, D, F, P, V;   // V = F * P video rows (0 when no placement applies)
+    int S, D, F, P, V;   // V = F * P video rows
+    int vid0;            // first video row (0: text last; context_length: text first, CogVideoX)
     svg_band_mask_t m;
     float scale;
     int f16;
@@ -103,7 +104,10 @@ __device__ inline bool allowed(const svg_band_mask_t& m, int q, int k) {
     const bool in = d < m.band || (k >= m.colfull_lo && k < m.colfull_hi) || (q >= m.rowfull_lo && q < m.rowfull_hi);
     return (rq && rk && in) || (!rq && !rk);
 }
-__device__ inline int phys_row(const RefGeom& g, bool temporal, int i) { return (temporal && i < g.V) ? (i % g.F) * g.P + i / g.F : i; }
+__device__ inline int phys_row(const RefGeom& g, bool temporal, int i) {
+    const int j = i - g.vid0;
+    return (temporal && j >= 0 && j < g.V) ? g.vid0 + (j % g.F) * g.P + j / g.F : i;
+}
 __device__ inline float ld16(const uint16_t* p, int f16) { return f16 ? f16_to_f32_dev(*p) : bf16_to_f32(*p); }
 
 // one workgroup per (checked head, checked logical row); scratch: S floats per workgroup; out: D floats per workgroup
@@ -170,18 +174,24 @@ struct Geom {
     const char* name;
     int H, D, F, P, ctx, L;
     double width_frames;   // band half-width in frames (sparsity_to_width of the model's script)
-    int wan;               // Wan rule: ceil + 1, sink columns, no text
+    int kind;              // 0 Hunyuan (text last, prompt L of ctx), 1 Wan (ceil + 1, sink columns, no text), 2 CogVideoX (text first)
 };
 // widths: svg/models/hyvideo/utils.py:142-151 at sparsity 0.25 (Hunyuan) / svg/models/wan/utils.py at 0.3 — SURVEY §8(d): bands 15616 / 12416
 static const Geom kGeoms[] = {{"hy720p", 24, 128, 33, 3600, 256, 64, 4.3487, 0},
                               {"wan720p", 40, 128, 21, 3600, 0, 0, 3.4301, 1},
                               {"hy480p", 24, 128, 33, 1350, 256, 64, 4.3487, 0},
-                              {"small", 4, 128, 5, 160, 256, 64, 1.7, 0}};
+                              {"small", 4, 128, 5, 160, 256, 64, 1.7, 0},
+                              // svg/models/cog/utils.py at sparsity 0.25: bands 2048 / 5760 (tools/svg1_models.py), cfg = 2 x 48 heads, head_dim 64
+                              {"cog480p", 96, 64, 13, 1350, 226, 226, 1.5724038952394224, 2},
+                              {"cog15", 96, 64, 11, 4080, 226, 226, 1.4173925802088359, 2},
+                              {"small64", 6, 64, 5, 160, 226, 226, 1.7, 2}};
 
 int main(int argc, char** argv) {
     std::string lib = "sparse-videogen_amd/lib/libsvgattn.so", geom = "hy720p", dtype = "bf16", flags = "half";
     int variant = 0, warm = 2, reps = 5, check = 10, heads = 0, prescaled = 0;
     uint64_t seed = 0;
+    std::string occ_sym;   // --occupancy <kernel handle symbol> <dynamic LDS bytes>: resident 512-thread workgroups per CU, then exit
+    int occ_lds = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -199,6 +209,7 @@ int main(int argc, char** argv) {
         else if (a == "--heads") heads = atoi(next());
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
         else if (a == "--prescaled") prescaled = 1;
+        else if (a == "--occupancy") occ_sym = next(), occ_lds = atoi(next());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     const Geom* G = nullptr;
@@ -216,9 +227,23 @@ int main(int argc, char** argv) {
     auto info = (const char* (*)())dlsym(so, "svg_build_info");
     if (!abi || !band || !band_pre || !strerr) { fprintf(stderr, "library lacks an entry point of include/svg_attn.h\n"); return 2; }
     if (abi() != SVG_ABI_VERSION) { fprintf(stderr, "ABI %d, header %d\n", abi(), SVG_ABI_VERSION); return 2; }
+    if (!occ_sym.empty()) {
+        const void* kh = dlsym(so, occ_sym.c_str());
+        if (!kh) { fprintf(stderr, "no symbol %s\n", occ_sym.c_str()); return 2; }
+        int nb = -1;
+        HIP_OK(hipFuncSetAttribute(kh, hipFuncAttributeMaxDynamicSharedMemorySize, occ_lds));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kh, 512, (size_t)occ_lds));
+        hipFuncAttributes fa;
+        HIP_OK(hipFuncGetAttributes(&fa, kh));
+        printf("{\"lib\": \"%s\", \"kernel\": \"%s\", \"dynamic_lds\": %d, \"workgroups_per_cu\": %d, \"num_regs\": %d, \"local_bytes_per_lane\": %zu, \"static_lds\": %zu}\n",
+               lib.c_str(), occ_sym.c_str(), occ_lds, nb, fa.numRegs, (size_t)fa.localSizeBytes, (size_t)fa.sharedSizeBytes);
+        return 0;
+    }
 
     svg_band_mask_t m;
-    if (G->wan) m = {S, (int)std::ceil(G->width_frames * G->P / 128.0) * 128 + 1, 0, G->P, 0, 0};
+    const int vid0 = G->kind == 2 ? G->ctx : 0;
+    if (G->kind == 1) m = {S, (int)std::ceil(G->width_frames * G->P / 128.0) * 128 + 1, 0, G->P, 0, 0};
+    else if (G->kind == 2) m = {S, (int)std::floor(G->width_frames * G->P / 128.0) * 128, 0, G->L, 0, G->L};
     else m = {V + G->L, (int)std::floor(G->width_frames * G->P / 128.0) * 128, V, V + G->L, V, V + G->L};
     const float sm_scale = 1.f / sqrtf((float)D);
 
@@ -238,7 +263,7 @@ int main(int argc, char** argv) {
     int64_t* dflags;
     HIP_OK(hipMalloc(&dflags, H * 8));
     HIP_OK(hipMemcpyAsync(dflags, hf.data(), H * 8, hipMemcpyHostToDevice, st));
-    svg_perm_desc_t perm = {dflags, 0, G->F, G->P};
+    svg_perm_desc_t perm = {dflags, vid0, G->F, G->P};
 
     auto launch = [&]() {
         const int rc = prescaled ? band_pre(q, k, v, o, H, S, D, f16 ? SVG_DTYPE_F16 : SVG_DTYPE_BF16, &m, &perm, st)
@@ -283,7 +308,7 @@ int main(int argc, char** argv) {
     int nck = 0;
     if (check > 0) {
         std::vector<int> rows, hs;
-        const int cand[] = {0, 1, G->P - 1, V / 2 + 17, V - 1, V, V + G->L - 1, V + G->L, S - 1, m.band, m.band + 63, V / 3};
+        const int cand[] = {0, 1, G->P - 1, V / 2 + 17, V - 1, V, V + G->L - 1, V + G->L, S - 1, m.band, m.band + 63, V / 3, vid0, vid0 + 1, vid0 + V - 1};
         for (int c : cand) if (c >= 0 && c < S && (int)rows.size() < check) rows.push_back(c);
         for (int h : {0, 1, H - 1}) if (h < H && (hs.empty() || hs.back() != h)) hs.push_back(h);
         int *drows, *dheads;
@@ -293,7 +318,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipMalloc(&scratch, (size_t)nb * S * 4)), HIP_OK(hipMalloc(&dout, (size_t)nb * D * 4));
         HIP_OK(hipMemcpy(drows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(dheads, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
-        RefGeom rg = {S, D, G->F, G->P, V, m, sm_scale, f16};
+        RefGeom rg = {S, D, G->F, G->P, V, vid0, m, sm_scale, f16};
         ref_rows_kernel<<<nb, 256, 0, st>>>(q, k, v, dflags, dheads, drows, (int)rows.size(), rg, scratch, dout, prescaled);
         HIP_OK(hipStreamSynchronize(st));
         std::vector<float> ref((size_t)nb * D);
@@ -302,7 +327,8 @@ int main(int argc, char** argv) {
         for (size_t hi = 0; hi < hs.size(); ++hi)
             for (size_t ri = 0; ri < rows.size(); ++ri) {
                 const int h = hs[hi], i = rows[ri];
-                const int pr = (hf[h] && i < V) ? (i % G->F) * G->P + i / G->F : i;
+                const int jv = i - vid0;
+                const int pr = (hf[h] && jv >= 0 && jv < V) ? vid0 + (jv % G->F) * G->P + jv / G->F : i;
                 HIP_OK(hipMemcpy(row.data(), o + ((size_t)h * S + pr) * D, D * 2, hipMemcpyDeviceToHost));
                 for (int d = 0; d < D; ++d) {
                     const double got = f16 ? f16_to_f32_host(row[d]) : bf16_to_f32(row[d]), want = ref[(hi * rows.size() + ri) * D + d];
