@@ -29,8 +29,20 @@ __global__ __launch_bounds__(512, (D == 64 ? 4 : 2)) void band_attn_pp2_kernel(t
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_pp2<T, D, BandPolicy<T, D, 8, false>, false, 0, false, D == 64>(prm, smem, nullptr);
 }
+// svg_band_attention_switch at head_dim 64: band_attn_pp2_kernel<T, 64> — four waves per SIMD, the LEAN form of the body — with the
+// device-side choice between two parameter blocks in front of it (`flag[0] != 0` selects prm_alt, the dense warm-up mask without the
+// layout transformation — the dense / sparse decision of attention_core_logic, hyvideo/attention.py:491-496, without reading the timestep
+// back to the host; a one-wave-per-SIMD switch kernel served this head size until the end of round 4)
+template <typename T>
+__global__ __launch_bounds__(512, 4) void band_attn_pp2_switch64_kernel(typename BandPolicy<T, 64, 8, false>::Params prm,
+                                                                        typename BandPolicy<T, 64, 8, false>::Params prm_alt,
+                                                                        const int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (flag[0] != 0) attn_body_pp2<T, 64, BandPolicy<T, 64, 8, false>, false, 0, false, true>(prm_alt, smem, nullptr);
+    else attn_body_pp2<T, 64, BandPolicy<T, 64, 8, false>, false, 0, false, true>(prm, smem, nullptr);
+}
 // Device-side switch between two masks on the pre-scaled two-phase body (svg_band_attention_switch_prescaled): `flag[0] != 0`
-// selects prm_alt — the dense warm-up mask without the layout transformation — otherwise prm (see band_attn_w4_switch_kernel)
+// selects prm_alt — the dense warm-up mask without the layout transformation — otherwise prm (see band_attn_pp2_switch64_kernel)
 template <typename T, int D>
 __global__ __launch_bounds__(512, 2) void band_attn_pp2q_switch_kernel(typename BandPolicy<T, D, 8, false>::Params prm,
                                                                        typename BandPolicy<T, D, 8, false>::Params prm_alt,
@@ -1060,7 +1072,20 @@ extern "C" int svg_band_attention_switch(const void* q, const void* k, const voi
         };
         return dtype == SVG_DTYPE_BF16 ? go(__bf16{}) : go(_Float16{});
     }
-    return run_band_w4_switch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, alt_mask, use_alt_flag, (hipStream_t)stream);
+    if (D == 64 && (dtype == SVG_DTYPE_BF16 || dtype == SVG_DTYPE_F16)) {    // ... and of this one (band_attn_pp2_kernel<T, 64>)
+        auto go = [&](auto t_c) -> int {
+            using T = decltype(t_c);
+            using Pol = BandPolicy<T, 64, 8, false>;
+            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
+            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
+            auto kern = band_attn_pp2_switch64_kernel<T>;
+            if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<64>()); r2 != SVG_OK) return r2;
+            hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<64>(), (hipStream_t)stream, a, b, use_alt_flag);
+            return launch_status();
+        };
+        return dtype == SVG_DTYPE_BF16 ? go(__bf16{}) : go(_Float16{});
+    }
+    return SVG_ERR_UNSUPPORTED;
 }
 
 extern "C" int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,

@@ -24,18 +24,6 @@ __global__ __launch_bounds__(256, 1) void band_attn_w4_trace_kernel(typename Ban
 }
 #endif
 
-// Device-side switch between two masks: `flag[0] != 0` selects prm_alt (the dense warm-up mask, no layout
-// transformation) — the dense / sparse decision of attention_core_logic (hyvideo/attention.py:491-496) without reading the
-// timestep back to the host.
-template <typename T, int D>
-__global__ __launch_bounds__(256, 1) void band_attn_w4_switch_kernel(typename BandW4<T, D>::Params prm,
-                                                                     typename BandW4<T, D>::Params prm_alt,
-                                                                     const int32_t* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (flag[0] != 0) attn_body_w4<T, D, BandW4<T, D>>(prm_alt, smem, nullptr);
-    else attn_body_w4<T, D, BandW4<T, D>>(prm, smem, nullptr);
-}
-
 template <typename T, int D>
 static int run_w4(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale, const svg_band_mask_t* mask,
                   const svg_perm_desc_t* perm, const BandOpts& opts, hipStream_t st) {
@@ -57,19 +45,6 @@ static int run_w4(const void* q, const void* k, const void* v, void* o, int BH, 
     return launch_attn(band_attn_w4_kernel<T, D>, p, dim3(p.nqt * BH), 256, attn_w4_lds_bytes<D>(), st);
 }
 
-template <typename T, int D>
-static int run_w4_switch(const void* q, const void* k, const void* v, void* o, int BH, int S, float sm_scale,
-                         const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const svg_band_mask_t* alt_mask,
-                         const int32_t* flag, hipStream_t st) {
-    using Pol = BandW4<T, D>;
-    const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
-    const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
-    auto kern = band_attn_w4_switch_kernel<T, D>;
-    if (const int rc = configure_lds((const void*)kern, attn_w4_lds_bytes<D>()); rc != SVG_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(256), attn_w4_lds_bytes<D>(), st, a, b, flag);
-    return launch_status();
-}
-
 #define SVG_W4_TD(FN, ...)                                                                      \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
     if (dtype == SVG_DTYPE_BF16 && D == 64) return FN<__bf16, 64>(__VA_ARGS__);                 \
@@ -82,11 +57,6 @@ int run_band_w4(const void* q, const void* k, const void* v, void* o, int BH, in
     SVG_W4_TD(run_w4, q, k, v, o, BH, S, sm_scale, mask, perm, opts, st)
 }
 
-int run_band_w4_switch(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,
-                       const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const svg_band_mask_t* alt_mask,
-                       const int32_t* flag, hipStream_t st) {
-    SVG_W4_TD(run_w4_switch, q, k, v, o, BH, S, sm_scale, mask, perm, alt_mask, flag, st)
-}
 #undef SVG_W4_TD
 
 int w4_read_trace(uint64_t* out104) {

@@ -466,9 +466,6 @@ int f8g_quantize(const void* q, const void* k, const void* v, int Hq, int Hkv, i
 // 4 waves x 64 rows, one wave per SIMD (attn_body_w4, attention_w4.hip)
 int run_band_w4(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,
                 const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const BandOpts& opts, hipStream_t st);
-int run_band_w4_switch(const void* q, const void* k, const void* v, void* o, int BH, int S, int D, int dtype, float sm_scale,
-                       const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const svg_band_mask_t* alt_mask,
-                       const int32_t* flag, hipStream_t st);
 int w4_read_trace(uint64_t* out104);   // per-phase cycle trace of the last traced w4 launch (diagnostics builds)
 // waves that report per 256-row q-tile of the kernel `variant` selects (completion-counter targets); -1: no counters
 int band_waves_per_tile(int variant);

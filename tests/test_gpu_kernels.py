@@ -247,7 +247,7 @@ def test_band_attention_device_switch(nat, D, dtype):
     dense = nat.BandMask(real_len=F_ * P_ + L, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
     best = dev(torch.tensor([[0, 1, 1, 0]]))
     kw = dict(head_perm_flag=best, vid0=vid0, num_frame=F_, frame_size=P_)
-    # (the switched kernel is built on the one-wave-per-SIMD body: variant 3 is the same arithmetic)
+    # (reference: the one-wave-per-SIMD schedule — another kernel than the switched ones, so equal up to rounding)
     sparse_ref = nat.band_attention(q, k, v, mask, variant=3, **kw)
     dense_ref = nat.band_attention(q, k, v, dense, variant=3)
     for flag, ref in ((0, sparse_ref), (1, dense_ref)):

@@ -51,7 +51,7 @@ def test_no_mfma_hazards_no_spills(listing, capsys):
         sys.argv = argv
     out = capsys.readouterr().out
     kernels = [l for l in out.splitlines() if l.startswith("_Z")]
-    assert len(kernels) >= 8, out            # {plain, switch} x {bf16, f16} x {D 128, 64}
+    assert len(kernels) >= 4, out            # {bf16, f16} x {D 128, 64}  (the switch kernels of this body were retired in round 4)
     assert rc == 0, out
     for l in kernels:
         assert " 0 hazards, 0 spill moves" in l, l

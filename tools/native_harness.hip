@@ -167,6 +167,8 @@ __global__ void __launch_bounds__(256) ref_rows_kernel(const uint16_t* q, const 
 // ---------------------------------------------------------------- library binding (dlopen: the harness times whichever build it is given)
 typedef int (*band_fn)(const void*, const void*, const void*, void*, int32_t, int32_t, int32_t, int32_t, float, const svg_band_mask_t*,
                        const svg_perm_desc_t*, int32_t, void*);
+typedef int (*band_switch_fn)(const void*, const void*, const void*, void*, int32_t, int32_t, int32_t, int32_t, float, const svg_band_mask_t*,
+                              const svg_perm_desc_t*, const svg_band_mask_t*, const int32_t*, void*);
 typedef int (*band_pre_fn)(const void*, const void*, const void*, void*, int32_t, int32_t, int32_t, int32_t, const svg_band_mask_t*,
                            const svg_perm_desc_t*, void*);
 
@@ -192,6 +194,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 0;
     std::string occ_sym;   // --occupancy <kernel handle symbol> <dynamic LDS bytes>: resident 512-thread workgroups per CU, then exit
     int occ_lds = 0;
+    int sw = -1;           // --switch F: svg_band_attention_switch with the device flag F (0: the sparse mask with placement, 1: the dense alternative without)
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* {
@@ -209,6 +212,7 @@ int main(int argc, char** argv) {
         else if (a == "--heads") heads = atoi(next());
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
         else if (a == "--prescaled") prescaled = 1;
+        else if (a == "--switch") sw = atoi(next());
         else if (a == "--occupancy") occ_sym = next(), occ_lds = atoi(next());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -223,6 +227,7 @@ int main(int argc, char** argv) {
     auto abi = (int (*)())dlsym(so, "svg_abi_version");
     auto band = (band_fn)dlsym(so, "svg_band_attention");
     auto band_pre = (band_pre_fn)dlsym(so, "svg_band_attention_prescaled");
+    auto band_sw = (band_switch_fn)dlsym(so, "svg_band_attention_switch");
     auto strerr = (const char* (*)(int))dlsym(so, "svg_strerror");
     auto info = (const char* (*)())dlsym(so, "svg_build_info");
     if (!abi || !band || !band_pre || !strerr) { fprintf(stderr, "library lacks an entry point of include/svg_attn.h\n"); return 2; }
@@ -265,7 +270,35 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(dflags, hf.data(), H * 8, hipMemcpyHostToDevice, st));
     svg_perm_desc_t perm = {dflags, vid0, G->F, G->P};
 
+    // --switch: the alternative is the dense warm-up mask of the processors (keys of the real sequence, no placement); with flag 1 the
+    // checks below are made against IT
+    const svg_band_mask_t sparse_m = m;
+    const svg_band_mask_t dense_m = {m.real_len, S + 1, 0, 0, 0, 0};
+    int32_t* dflag = nullptr;
+    if (sw >= 0) {
+        if (!band_sw) { fprintf(stderr, "library lacks svg_band_attention_switch\n"); return 2; }
+        HIP_OK(hipMalloc(&dflag, 4));
+        HIP_OK(hipMemcpyAsync(dflag, &sw, 4, hipMemcpyHostToDevice, st));
+        if (sw) {
+            m = dense_m;
+            for (auto& f : hf) f = 0;
+            HIP_OK(hipMemsetAsync(dflags, 0, H * 8, st));   // (the reference rows below see no placement; the call still gets the real flags)
+        }
+    }
+    int64_t* dflags_call = dflags;
+    if (sw == 1) {   // the call keeps the sparse side's placement flags: a dense step must ignore them
+        std::vector<int64_t> hf2(H);
+        for (int h = 0; h < H; ++h) hf2[h] = flags == "one" ? 1 : flags == "zero" ? 0 : (h & 1);
+        HIP_OK(hipMalloc(&dflags_call, H * 8));
+        HIP_OK(hipMemcpyAsync(dflags_call, hf2.data(), H * 8, hipMemcpyHostToDevice, st));
+    }
+    svg_perm_desc_t perm_call = {dflags_call, vid0, G->F, G->P};
     auto launch = [&]() {
+        if (sw >= 0) {
+            const int rc = band_sw(q, k, v, o, H, S, D, f16 ? SVG_DTYPE_F16 : SVG_DTYPE_BF16, sm_scale, &sparse_m, &perm_call, &dense_m, dflag, st);
+            if (rc != 0) { fprintf(stderr, "band attention switch: %s\n", strerr(rc)); exit(3); }
+            return;
+        }
         const int rc = prescaled ? band_pre(q, k, v, o, H, S, D, f16 ? SVG_DTYPE_F16 : SVG_DTYPE_BF16, &m, &perm, st)
                                  : band(q, k, v, o, H, S, D, f16 ? SVG_DTYPE_F16 : SVG_DTYPE_BF16, sm_scale, &m, &perm, variant, st);
         if (rc != 0) { fprintf(stderr, "band attention: %s\n", strerr(rc)); exit(3); }
@@ -340,8 +373,8 @@ int main(int argc, char** argv) {
     }
     const double rel = ref2 > 0 ? std::sqrt(err2 / ref2) : 0.0;
     printf("{\"tool\": \"tools/native_harness\", \"lib\": \"%s\", \"build\": \"%s\", \"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"dtype\": \"%s\", "
-           "\"band\": %d, \"variant\": %d, \"prescaled\": %d, \"head_flags\": \"%s\", \"ms\": [",
-           lib.c_str(), info ? info() : "?", G->name, H, S, D, dtype.c_str(), m.band, variant, prescaled, flags.c_str());
+           "\"band\": %d, \"variant\": %d, \"prescaled\": %d, \"switch\": %d, \"head_flags\": \"%s\", \"ms\": [",
+           lib.c_str(), info ? info() : "?", G->name, H, S, D, dtype.c_str(), m.band, variant, prescaled, sw, flags.c_str());
     for (int i = 0; i < reps; ++i) printf("%s%.3f", i ? ", " : "", ms[i]);
     printf("], \"ms_mean\": %.3f, \"density\": %.4f, \"algorithmic_tflop\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.4f, "
            "\"spot_rows\": %d, \"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\"}\n",
