@@ -798,11 +798,10 @@ enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, 
 // Round 4: head_dim 128 runs the two-phase schedule on 16x16x32 MFMAs (attn_m16.h, variant 8): 32.6 ms against 34.1 - 35.7 for the
 // 32x32x16 body on the plain q, same box (profiles/r04f_ab_m16.txt, r04g_ab_m16_cfg.txt); head_dim 64 and the pre-scaled entry points keep
 // the 32x32x16 body (variant 2).
-// head_dim 64 (CogVideoX) on the plain q: the one-wave-per-SIMD body again — 13.6 / 13.9 ms against 14.2 / 14.7 for the two-phase body on two
-// boxes (profiles/r04p_clock_by_variant.txt, r04zx_clock_by_variant.txt; round 3 had measured them equal and the pre-scaled two-phase
-// form, then the default, ahead of both).  Launches that count completions and the pre-scaled entry points keep the two-phase body
-// (8 reporting waves per q-tile; the PRE form exists for it only).
-static inline int band_default(int D, bool with_counters, bool prescaled) {
+// head_dim 64 (CogVideoX) on the plain q: for a few hours of round 4 the one-wave-per-SIMD body again (13.6 / 13.9 ms against 14.2 / 14.7 for the
+// two-phase body at two waves per SIMD, profiles/r04p_clock_by_variant.txt, r04zx_clock_by_variant.txt) — until the two-phase body got its
+// four-waves form there (band_attn_pp2_kernel, 12.2 - 12.9 ms).
+static inline int band_default(int D, bool /*with_counters*/, bool /*prescaled*/) {
     // head_dim 64: the two-phase body — since it runs four waves per SIMD there (band_attn_pp2_kernel) it is ahead of the
     // one-wave-per-SIMD body on the plain q as well (12.7 - 12.9 against 13.7 - 14.3 ms on CogVideoX-v1.5, profiles/r04zr_*, r04zs_*)
     return D == 128 ? kBandM16 : kBandPingPong;
