@@ -1,0 +1,334 @@
+// native_svg2 — the SVG2 layer-call (flash-kmeans on q and k, top-p block map, variable-block attention with the fused token permutation)
+// driven through the C ABI without torch, like tools/native_harness.hip does for the band entry points: device-generated clustered inputs
+// (the 64-mode Gaussian mixture of bench_svg2.py), HIP-event timing of the three stages, an fp32 restatement of its own for spot rows, an
+// output checksum for bit-exact A/B of library builds.  Diagnostics only; nothing of the product loads it.
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/native_svg2.hip -o tools/native_svg2 -ldl
+//   tools/native_svg2 [--lib PATH] [--geom wan720p|small] [--heads H] [--variant N] [--warm W] [--reps R] [--check ROWS_PER_HEAD] [--seed N]
+//
+// Pipeline per timed step (bench_svg2.measure, svg/models/_core.py svg2_sparse_attention; reference svg/models/wan/attention.py:529-559):
+//   svg_kmeans_loop(q, 2 iterations from the previous centroids), svg_kmeans_loop(k, ...)        ref svg/kmeans_utils.py:684-733
+//   svg_identify_dynamic_map(qc, kc, k sizes, top_p 0.9, preserve 0.1 KC)                        ref svg/kmeans_utils.py:864-896
+//   svg_varblock_attention(q, k, v, map, q sizes, k sizes, q_row_idx / kv_row_idx = the sorted indices)   ref :1319-1392
+// The first call of a "layer" runs 50 iterations from rows drawn from the data (kmeans_iter_init), untimed here except as init_ms.
+// The restatement (ref_rows_kernel): row r of head h attends key j iff map[h][label_q(r)][label_k(j)] — the semantics of the reference's
+// dynamic_block_sparse_fwd_torch (svg/kmeans_utils.py:902-995) on unpermuted tensors; a row without an active key gives zeros.
+// NOTE (round 4): written at the end of the round with the GPU budget spent — compiled, first run pending.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../include/svg_attn.h"
+
+static inline void hip_ok(hipError_t e, const char* what, int line) {
+    if (e != hipSuccess) {
+        fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, line, what, hipGetErrorString(e));
+        exit(2);
+    }
+}
+#define HIP_OK(x) hip_ok((x), #x, __LINE__)
+
+__host__ __device__ inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__device__ inline uint32_t mix32(uint64_t x) {
+    x ^= x >> 33, x *= 0xff51afd7ed558ccdull, x ^= x >> 33, x *= 0xc4ceb9fe1a85ec53ull, x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ inline float normal_at(uint64_t seed, uint64_t i) {
+    const uint32_t a = mix32(seed * 0x9e3779b97f4a7c15ull + 2 * i), b = mix32(seed * 0x9e3779b97f4a7c15ull + 2 * i + 1);
+    const float u1 = ((a >> 8) + 1) * (1.f / 16777216.f), u2 = (b >> 8) * (1.f / 16777216.f);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+// x[h][n][:] = 1.5 * centre[h][mode(h, n)][:] + spread * noise: bench_svg2.clustered (64 modes per head, spread 0.35)
+__global__ void fill_clustered_kernel(uint16_t* dst, int H, int N, int D, int modes, float spread, uint64_t seed) {
+    const size_t total = (size_t)H * N * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t hn = i / D;
+        const int h = (int)(hn / N);
+        const int m = (int)(mix32(seed * 1315423911ull + hn) % (uint32_t)modes);
+        const float c = 1.5f * normal_at(seed + 101, ((uint64_t)h * modes + m) * D + d);
+        dst[i] = f32_to_bf16(c + spread * normal_at(seed + 202, i));
+    }
+}
+__global__ void fill_normal_kernel(uint16_t* dst, size_t n, uint64_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = f32_to_bf16(normal_at(seed, i));
+}
+// initial centroids: K rows of the data per head (ref svg/kmeans_utils.py:706-709 draws them with torch.randint)
+__global__ void gather_init_kernel(const uint16_t* x, uint16_t* c, int B, int N, int K, int D, uint64_t seed) {
+    const size_t total = (size_t)B * K * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const size_t bk = i / D;
+        const int b = (int)(bk / K);
+        const int row = (int)(mix32(seed * 2654435761ull + bk) % (uint32_t)N);
+        c[i] = x[((size_t)b * N + row) * D + d];
+    }
+}
+__global__ void checksum_kernel(const uint32_t* p, size_t nwords, unsigned long long* out) {
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        h += (unsigned long long)p[i] * (2ull * mix32(i) + 1ull) + mix32(i ^ p[i]);
+    atomicAdd(out, h);
+}
+
+// one workgroup per (checked head, checked row): fp32 attention over the keys whose cluster the row's cluster selects
+__global__ void __launch_bounds__(256) ref_rows_kernel(const uint16_t* q, const uint16_t* k, const uint16_t* v, const int32_t* qlab,
+                                                       const int32_t* klab, const uint8_t* map, const int* heads, const int* rows, int nrows,
+                                                       int S, int D, int QC, int KC, float scale, float* scratch, float* out) {
+    const int h = heads[blockIdx.x / nrows], i = rows[blockIdx.x % nrows];
+    const size_t hb = (size_t)h * S * D;
+    __shared__ float qs[128];
+    __shared__ float red[256];
+    __shared__ float accs[256], ls[256];
+    float* sc = scratch + (size_t)blockIdx.x * S;
+    if ((int)threadIdx.x < D) qs[threadIdx.x] = bf16_to_f32(q[hb + (size_t)i * D + threadIdx.x]);
+    __syncthreads();
+    const uint8_t* mrow = map + ((size_t)h * QC + qlab[(size_t)h * S + i]) * KC;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < S; j += 256) {
+        float s = -INFINITY;
+        if (mrow[klab[(size_t)h * S + j]]) {
+            const uint16_t* kr = k + hb + (size_t)j * D;
+            float acc = 0.f;
+            for (int d = 0; d < D; ++d) acc += qs[d] * bf16_to_f32(kr[d]);
+            s = acc * scale;
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    const int d = threadIdx.x % D, part = threadIdx.x / D, nparts = 256 / D;
+    float acc = 0.f, l = 0.f;
+    if (mx != -INFINITY) {
+        for (int j = part; j < S; j += nparts) {
+            const float s = sc[j];
+            if (s == -INFINITY) continue;
+            const float p = expf(s - mx);
+            l += p;
+            acc += p * bf16_to_f32(v[hb + (size_t)j * D + d]);
+        }
+    }
+    accs[threadIdx.x] = acc, ls[threadIdx.x] = l;
+    __syncthreads();
+    if (part == 0) {
+        for (int p2 = 1; p2 < nparts; ++p2) acc += accs[p2 * D + d], l += ls[p2 * D + d];
+        out[(size_t)blockIdx.x * D + d] = l > 0.f ? acc / l : 0.f;
+    }
+}
+
+typedef size_t (*loop_ws_fn)(int32_t, int32_t, int32_t, int32_t);
+typedef int (*loop_fn)(const void*, const float*, const void*, void*, void*, int32_t*, int32_t*, int32_t*, void*, int32_t*, int32_t, int32_t, int32_t,
+                       int32_t, int32_t, int32_t, float, void*, size_t, void*);
+typedef int (*dynmap_fn)(const void*, const void*, const int32_t*, uint8_t*, int32_t, int32_t, int32_t, int32_t, int32_t, float, int32_t, void*);
+typedef size_t (*vb_ws_fn)(int32_t, int32_t, int32_t, int32_t, int32_t);
+typedef int (*vb_fn)(const void*, const void*, const void*, void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, float, const uint8_t*,
+                     const int32_t*, const int32_t*, int32_t, int32_t, const int32_t*, const int32_t*, void*, size_t, int32_t, void*);
+
+struct Geom {
+    const char* name;
+    int H, D, S, QC, KC;
+};
+static const Geom kGeoms[] = {{"wan720p", 40, 128, 21 * 3600, 300, 1000}, {"small", 4, 128, 5000, 40, 100}};   // bench_svg2.WORKLOADS (no text rows)
+
+int main(int argc, char** argv) {
+    std::string lib = "sparse-videogen_amd/lib/libsvgattn.so", geom = "wan720p";
+    int variant = -1, warm = 1, reps = 3, check = 8, heads = 0;
+    uint64_t seed = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* {
+            if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); }
+            return argv[++i];
+        };
+        if (a == "--lib") lib = next();
+        else if (a == "--geom") geom = next();
+        else if (a == "--variant") variant = atoi(next());
+        else if (a == "--warm") warm = atoi(next());
+        else if (a == "--reps") reps = atoi(next());
+        else if (a == "--check") check = atoi(next());
+        else if (a == "--heads") heads = atoi(next());
+        else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    const Geom* G = nullptr;
+    for (const Geom& g : kGeoms) if (geom == g.name) G = &g;
+    if (!G) { fprintf(stderr, "unknown geometry %s\n", geom.c_str()); return 2; }
+    const int H = heads > 0 ? heads : G->H, D = G->D, S = G->S, QC = G->QC, KC = G->KC;
+
+    void* so = dlopen(lib.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!so) { fprintf(stderr, "dlopen %s: %s\n", lib.c_str(), dlerror()); return 2; }
+    auto abi = (int (*)())dlsym(so, "svg_abi_version");
+    auto strerr = (const char* (*)(int))dlsym(so, "svg_strerror");
+    auto info = (const char* (*)())dlsym(so, "svg_build_info");
+    auto loop_ws = (loop_ws_fn)dlsym(so, "svg_kmeans_loop_workspace_bytes");
+    auto loop = (loop_fn)dlsym(so, "svg_kmeans_loop");
+    auto dynmap = (dynmap_fn)dlsym(so, "svg_identify_dynamic_map");
+    auto vb_ws = (vb_ws_fn)dlsym(so, "svg_varblock_workspace_bytes");
+    auto vb = (vb_fn)dlsym(so, "svg_varblock_attention");
+    if (!abi || !strerr || !loop_ws || !loop || !dynmap || !vb_ws || !vb) { fprintf(stderr, "library lacks an entry point of include/svg_attn.h\n"); return 2; }
+    if (abi() != SVG_ABI_VERSION) { fprintf(stderr, "ABI %d, header %d\n", abi(), SVG_ABI_VERSION); return 2; }
+    auto ok = [&](int rc, const char* what) { if (rc != 0) { fprintf(stderr, "%s: %s\n", what, strerr(rc)); exit(3); } };
+
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+    const size_t n = (size_t)H * S * D;
+    uint16_t *q, *k, *v, *o;
+    HIP_OK(hipMalloc(&q, n * 2)), HIP_OK(hipMalloc(&k, n * 2)), HIP_OK(hipMalloc(&v, n * 2)), HIP_OK(hipMalloc(&o, n * 2));
+    fill_clustered_kernel<<<4096, 256, 0, st>>>(q, H, S, D, 64, 0.35f, 7 * seed + 1);
+    fill_clustered_kernel<<<4096, 256, 0, st>>>(k, H, S, D, 64, 0.35f, 7 * seed + 2);
+    fill_normal_kernel<<<4096, 256, 0, st>>>(v, n, 7 * seed + 3);
+    HIP_OK(hipMemsetAsync(o, 0xff, n * 2, st));
+
+    // k-means state of the two tensors
+    struct Side {
+        int K;
+        uint16_t *cur, *next, *wa, *wb;   // centroids [H, K, D]: warm start, result, scratch
+        int32_t *labels, *counts, *sorted, *nit;
+        void* ws;
+        size_t ws_bytes;
+    } sq{QC}, sk{KC};
+    for (Side* sd : {&sq, &sk}) {
+        const size_t cb = (size_t)H * sd->K * D * 2;
+        HIP_OK(hipMalloc(&sd->cur, cb)), HIP_OK(hipMalloc(&sd->next, cb)), HIP_OK(hipMalloc(&sd->wa, cb)), HIP_OK(hipMalloc(&sd->wb, cb));
+        HIP_OK(hipMalloc(&sd->labels, (size_t)H * S * 4)), HIP_OK(hipMalloc(&sd->sorted, (size_t)H * S * 4));
+        HIP_OK(hipMalloc(&sd->counts, (size_t)H * sd->K * 4)), HIP_OK(hipMalloc(&sd->nit, 4));
+        sd->ws_bytes = loop_ws(H, S, sd->K, D);
+        HIP_OK(hipMalloc(&sd->ws, sd->ws_bytes));
+    }
+    auto kmeans = [&](Side& sd, const uint16_t* x, int iters) {   // warm start from sd.cur, result into sd.next, then swap
+        ok(loop(x, nullptr, sd.cur, sd.wa, sd.wb, sd.labels, sd.counts, sd.sorted, sd.next, sd.nit, H, S, sd.K, D, SVG_DTYPE_BF16, iters, 1e-4f,
+                sd.ws, sd.ws_bytes, st), "svg_kmeans_loop");
+        std::swap(sd.cur, sd.next);
+    };
+    uint8_t* dmap;
+    HIP_OK(hipMalloc(&dmap, (size_t)H * QC * KC));
+    const size_t vws_bytes = vb_ws(H, H, QC, KC, S);
+    void* vws;
+    HIP_OK(hipMalloc(&vws, vws_bytes));
+    const float sm_scale = 1.f / sqrtf((float)D);
+
+    hipEvent_t i0, i1;
+    HIP_OK(hipEventCreate(&i0)), HIP_OK(hipEventCreate(&i1));
+    gather_init_kernel<<<1024, 256, 0, st>>>(q, sq.cur, H, S, QC, D, 7 * seed + 4);
+    gather_init_kernel<<<1024, 256, 0, st>>>(k, sk.cur, H, S, KC, D, 7 * seed + 5);
+    HIP_OK(hipEventRecord(i0, st));
+    kmeans(sq, q, 50), kmeans(sk, k, 50);
+    HIP_OK(hipEventRecord(i1, st));
+
+    const int total = warm + reps;
+    std::vector<hipEvent_t> ev(4 * total);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    for (int it = 0; it < total; ++it) {
+        HIP_OK(hipEventRecord(ev[4 * it + 0], st));
+        kmeans(sq, q, 2), kmeans(sk, k, 2);
+        HIP_OK(hipEventRecord(ev[4 * it + 1], st));
+        ok(dynmap(sq.cur, sk.cur, sk.counts, dmap, H, QC, KC, D, SVG_DTYPE_BF16, 0.9f, (int)(0.1 * KC), st), "svg_identify_dynamic_map");
+        HIP_OK(hipEventRecord(ev[4 * it + 2], st));
+        ok(vb(q, k, v, o, H, H, S, S, D, SVG_DTYPE_BF16, sm_scale, dmap, sq.counts, sk.counts, QC, KC, sq.sorted, sk.sorted, vws, vws_bytes, variant, st),
+           "svg_varblock_attention");
+        HIP_OK(hipEventRecord(ev[4 * it + 3], st));
+    }
+    HIP_OK(hipStreamSynchronize(st));
+    float init_ms = 0;
+    HIP_OK(hipEventElapsedTime(&init_ms, i0, i1));
+    double ms[4] = {0, 0, 0, 0};   // k-means, map, attention, total
+    for (int it = warm; it < total; ++it) {
+        float a = 0, b = 0, c = 0;
+        HIP_OK(hipEventElapsedTime(&a, ev[4 * it], ev[4 * it + 1])), HIP_OK(hipEventElapsedTime(&b, ev[4 * it + 1], ev[4 * it + 2]));
+        HIP_OK(hipEventElapsedTime(&c, ev[4 * it + 2], ev[4 * it + 3]));
+        ms[0] += a / reps, ms[1] += b / reps, ms[2] += c / reps, ms[3] += (a + b + c) / reps;
+    }
+
+    // algorithmic pairs of the last map: sum over heads of map x |q cluster| x |k cluster|
+    std::vector<uint8_t> hmap((size_t)H * QC * KC);
+    std::vector<int32_t> hqs((size_t)H * QC), hks((size_t)H * KC);
+    HIP_OK(hipMemcpy(hmap.data(), dmap, hmap.size(), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(hqs.data(), sq.counts, hqs.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(hks.data(), sk.counts, hks.size() * 4, hipMemcpyDeviceToHost));
+    double pairs = 0;
+    long long qsum = 0, ksum = 0;
+    for (int h = 0; h < H; ++h) {
+        for (int i = 0; i < QC; ++i) {
+            long long keys = 0;
+            for (int j = 0; j < KC; ++j) keys += hmap[((size_t)h * QC + i) * KC + j] ? hks[(size_t)h * KC + j] : 0;
+            pairs += (double)keys * hqs[(size_t)h * QC + i];
+        }
+        for (int i = 0; i < QC; ++i) qsum += hqs[(size_t)h * QC + i];
+        for (int j = 0; j < KC; ++j) ksum += hks[(size_t)h * KC + j];
+    }
+    const double flop = 4.0 * D * pairs;
+
+    unsigned long long* dsum;
+    unsigned long long osum = 0;
+    HIP_OK(hipMalloc(&dsum, 8)), HIP_OK(hipMemset(dsum, 0, 8));
+    checksum_kernel<<<2048, 256, 0, st>>>((const uint32_t*)o, n / 2, dsum);
+    HIP_OK(hipMemcpyAsync(&osum, dsum, 8, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+
+    double err2 = 0, ref2 = 0, maxabs = 0;
+    int nck = 0;
+    if (check > 0) {
+        std::vector<int> rows, hs;
+        for (int r = 0; r < check; ++r) rows.push_back((int)(((long long)r * 7919 + 13) * (S / check + 1) % S));
+        for (int h : {0, H / 2, H - 1}) if (hs.empty() || hs.back() != h) hs.push_back(h);
+        const int nb = (int)(rows.size() * hs.size());
+        int *drows, *dheads;
+        float *scratch, *dout;
+        HIP_OK(hipMalloc(&drows, rows.size() * 4)), HIP_OK(hipMalloc(&dheads, hs.size() * 4));
+        HIP_OK(hipMalloc(&scratch, (size_t)nb * S * 4)), HIP_OK(hipMalloc(&dout, (size_t)nb * D * 4));
+        HIP_OK(hipMemcpy(drows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(dheads, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+        ref_rows_kernel<<<nb, 256, 0, st>>>(q, k, v, sq.labels, sk.labels, dmap, dheads, drows, (int)rows.size(), S, D, QC, KC, sm_scale, scratch, dout);
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<float> ref((size_t)nb * D);
+        HIP_OK(hipMemcpy(ref.data(), dout, ref.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint16_t> row(D);
+        for (size_t hi = 0; hi < hs.size(); ++hi)
+            for (size_t ri = 0; ri < rows.size(); ++ri) {
+                HIP_OK(hipMemcpy(row.data(), o + ((size_t)hs[hi] * S + rows[ri]) * D, D * 2, hipMemcpyDeviceToHost));
+                for (int d = 0; d < D; ++d) {
+                    const double got = bf16_to_f32(row[d]), want = ref[(hi * rows.size() + ri) * D + d];
+                    err2 += (got - want) * (got - want), ref2 += want * want;
+                    maxabs = std::max(maxabs, std::fabs(got - want));
+                }
+                ++nck;
+            }
+    }
+    const double rel = ref2 > 0 ? std::sqrt(err2 / ref2) : 0.0;
+    printf("{\"tool\": \"tools/native_svg2\", \"lib\": \"%s\", \"build\": \"%s\", \"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"QC\": %d, \"KC\": %d, "
+           "\"variant\": %d, \"kmeans_init_50it_ms\": %.2f, \"ms\": {\"kmeans_2it_qk\": %.3f, \"identify_map\": %.3f, \"attention\": %.3f, \"total\": %.3f}, "
+           "\"density\": %.4f, \"rows_in_clusters\": [%lld, %lld], \"attention_tflops\": %.1f, \"attention_frac_of_2500\": %.4f, \"spot_rows\": %d, "
+           "\"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\"}\n",
+           lib.c_str(), info ? info() : "?", G->name, H, S, D, QC, KC, variant, init_ms, ms[0], ms[1], ms[2], ms[3], pairs / ((double)H * S * S), qsum, ksum,
+           flop / (ms[2] * 1e-3) / 1e12, flop / (ms[2] * 1e-3) / 2.5e15, nck, rel, maxabs, osum);
+    if (qsum != (long long)H * S || ksum != (long long)H * S) { fprintf(stderr, "cluster sizes do not add up to the token count\n"); return 4; }
+    if (nck > 0 && !(rel <= 4e-3)) { fprintf(stderr, "spot rows: rel. L2 %.3e above 4e-3 (bench_svg2's bound)\n", rel); return 4; }
+    return 0;
+}
