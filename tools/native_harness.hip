@@ -178,15 +178,31 @@ struct Geom {
     double width_frames;   // band half-width in frames (sparsity_to_width of the model's script)
     int kind;              // 0 Hunyuan (text last, prompt L of ctx), 1 Wan (ceil + 1, sink columns, no text), 2 CogVideoX (text first)
 };
-// widths: svg/models/hyvideo/utils.py:142-151 at sparsity 0.25 (Hunyuan) / svg/models/wan/utils.py at 0.3 — SURVEY §8(d): bands 15616 / 12416
-static const Geom kGeoms[] = {{"hy720p", 24, 128, 33, 3600, 256, 64, 4.3487, 0},
-                              {"wan720p", 40, 128, 21, 3600, 0, 0, 3.4301, 1},
-                              {"hy480p", 24, 128, 33, 1350, 256, 64, 4.3487, 0},
+// widths: sparsity_to_width (svg/models/hyvideo/utils.py:142-151) of each geometry at sparsity 0.25 (Hunyuan) / 0.3 (Wan) — SURVEY §8(d): bands
+// 15616 / 12416 + 1 at 720p, 5632 at Hunyuan 480p; tests/test_native_harness_cpu.py holds these constants to the product's mask builders
+static const Geom kGeoms[] = {{"hy720p", 24, 128, 33, 3600, 256, 64, 4.348694090495091, 0},
+                              {"wan720p", 40, 128, 21, 3600, 0, 0, 3.430139442784413, 1},
+                              {"hy480p", 24, 128, 33, 1350, 256, 64, 4.228429541193822, 0},
                               {"small", 4, 128, 5, 160, 256, 64, 1.7, 0},
                               // svg/models/cog/utils.py at sparsity 0.25: bands 2048 / 5760 (tools/svg1_models.py), cfg = 2 x 48 heads, head_dim 64
                               {"cog480p", 96, 64, 13, 1350, 226, 226, 1.5724038952394224, 2},
                               {"cog15", 96, 64, 11, 4080, 226, 226, 1.4173925802088359, 2},
                               {"small64", 6, 64, 5, 160, 226, 226, 1.7, 2}};
+
+// #allowed (q, k) pairs of a mask, counted from the predicate row by row (closed forms: SURVEY §8(d))
+static double count_pairs(const svg_band_mask_t& m, int S) {
+    double pairs = 0;
+    for (int i = 0; i < S; ++i) {
+        if (i >= m.real_len) { pairs += S - m.real_len; continue; }
+        if (i >= m.rowfull_lo && i < m.rowfull_hi) { pairs += m.real_len; continue; }
+        const int lo = std::max(0, i - m.band + 1), hi = std::min(m.real_len, i + m.band);   // band: [lo, hi)
+        double c = hi - lo;
+        const int clo = std::max(m.colfull_lo, 0), chi = std::min(m.colfull_hi, m.real_len);
+        if (chi > clo) c += (chi - clo) - std::max(0, std::min(hi, chi) - std::max(lo, clo));
+        pairs += c;
+    }
+    return pairs;
+}
 
 int main(int argc, char** argv) {
     std::string lib = "sparse-videogen_amd/lib/libsvgattn.so", geom = "hy720p", dtype = "bf16", flags = "half";
@@ -194,6 +210,7 @@ int main(int argc, char** argv) {
     uint64_t seed = 0;
     std::string occ_sym;   // --occupancy <kernel handle symbol> <dynamic LDS bytes>: resident 512-thread workgroups per CU, then exit
     int occ_lds = 0;
+    int dry = 0;           // --dry: print the geometry and the mask the run would use (no GPU, no library call), then exit
     int sw = -1;           // --switch F: svg_band_attention_switch with the device flag F (0: the sparse mask with placement, 1: the dense alternative without)
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -212,6 +229,7 @@ int main(int argc, char** argv) {
         else if (a == "--heads") heads = atoi(next());
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
         else if (a == "--prescaled") prescaled = 1;
+        else if (a == "--dry") dry = 1;
         else if (a == "--switch") sw = atoi(next());
         else if (a == "--occupancy") occ_sym = next(), occ_lds = atoi(next());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -251,6 +269,11 @@ int main(int argc, char** argv) {
     else if (G->kind == 2) m = {S, (int)std::floor(G->width_frames * G->P / 128.0) * 128, 0, G->L, 0, G->L};
     else m = {V + G->L, (int)std::floor(G->width_frames * G->P / 128.0) * 128, V, V + G->L, V, V + G->L};
     const float sm_scale = 1.f / sqrtf((float)D);
+    if (dry) {   // what tests/test_boundary_cpu.py holds against the oracle's mask builders
+        printf("{\"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"vid0\": %d, \"F\": %d, \"P\": %d, \"mask\": [%d, %d, %d, %d, %d, %d], \"pairs\": %.0f}\n", G->name, H, S, D,
+               vid0, G->F, G->P, m.real_len, m.band, m.colfull_lo, m.colfull_hi, m.rowfull_lo, m.rowfull_hi, count_pairs(m, S));
+        return 0;
+    }
 
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
@@ -323,17 +346,7 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpyAsync(&osum, dsum, 8, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
 
-    // algorithmic pairs: counted from the predicate, row by row (closed forms: SURVEY §8(d))
-    double pairs = 0;
-    for (int i = 0; i < S; ++i) {
-        if (i >= m.real_len) { pairs += S - m.real_len; continue; }
-        if (i >= m.rowfull_lo && i < m.rowfull_hi) { pairs += m.real_len; continue; }
-        const int lo = std::max(0, i - m.band + 1), hi = std::min(m.real_len, i + m.band);   // band: [lo, hi)
-        double c = hi - lo;
-        const int clo = std::max(m.colfull_lo, 0), chi = std::min(m.colfull_hi, m.real_len);
-        if (chi > clo) c += (chi - clo) - std::max(0, std::min(hi, chi) - std::max(lo, clo));
-        pairs += c;
-    }
+    const double pairs = count_pairs(m, S);
     const double flop = 4.0 * D * H * pairs;
 
     // spot rows against the fp32 restatement
