@@ -63,7 +63,10 @@ __global__ __launch_bounds__(512, 2) void band_attn_pp2_frozen_kernel(typename B
 // the two-phase schedule on v_mfma_f32_16x16x32 (attn_m16.h): head_dim 128; variant 8
 // (issue priority in the matrix phase, ONE barrier per tile: 32.55 ms against 33.1 with two — profiles/r04g_ab_m16_cfg.txt; the 32x32x16
 //  body gained nothing from the single barrier because the clock took it back, this one runs ~300 MHz further from the power limit)
-template <typename T, int PRIO = 1, int ONEBAR = 1>
+#ifndef SVG_M16_PRIO
+#define SVG_M16_PRIO 1
+#endif
+template <typename T, int PRIO = SVG_M16_PRIO, int ONEBAR = 1>
 __global__ __launch_bounds__(512, 2) void band_attn_m16_kernel(typename BandPolicy<T, 128, 8, false>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, PRIO, ONEBAR>(prm, smem, nullptr);

@@ -110,6 +110,18 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     constexpr int kPF = 8;                  // operand fragments in flight ahead of their MFMAs
     constexpr bool kOneBar = ONEBAR < 0 ? P::kOneBarrier : (ONEBAR != 0);   // one workgroup barrier per tile instead of two (attn_body_pp2: on for the variable-block policy)
     static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1 && !P::kPartialOut && !P::kFixup && P::kIntervalMask, "band / variable-block policy");
+    // MSUM (SVG_M16_MFMASUM, bf16, plain form): the row sum on the matrix pipe.  Four extra MFMAs per tile (A = a fragment of ones, B = the
+    // P fragment: every accumulator of a lane receives the COMPLETE sum of its query row over the chunk's 32 keys) replace the 32 v_add of
+    // the vector phase; the overflow test of the max-free softmax — a probability above the reference by more than 2^kBias — becomes a bit
+    // test on the packed bf16 probabilities: with the exponent argument lowered by kBias a probability reaches 2.0 (exponent field >= 128,
+    // bit 14 / 30 of the packed word: the OR of all sixteen words shows it, 8 v_or3_b32) exactly when the row sum test of the plain
+    // form would be near its 2048.  O and l carry the common factor 2^-kBias, which the final division removes.
+#ifdef SVG_M16_MFMASUM
+    constexpr bool MSUM = std::is_same_v<T, __bf16> && !PRE;
+#else
+    constexpr bool MSUM = false;
+#endif
+    constexpr float kBias = MSUM ? 10.f : 0.f;
 
     typename P::Ctx ctx;
     if (!P::init(prm, ctx, policy_lds)) return;
@@ -196,6 +208,12 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     const int v_lane1 = v_lane0 ^ 32;                                                                // odd ones
 
     float m_run[2] = {-INFINITY, -INFINITY}, m_use[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
+    float m_sub[2] = {kBias, kBias};                                   // what the exponent argument subtracts: m_use + kBias
+    f32x4 acc_l[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // MSUM: row sums (every element the same complete sum)
+    V8 ones8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones8[j] = E::from_float(1.f);
+    bool force_exact = true;                                           // MSUM: psum_thr < 0
     f32x4 acc_o[NDB][2];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -204,6 +222,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc_o[db][rb][r] = 0.f;
     const float c_log2 = prm.scale_log2;
+    if constexpr (MSUM) asm volatile("" : "+v"(ones8));
 
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -255,8 +274,8 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                     float p;
                     if constexpr (PRE && shifted) p = __builtin_amdgcn_exp2f(sc[2 * kc + h][rb][r] + pre_shift[rb]);
                     else if constexpr (PRE) p = __builtin_amdgcn_exp2f(sc[2 * kc + h][rb][r]);    // the MFMAs delivered the exponent argument
-                    else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * kc + h][rb][r], c_log2, -m_use[rb]));
-                    psum[rb] += p;
+                    else p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[2 * kc + h][rb][r], c_log2, -m_sub[rb]));
+                    if constexpr (!MSUM) psum[rb] += p;
                     pf[kc][rb][4 * h + r] = E::from_float(p);
                 }
     };
@@ -302,7 +321,18 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
             probs(kc);
             asm volatile("" : "+v"(pf[kc][0]), "+v"(pf[kc][1]), "+v"(psum[0]), "+v"(psum[1]));   // stays in this phase
         }
-        const bool exact = !__all(psum[0] + psum[1] <= psum_thr);
+        bool exact;
+        if constexpr (MSUM) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t w0 = __builtin_bit_cast(u32x4_t, pf[0][0]), w1 = __builtin_bit_cast(u32x4_t, pf[0][1]);
+            const u32x4_t w2 = __builtin_bit_cast(u32x4_t, pf[1][0]), w3 = __builtin_bit_cast(u32x4_t, pf[1][1]);
+            const unsigned o0 = w0[0] | w0[1] | w0[2], o1 = w0[3] | w1[0] | w1[1], o2 = w1[2] | w1[3] | w2[0];   // (v_or3_b32, depth 3)
+            const unsigned o3 = w2[1] | w2[2] | w2[3], o4 = w3[0] | w3[1] | w3[2];
+            const unsigned bits = (o0 | o1 | o2) | (o3 | o4 | w3[3]);
+            exact = force_exact || __any((bits & 0x40004000u) != 0u);
+        } else {
+            exact = !__all(psum[0] + psum[1] <= psum_thr);
+        }
         if (exact) {      // exact path (rare; always until every row has a finite reference; also a non-finite sum)
             bool all_finite = true;
             float alpha[2];
@@ -322,12 +352,21 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 else mx *= c_log2;
                 const float m_new = fmaxf(m_run[rb], mx);
                 m_use[rb] = (m_new == -INFINITY) ? m_prev : m_new;
+                m_sub[rb] = m_use[rb] + kBias;
                 float a = __builtin_amdgcn_exp2f(fminf(m_prev - m_use[rb], 126.f));
                 asm volatile("s_nop 1" : "+v"(a));  // v_exp_f32 -> inline-asm consumer: hipcc does not insert the wait state
                 alpha[rb] = a;
                 m_run[rb] = m_new;
                 all_finite = all_finite && (m_new != -INFINITY);
                 l_run[rb] *= a;
+                if constexpr (MSUM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc_l[rb][r];
+                        asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x) : "v"(a));
+                        acc_l[rb][r] = x;
+                    }
+                }
                 if constexpr (PRE) {
                     pre_shift[rb] = m_prev - m_use[rb];
                     // what the next S^T accumulators start from.  Rewritten IN PLACE (tied asm operands): as plain assignments hipcc keeps
@@ -342,6 +381,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 }
             }
             psum_thr = __all(all_finite) ? 2048.f : -1.f;
+            force_exact = !__all(all_finite);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -365,6 +405,11 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     // Matrix phase: O^T += V(t)^T P(t)^T (16 fragments, 32 MFMAs), then S(t+1)^T = K(t+1) Q^T (16 fragments, 32 MFMAs).  One step =
     // { LDS read of the fragment kPF steps ahead; the fragment's two MFMAs (row blocks 0 and 1) }, fenced with sched_barrier.
     constexpr int NPV = 2 * NDB;
+#ifdef SVG_M16_MSUM_AT
+    constexpr int kMsumAt = SVG_M16_MSUM_AT;
+#else
+    constexpr int kMsumAt = NDB - 1;   // the d block after whose MFMAs the chunk's two row-sum MFMAs are issued
+#endif
     i16x8 ring[kPF + 1];
     i16x8 carry[kCarry];
     auto carry_load = [&](int t, int i) { carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB); };
@@ -397,7 +442,14 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 const V8 a = __builtin_bit_cast(V8, i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)]);
                 acc_o[db][0] = M::mfma(a, pf[kc][0], acc_o[db][0]);
                 acc_o[db][1] = M::mfma(a, pf[kc][1], acc_o[db][1]);
-                if (i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
+                if constexpr (MSUM) {
+                    if (db == kMsumAt) {
+                        acc_l[0] = M::mfma(ones8, pf[kc][0], acc_l[0]);
+                        acc_l[1] = M::mfma(ones8, pf[kc][1], acc_l[1]);
+                    }
+                } else {
+                    if (i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
+                }
             } else {
                 const int j = i - NPV, ks = j >> 2, b = j & 3;
                 const Q8 a = __builtin_bit_cast(Q8, ring[i % (kPF + 1)]);
@@ -467,6 +519,9 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         matrix_phase(t, has_next_c);
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
+    if constexpr (PRIO == 3) {   // static priority for the younger half (cdna_hip_programming.md T5, static form): no per-phase flips
+        if (lagging) __builtin_amdgcn_s_setprio(1);
+    }
     // steady state: every tile a phase of tile t touches (t + dist + 1 at most) exists; then the guarded tail; then the peeled last tile
     int t = 0;
     for (const int n_main = nT - dist - 1; t < n_main; ++t) tile(t, std::true_type{}, std::false_type{});
@@ -488,7 +543,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     char* erow = smem + (size_t)(wave * 32) * kEpiStride;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-        const float l_tot = quad_group_sum(l_run[rb]);
+        const float l_tot = MSUM ? acc_l[rb][0] : quad_group_sum(l_run[rb]);
         const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {

@@ -170,6 +170,125 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
     sink[blockIdx.x * 512 + threadIdx.x] = c[0][0] + c[1][1] + c[2][2] + c[3][3] + a0 + a1 + a2 + a3 + a4 + acc16;
 }
 
+// "the kernel" row (round 5, VERDICT r04 next #1b): a synthetic stream that should REPRODUCE band_attn_m16_kernel's operating point (matrix pipe
+// busy 0.64, 1.96 - 2.04 GHz) — if it does, the table's other rows can be trusted for what-if questions about that kernel.  Beyond mix_kernel<4, 4, 2, 1>:
+//   * the tile structure of attn_body_m16 with ONE barrier per tile (leading waves: N, barrier, M; lagging waves: barrier, N, M);
+//   * XV extra VALU and XS extra SALU per tile in the vector phase (the mask classification, DMA address arithmetic, reference test: the listing
+//     has ~24 vector and ~50 scalar instructions beside the 112);
+//   * the K / V stream at the kernel's prefetch distance (2 tiles for the leading, 3 for the lagging waves; the wait leaves one tile's four
+//     requests in flight), every `miss_every`-th request of a wave going to a window of `window` bytes that it shares with every other workgroup
+//     in a scattered order (64 MiB - 192 MiB: resident in the 256 MiB Infinity Cache, not in a 4 MiB L2: the kernel's 19 % L2 misses are its
+//     neighbours' tiles, i.e. fabric / MALL traffic, not first-touch HBM reads), the others to a 1 MiB window (L2 hits).
+template <int XV, int XS>
+__global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src, unsigned long long window, int miss_every, int tiles,
+                                                    unsigned long long* __restrict__ ticks, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < kStage * kStages / 4; i += blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        x ^= x >> 13;
+        const unsigned hi = 0x3f000000u | ((x & 0x7f00u) << 8) | ((x & 0x8000u) << 16);
+        const unsigned lo = 0x3f00u | ((x >> 16) & 0x7fu) | ((x >> 8) & 0x8000u);
+        ((unsigned*)lds)[i] = hi | lo;
+    }
+    __syncthreads();
+    float a0 = threadIdx.x * 0.001f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = 0;
+    unsigned x0 = threadIdx.x * 7u + 1u, x1 = threadIdx.x * 13u + 5u;
+    f32x4m d16[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+    bf16x8 Bq[4];
+    for (int j = 0; j < 4; ++j)
+        for (int e = 0; e < 8; ++e) Bq[j][e] = (__bf16)(0.01f * (float)(((lane * 8 + e) * 37 + j * 11) % 97 - 48));
+    const char* pk = lds + lane * 16;
+    const char* pv = lds + lane * 8;
+    const bool second = wave >= 4;
+    constexpr int PF = 8;
+    bf16x8 ring[PF + 1];
+    auto fetch = [&](int i, int stage, int slot) {
+        const char* base_k = pk + stage * kStage;
+        const char* base_v = pv + stage * kStage + kStage / 2;
+        if (i >= 16) {   // (the kernel's order: V fragments first, then K)
+            i32x4 x = *((__attribute__((address_space(3))) i32x4*)(base_k + (i - 16) * 1024));
+            ring[slot] = __builtin_bit_cast(bf16x8, x);
+        } else {
+            const int off = i * 1024;
+            i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base_v + off));
+            i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(base_v + off + 512));
+            i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            ring[slot] = __builtin_bit_cast(bf16x8, both);
+        }
+    };
+    auto matrix_phase = [&](int stage) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) fetch(i, stage, i % (PF + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i + PF < 32) fetch(i + PF, stage, (i + PF) % (PF + 1));
+            d16[(2 * i) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i % (PF + 1)], Bq[i & 3], d16[(2 * i) & 7], 0, 0, 0);
+            d16[(2 * i + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i % (PF + 1)], Bq[(i + 1) & 3], d16[(2 * i + 1) & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    const int dist = second ? 3 : 2;
+    unsigned req = (blockIdx.x * 8u + wave) * 977u;   // request counter of this wave (which requests miss)
+    auto dma = [&](int t) {
+        const unsigned stage = (unsigned)((t + dist) % kStages);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + stage * kStage + (wave * 4 + j) * 1024u);
+            unsigned long long off;
+            ++req;
+            if (miss_every > 0 && (req % (unsigned)miss_every) == 0u) {
+                unsigned long long h = (unsigned long long)req * 0x9e3779b97f4a7c15ull + (unsigned long long)t * 0xbf58476d1ce4e5b9ull;
+                h ^= h >> 29;
+                off = ((h % (window >> 10)) << 10) + (1ull << 20);
+            } else {
+                off = (((unsigned)t * 32768u + (wave * 4 + j) * 1024u) & (1048576u - 1));
+            }
+            const char* base = src + off;
+            const unsigned voff = lane * 16u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsb), "v"(voff), "s"(base) : "memory");
+        }
+    };
+    auto vector_phase = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            asm volatile("v_exp_f32 %0, %1\n\tv_add_f32 %1, %1, %0\n\tv_fract_f32 %1, %1\n\tv_exp_f32 %2, %3\n\t"
+                         "v_fma_f32 %3, %3, %6, %2\n\tv_fract_f32 %3, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %2"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=v"(a4) : "v"(0.001f), "v"(0.999f));
+            if (r == 3) dma(t);
+        }
+#pragma unroll
+        for (int r = 0; r < XV / 2; ++r) asm volatile("v_xor_b32 %0, %0, %1\n\tv_add_u32 %1, %1, %0" : "+v"(x0), "+v"(x1));
+        unsigned s0 = (unsigned)t, s1 = 17u;
+#pragma unroll
+        for (int r = 0; r < XS / 2; ++r) asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0" : "+s"(s0), "+s"(s1) : : "scc");
+        asm volatile("" :: "s"(s0), "s"(s1));
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    for (int t = 0; t < 2; ++t) dma(t - dist);   // (stages 0, 1 requested up front; the addresses do not matter)
+    __syncthreads();
+    const unsigned long long w0 = wall_clock64(), t0 = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < tiles; ++t) {
+        if (second) __syncthreads();
+        vector_phase(t);
+        if (!second) __syncthreads();
+        matrix_phase(t % kStages);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        ticks[blockIdx.x * 2 + 0] = t1 - t0;
+        ticks[blockIdx.x * 2 + 1] = w1 - w0;
+    }
+    float acc16 = 0.f;
+    for (int j = 0; j < 8; ++j) acc16 += d16[j][0] + d16[j][3];
+    sink[blockIdx.x * 512 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + acc16 + (float)(x0 ^ x1);
+}
+
 // duty 1.0 reference: both waves of a SIMD issue MFMAs back to back, nothing else.  SHAPE 0: 32x32x16 (32 per tile and wave), 1: 16x16x32
 // (64 per tile and wave: the same FLOPs).  TOGGLE: four different A and four different B fragments in rotation (operand data that changes
 // from MFMA to MFMA, like real K / V / P); else one constant fragment of small values for everything.
@@ -295,6 +414,33 @@ void row(const char* name, double target, int tiles, const char* src, unsigned l
     fflush(stdout);
 }
 
+template <int XV, int XS>
+void kernel_row(const char* name, const char* src, unsigned long long window, int miss_every, int tiles, unsigned long long* ticks, float* sink, Power* pw) {
+    CHECK(hipFuncSetAttribute((const void*)kernel_like<XV, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, kStage * kStages));
+    double mhz = 0, duty = 0, watts = 0;
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        if (rep) pw->start();
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((kernel_like<XV, XS>), dim3(256), dim3(512), kStage * kStages, 0, src, window, miss_every, tiles, ticks, sink);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        if (rep) watts = pw->stop();
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(512);
+        CHECK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
+        double sh = 0, wl = 0;
+        for (int b = 0; b < 256; ++b) { sh += (double)h[2 * b]; wl += (double)h[2 * b + 1]; }
+        mhz = 100.0 * sh / wl;
+        duty = (double)tiles * 64.0 * 32.0 / (ms * 1e-3 * mhz * 1e6);
+        CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+    }
+    printf("| %-58s | %3d | %.3f | %.3f | %4.0f | %.4f | %6.1f | %5.0f |\n", name, 0, duty, duty, mhz, duty * mhz / 2400.0, ms, watts);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const double target = (argc > 1 ? atof(argv[1]) : 77.0) / 100.0;
     const int tiles = argc > 2 ? atoi(argv[2]) : 40000;
@@ -305,6 +451,7 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&ticks, 256 * 8 * 2 * 8));
     CHECK(hipMalloc(&sink, 256 * 512 * 4));
     Power pw;
+    const bool only_kernel_rows = argc > 3 && std::string(argv[3]) == "kernel";
     printf("energy table: 256 workgroups x 8 waves, 32 MFMA 32x32x16 bf16 per wave and tile, %d tiles per launch, target duty %.2f; power sensor: %s\n",
            tiles, target, pw.path.empty() ? "none found" : pw.path.c_str());
     printf("| mix (per 32 MFMAs and wave)                                | pad | duty unpadded | duty | MHz | frac of nominal peak | ms | W (max sample) |\n|---|---|---|---|---|---|---|---|\n");
@@ -327,6 +474,7 @@ int main(int argc, char** argv) {
         }
         fflush(stdout);
     };
+    if (!only_kernel_rows) {
     only(mfma_only_kernel<0, true>, "MFMA 32x32x16 only, back to back, operands toggling");
     only(mfma_only_kernel<0, false>, "MFMA 32x32x16 only, back to back, constant operands");
     only(mfma_only_kernel<1, true>, "MFMA 16x16x32 only, back to back, operands toggling");
@@ -351,5 +499,15 @@ int main(int argc, char** argv) {
     row<4, 4, 1, 1>("16x16x32: + 48 LDS + 112 VALU + DMA (L2 hits)", target, tiles, src, stream_bytes, ticks, sink, &pw);
     row<4, 4, 2, 1>("16x16x32: + 48 LDS + 112 VALU + DMA (1/4 misses)", target, tiles, src, stream_bytes, ticks, sink, &pw);
     row<4, 4, 1, 0>("32x32x16 again: + 48 LDS + 112 VALU + DMA (L2 hits)", target, tiles, src, stream_bytes, ticks, sink, &pw);
+    }
+    printf("| kernel-like rows: attn_body_m16's tile structure, one barrier per tile, prefetch distance 2 / 3, no padding (what should reproduce duty 0.64 at 1.96 - 2.04 GHz) | | | | | | | |\n");
+    kernel_row<0, 0>("kernel-like, no misses, no bookkeeping", src, 64ull << 20, 0, tiles, ticks, sink, &pw);
+    kernel_row<24, 48>("kernel-like, no misses, + 24 VALU + 48 SALU bookkeeping", src, 64ull << 20, 0, tiles, ticks, sink, &pw);
+    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 64 MiB window (MALL)", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
+    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 192 MiB window (MALL)", src, 192ull << 20, 5, tiles, ticks, sink, &pw);
+    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 2 GiB window (HBM)", src, 2047ull << 20, 5, tiles, ticks, sink, &pw);
+    kernel_row<24, 48>("kernel-like, 1 request in 3 to a 64 MiB window (MALL)", src, 64ull << 20, 3, tiles, ticks, sink, &pw);
+    kernel_row<0, 0>("kernel-like, 1 in 5 to 64 MiB, no bookkeeping", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
+    kernel_row<48, 96>("kernel-like, 1 in 5 to 64 MiB, 48 VALU + 96 SALU", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
     return 0;
 }

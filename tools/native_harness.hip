@@ -7,6 +7,14 @@
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/native_harness.hip -o tools/native_harness -ldl
 //   tools/native_harness [--lib PATH] [--geom hy720p|wan720p|hy480p|small|cog480p|cog15|small64] [--dtype bf16|f16] [--variant N] [--prescaled]
 //                        [--flags half|zero|one] [--heads H] [--warm W] [--reps R] [--check ROWS] [--seed N]
+//                        [--fill normal|zero|const] [--band KEYS] [--no-clock] [--profiler]
+// --profiler: time svg_sample_mse (the online profiler, 64 sampled rows below min(10000, V), the model's profiling masks with the bf16
+// emulation on — what bench.py's timed step runs in front of the attention launch) instead of the attention; prints the 2 x H mse values'
+// sum and a checksum of their bits (A/B of library builds).
+// --fill zero / const: q, k, v all zero / all 1.0 — the same instruction stream on operands that never toggle (the schedule-only ceiling:
+// what the launch takes when the power management has nothing to limit; MI355X_MICROARCH.md "DVFS give-back").  --band overrides the
+// band half-width of the geometry's mask (tools/band_sweep through the harness).  The shader clock granted to the timed launches is
+// read by the library's one-wave probe (svg_debug_clock_probe) on a second stream: "sclk_mhz", and "mcycles" = ms x sclk.
 // Output: one JSON line (ms per launch, algorithmic TFLOP/s, spot-row error against the fp32 restatement below).
 //
 // The fp32 restatement (ref_rows_kernel) follows the predicate documented at svg_band_mask_t in include/svg_attn.h and the fused
@@ -68,11 +76,19 @@ static float f16_to_f32_host(uint16_t b) {
     return s ? -v : v;
 }
 
+static inline uint32_t mix32_host(uint64_t x) {
+    x ^= x >> 33, x *= 0xff51afd7ed558ccdull, x ^= x >> 33, x *= 0xc4ceb9fe1a85ec53ull, x ^= x >> 33;
+    return (uint32_t)x;
+}
 // ---------------------------------------------------------------- input generator: counter-based normal variates
 __device__ inline uint32_t mix32(uint64_t x) {
     x ^= x >> 33, x *= 0xff51afd7ed558ccdull, x ^= x >> 33, x *= 0xc4ceb9fe1a85ec53ull, x ^= x >> 33;
     return (uint32_t)x;
 }
+__global__ void fill_const_kernel(uint16_t* dst, size_t n, uint16_t bits) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = bits;
+}
+__global__ void set_flag_kernel(int32_t* f, int32_t v) { *f = v; }
 __global__ void fill_normal_kernel(uint16_t* dst, size_t n, uint64_t seed, float scale, int f16) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t a = mix32(seed * 0x9e3779b97f4a7c15ull + 2 * i), b = mix32(seed * 0x9e3779b97f4a7c15ull + 2 * i + 1);
@@ -211,6 +227,8 @@ int main(int argc, char** argv) {
     std::string occ_sym;   // --occupancy <kernel handle symbol> <dynamic LDS bytes>: resident 512-thread workgroups per CU, then exit
     int occ_lds = 0;
     int dry = 0;           // --dry: print the geometry and the mask the run would use (no GPU, no library call), then exit
+    std::string fill = "normal";
+    int band_override = 0, use_clock = 1, profiler = 0;
     int sw = -1;           // --switch F: svg_band_attention_switch with the device flag F (0: the sparse mask with placement, 1: the dense alternative without)
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -230,6 +248,10 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
         else if (a == "--prescaled") prescaled = 1;
         else if (a == "--dry") dry = 1;
+        else if (a == "--fill") fill = next();
+        else if (a == "--band") band_override = atoi(next());
+        else if (a == "--no-clock") use_clock = 0;
+        else if (a == "--profiler") profiler = 1;
         else if (a == "--switch") sw = atoi(next());
         else if (a == "--occupancy") occ_sym = next(), occ_lds = atoi(next());
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -268,6 +290,7 @@ int main(int argc, char** argv) {
     if (G->kind == 1) m = {S, (int)std::ceil(G->width_frames * G->P / 128.0) * 128 + 1, 0, G->P, 0, 0};
     else if (G->kind == 2) m = {S, (int)std::floor(G->width_frames * G->P / 128.0) * 128, 0, G->L, 0, G->L};
     else m = {V + G->L, (int)std::floor(G->width_frames * G->P / 128.0) * 128, V, V + G->L, V, V + G->L};
+    if (band_override > 0) m.band = band_override;
     const float sm_scale = 1.f / sqrtf((float)D);
     if (dry) {   // what tests/test_boundary_cpu.py holds against the oracle's mask builders
         printf("{\"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"vid0\": %d, \"F\": %d, \"P\": %d, \"mask\": [%d, %d, %d, %d, %d, %d], \"pairs\": %.0f}\n", G->name, H, S, D,
@@ -281,10 +304,87 @@ int main(int argc, char** argv) {
     uint16_t *q, *k, *v, *o;
     HIP_OK(hipMalloc(&q, n * 2)), HIP_OK(hipMalloc(&k, n * 2)), HIP_OK(hipMalloc(&v, n * 2)), HIP_OK(hipMalloc(&o, n * 2));
     const float qmul = prescaled ? sm_scale * 1.4426950408889634f : 1.f;   // rounded once, like the prologue's q_scale
-    fill_normal_kernel<<<4096, 256, 0, st>>>(q, n, 3 * seed + 1, qmul, f16);
-    fill_normal_kernel<<<4096, 256, 0, st>>>(k, n, 3 * seed + 2, 1.f, f16);
-    fill_normal_kernel<<<4096, 256, 0, st>>>(v, n, 3 * seed + 3, 1.f, f16);
+    if (fill == "normal") {
+        fill_normal_kernel<<<4096, 256, 0, st>>>(q, n, 3 * seed + 1, qmul, f16);
+        fill_normal_kernel<<<4096, 256, 0, st>>>(k, n, 3 * seed + 2, 1.f, f16);
+        fill_normal_kernel<<<4096, 256, 0, st>>>(v, n, 3 * seed + 3, 1.f, f16);
+    } else if (fill == "zero" || fill == "const") {
+        const uint16_t bits = fill == "zero" ? 0 : (f16 ? 0x3c00 : 0x3f80);   // 1.0
+        fill_const_kernel<<<4096, 256, 0, st>>>(q, n, bits);
+        fill_const_kernel<<<4096, 256, 0, st>>>(k, n, bits);
+        fill_const_kernel<<<4096, 256, 0, st>>>(v, n, bits);
+    } else { fprintf(stderr, "unknown --fill %s\n", fill.c_str()); return 2; }
     HIP_OK(hipMemsetAsync(o, 0xff, n * 2, st));
+
+    if (profiler) {
+        typedef size_t (*ws_fn)(int32_t, int32_t, int32_t, int32_t);
+        typedef int (*mse_fn)(const void*, const void*, const void*, const int64_t*, int32_t, int32_t, int32_t, int32_t, int32_t, float,
+                              const svg_profile_desc_t*, float*, void*, size_t, void*);
+        auto ws_bytes = (ws_fn)dlsym(so, "svg_sample_mse_workspace_bytes");
+        auto mse = (mse_fn)dlsym(so, "svg_sample_mse");
+        if (!ws_bytes || !mse) { fprintf(stderr, "library lacks svg_sample_mse\n"); return 2; }
+        const int R = 64;
+        std::vector<int64_t> hrows(R);
+        for (int i = 0; i < R; ++i) hrows[i] = (int64_t)(mix32_host(seed * 1315423911ull + i) % (uint32_t)std::min(10000, V)) + (G->kind == 2 ? 0 : 0);
+        int64_t* drows;
+        HIP_OK(hipMalloc(&drows, R * 8));
+        HIP_OK(hipMemcpyAsync(drows, hrows.data(), R * 8, hipMemcpyHostToDevice, st));
+        svg_profile_desc_t pd;
+        memset(&pd, 0, sizeof(pd));
+        pd.vid0 = vid0, pd.num_frame = G->F, pd.frame_size = G->P, pd.emulate_bf16 = 1;
+        if (G->kind == 0) {          // svg/models/hyvideo/utils.py get_attention_mask (bench.py uses text_hi = S)
+            const int bb = (int)((G->P * 1.5) / 128);
+            pd.variant[0] = {0, 0, V, bb, 0, V, S};
+            pd.variant[1] = {1, 0, V, bb, 0, V, S};
+        } else if (G->kind == 1) {   // svg/models/wan/utils.py
+            const int bb = (int)((G->P * 2) / 128);
+            pd.variant[0] = {0, 0, V, bb, G->P, 0, 0};
+            pd.variant[1] = {1, 0, V, bb, G->P, 0, 0};
+        } else {                     // svg/models/cog/utils.py
+            const int bb = (int)((G->P * 1.5) / 128);
+            pd.variant[0] = {0, 0, std::min(S, (V + 127) / 128 * 128), bb, 0, 0, G->ctx};
+            pd.variant[1] = {1, G->ctx, V, bb, 0, 0, 0};
+        }
+        const size_t wsb = ws_bytes(H, R, D, S);
+        void* ws;
+        float* dmse;
+        HIP_OK(hipMalloc(&ws, wsb)), HIP_OK(hipMalloc(&dmse, 2 * H * 4));
+        auto call = [&]() {
+            const int rc = mse(q, k, v, drows, R, H, S, D, f16 ? SVG_DTYPE_F16 : SVG_DTYPE_BF16, sm_scale, &pd, dmse, ws, wsb, st);
+            if (rc != 0) { fprintf(stderr, "svg_sample_mse: %s\n", strerr(rc)); exit(3); }
+        };
+        for (int i = 0; i < warm; ++i) call();
+        std::vector<hipEvent_t> e0(reps), e1(reps);
+        for (int i = 0; i < reps; ++i) {
+            HIP_OK(hipEventCreate(&e0[i])), HIP_OK(hipEventCreate(&e1[i]));
+            HIP_OK(hipEventRecord(e0[i], st));
+            call();
+            HIP_OK(hipEventRecord(e1[i], st));
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        std::vector<float> hm(2 * H);
+        HIP_OK(hipMemcpy(hm.data(), dmse, 2 * H * 4, hipMemcpyDeviceToHost));
+        double sum = 0, mean = 0;
+        unsigned long long bits = 0;
+        for (int i = 0; i < 2 * H; ++i) {
+            uint32_t u;
+            memcpy(&u, &hm[i], 4);
+            bits = bits * 1099511628211ull + u;
+            if (hm[i] == hm[i]) sum += hm[i];
+        }
+        printf("{\"tool\": \"tools/native_harness --profiler\", \"lib\": \"%s\", \"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"R\": %d, \"workspace_bytes\": %zu, \"ms\": [",
+               lib.c_str(), G->name, H, S, D, R, wsb);
+        for (int i = 0; i < reps; ++i) {
+            float t;
+            HIP_OK(hipEventElapsedTime(&t, e0[i], e1[i]));
+            mean += t / reps;
+            printf("%s%.4f", i ? ", " : "", t);
+        }
+        const double kv_bytes = 2.0 * H * (double)S * D * 2;
+        printf("], \"ms_mean\": %.4f, \"kv_bytes\": %.0f, \"gbps\": %.1f, \"frac_of_8tbps\": %.4f, \"mse_sum\": %.9e, \"mse0\": [%.6e, %.6e], \"mse_bits\": \"%016llx\"}\n",
+               mean, kv_bytes, kv_bytes / (mean * 1e-3) / 1e9, kv_bytes / (mean * 1e-3) / 8e12, sum, hm[0], hm[H], bits);
+        return 0;
+    }
 
     std::vector<int64_t> hf(H);
     for (int h = 0; h < H; ++h) hf[h] = flags == "one" ? 1 : flags == "zero" ? 0 : (h & 1);
@@ -327,12 +427,38 @@ int main(int argc, char** argv) {
         if (rc != 0) { fprintf(stderr, "band attention: %s\n", strerr(rc)); exit(3); }
     };
     for (int i = 0; i < warm; ++i) launch();
+    // shader-clock probe beside the timed launches: started on its own stream once the warm-up is through, stopped by a flag store that
+    // a third stream issues behind the last timed launch
+    auto clock_probe = (int (*)(const int32_t*, uint64_t*, int32_t, void*))dlsym(so, "svg_debug_clock_probe");
+    hipStream_t st_probe = nullptr, st_flag = nullptr;
+    int32_t* stop_flag = nullptr;
+    uint64_t* probe_out = nullptr;
+    hipEvent_t ev_done;
+    if (!clock_probe) use_clock = 0;
+    if (use_clock) {
+        HIP_OK(hipStreamCreate(&st_probe)), HIP_OK(hipStreamCreate(&st_flag));
+        HIP_OK(hipMalloc(&stop_flag, 4)), HIP_OK(hipMalloc(&probe_out, 16));
+        HIP_OK(hipMemset(stop_flag, 0, 4)), HIP_OK(hipMemset(probe_out, 0, 16));
+        HIP_OK(hipEventCreate(&ev_done));
+        HIP_OK(hipStreamSynchronize(st));
+        if (clock_probe(stop_flag, probe_out, 20000, st_probe) != 0) use_clock = 0;
+    }
     std::vector<hipEvent_t> e0(reps), e1(reps);
     for (int i = 0; i < reps; ++i) {
         HIP_OK(hipEventCreate(&e0[i])), HIP_OK(hipEventCreate(&e1[i]));
         HIP_OK(hipEventRecord(e0[i], st));
         launch();
         HIP_OK(hipEventRecord(e1[i], st));
+    }
+    double sclk_mhz = 0;
+    if (use_clock) {
+        HIP_OK(hipEventRecord(ev_done, st));
+        HIP_OK(hipStreamWaitEvent(st_flag, ev_done, 0));
+        set_flag_kernel<<<1, 1, 0, st_flag>>>(stop_flag, 1);
+        HIP_OK(hipStreamSynchronize(st_probe));
+        uint64_t po[2] = {0, 0};
+        HIP_OK(hipMemcpy(po, probe_out, 16, hipMemcpyDeviceToHost));
+        if (po[0] > 0 && po[1] > 0) sclk_mhz = 100.0 * (double)po[0] / (double)po[1];
     }
     HIP_OK(hipStreamSynchronize(st));
     std::vector<float> ms(reps);
@@ -386,8 +512,9 @@ int main(int argc, char** argv) {
     }
     const double rel = ref2 > 0 ? std::sqrt(err2 / ref2) : 0.0;
     printf("{\"tool\": \"tools/native_harness\", \"lib\": \"%s\", \"build\": \"%s\", \"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"dtype\": \"%s\", "
-           "\"band\": %d, \"variant\": %d, \"prescaled\": %d, \"switch\": %d, \"head_flags\": \"%s\", \"ms\": [",
-           lib.c_str(), info ? info() : "?", G->name, H, S, D, dtype.c_str(), m.band, variant, prescaled, sw, flags.c_str());
+           "\"band\": %d, \"variant\": %d, \"prescaled\": %d, \"switch\": %d, \"head_flags\": \"%s\", \"fill\": \"%s\", \"sclk_mhz\": %.1f, \"mcycles\": %.2f, \"ms\": [",
+           lib.c_str(), info ? info() : "?", G->name, H, S, D, dtype.c_str(), m.band, variant, prescaled, sw, flags.c_str(), fill.c_str(), sclk_mhz,
+           sclk_mhz * mean * 1e-3);
     for (int i = 0; i < reps; ++i) printf("%s%.3f", i ? ", " : "", ms[i]);
     printf("], \"ms_mean\": %.3f, \"density\": %.4f, \"algorithmic_tflop\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.4f, "
            "\"spot_rows\": %d, \"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\"}\n",
