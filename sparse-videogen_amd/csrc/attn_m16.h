@@ -63,7 +63,8 @@ struct Mfma16<_Float16> {
     }
 };
 
-constexpr int attn_m16_lds_bytes() { return attn_pp2_lds_bytes<128>(); }
+template <int D = 128>
+constexpr int attn_m16_lds_bytes() { return attn_pp2_lds_bytes<D>(); }
 
 // lanes l, l ^ 16, l ^ 32, l ^ 48 hold one query row: maximum / sum over them (rare paths and the epilogue only)
 __device__ __forceinline__ float quad_group_max(float x) {
@@ -89,7 +90,7 @@ __device__ __forceinline__ float quad_group_sum(float x) {
 // for the conversion pass (profiles/r04m_f16qk_kernel_trace.txt, r04l_ab_m16_f16qk.txt: 32.9 vs 33.4 ms end to end, -1.4 %).  The f16
 // MFMA's wider multipliers take back in clock what the missing FMAs save — the power limit once more.  The template flag stays (it is
 // four lines of the body); nothing instantiates it.
-template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1, bool PRE = false, bool QKF16 = false>
+template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1, bool PRE = false, bool QKF16 = false, int D = 128, bool LEAN = false>
 __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
     using M = Mfma16<T>;                                                  // PV
@@ -98,16 +99,20 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     using V8 = typename E::v8;
     using Q8 = typename Elt<TQ>::v8;
     static_assert(!QKF16 || PRE, "fp16 q / k carriers exist for the pre-scaled form only");
-    constexpr int D = 128;
+    static_assert(D == 128 || D == 64, "head dim");
     constexpr int NW = 8;
     constexpr int KS = D / 32;              // 32-wide contraction steps of S^T
     constexpr int NDB = D / 16;             // 16-wide d blocks of O^T
     constexpr int NS = 4;                   // LDS stages
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;
-    constexpr int NP = 2;                   // DMA pieces (16 keys x 64 B) per wave per tensor per tile
-    constexpr int kCarry = 8;               // V fragments of the next matrix phase read in the tail of this one (attn_body_pp2: SVG_PP2_CARRY)
-    constexpr int kPF = 8;                  // operand fragments in flight ahead of their MFMAs
+    constexpr int NP = D / 64;              // DMA pieces (16 keys x 64 B) per wave per tensor per tile
+    // LEAN: the register diet of the four-waves-per-SIMD instance (head_dim 64, cf. attn_body_pp2): nothing carried, ring 4 ahead
+    constexpr int kCarry = LEAN ? 0 : 8;    // V fragments of the next matrix phase read in the tail of this one (attn_body_pp2: SVG_PP2_CARRY)
+#ifndef SVG_M16_LEAN_PF
+#define SVG_M16_LEAN_PF 4
+#endif
+    constexpr int kPF = LEAN ? SVG_M16_LEAN_PF : 8;       // operand fragments in flight ahead of their MFMAs
     constexpr bool kOneBar = ONEBAR < 0 ? P::kOneBarrier : (ONEBAR != 0);   // one workgroup barrier per tile instead of two (attn_body_pp2: on for the variable-block policy)
     static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1 && !P::kPartialOut && !P::kFixup && P::kIntervalMask, "band / variable-block policy");
 
@@ -165,7 +170,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     };
     auto dma_issue = [&](int t) {
         dma_piece(t, std::integral_constant<int, 0>{});
-        dma_piece(t, std::integral_constant<int, 1>{});
+        if constexpr (NP > 1) dma_piece(t, std::integral_constant<int, 1>{});
     };
     const int dist = lagging ? 3 : 2;   // tile u + dist is requested in N(u)
     for (int t = 0; t < dist; ++t) {
@@ -295,7 +300,9 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                     }
             }
         }
-        if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
+        if constexpr (NP > 1) {
+            if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
+        }
         psum[0] = 0.f, psum[1] = 0.f;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -366,8 +373,10 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     // { LDS read of the fragment kPF steps ahead; the fragment's two MFMAs (row blocks 0 and 1) }, fenced with sched_barrier.
     constexpr int NPV = 2 * NDB;
     i16x8 ring[kPF + 1];
-    i16x8 carry[kCarry];
-    auto carry_load = [&](int t, int i) { carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB); };
+    i16x8 carry[kCarry > 0 ? kCarry : 1];
+    auto carry_load = [&](int t, int i) {
+        if constexpr (kCarry > 0) carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB);
+    };
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int NALL = has_next ? NPV + 4 * KS : NPV;
