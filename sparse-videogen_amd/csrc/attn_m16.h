@@ -193,7 +193,8 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         const T* qrow = qb + (size_t)(qp >= 0 ? qp : 0) * D + g4 * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const Q8*)(qrow + ks * 32);
-        P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
+        if constexpr (!LEAN) P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
+        else m_a0[rb] = m_b0[rb] = 0, m_alen[rb] = m_blen[rb] = 0;
     }
 
     const int k_lane = n16 * 64 + ((g4 ^ (((n16 >> 2) & 1) << 1)) << 4);
@@ -288,6 +289,10 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
             const bool part = (cls == TILE_PARTIAL);  // a tile this wave does not need at all is processed fully masked
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
+                if constexpr (LEAN) {   // four waves per SIMD: the intervals are not kept in registers across the tiles, partial tiles recompute them
+                    asm volatile("" : "+v"(q_log[rb]));
+                    P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
+                }
                 int ka = tk0 + 4 * g4 - m_a0[rb], kb2 = tk0 + 4 * g4 - m_b0[rb];
                 asm volatile("" : "+v"(ka), "+v"(kb2));   // opaque: keeps LICM from hoisting the per-element terms out of the loop
 #pragma unroll
