@@ -290,8 +290,9 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 if constexpr (LEAN) {   // four waves per SIMD: the intervals are not kept in registers across the tiles, partial tiles recompute them
-                    asm volatile("" : "+v"(q_log[rb]));
-                    P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
+                    int ql = P::q_logical(ctx, wave * 32 + rb * 16 + n16);
+                    asm volatile("" : "+v"(ql));
+                    P::row_intervals(prm, ctx, ql, m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
                 }
                 int ka = tk0 + 4 * g4 - m_a0[rb], kb2 = tk0 + 4 * g4 - m_b0[rb];
                 asm volatile("" : "+v"(ka), "+v"(kb2));   // opaque: keeps LICM from hoisting the per-element terms out of the loop
@@ -371,6 +372,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 asm volatile("" : "+v"(pf[kc][0]), "+v"(pf[kc][1]), "+v"(psum[0]), "+v"(psum[1]));
             }
         }
+        if constexpr (LEAN) l_run[0] += psum[0], l_run[1] += psum[1];   // (the other forms add in the shadow of the PV MFMAs)
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -411,7 +413,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 const V8 a = __builtin_bit_cast(V8, i < kCarry ? carry[i < kCarry ? i : 0] : ring[i % (kPF + 1)]);
                 acc_o[db][0] = M::mfma(a, pf[kc][0], acc_o[db][0]);
                 acc_o[db][1] = M::mfma(a, pf[kc][1], acc_o[db][1]);
-                if (i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
+                if (!LEAN && i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
             } else {
                 const int j = i - NPV, ks = j >> 2, b = j & 3;
                 const Q8 a = __builtin_bit_cast(Q8, ring[i % (kPF + 1)]);
