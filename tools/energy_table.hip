@@ -180,25 +180,39 @@ __global__ __launch_bounds__(512) void mix_kernel(const char* __restrict__ src, 
 //     in a scattered order (64 MiB - 192 MiB: resident in the 256 MiB Infinity Cache, not in a 4 MiB L2: the kernel's 19 % L2 misses are its
 //     neighbours' tiles, i.e. fabric / MALL traffic, not first-touch HBM reads), the others to a 1 MiB window (L2 hits).
 template <int XV, int XS>
-__global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src, unsigned long long window, int miss_every, int tiles,
+__global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src, unsigned long long window, int miss_every, int normal, int tiles,
                                                     unsigned long long* __restrict__ ticks, float* __restrict__ sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // LDS operand data: normal = 0: +-[0.5, 1) with random mantissas (ONE exponent, as mix_kernel); 1: approximately N(0, 1) bf16 (sum of four uniform bytes:
+    // exponents vary over ~8 binades like real K / V rows — products then need alignment shifts in the MFMA's adder tree)
     for (int i = threadIdx.x; i < kStage * kStages / 4; i += blockDim.x) {
         unsigned x = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
         x ^= x >> 13;
-        const unsigned hi = 0x3f000000u | ((x & 0x7f00u) << 8) | ((x & 0x8000u) << 16);
-        const unsigned lo = 0x3f00u | ((x >> 16) & 0x7fu) | ((x >> 8) & 0x8000u);
-        ((unsigned*)lds)[i] = hi | lo;
+        if (normal) {
+            unsigned y = x * 2246822519u;
+            y ^= y >> 15;
+            const float f0 = ((float)((x & 255u) + ((x >> 8) & 255u) + ((x >> 16) & 255u) + (x >> 24)) - 510.f) * (1.f / 148.f);
+            const float f1 = ((float)((y & 255u) + ((y >> 8) & 255u) + ((y >> 16) & 255u) + (y >> 24)) - 510.f) * (1.f / 148.f);
+            ((unsigned*)lds)[i] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+        } else {
+            const unsigned hi = 0x3f000000u | ((x & 0x7f00u) << 8) | ((x & 0x8000u) << 16);
+            const unsigned lo = 0x3f00u | ((x >> 16) & 0x7fu) | ((x >> 8) & 0x8000u);
+            ((unsigned*)lds)[i] = hi | lo;
+        }
     }
     __syncthreads();
-    float a0 = threadIdx.x * 0.001f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = 0;
     unsigned x0 = threadIdx.x * 7u + 1u, x1 = threadIdx.x * 13u + 5u;
     f32x4m d16[8] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
     bf16x8 Bq[4];
     for (int j = 0; j < 4; ++j)
-        for (int e = 0; e < 8; ++e) Bq[j][e] = (__bf16)(0.01f * (float)(((lane * 8 + e) * 37 + j * 11) % 97 - 48));
+        for (int e = 0; e < 8; ++e) {
+            unsigned z = (unsigned)((lane * 8 + e) * 4 + j) * 2654435761u;
+            z ^= z >> 13;
+            Bq[j][e] = normal ? (__bf16)(((float)((z & 255u) + ((z >> 8) & 255u) + ((z >> 16) & 255u) + (z >> 24)) - 510.f) * (1.f / 148.f))
+                              : (__bf16)(0.01f * (float)(((lane * 8 + e) * 37 + j * 11) % 97 - 48));
+        }
     const char* pk = lds + lane * 16;
     const char* pv = lds + lane * 8;
     const bool second = wave >= 4;
@@ -233,7 +247,8 @@ __global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src,
         __builtin_amdgcn_s_setprio(0);
     };
     const int dist = second ? 3 : 2;
-    unsigned req = (blockIdx.x * 8u + wave) * 977u;   // request counter of this wave (which requests miss)
+    unsigned req = (blockIdx.x * 8u + wave) * 977u;
+    unsigned miss_seq = 0;   // request counter of this wave (which requests miss)
     auto dma = [&](int t) {
         const unsigned stage = (unsigned)((t + dist) % kStages);
 #pragma unroll
@@ -242,9 +257,11 @@ __global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src,
             unsigned long long off;
             ++req;
             if (miss_every > 0 && (req % (unsigned)miss_every) == 0u) {
-                unsigned long long h = (unsigned long long)req * 0x9e3779b97f4a7c15ull + (unsigned long long)t * 0xbf58476d1ce4e5b9ull;
-                h ^= h >> 29;
-                off = ((h % (window >> 10)) << 10) + (1ull << 20);
+                // this wave's own slice of the window, walked 1 KiB at a time (a sequential stream like a neighbour's K / V tiles: page-friendly; the
+                // slices of an XCD's 256 waves together exceed its 4 MiB L2 from a 64 MiB window on, so every such request goes to the fabric)
+                const unsigned long long slice = window / 2048ull;
+                const unsigned long long wid = (unsigned long long)blockIdx.x * 8ull + (unsigned long long)wave;
+                off = (1ull << 20) + wid * slice + (((unsigned long long)(miss_seq++) << 10) % slice);
             } else {
                 off = (((unsigned)t * 32768u + (wave * 4 + j) * 1024u) & (1048576u - 1));
             }
@@ -253,13 +270,31 @@ __global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src,
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsb), "v"(voff), "s"(base) : "memory");
         }
     };
+    // 32 elements per lane and tile like the kernel's probabilities: e = 2^x, y = fma(x, 0.5, e), x = y + k (k in [-1.5, -0.5), a new one per group of
+    // eight and tile: the values wander in [-2.3, 0.5) and keep toggling), one cvt_pk per two e — 32 v_exp, 32 v_fma, 32 v_add, 16 v_cvt_pk, eight independent
+    // elements per group (the kernel's vector phase has no dependent chains either)
+    float xs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xs[e] = -0.25f * (float)e - 0.001f * (float)(threadIdx.x & 63);
+    float pk0 = 0.f, pk1 = 0.f, pk2 = 0.f, pk3 = 0.f;
     auto vector_phase = [&](int t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            asm volatile("v_exp_f32 %0, %1\n\tv_add_f32 %1, %1, %0\n\tv_fract_f32 %1, %1\n\tv_exp_f32 %2, %3\n\t"
-                         "v_fma_f32 %3, %3, %6, %2\n\tv_fract_f32 %3, %3\n\tv_cvt_pk_bf16_f32 %4, %0, %2"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=v"(a4) : "v"(0.001f), "v"(0.999f));
-            if (r == 3) dma(t);
+        for (int g = 0; g < 4; ++g) {
+            unsigned hsh = ((unsigned)t * 4u + (unsigned)g) * 2654435761u;
+            hsh ^= hsh >> 15;
+            const float kk = -1.5f + (float)(hsh & 1023u) * (1.f / 1024.f);
+            float e0, e1, e2, e3, e4, e5, e6, e7;
+            asm volatile("v_exp_f32 %0, %8\n\tv_exp_f32 %1, %9\n\tv_exp_f32 %2, %10\n\tv_exp_f32 %3, %11\n\t"
+                         "v_exp_f32 %4, %12\n\tv_exp_f32 %5, %13\n\tv_exp_f32 %6, %14\n\tv_exp_f32 %7, %15\n\t"
+                         "v_fma_f32 %8, %8, 0.5, %0\n\tv_fma_f32 %9, %9, 0.5, %1\n\tv_fma_f32 %10, %10, 0.5, %2\n\tv_fma_f32 %11, %11, 0.5, %3\n\t"
+                         "v_fma_f32 %12, %12, 0.5, %4\n\tv_fma_f32 %13, %13, 0.5, %5\n\tv_fma_f32 %14, %14, 0.5, %6\n\tv_fma_f32 %15, %15, 0.5, %7\n\t"
+                         "v_add_f32 %8, %8, %20\n\tv_add_f32 %9, %9, %20\n\tv_add_f32 %10, %10, %20\n\tv_add_f32 %11, %11, %20\n\t"
+                         "v_add_f32 %12, %12, %20\n\tv_add_f32 %13, %13, %20\n\tv_add_f32 %14, %14, %20\n\tv_add_f32 %15, %15, %20\n\t"
+                         "v_cvt_pk_bf16_f32 %16, %0, %1\n\tv_cvt_pk_bf16_f32 %17, %2, %3\n\tv_cvt_pk_bf16_f32 %18, %4, %5\n\tv_cvt_pk_bf16_f32 %19, %6, %7"
+                         : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7), "+v"(xs[0]), "+v"(xs[1]), "+v"(xs[2]),
+                           "+v"(xs[3]), "+v"(xs[4]), "+v"(xs[5]), "+v"(xs[6]), "+v"(xs[7]), "=v"(pk0), "=v"(pk1), "=v"(pk2), "=v"(pk3)
+                         : "v"(kk));
+            if (g == 0) dma(t);
         }
 #pragma unroll
         for (int r = 0; r < XV / 2; ++r) asm volatile("v_xor_b32 %0, %0, %1\n\tv_add_u32 %1, %1, %0" : "+v"(x0), "+v"(x1));
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(512) void kernel_like(const char* __restrict__ src,
     }
     float acc16 = 0.f;
     for (int j = 0; j < 8; ++j) acc16 += d16[j][0] + d16[j][3];
-    sink[blockIdx.x * 512 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + acc16 + (float)(x0 ^ x1);
+    sink[blockIdx.x * 512 + threadIdx.x] = xs[0] + xs[3] + xs[7] + pk0 + pk1 + pk2 + pk3 + acc16 + (float)(x0 ^ x1);
 }
 
 // duty 1.0 reference: both waves of a SIMD issue MFMAs back to back, nothing else.  SHAPE 0: 32x32x16 (32 per tile and wave), 1: 16x16x32
@@ -415,19 +450,19 @@ void row(const char* name, double target, int tiles, const char* src, unsigned l
 }
 
 template <int XV, int XS>
-void kernel_row(const char* name, const char* src, unsigned long long window, int miss_every, int tiles, unsigned long long* ticks, float* sink, Power* pw) {
+void kernel_row(const char* name, const char* src, unsigned long long window, int miss_every, int normal, int tiles, unsigned long long* ticks, float* sink, Power* pw) {
     CHECK(hipFuncSetAttribute((const void*)kernel_like<XV, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, kStage * kStages));
     double mhz = 0, duty = 0, watts = 0;
     float ms = 0;
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 3; ++rep) {
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        if (rep) pw->start();
+        if (rep == 2) pw->start();
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((kernel_like<XV, XS>), dim3(256), dim3(512), kStage * kStages, 0, src, window, miss_every, tiles, ticks, sink);
+        hipLaunchKernelGGL((kernel_like<XV, XS>), dim3(256), dim3(512), kStage * kStages, 0, src, window, miss_every, normal, tiles, ticks, sink);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
-        if (rep) watts = pw->stop();
+        if (rep == 2) watts = pw->stop();
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         std::vector<unsigned long long> h(512);
         CHECK(hipMemcpy(h.data(), ticks, 512 * 8, hipMemcpyDeviceToHost));
@@ -501,13 +536,13 @@ int main(int argc, char** argv) {
     row<4, 4, 1, 0>("32x32x16 again: + 48 LDS + 112 VALU + DMA (L2 hits)", target, tiles, src, stream_bytes, ticks, sink, &pw);
     }
     printf("| kernel-like rows: attn_body_m16's tile structure, one barrier per tile, prefetch distance 2 / 3, no padding (what should reproduce duty 0.64 at 1.96 - 2.04 GHz) | | | | | | | |\n");
-    kernel_row<0, 0>("kernel-like, no misses, no bookkeeping", src, 64ull << 20, 0, tiles, ticks, sink, &pw);
-    kernel_row<24, 48>("kernel-like, no misses, + 24 VALU + 48 SALU bookkeeping", src, 64ull << 20, 0, tiles, ticks, sink, &pw);
-    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 64 MiB window (MALL)", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
-    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 192 MiB window (MALL)", src, 192ull << 20, 5, tiles, ticks, sink, &pw);
-    kernel_row<24, 48>("kernel-like, 1 request in 5 to a 2 GiB window (HBM)", src, 2047ull << 20, 5, tiles, ticks, sink, &pw);
-    kernel_row<24, 48>("kernel-like, 1 request in 3 to a 64 MiB window (MALL)", src, 64ull << 20, 3, tiles, ticks, sink, &pw);
-    kernel_row<0, 0>("kernel-like, 1 in 5 to 64 MiB, no bookkeeping", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
-    kernel_row<48, 96>("kernel-like, 1 in 5 to 64 MiB, 48 VALU + 96 SALU", src, 64ull << 20, 5, tiles, ticks, sink, &pw);
+    for (int normal = 0; normal < 2; ++normal) {
+        printf("| operand data: %s | | | | | | | |\n", normal ? "approximately N(0, 1) bf16 (exponents vary)" : "+-[0.5, 1), one exponent (the rows above)");
+        kernel_row<0, 0>("kernel-like, no misses, no bookkeeping", src, 64ull << 20, 0, normal, tiles, ticks, sink, &pw);
+        kernel_row<24, 48>("kernel-like, no misses, + 24 VALU + 48 SALU bookkeeping", src, 64ull << 20, 0, normal, tiles, ticks, sink, &pw);
+        kernel_row<0, 0>("kernel-like, 1 request in 5 to a 192 MiB window, no bookk.", src, 192ull << 20, 5, normal, tiles, ticks, sink, &pw);
+        kernel_row<24, 48>("kernel-like, 1 in 5 to 192 MiB, 24 VALU + 48 SALU", src, 192ull << 20, 5, normal, tiles, ticks, sink, &pw);
+        kernel_row<24, 48>("kernel-like, 1 in 5 to a 2 GiB window (HBM), 24 + 48", src, 2047ull << 20, 5, normal, tiles, ticks, sink, &pw);
+    }
     return 0;
 }
