@@ -71,15 +71,6 @@ __global__ __launch_bounds__(512, 2) void band_attn_m16_kernel(typename BandPoli
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_m16<T, BandPolicy<T, 128, 8, false>, false, PRIO, ONEBAR>(prm, smem, nullptr);
 }
-// head_dim 64 on 16x16x32 MFMAs, four waves per SIMD like band_attn_pp2_kernel<T, 64> (LEAN form).  EXPERIMENT of the r05-m16-d64 branch:
-// compiled, never executed — reachable through the explicit variant 8 at head_dim 64 only.  Expectation (energy model of DESIGN §0): the
-// four-waves two-phase kernel is power-limited at head_dim 64 (2.0 GHz at a 0.49 busy matrix pipe); a quarter less MFMA energy is ~ -15 % of
-// a tile's dynamic energy there.
-template <typename T, bool PRE = false>
-__global__ __launch_bounds__(512, 4) void band_attn_m16d64_kernel(typename BandPolicy<T, 64, 8, false>::Params prm) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_body_m16<T, BandPolicy<T, 64, 8, false>, false, 1, 1, PRE, false, 64, true>(prm, smem, nullptr);
-}
 // pre-scaled q on the 16x16x32 body (PRE form of attn_body_m16).  QKF16 = true (q and k as fp16 carriers with S^T on the f16 MFMA) was
 // built and measured in round 4 and is not instantiated: see the note at attn_body_m16.
 template <typename T, bool QKF16>
@@ -936,19 +927,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
             const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
             return launch_attn(band_attn_pp2_frozen_kernel, p, dim3(p.nqt * BH), 512, attn_pp2_lds_bytes<128>(), st);
         }
-        case kBandM16: {   // two-phase body on 16x16x32 MFMAs (attn_m16.h): head_dim 128; head_dim 64: r05-m16-d64 experiment, plain q only
-            if (D == 64 && !opts.prescaled && !opts.done) {
-                if (dtype == SVG_DTYPE_BF16) {
-                    using Pol = BandPolicy<__bf16, 64, 8, false>;
-                    const typename Pol::Params p = make_band_params<Pol, __bf16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
-                    return launch_attn(band_attn_m16d64_kernel<__bf16>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes<64>(), st);
-                }
-                if (dtype == SVG_DTYPE_F16) {
-                    using Pol = BandPolicy<_Float16, 64, 8, false>;
-                    const typename Pol::Params p = make_band_params<Pol, _Float16>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
-                    return launch_attn(band_attn_m16d64_kernel<_Float16>, p, dim3(p.nqt * BH), 512, attn_m16_lds_bytes<64>(), st);
-                }
-            }
+        case kBandM16: {   // two-phase body on 16x16x32 MFMAs (attn_m16.h): head_dim 128
             if (D != 128) return SVG_ERR_UNSUPPORTED;
             if (opts.prescaled) {   // PRE form: q carries the softmax scale
                 if (dtype == SVG_DTYPE_BF16) {

@@ -63,8 +63,7 @@ struct Mfma16<_Float16> {
     }
 };
 
-template <int D = 128>
-constexpr int attn_m16_lds_bytes() { return attn_pp2_lds_bytes<D>(); }
+constexpr int attn_m16_lds_bytes() { return attn_pp2_lds_bytes<128>(); }
 
 // lanes l, l ^ 16, l ^ 32, l ^ 48 hold one query row: maximum / sum over them (rare paths and the epilogue only)
 __device__ __forceinline__ float quad_group_max(float x) {
@@ -90,7 +89,7 @@ __device__ __forceinline__ float quad_group_sum(float x) {
 // for the conversion pass (profiles/r04m_f16qk_kernel_trace.txt, r04l_ab_m16_f16qk.txt: 32.9 vs 33.4 ms end to end, -1.4 %).  The f16
 // MFMA's wider multipliers take back in clock what the missing FMAs save — the power limit once more.  The template flag stays (it is
 // four lines of the body); nothing instantiates it.
-template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1, bool PRE = false, bool QKF16 = false, int D = 128, bool LEAN = false>
+template <typename T, typename P, bool TRACE = false, int PRIO = 1, int ONEBAR = -1, bool PRE = false, bool QKF16 = false>
 __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, char* smem, char* policy_lds) {
     using E = Elt<T>;
     using M = Mfma16<T>;                                                  // PV
@@ -99,20 +98,16 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     using V8 = typename E::v8;
     using Q8 = typename Elt<TQ>::v8;
     static_assert(!QKF16 || PRE, "fp16 q / k carriers exist for the pre-scaled form only");
-    static_assert(D == 128 || D == 64, "head dim");
+    constexpr int D = 128;
     constexpr int NW = 8;
     constexpr int KS = D / 32;              // 32-wide contraction steps of S^T
     constexpr int NDB = D / 16;             // 16-wide d blocks of O^T
     constexpr int NS = 4;                   // LDS stages
     constexpr int kImg = kBN * D * 2;       // bytes of a K or V image
     constexpr int kStage = 2 * kImg;
-    constexpr int NP = D / 64;              // DMA pieces (16 keys x 64 B) per wave per tensor per tile
-    // LEAN: the register diet of the four-waves-per-SIMD instance (head_dim 64, cf. attn_body_pp2): nothing carried, ring 4 ahead
-    constexpr int kCarry = LEAN ? 0 : 8;    // V fragments of the next matrix phase read in the tail of this one (attn_body_pp2: SVG_PP2_CARRY)
-#ifndef SVG_M16_LEAN_PF
-#define SVG_M16_LEAN_PF 4
-#endif
-    constexpr int kPF = LEAN ? SVG_M16_LEAN_PF : 8;       // operand fragments in flight ahead of their MFMAs
+    constexpr int NP = 2;                   // DMA pieces (16 keys x 64 B) per wave per tensor per tile
+    constexpr int kCarry = 8;               // V fragments of the next matrix phase read in the tail of this one (attn_body_pp2: SVG_PP2_CARRY)
+    constexpr int kPF = 8;                  // operand fragments in flight ahead of their MFMAs
     constexpr bool kOneBar = ONEBAR < 0 ? P::kOneBarrier : (ONEBAR != 0);   // one workgroup barrier per tile instead of two (attn_body_pp2: on for the variable-block policy)
     static_assert(P::kRowBlocks == 1 && P::kSubTiles == 1 && !P::kPartialOut && !P::kFixup && P::kIntervalMask, "band / variable-block policy");
     // MSUM (SVG_M16_MFMASUM, bf16, plain form): the row sum on the matrix pipe.  Four extra MFMAs per tile (A = a fragment of ones, B = the
@@ -182,7 +177,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     };
     auto dma_issue = [&](int t) {
         dma_piece(t, std::integral_constant<int, 0>{});
-        if constexpr (NP > 1) dma_piece(t, std::integral_constant<int, 1>{});
+        dma_piece(t, std::integral_constant<int, 1>{});
     };
     const int dist = lagging ? 3 : 2;   // tile u + dist is requested in N(u)
     for (int t = 0; t < dist; ++t) {
@@ -205,8 +200,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         const T* qrow = qb + (size_t)(qp >= 0 ? qp : 0) * D + g4 * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const Q8*)(qrow + ks * 32);
-        if constexpr (!LEAN) P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
-        else m_a0[rb] = m_b0[rb] = 0, m_alen[rb] = m_blen[rb] = 0;
+        P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
     }
 
     const int k_lane = n16 * 64 + ((g4 ^ (((n16 >> 2) & 1) << 1)) << 4);
@@ -308,11 +302,6 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
             const bool part = (cls == TILE_PARTIAL);  // a tile this wave does not need at all is processed fully masked
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                if constexpr (LEAN) {   // four waves per SIMD: the intervals are not kept in registers across the tiles, partial tiles recompute them
-                    int ql = P::q_logical(ctx, wave * 32 + rb * 16 + n16);
-                    asm volatile("" : "+v"(ql));
-                    P::row_intervals(prm, ctx, ql, m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
-                }
                 int ka = tk0 + 4 * g4 - m_a0[rb], kb2 = tk0 + 4 * g4 - m_b0[rb];
                 asm volatile("" : "+v"(ka), "+v"(kb2));   // opaque: keeps LICM from hoisting the per-element terms out of the loop
 #pragma unroll
@@ -325,9 +314,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                     }
             }
         }
-        if constexpr (NP > 1) {
-            if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
-        }
+        if (more) dma_piece(t + dist, std::integral_constant<int, 1>{});
         psum[0] = 0.f, psum[1] = 0.f;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
@@ -412,7 +399,6 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                 asm volatile("" : "+v"(pf[kc][0]), "+v"(pf[kc][1]), "+v"(psum[0]), "+v"(psum[1]));
             }
         }
-        if constexpr (LEAN && !MSUM) l_run[0] += psum[0], l_run[1] += psum[1];   // (the other forms add in the shadow of the PV MFMAs)
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -420,15 +406,13 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     // { LDS read of the fragment kPF steps ahead; the fragment's two MFMAs (row blocks 0 and 1) }, fenced with sched_barrier.
     constexpr int NPV = 2 * NDB;
 #ifdef SVG_M16_MSUM_AT
-    constexpr int kMsumAt = SVG_M16_MSUM_AT < NDB ? SVG_M16_MSUM_AT : NDB - 1;
+    constexpr int kMsumAt = SVG_M16_MSUM_AT;
 #else
     constexpr int kMsumAt = NDB - 1;   // the d block after whose MFMAs the chunk's two row-sum MFMAs are issued
 #endif
     i16x8 ring[kPF + 1];
-    i16x8 carry[kCarry > 0 ? kCarry : 1];
-    auto carry_load = [&](int t, int i) {
-        if constexpr (kCarry > 0) carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB);
-    };
+    i16x8 carry[kCarry];
+    auto carry_load = [&](int t, int i) { carry[i] = vfrag(smem + (t % NS) * kStage, i / NDB, i % NDB); };
     auto matrix_phase = [&](int t, auto has_next_c) {
         constexpr bool has_next = decltype(has_next_c)::value;
         constexpr int NALL = has_next ? NPV + 4 * KS : NPV;
@@ -464,7 +448,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
                         acc_l[1] = M::mfma(ones8, pf[kc][1], acc_l[1]);
                     }
                 } else {
-                    if (!LEAN && i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
+                    if (i == NPV - 1) l_run[0] += psum[0], l_run[1] += psum[1];
                 }
             } else {
                 const int j = i - NPV, ks = j >> 2, b = j & 3;
