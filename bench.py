@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-dense", action="store_true")
     ap.add_argument("--no-svg2", action="store_true", help="skip the SVG2 (BASELINE.json configs[2]) extras block")
+    ap.add_argument("--no-hbm", action="store_true", help="skip the HBM-bound kernels block (bench_hbm.measure)")
     ap.add_argument("--no-step", action="store_true", help="skip the measured 60-layer denoise step (bench_step.measure)")
     ap.add_argument("--no-profiler", action="store_true", help="time the attention kernel only")
     ap.add_argument("--no-ab", action="store_true", help="skip the same-box A/B block (frozen reference schedule and the other schedules timed beside the default)")
@@ -749,6 +750,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             failed_extras.append("denoise_step_hy720p")
+        torch.cuda.empty_cache()
+    if world == 1 and not a.no_hbm and (extras_full or extras_small):
+        # the HBM-bound rows of SURVEY §8(d) (placement, inverse placement, SVG2 gather / scatter, label sort, prologue, block glue) at
+        # production sizes: ms, GB/s, fraction of the 8 TB/s spec and of the 6.29 TB/s measured copy (bench_hbm.py)
+        try:
+            import bench_hbm
+
+            out["hbm_kernels"] = bench_hbm.measure("full" if extras_full else "small", reps=5 if extras_full else 2)
+        except Exception as e:  # noqa: BLE001
+            out["hbm_kernels"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            failed_extras.append("hbm_kernels")
         torch.cuda.empty_cache()
     if world > 1 and not a.no_step and not fp8:
         # BASELINE.json configs[3] at N > 1: the denoise step token-sharded over the ranks (bench_step.py: tokens/N for norms, GEMMs,

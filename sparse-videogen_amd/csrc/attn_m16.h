@@ -116,10 +116,13 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     // test on the packed bf16 probabilities: with the exponent argument lowered by kBias a probability reaches 2.0 (exponent field >= 128,
     // bit 14 / 30 of the packed word: the OR of all sixteen words shows it, 8 v_or3_b32) exactly when the row sum test of the plain
     // form would be near its 2048.  O and l carry the common factor 2^-kBias, which the final division removes.
-#ifdef SVG_M16_MFMASUM
-    constexpr bool MSUM = std::is_same_v<T, __bf16> && !PRE;
-#else
+    // Measured (profiles/r05a_ab_m16_msum_prio3.txt, same box, HunyuanVideo 720p): 64.1 instead of 65.1 Mcycles per launch, of which the power
+    // management returns half as clock (1985 vs 2000 MHz): 32.3 against 32.55 ms; with the sum MFMAs after the chunk's LAST PV step instead of
+    // its first the gain is gone (65.4 Mcycles).  fp16 keeps the vector-phase sum: 2^-10 would push small probabilities into fp16's subnormals.
+#ifdef SVG_M16_NO_MFMASUM
     constexpr bool MSUM = false;
+#else
+    constexpr bool MSUM = std::is_same_v<T, __bf16> && !PRE;
 #endif
     constexpr float kBias = MSUM ? 10.f : 0.f;
 
@@ -408,7 +411,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
 #ifdef SVG_M16_MSUM_AT
     constexpr int kMsumAt = SVG_M16_MSUM_AT;
 #else
-    constexpr int kMsumAt = NDB - 1;   // the d block after whose MFMAs the chunk's two row-sum MFMAs are issued
+    constexpr int kMsumAt = 0;         // the d block after whose MFMAs the chunk's two row-sum MFMAs are issued
 #endif
     i16x8 ring[kPF + 1];
     i16x8 carry[kCarry];

@@ -133,6 +133,30 @@ def test_bench_svg2_measure_small(fp8):
         assert "rel_l2_vs_16bit_kernel" in d
 
 
+HBM_ROWS = ("placement_qkv", "inverse_placement_o", "qk_norm_rope_inplace", "qk_norm_rope_transpose", "label_sort", "svg2_gather",
+            "svg2_scatter", "layernorm_modulate", "modulate_gate_residual")
+
+
+def _check_hbm_block(block):
+    """the `hbm_kernels` block of the bench line (bench_hbm.measure): one roofline row per HBM-bound kernel of SURVEY §8(d)"""
+    assert not _error_keys(block), _error_keys(block)
+    assert block["peak_GBs"]["spec"] == 8000.0 and block["torch_copy_this_box"]["GBs"] > 0
+    for name in HBM_ROWS:
+        r = block["kernels"][name]
+        assert r["ms"] > 0 and r["algorithmic_bytes"] > 0 and r["GBs"] > 0
+        assert abs(r["GBs"] - r["algorithmic_bytes"] / r["ms"] / 1e6) <= 0.01 * r["GBs"] + 0.1      # (ms is rounded to 1e-4)
+        assert abs(r["frac_of_8TBs"] - r["GBs"] / 8000.0) < 1e-3 and 0 < r["frac_of_8TBs"] < 1.0
+        assert "svg/" in r["reference"]
+
+
+def test_bench_hbm_measure_small():
+    """bench_hbm.measure() is what bench.py embeds as `hbm_kernels`: called the way bench.py calls it, on the reduced geometry."""
+    sys.path.insert(0, str(ROOT))
+    import bench_hbm
+
+    _check_hbm_block(bench_hbm.measure("small", reps=2))
+
+
 def test_bench_line_with_extras_has_no_error_key():
     """bench.py with every extras block switched on (reduced geometries): exit code 0 and no "error" key anywhere in the line."""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu",
@@ -140,8 +164,9 @@ def test_bench_line_with_extras_has_no_error_key():
     assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-1500:])
     d = _last_json(r.stdout)
     assert not _error_keys(d), _error_keys(d)
-    for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p"):
+    for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p", "hbm_kernels"):
         assert key in d, sorted(d)
+    _check_hbm_block(d["hbm_kernels"])
     assert d["svg2_wan720p"]["ms"]["total"] > 0 and d["svg2_wan720p_fp8"]["ms"]["total"] > 0
     assert d["denoise_step_hy720p"]["denoise_steps_per_s"] > 0
 
