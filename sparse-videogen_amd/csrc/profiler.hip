@@ -319,6 +319,9 @@ static int prof_chunks(int BH, int S) {
     n = n < 1 ? 1 : n;
     n = n > ntiles ? ntiles : n;
     n = n > 64 ? 64 : n;
+#ifdef SVG_PROF_CHUNKS_ENV
+    if (const char* e = getenv("SVG_PROF_CHUNKS")) n = std::max(1, std::min(atoi(e), ntiles));   // (A/B builds only)
+#endif
     return n;
 }
 

@@ -159,7 +159,7 @@ static const Geom kGeoms[] = {{"wan720p", 40, 128, 21 * 3600, 300, 1000}, {"smal
 
 int main(int argc, char** argv) {
     std::string lib = "sparse-videogen_amd/lib/libsvgattn.so", geom = "wan720p";
-    int variant = -1, warm = 1, reps = 3, check = 8, heads = 0;
+    int variant = -1, warm = 1, reps = 3, check = 8, heads = 0, two_streams = 0;
     uint64_t seed = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -175,6 +175,7 @@ int main(int argc, char** argv) {
         else if (a == "--check") check = atoi(next());
         else if (a == "--heads") heads = atoi(next());
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
+        else if (a == "--two-streams") two_streams = 1;
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     const Geom* G = nullptr;
@@ -222,10 +223,24 @@ int main(int argc, char** argv) {
         sd->ws_bytes = loop_ws(H, S, sd->K, D);
         HIP_OK(hipMalloc(&sd->ws, sd->ws_bytes));
     }
-    auto kmeans = [&](Side& sd, const uint16_t* x, int iters) {   // warm start from sd.cur, result into sd.next, then swap
+    hipStream_t st2;
+    hipEvent_t fork_ev, join_ev;
+    HIP_OK(hipStreamCreate(&st2)), HIP_OK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming)), HIP_OK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    auto kmeans_on = [&](Side& sd, const uint16_t* x, int iters, hipStream_t s_) {   // warm start from sd.cur, result into sd.next, then swap
         ok(loop(x, nullptr, sd.cur, sd.wa, sd.wb, sd.labels, sd.counts, sd.sorted, sd.next, sd.nit, H, S, sd.K, D, SVG_DTYPE_BF16, iters, 1e-4f,
-                sd.ws, sd.ws_bytes, st), "svg_kmeans_loop");
+                sd.ws, sd.ws_bytes, s_), "svg_kmeans_loop");
         std::swap(sd.cur, sd.next);
+    };
+    auto kmeans = [&](Side& sd, const uint16_t* x, int iters) { kmeans_on(sd, x, iters, st); };
+    // --two-streams: the q-side loop on a second stream beside the k-side loop (the two chains are independent until the block map)
+    auto kmeans_pair = [&](int iters) {
+        if (!two_streams) { kmeans(sq, q, iters), kmeans(sk, k, iters); return; }
+        HIP_OK(hipEventRecord(fork_ev, st));
+        HIP_OK(hipStreamWaitEvent(st2, fork_ev, 0));
+        kmeans_on(sq, q, iters, st2);
+        kmeans_on(sk, k, iters, st);
+        HIP_OK(hipEventRecord(join_ev, st2));
+        HIP_OK(hipStreamWaitEvent(st, join_ev, 0));
     };
     uint8_t* dmap;
     HIP_OK(hipMalloc(&dmap, (size_t)H * QC * KC));
@@ -239,7 +254,7 @@ int main(int argc, char** argv) {
     gather_init_kernel<<<1024, 256, 0, st>>>(q, sq.cur, H, S, QC, D, 7 * seed + 4);
     gather_init_kernel<<<1024, 256, 0, st>>>(k, sk.cur, H, S, KC, D, 7 * seed + 5);
     HIP_OK(hipEventRecord(i0, st));
-    kmeans(sq, q, 50), kmeans(sk, k, 50);
+    kmeans_pair(50);
     HIP_OK(hipEventRecord(i1, st));
 
     const int total = warm + reps;
@@ -247,7 +262,7 @@ int main(int argc, char** argv) {
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
     for (int it = 0; it < total; ++it) {
         HIP_OK(hipEventRecord(ev[4 * it + 0], st));
-        kmeans(sq, q, 2), kmeans(sk, k, 2);
+        kmeans_pair(2);
         HIP_OK(hipEventRecord(ev[4 * it + 1], st));
         ok(dynmap(sq.cur, sk.cur, sk.counts, dmap, H, QC, KC, D, SVG_DTYPE_BF16, 0.9f, (int)(0.1 * KC), st), "svg_identify_dynamic_map");
         HIP_OK(hipEventRecord(ev[4 * it + 2], st));
