@@ -67,6 +67,9 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
 #pragma unroll
                 for (int u = 0; u < kJB; ++u) acc[u] = __builtin_fma(qd, (double)Elt<T>::to_float(v[u][e]), acc[u]);
             }
+#ifdef SVG_DYN_ABL
+            if ((SVG_DYN_ABL) & 1) break;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < kJB; ++u) {
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
         keys[j] = key;
     }
     __syncthreads();
+#ifdef SVG_DYN_ABL
+    if (!((SVG_DYN_ABL) & 2))
+#endif
     for (int k = 2; k <= N2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < N2 / 2; t += kDynThreads) {
@@ -131,6 +137,9 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
         // (the same sequence of fp32 additions as a one-by-one walk; the keys of a block of 8 are loaded together, so the walk pays
         //  one LDS round trip per 8 positions instead of one per position — N2 is a power of two >= 2, entries behind KC hold the
         //  probability 0 sentinel and are never reached: the r < KC test comes first)
+#ifdef SVG_DYN_ABL
+        if ((SVG_DYN_ABL) & 4) done = true, r = KC / 4;
+#endif
         for (int r0 = 0; r0 < KC && !done; r0 += 8) {
             unsigned long long kq[8];
 #pragma unroll
