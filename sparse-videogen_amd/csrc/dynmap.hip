@@ -166,6 +166,179 @@ __global__ __launch_bounds__(kDynThreads) void dynmap_kernel(const T* __restrict
     for (int r = tid; r < KC; r += kDynThreads) orow[(unsigned)keys[r]] = r < cut ? 1 : 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second form (round 5; KC <= 1024, the production sizes): one workgroup per 16 query clusters.
+//   1. scores of 16 rows x KC columns on v_mfma_f64_16x16x4_f64 (fp64 accumulation as above: the rounding argument of the header holds
+//      for ANY summation order; a lane group g4 contracts d = (D / 4) g4 + [0, D / 4)), rounded like the first form and kept in LDS as
+//      16-bit patterns;  2. one WAVE per row: weighted softmax in fp64, 32-bit sort keys ((0xffff - probability bits) << 16 | cluster), a
+//      bitonic sort of 1024 keys in the wave's registers — 16 keys per lane, partner lanes by ds_bpermute, no barrier, no LDS traffic —,
+//      the sequential cumulative sum by one lane, scatter.
+// The first form (dynmap_kernel: one workgroup per row, fp64 FMA chains on the vector pipe, a bitonic network in LDS with 55 barrier
+// rounds) took 0.80 ms at Wan 2.1 720p (40 x 300 x 1000): 0.36 ms of it the dot products, 0.35 the sort (profiles/r05f_dynmap_ablation.txt).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kDyn2Rows = 16;
+constexpr int kDyn2E = 16;                  // keys per lane
+constexpr int kDyn2N = 64 * kDyn2E;         // 1024
+#ifndef SVG_DYN2_WAVES
+#define SVG_DYN2_WAVES 8
+#endif
+constexpr int kDyn2Waves = SVG_DYN2_WAVES;   // waves per workgroup: the key blocks of step 1 and the rows of step 2 are dealt round-robin
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned (&key)[E], int lane) {
+    constexpr int N = 64 * E;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                const int lj = j / E;
+                const bool lower = (lane & lj) == 0;
+                const bool asc = (k >= N) ? true : ((lane & (k / E)) == 0);
+                const bool keep_min = lower == asc;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const unsigned other = (unsigned)__shfl_xor((int)key[e], lj);
+                    const unsigned lo = key[e] < other ? key[e] : other, hi = key[e] < other ? other : key[e];
+                    key[e] = keep_min ? lo : hi;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) != 0) continue;
+                    const bool asc = (k >= N) ? true : (k >= E ? ((lane & (k / E)) == 0) : ((e & k) == 0));
+                    const unsigned a = key[e], b = key[e | j];
+                    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+                    key[e] = asc ? lo : hi;
+                    key[e | j] = asc ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(64 * kDyn2Waves) void dynmap16_kernel(const T* __restrict__ qc, const T* __restrict__ kc, const int32_t* __restrict__ k_sizes,
+                                                       uint8_t* __restrict__ out, int QC, int KC, float sqrt_d, float top_p, int preserve) {
+    constexpr int CH = D / 4;                           // contraction elements of a lane group
+    __shared__ unsigned short sc16[kDyn2Rows][kDyn2N];  // rounded scores as bit patterns of T
+    __shared__ unsigned sorted[kDyn2Waves][kDyn2N];     // a wave's sorted keys (for the walk and the scatter)
+    const int bh = blockIdx.y, row0 = blockIdx.x * kDyn2Rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int n16 = lane & 15, g4 = lane >> 4;
+    const T* kb = kc + (size_t)bh * KC * D;
+    const int32_t* ks = k_sizes + (size_t)bh * KC;
+
+    // ---- 1. scores ----
+    double qd[CH];
+    {
+        const int qr = min(row0 + n16, QC - 1);
+        const T* qrow = qc + ((size_t)bh * QC + qr) * D + CH * g4;
+#pragma unroll
+        for (int c = 0; c < CH; c += 8) {
+            const typename Elt<T>::v8 v = *(const typename Elt<T>::v8*)(qrow + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qd[c + e] = (double)Elt<T>::to_float(v[e]);
+        }
+    }
+    const int nkb = (KC + 15) / 16;
+    for (int kblk = wave; kblk < nkb; kblk += kDyn2Waves) {
+        const int kr = min(kblk * 16 + n16, KC - 1);
+        const T* krow = kb + (size_t)kr * D + CH * g4;
+        typename Elt<T>::v8 kv[CH / 8];
+#pragma unroll
+        for (int c = 0; c < CH / 8; ++c) kv[c] = *(const typename Elt<T>::v8*)(krow + 8 * c);
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)   // A: query cluster n16 (rows of the product), B: key cluster n16 (columns); both at d = CH g4 + c
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qd[c], (double)Elt<T>::to_float(kv[c / 8][c % 8]), acc, 0, 0, 0);
+        // lane (g4, n16) holds the product's rows 4 i + g4 (query clusters), column n16 (key cluster) in acc[i] — measured: tools/probe_dynmap.hip
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s2 = Elt<T>::to_float(Elt<T>::from_double(acc[i]));
+            const T r2 = Elt<T>::from_float(s2 / sqrt_d);
+            sc16[4 * i + g4][kblk * 16 + n16] = __builtin_bit_cast(unsigned short, r2);
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. one wave per row ----
+    unsigned* srt = sorted[wave];
+    for (int rr = wave; rr < kDyn2Rows; rr += kDyn2Waves) {
+        const int row = row0 + rr;
+        if (row >= QC) break;                                 // (wave-uniform)
+        float sv[kDyn2E];
+        float lmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < kDyn2E; ++e) {
+            const int j = lane * kDyn2E + e;
+            sv[e] = Elt<T>::to_float(__builtin_bit_cast(T, sc16[rr][j]));
+            if (j < KC) lmax = fmaxf(lmax, sv[e]);
+        }
+        const double gmax = (double)wave_max(lmax);
+        double we[kDyn2E];
+        double lsum = 0.0;
+#pragma unroll
+        for (int e = 0; e < kDyn2E; ++e) {
+            const int j = lane * kDyn2E + e;
+            we[e] = j < KC ? (double)ks[j] * exp((double)sv[e] - gmax) : 0.0;
+            lsum += we[e];
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o);
+        const double gsum = fmax(lsum, 1e-12);
+        unsigned key[kDyn2E];
+#pragma unroll
+        for (int e = 0; e < kDyn2E; ++e) {
+            const int j = lane * kDyn2E + e;
+            const T pj = Elt<T>::from_double(we[e] / gsum);
+            key[e] = j < KC ? (((0xffffu - (unsigned)__builtin_bit_cast(unsigned short, pj)) << 16) | (unsigned)j) : 0xffffffffu;
+        }
+        wave_bitonic_sort<kDyn2E>(key, lane);
+#pragma unroll
+        for (int e = 0; e < kDyn2E; e += 4) {
+            const u32x4 k4 = {key[e], key[e + 1], key[e + 2], key[e + 3]};
+            *(u32x4*)(srt + lane * kDyn2E + e) = k4;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int cut = 0;
+        if (lane == 0) {   // the cumulative sum of the first form, on 32-bit keys
+            const float p_cmp = Elt<T>::to_float(Elt<T>::from_float(top_p));
+            float acc = 0.f, prev_cum = 0.f;
+            int r = 0;
+            bool done = false;
+            for (int r0 = 0; r0 < KC && !done; r0 += 8) {
+                unsigned kq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kq[u] = srt[min(r0 + u, kDyn2N - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (done) continue;
+                    r = r0 + u;
+                    if (r >= KC || (r > 0 && prev_cum > p_cmp)) {
+                        done = true;
+                        continue;
+                    }
+                    acc += __uint_as_float((0xffffu - (kq[u] >> 16)) << 16);
+                    prev_cum = Elt<T>::to_float(Elt<T>::from_float(acc));
+                    r = r0 + u + 1;
+                }
+            }
+            cut = max(r, preserve);
+        }
+        cut = __shfl(cut, 0);
+        uint8_t* orow = out + ((size_t)bh * QC + row) * KC;
+#pragma unroll
+        for (int e = 0; e < kDyn2E; ++e) {
+            const int r = lane * kDyn2E + e;
+            if (r < KC) orow[key[e] & 0xffffu] = r < cut ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();   // (the next row overwrites srt; the walk above has finished: same wave, program order)
+    }
+}
+
 }  // namespace svg
 
 using namespace svg;
@@ -182,6 +355,21 @@ extern "C" int svg_identify_dynamic_map(const void* qc, const void* kc, const in
     const float inv = sqrtf((float)D);  // scores are divided by sqrt(D) like the reference
     dim3 grid(QC, BH);
     hipStream_t st = (hipStream_t)stream;
+    // 256 < KC <= 1024: the second form (dynmap16_kernel); smaller and larger maps keep the first one
+#ifndef SVG_DYNMAP_FIRST_FORM
+    if (KC > 256 && KC <= kDyn2N) {   // (small maps: the first form sorts the next power of two of KC, this one always 1024 keys)
+        dim3 grid16((QC + kDyn2Rows - 1) / kDyn2Rows, BH);
+#define SVG_DYN16(T, DD) \
+    hipLaunchKernelGGL((dynmap16_kernel<T, DD>), grid16, dim3(64 * kDyn2Waves), 0, st, (const T*)qc, (const T*)kc, k_sizes, out_map, QC, KC, inv, top_p, preserve_length)
+        if (dtype == SVG_DTYPE_BF16 && D == 128) SVG_DYN16(__bf16, 128);
+        else if (dtype == SVG_DTYPE_BF16 && D == 64) SVG_DYN16(__bf16, 64);
+        else if (dtype == SVG_DTYPE_F16 && D == 128) SVG_DYN16(_Float16, 128);
+        else if (dtype == SVG_DTYPE_F16 && D == 64) SVG_DYN16(_Float16, 64);
+        else return SVG_ERR_UNSUPPORTED;
+#undef SVG_DYN16
+        return launch_status();
+    }
+#endif
 #define SVG_DYN(T, DD)                                                                                                   \
     hipLaunchKernelGGL((dynmap_kernel<T, DD>), grid, dim3(kDynThreads), lds, st, (const T*)qc, (const T*)kc, k_sizes, out_map, \
                        QC, KC, inv, top_p, preserve_length)

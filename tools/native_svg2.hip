@@ -299,6 +299,8 @@ int main(int argc, char** argv) {
         for (int j = 0; j < KC; ++j) ksum += hks[(size_t)h * KC + j];
     }
     const double flop = 4.0 * D * pairs;
+    unsigned long long map_sum = 1469598103934665603ull;   // FNV-1a of the last block map (A/B of svg_identify_dynamic_map builds)
+    for (uint8_t m8 : hmap) map_sum = (map_sum ^ m8) * 1099511628211ull;
 
     unsigned long long* dsum;
     unsigned long long osum = 0;
@@ -340,9 +342,9 @@ int main(int argc, char** argv) {
     printf("{\"tool\": \"tools/native_svg2\", \"lib\": \"%s\", \"build\": \"%s\", \"geom\": \"%s\", \"H\": %d, \"S\": %d, \"D\": %d, \"QC\": %d, \"KC\": %d, "
            "\"variant\": %d, \"kmeans_init_50it_ms\": %.2f, \"ms\": {\"kmeans_2it_qk\": %.3f, \"identify_map\": %.3f, \"attention\": %.3f, \"total\": %.3f}, "
            "\"density\": %.4f, \"rows_in_clusters\": [%lld, %lld], \"attention_tflops\": %.1f, \"attention_frac_of_2500\": %.4f, \"spot_rows\": %d, "
-           "\"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\"}\n",
+           "\"rel_l2\": %.3e, \"max_abs\": %.3e, \"o_checksum\": \"%016llx\", \"map_checksum\": \"%016llx\"}\n",
            lib.c_str(), info ? info() : "?", G->name, H, S, D, QC, KC, variant, init_ms, ms[0], ms[1], ms[2], ms[3], pairs / ((double)H * S * S), qsum, ksum,
-           flop / (ms[2] * 1e-3) / 1e12, flop / (ms[2] * 1e-3) / 2.5e15, nck, rel, maxabs, osum);
+           flop / (ms[2] * 1e-3) / 1e12, flop / (ms[2] * 1e-3) / 2.5e15, nck, rel, maxabs, osum, map_sum);
     if (qsum != (long long)H * S || ksum != (long long)H * S) { fprintf(stderr, "cluster sizes do not add up to the token count\n"); return 4; }
     if (nck > 0 && !(rel <= 4e-3)) { fprintf(stderr, "spot rows: rel. L2 %.3e above 4e-3 (bench_svg2's bound)\n", rel); return 4; }
     return 0;
