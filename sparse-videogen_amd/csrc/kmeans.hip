@@ -130,6 +130,11 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     // argmin_c |x - c|^2 = argmax_c (x.c - |c|^2 / 2): the accumulators start at -|c|^2 / 2, so an element of the epilogue is a
     // compare and two selects (the distance form — fma, clamp, bounds test, compare, two selects — made this kernel VALU-bound:
     // 192 VALU against 16 MFMAs per tile).  Ties keep the lowest index, like argmin.
+    // (Round 5, measured and removed — profiles/r05j_ab_kmeans_assign.txt, labels bit-identical in both: (i) the MFMAs of tile t + 1 between the epilogue
+    //  elements of tile t with a second score set: 168 registers, one workgroup per CU, 0.70 instead of 0.57 ms per call; (ii) a rolling half-tile
+    //  pipeline — the epilogue of one 32-centroid half between the MFMAs of the other — at 128 registers and two workgroups per CU: 0.56 ms, no gain.
+    //  Four waves per SIMD already overlap one wave's epilogue with another's MFMAs; the matrix pipe is 0.41 busy because 43 % of the wave cycles
+    //  sit at the tile barrier / waitcnt, profiles/r05i_pmc_svg2_native.json.)
     float best = -INFINITY;
     int best_idx = 0;
     for (int t = 0; t < nT; ++t) {
