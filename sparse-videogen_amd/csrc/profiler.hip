@@ -40,6 +40,11 @@ struct ProfilePolicy {
     static constexpr int kRowBlocks = 1;
     static constexpr int kSubTiles = 1;
     static constexpr int kPrefetch = 1;
+    // (225 registers: ONE workgroup per CU, so the 504 workgroups of a HunyuanVideo call run in two rounds of ~0.25 ms, each tile waiting out the
+    //  latency of loads issued one tile ahead.  Round 5 tried a second staging register set (loads of tile t + 3 in flight during tile t, 241
+    //  registers): as plain loads hipcc's waitcnt pass drains both sets (vmcnt(0)) in front of the older set's LDS writes — nothing gained —, and
+    //  as inline-asm loads with hand-placed waits the compiler copies the destination registers ahead of the wait across the loop's parity
+    //  branches: memory faults.  Removed; what shipped is the fast predicate on frame-major tiles in classify() below.)
     static constexpr int NW = kProfNW;
 
     struct Params {
@@ -67,7 +72,7 @@ struct ProfilePolicy {
         // token-major fast tiles (TILE_PARTIAL_FAST): the keys of the tile are y = ybase + off * F in mask coordinates (one frame,
         // no text keys), and this lane's row sees y in [fa0, fa0 + falen) u [0, fblen): band blocks n domain, sink columns n domain
         mutable int ybase;
-        int fa0, g4F;
+        int fa0, g4F, ystride;   // ystride: coordinate step between consecutive keys of a fast tile (F token-major, 1 frame-major)
         unsigned falen, fblen;
     };
     struct KvCursor {};
@@ -116,7 +121,8 @@ struct ProfilePolicy {
         }
         c.xlo_blk = lo, c.xhi_blk = hi, c.any_text = anyt;
         c.tk0 = 0, c.f0 = 0, c.p0 = 0;
-        c.ybase = 0, c.g4F = 4 * (int)((threadIdx.x >> 5) & 1) * p.F;
+        c.ystride = c.pv.coord == 1 ? p.F : 1;
+        c.ybase = 0, c.g4F = 4 * (int)((threadIdx.x >> 5) & 1) * c.ystride;
         {
             const int x = c.qx, span = c.pv.span;
             const bool xdom = have && ((unsigned)x < (unsigned)span);
@@ -161,6 +167,16 @@ struct ProfilePolicy {
                 const bool no_sink = y0 >= pv.sink_cols;
                 if (outside || (far && no_sink && y0 >= 0)) return TILE_SKIP;
             }
+            // frame-major mask, all 64 keys inside the band domain and none of them a text column: the keys are consecutive coordinates
+            // y = ybase + off, and the element predicate collapses to the two interval tests of allowed_fast like the token-major tiles
+            // below.  (Without this every tile the spatial role does not skip paid the general predicate, ~25 instructions per element:
+            // the workgroups of a head's first chunks — where the sampled rows' bands lie — ran 2.5x as long as the others and set the
+            // launch time: 0.66 ms at HunyuanVideo 720p with the average wave alive for 40 % of it, profiles/r05a_profiler_kernel_trace.txt.)
+            if (!text_keys && k0 + kBN <= p.S && k0 - pv.origin >= 0 && k0 + kBN - pv.origin <= pv.span) {
+                c.tk0 = k0;
+                c.ybase = k0 - pv.origin;
+                return TILE_PARTIAL_FAST;
+            }
         } else {
             // token-major mask: one division per tile instead of one per element (keys of a tile are consecutive)
             const int i0 = max(k0 - p.vid0, 0);
@@ -200,7 +216,7 @@ struct ProfilePolicy {
         return (k < p.S) & (bool)(c.qtext | tk | (dom & (band | sink)));
     }
     static __device__ __forceinline__ bool allowed_fast(const Params& p, const Ctx& c, int off) {
-        const int y = c.ybase + c.g4F + off * p.F;   // off: key offset inside the tile without the lane's 4 g
+        const int y = c.ybase + c.g4F + off * c.ystride;   // off: key offset inside the tile without the lane's 4 g
         return ((unsigned)(y - c.fa0) < c.falen) | ((unsigned)y < c.fblen);
     }
     static __device__ __forceinline__ float score_fixup(const Params& p, float s) {
@@ -232,15 +248,33 @@ struct ProfilePolicy {
 
 // (The two-phase ping-pong body was tried here and is slower, 1.89 ms vs 1.22 ms: it walks every wave through every tile, and a
 //  tile a masked role does not need still pays the element predicate, which the lock-step body skips.)
+#ifdef SVG_PROF_TRACE
+static __device__ unsigned long long g_prof_trace[2048 * 4];   // diagnostics build: per workgroup { start, end (s_memtime), hw id, chunk << 16 | head }
+#endif
 template <typename T, int D>
 __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename ProfilePolicy<T, D>::Params prm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SVG_PROF_TRACE
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     attn_body<T, D, kProfNW, ProfilePolicy<T, D>>(prm, smem, nullptr);
+#ifdef SVG_PROF_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 2048) {
+            g_prof_trace[wg * 4 + 0] = t0;
+            g_prof_trace[wg * 4 + 1] = __builtin_amdgcn_s_memtime();
+            g_prof_trace[wg * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+            g_prof_trace[wg * 4 + 3] = ((unsigned long long)blockIdx.y << 16) | blockIdx.x;
+        }
+    }
+#endif
 }
 
 // merge the split-KV partials, normalise, and reduce squared errors.  grid = (kProfRowGroups, BH), block = 256:
 // row group rg of head h -> sq_part[h][rg][0..1] (sum of squared errors of the two masks), [2..3] NaN flags
-constexpr int kProfRowGroups = 8;
+constexpr int kProfRowGroups = 32;   // (8 until round 5: 192 workgroups read 51 MB of partials in 0.112 ms; 32: 768 workgroups)
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void profile_combine_kernel(const float* __restrict__ part, float* __restrict__ sq_part, int BH,
@@ -370,6 +404,13 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
 }  // namespace svg
 
 using namespace svg;
+
+#ifdef SVG_PROF_TRACE
+extern "C" int svg_debug_prof_trace(uint64_t* out, int n_workgroups) {
+    if (!out || n_workgroups <= 0 || n_workgroups > 2048) return SVG_ERR_BAD_ARG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_trace), (size_t)n_workgroups * 4 * sizeof(uint64_t)) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
+}
+#endif
 
 extern "C" size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t D, int32_t S) {
     if (BH <= 0 || R <= 0 || D <= 0 || S <= 0) return 0;

@@ -380,6 +380,25 @@ int main(int argc, char** argv) {
             mean += t / reps;
             printf("%s%.4f", i ? ", " : "", t);
         }
+        if (auto ptrace = (int (*)(uint64_t*, int))dlsym(so, "svg_debug_prof_trace")) {   // -DSVG_PROF_TRACE builds: per-workgroup timeline of the last launch
+            const int nwg = 2048;
+            std::vector<uint64_t> tr((size_t)nwg * 4);
+            if (ptrace(tr.data(), nwg) == 0) {
+                uint64_t t_min = ~0ull, t_max = 0;
+                int n = 0;
+                for (int w = 0; w < nwg; ++w) if (tr[4 * w + 1] > tr[4 * w]) { t_min = std::min(t_min, tr[4 * w]); t_max = std::max(t_max, tr[4 * w + 1]); ++n; }
+                fprintf(stderr, "prof trace: %d workgroups, span %llu ticks\n", n, (unsigned long long)(t_max - t_min));
+                // per chunk: mean start, mean duration, max end (ticks of s_memtime relative to the first start)
+                for (int c = 0; c < 64; ++c) {
+                    double st = 0, du = 0; uint64_t en = 0, dmax = 0; int m = 0;
+                    for (int w = 0; w < nwg; ++w) {
+                        if (!(tr[4 * w + 1] > tr[4 * w]) || (int)(tr[4 * w + 3] >> 16) != c) continue;
+                        st += (double)(tr[4 * w] - t_min), du += (double)(tr[4 * w + 1] - tr[4 * w]), en = std::max(en, tr[4 * w + 1] - t_min), dmax = std::max(dmax, tr[4 * w + 1] - tr[4 * w]), ++m;
+                    }
+                    if (m) fprintf(stderr, "  chunk %2d: %2d wgs  mean start %9.0f  mean dur %9.0f  max dur %9llu  last end %9llu\n", c, m, st / m, du / m, (unsigned long long)dmax, (unsigned long long)en);
+                }
+            }
+        }
         const double kv_bytes = 2.0 * H * (double)S * D * 2;
         printf("], \"ms_mean\": %.4f, \"kv_bytes\": %.0f, \"gbps\": %.1f, \"frac_of_8tbps\": %.4f, \"mse_sum\": %.9e, \"mse0\": [%.6e, %.6e], \"mse_bits\": \"%016llx\"}\n",
                mean, kv_bytes, kv_bytes / (mean * 1e-3) / 1e9, kv_bytes / (mean * 1e-3) / 8e12, sum, hm[0], hm[H], bits);
