@@ -267,19 +267,25 @@ def main():
         n_chunks, n_per = a.chunks, H // a.chunks
     Hl = len(my_heads)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def head_rows(h: int, which: int, lo: int = 0, hi: int = S) -> "torch.Tensor":
+        """rows [lo, hi) of head h of q (0) / k (1) / v (2): seeded by the GLOBAL head index, so that every world size sees the same
+        tensors and the gathered output of an N-rank run can be held against the 1-rank run bit for bit (`output_checksum` below)"""
+        gh = torch.Generator(device=dev).manual_seed(7919 * (3 * h + which) + 1234)
+        return torch.randn(S, D, device=dev, dtype=torch.bfloat16, generator=gh)[lo:hi]
     if world > 1:
         # token-sharded inputs: ALL heads (ordered owner by owner, as the fused prologue would write them) of this rank's tokens
         # (shards in units of 128 tokens like bench_step.StepGeo.unit: largest / mean 1.006 at N = 8 where whole frames give 1.21)
         TOKEN_UNIT = 128 if S >= 8 * 128 * world else 8
         head_lists = [chunked_head_layout(H, r, world, max_chunks=24)[2] for r in range(world)]
         ta, tb = token_range(S, rank, world, unit=TOKEN_UNIT)
-        q_tok, k_tok, v_tok = (torch.randn(H, tb - ta, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        q_tok, k_tok, v_tok = (torch.stack([head_rows(h, w, ta, tb) for h in range(H)]) for w in range(3))
         q, k, v = (torch.empty(1, Hl, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
         seen = torch.ones(1, device=dev)
         dist.all_reduce(seen)                      # every rank of the communicator answered
         rccl_ranks_seen = int(seen.item())
     else:
-        q, k, v = (torch.randn(1, Hl, S, D, device=dev, dtype=torch.bfloat16, generator=g) for _ in range(3))
+        q, k, v = (torch.stack([head_rows(h, w) for h in my_heads])[None] for w in range(3))
     o = torch.empty_like(q)
     pat = {"alt": lambda h: h % 2, "spatial": lambda h: 0, "temporal": lambda h: 1}[a.heads]
     best = torch.tensor([[pat(h) for h in my_heads]], device=dev, dtype=torch.int64)  # default: alternate spatial / temporal
@@ -480,6 +486,16 @@ def main():
             assert torch.equal(full.index_select(0, idx), outs[r]), f"exchange of rank {r}'s heads is wrong or ran ahead of the kernel"
     ms_step = dt / a.steps * 1e3
     attn_ms = sum(x.elapsed_time(y) for x, y in zip(ev_a0, ev_a1)) / len(ev_a0)
+    # 64-bit checksum of the WHOLE layer-call output (all H heads: `o` at N = 1, the gathered `full` at N > 1), order-dependent over
+    # heads: equal across world sizes and across the overlapped / fallback exchange paths, or something is wrong (tools/scale_run.sh,
+    # tests/test_gpu_bench_contract.py)
+    torch.cuda.synchronize()
+    whole = full if world > 1 else o[0]
+    acc = 0
+    for h in range(whole.shape[0]):
+        bits = whole[h].contiguous().view(torch.int16).to(torch.int64)
+        acc = (acc * 1000003 + int((bits * (torch.arange(bits.shape[-1], device=dev) + 1)).sum().item()) + 31 * int(bits.sum().item())) % (1 << 64)
+    output_checksum = f"{acc:016x}"
 
     out = None
     if rank == 0:
@@ -515,6 +531,7 @@ def main():
                 "heads": a.heads,
             },
             "algorithmic_tflop_per_step": round(flops_call / 1e12, 3),
+            "output_checksum": output_checksum,    # all heads of the last step's output; the same at every N (inputs are seeded per global head)
             # 60 sparse attention layer-calls per second and NOTHING else of a denoise step (no projections / norms / MLPs / VAE)
             "attention_only_steps_per_s": round(1.0 / (60 * ms_step * 1e-3), 4),
             "exchange": None if world == 1 else {

@@ -369,7 +369,6 @@ __global__ __launch_bounds__(512, 2) void varblock_attn_m16_kernel(typename Varb
     extern __shared__ __attribute__((aligned(16))) char smem[];
     attn_body_m16<T, VarblockPolicy<T, 128, 8>>(prm, smem, smem + attn_m16_lds_bytes());
 }
-static thread_local bool tl_vb_m16 = false;   // set by svg_varblock_attention for variant 8 (the launch below picks the m16 kernel)
 
 #ifdef SVG_ABLATIONS
 // the same kernel with the launch timeline of svg_debug_wg_trace (variant 5, diagnostics build only)
@@ -792,23 +791,12 @@ thread_local int g_last_hip_error = 0;
 
 // Schedules of svg_band_attention (`variant`, include/svg_attn.h).
 enum BandSchedule : int { kBandAuto = 0, kBandLockstep4 = 1, kBandPingPong = 2, kBandW4 = 3, kBandFrozen = 6, kBandM16 = 8 };
-// default (variant 0): the two-phase ping-pong body with the max-free softmax for head_dim 128 (round 2, late: 33.7 vs 35.0 ms for the
-// one-wave-per-SIMD body on the same box), the one-wave-per-SIMD body for head_dim 64 (2.60 vs 2.67 ms, 13.6 vs 13.8 ms on the
-// CogVideoX geometries).  Launches that count completions (svg_band_attention_notify*) always run the two-phase body: their targets
-// (svg_band_attention_notify_target / _layout) do not know the head size.
-// Round 3: with the carried operands the two-phase body is the faster one at head_dim 64 too (CogVideoX-v1 2.62 vs 2.73 ms, v1.5
-// 13.80 vs 13.84 ms; pre-scaled 2.45 / 13.03 ms): one default for both head sizes.
-// Round 4: head_dim 128 runs the two-phase schedule on 16x16x32 MFMAs (attn_m16.h, variant 8): 32.6 ms against 34.1 - 35.7 for the
-// 32x32x16 body on the plain q, same box (profiles/r04f_ab_m16.txt, r04g_ab_m16_cfg.txt); head_dim 64 and the pre-scaled entry points keep
-// the 32x32x16 body (variant 2).
-// head_dim 64 (CogVideoX) on the plain q: for a few hours of round 4 the one-wave-per-SIMD body again (13.6 / 13.9 ms against 14.2 / 14.7 for the
-// two-phase body at two waves per SIMD, profiles/r04p_clock_by_variant.txt, r04zx_clock_by_variant.txt) — until the two-phase body got its
-// four-waves form there (band_attn_pp2_kernel, 12.2 - 12.9 ms).
-static inline int band_default(int D, bool /*with_counters*/, bool /*prescaled*/) {
-    // head_dim 64: the two-phase body — since it runs four waves per SIMD there (band_attn_pp2_kernel) it is ahead of the
-    // one-wave-per-SIMD body on the plain q as well (12.7 - 12.9 against 13.7 - 14.3 ms on CogVideoX-v1.5, profiles/r04zr_*, r04zs_*)
-    return D == 128 ? kBandM16 : kBandPingPong;
-}
+// default (variant 0): head_dim 128 -> the two-phase schedule on 16x16x32 MFMAs (attn_m16.h, variant 8; profiles/r04f_ab_m16.txt);
+// head_dim 64 -> the two-phase 32x32x16 body in its four-waves-per-SIMD (LEAN) form (band_attn_pp2_kernel, variant 2; profiles/r04zr_*).
+// Measured alternatives at head_dim 64: the one-wave-per-SIMD body (variant 3, 13.7 - 14.3 against 12.7 - 12.9 ms on CogVideoX-v1.5) and the
+// 16x16x32 body at four waves per SIMD (round 5, no gain: profiles/r05b_ab_d64_m16.txt, removed).  Launches that count completions
+// (svg_band_attention_notify*) take the same defaults.
+static inline int band_default(int D) { return D == 128 ? kBandM16 : kBandPingPong; }
 
 int band_waves_per_tile(int variant) {
     const int v = variant == kBandAuto ? kBandPingPong : variant;
@@ -909,7 +897,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
         variant = kBandPingPong;
         g_trace_is_w4 = false;
     }
-    if (variant == kBandAuto) variant = band_default(D, opts.done != nullptr, opts.prescaled);
+    if (variant == kBandAuto) variant = band_default(D);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
@@ -1172,7 +1160,8 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0, bool body_m16 = false) {
+    // body_m16 (NW == -8, head_dim 128): the two-phase body on 16x16x32 MFMAs (attn_m16.h) instead of the 32x32x16 one
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
     int32_t* k_off = tile_off + (size_t)Hkv * (QB + 1);
@@ -1251,7 +1240,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
 #endif
                     if (trace) return SVG_ERR_UNSUPPORTED;   // diagnostics builds only (-DSVG_ABLATIONS)
                     if constexpr (D == 128) {
-                        if (tl_vb_m16)
+                        if (body_m16)
                             return launch_attn(varblock_attn_m16_kernel<T>, p, dim3(p.max_tiles * Hq), 512,
                                                attn_m16_lds_bytes() + vb_policy_lds(p.kb_cap), st);
                     }
@@ -1263,7 +1252,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
                 return SVG_ERR_UNSUPPORTED;   // (the fp8 kernel takes the ordered 1-D launch only)
             else {
                 if constexpr (D == 128) {
-                    if (tl_vb_m16)
+                    if (body_m16)
                         return launch_attn(varblock_attn_m16_kernel<T>, p, dim3(p.max_tiles, Hq), 512,
                                            attn_m16_lds_bytes() + vb_policy_lds(p.kb_cap), st);
                 }
@@ -1309,7 +1298,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (variant == 8 || variant == 9) variant = 3;
     const bool block_row_order = (variant == 4), trace = (variant == 5);
     const int order_mode = variant == 7 ? 2 : (variant == 6 ? 1 : 0);   // 0: longest-first + remainder packing, 1: longest-first, 2: similarity order
-#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode
+#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode, body_m16
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
@@ -1325,7 +1314,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     // -1 (auto): 256-row q tiles with the two-phase ping-pong body once the average block-row is large enough to fill them
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
-    tl_vb_m16 = (variant >= 3 && D == 128 && !force_pp2);
+    const bool body_m16 = (variant >= 3 && D == 128 && !force_pp2);
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {

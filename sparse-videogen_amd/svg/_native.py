@@ -592,6 +592,9 @@ def clear_workspace_cache() -> None:
     at most WorkspaceCache.capacity of each kind)."""
     _F8_WS.clear()
     _KMEANS_WS.clear()
+    from . import kmeans_utils as _ku   # (its KMeansState cache of the per-iteration path follows the same policy)
+
+    _ku._STATE_CACHE.clear()
 
 
 def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,

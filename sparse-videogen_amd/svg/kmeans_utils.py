@@ -47,7 +47,9 @@ class KMeansState:
         return self.shape == (B, N, n_clusters, D, x.dtype, x.device)
 
 
-_STATE_CACHE: dict = {}   # per-iteration path (check_every >= 1, sharded stopping rule): label / count / centroid buffers per shape
+# per-iteration path (check_every >= 1, sharded stopping rule): label / count / centroid buffers per (shape, device, stream), bounded like
+# the other workspaces (svg._native.WorkspaceCache) — two streams on one shape never share a KMeansState
+_STATE_CACHE = _native.WorkspaceCache()
 _LOOP_WORK = _native._KMEANS_WS   # scratch of svg_kmeans_loop per (B, N, K, D, dtype, device, stream), bounded (svg._native.WorkspaceCache)
 
 
@@ -81,7 +83,7 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
     loop_in_library = not check_every and shift_reduce is None and not verbose
     st = None
     if not loop_in_library:     # (the svg_kmeans_loop path keeps its own scratch: no KMeansState for it)
-        key = (B, N, n_clusters, D, x.dtype, x.device)
+        key = _native.WorkspaceCache.key(B, N, n_clusters, D, x.dtype, device=x.device)
         st = _STATE_CACHE.get(key)
         if st is None:
             st = _STATE_CACHE[key] = KMeansState(x, n_clusters)

@@ -90,7 +90,9 @@ class WanAttn_SVGAttn_Processor2_0:
             # dependency here, so its class is recognised by name, and a module with a bias (LayerNorm) is never an RMSNorm
             if isinstance(mod, torch.nn.RMSNorm):
                 return True
-            return type(mod).__name__ == "RMSNorm" and getattr(mod, "bias", None) is None and getattr(mod, "weight", None) is not None
+            # any class of the module's MRO named RMSNorm (the reference's isinstance also accepts subclasses of diffusers' RMSNorm);
+            # the reference's kernel call uses weight and eps only, so a bias on the module does not disqualify it
+            return any(c.__name__ == "RMSNorm" for c in type(mod).__mro__) and getattr(mod, "weight", None) is not None
 
         def norm(mod, x):
             if not is_rms(mod):

@@ -16,6 +16,9 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "data", "config", "roofline", "cpu_baseline"}
 
 
+_CHECKSUMS = {}   # bench.py --workload tiny: output_checksum by run ("n1", "n2", "n2_fallback") — the same inputs at every world size
+
+
 def _last_json(out: str):
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert lines, out[-2000:]
@@ -33,6 +36,8 @@ def test_bench_single_gpu_json_line():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert len(d["output_checksum"]) == 16
+    _CHECKSUMS["n1"] = d["output_checksum"]
 
 
 def test_bench_two_rank_control_flow_smoke():
@@ -47,6 +52,9 @@ def test_bench_two_rank_control_flow_smoke():
     ex = d["exchange"]
     assert ex["rccl_ranks_seen"] == 2 and ex["fallback_to_chunk_launches"] is False and ex["waiter_timeouts_in_timed_steps"] == 0
     assert ex["inbound_bytes_received_per_rank"] > 0 and ex["outbound_bytes_received_per_rank"] > 0
+    _CHECKSUMS["n2"] = d["output_checksum"]
+    if "n1" in _CHECKSUMS:   # the gathered output of the two-rank run == the one-rank run's, bit for bit (inputs are seeded per global head)
+        assert d["output_checksum"] == _CHECKSUMS["n1"], (d["output_checksum"], _CHECKSUMS["n1"])
     sd = d["denoise_step_hy720p"]     # the token-sharded denoise step at N = 2 (reduced stack on the tiny workload)
     assert sd["n_gpus"] == 2 and sd["sparse_step"]["ms"] > 0 and sd["sparse_step"]["rccl_bytes_received_per_step_this_rank"] > 0
 
@@ -59,9 +67,15 @@ def test_bench_two_rank_watchdog_falls_back():
            "--master-port", "29543", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    ex = _last_json(r.stdout)["exchange"]
+    d = _last_json(r.stdout)
+    ex = d["exchange"]
     assert ex["fallback_to_chunk_launches"] is True and ex["waiter_timeouts_in_timed_steps"] == 0
     assert "per chunk" in ex["outbound"]
+    # the fallback path (one launch + all-gather per chunk of heads) leaves the same bytes as the overlapped path and as the one-rank run
+    for other in ("n2", "n1"):
+        if other in _CHECKSUMS:
+            assert d["output_checksum"] == _CHECKSUMS[other], (other, d["output_checksum"], _CHECKSUMS[other])
+    assert _CHECKSUMS, "run the whole module: the one-rank / overlapped two-rank tests provide the reference checksum"
 
 
 def test_bench_fp8_line():

@@ -18,7 +18,9 @@ def harness():
     sys.path.insert(0, str(ROOT))
     import __graft_entry__ as entry
 
-    return entry.build_native_harness()   # (the prebuilt binary travels with the tree; rebuilt only when its source is newer)
+    # (tools/native_harness is git-ignored: build() compiles it in the build container and the GPU-box snapshot carries it; anywhere else it is
+    #  compiled from tools/native_harness.hip here, and again whenever the source or the C-ABI header is newer)
+    return entry.build_native_harness()
 
 
 CASES = [
@@ -32,6 +34,8 @@ CASES = [
     ["--geom", "small64", "--switch", "0"],                     # svg_band_attention_switch, sparse side
     ["--geom", "small64", "--switch", "1", "--flags", "one"],   # ... dense side: the placement flags must be ignored
     ["--geom", "cog480p", "--heads", "4"],                      # production sequence length of CogVideoX-v1 480p, four heads
+    ["--geom", "small", "--fill", "zero"],                      # all-zero operands (the schedule-only ceiling runs of profiles/r05a_*): output exactly 0
+    ["--geom", "small", "--band", "256"],                       # band override (tools/gpu_r05a.sh band sweep)
 ]
 
 
@@ -57,3 +61,29 @@ def test_native_harness_switch_equals_plain_call(harness):
 
     for extra in ((), ("--dtype", "f16", "--flags", "one")):
         assert checksum("--geom", "small64", *extra) == checksum("--geom", "small64", "--switch", "0", *extra), extra
+
+
+def test_native_harness_profiler_mode(harness):
+    """--profiler: svg_sample_mse through the C ABI without torch (the instrument of profiles/r05k_*): finite mse values, a plausible time"""
+    r = subprocess.run([str(harness), "--lib", str(ROOT / "sparse-videogen_amd" / "lib" / "libsvgattn.so"), "--geom", "small", "--profiler",
+                        "--warm", "1", "--reps", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ms_mean"] > 0 and d["mse_sum"] > 0 and d["mse0"][0] == d["mse0"][0]
+
+
+def test_native_svg2_small():
+    """tools/native_svg2: the SVG2 layer-call (k-means loops, block map, variable-block attention) through the C ABI without torch, one stream
+    and two: spot rows against its own fp32 restatement (exit code), identical outputs and block maps in both modes."""
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as entry
+
+    exe = entry.build_native_svg2()
+    outs = []
+    for extra in ([], ["--two-streams"]):
+        r = subprocess.run([str(exe), "--lib", str(ROOT / "sparse-videogen_amd" / "lib" / "libsvgattn.so"), "--geom", "small", *extra],
+                           capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["rel_l2"] <= 4e-3 and outs[0]["spot_rows"] > 0
+    assert outs[0]["o_checksum"] == outs[1]["o_checksum"] and outs[0]["map_checksum"] == outs[1]["map_checksum"]
