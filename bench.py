@@ -279,7 +279,8 @@ def main():
         TOKEN_UNIT = 128 if S >= 8 * 128 * world else 8
         head_lists = [chunked_head_layout(H, r, world, max_chunks=24)[2] for r in range(world)]
         ta, tb = token_range(S, rank, world, unit=TOKEN_UNIT)
-        q_tok, k_tok, v_tok = (torch.stack([head_rows(h, w, ta, tb) for h in range(H)]) for w in range(3))
+        owner_order = [h for hl in head_lists for h in hl]     # position p of a token shard holds head owner_order[p]
+        q_tok, k_tok, v_tok = (torch.stack([head_rows(h, w, ta, tb) for h in owner_order]) for w in range(3))
         q, k, v = (torch.empty(1, Hl, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
         seen = torch.ones(1, device=dev)
         dist.all_reduce(seen)                      # every rank of the communicator answered
