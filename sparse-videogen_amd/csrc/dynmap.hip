@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * kDyn2Waves) void dynmap16_kernel(const T* __re
                         done = true;
                         continue;
                     }
-                    acc += __uint_as_float((0xffffu - (kq[u] >> 16)) << 16);
+                    acc += Elt<T>::to_float(__builtin_bit_cast(T, (unsigned short)(0xffffu - (kq[u] >> 16))));   // (the key carries T's bit pattern)
                     prev_cum = Elt<T>::to_float(Elt<T>::from_float(acc));
                     r = r0 + u + 1;
                 }
