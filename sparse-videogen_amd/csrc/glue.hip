@@ -63,6 +63,9 @@ __device__ __forceinline__ void store8(void* base, size_t elem, int dt, const fl
 }
 
 // one wave per row; lane l owns the 8-element chunks l, l + 64, ... (NCH of them at most)
+// (Round 5: svg_layernorm_modulate_forward runs at 2.5 TB/s at Wan's hidden size (0.62 ms for [75600, 5120] bf16) where the gate-residual kernel reaches
+//  6.0: a row's scale and shift come from global memory as four 16-byte fp32 loads per 16-byte chunk of x, behind the statistics, at two waves per SIMD
+//  (182 registers).  Staging scale / shift in LDS once per workgroup of 32 rows was measured: 256 registers, one wave per SIMD, 0.99 ms — removed.)
 template <int NCH>
 __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
     const int lane = threadIdx.x & 63;
