@@ -66,7 +66,10 @@ __device__ __forceinline__ void store8(void* base, size_t elem, int dt, const fl
 // (Round 5: svg_layernorm_modulate_forward runs at 2.5 TB/s at Wan's hidden size (0.62 ms for [75600, 5120] bf16) where the gate-residual kernel reaches
 //  6.0: a row's scale and shift come from global memory as four 16-byte fp32 loads per 16-byte chunk of x, behind the statistics, at two waves per SIMD
 //  (182 registers).  Staging scale / shift in LDS once per workgroup of 32 rows was measured: 256 registers, one wave per SIMD, 0.99 ms — removed.)
-template <int NCH>
+// LN: p.do_ln as a compile-time constant — with the three normalisation forms behind run-time branches of one kernel the hidden-size-5120
+// instance needed 182 registers (two waves per SIMD) where the LayerNorm-only kernel of round 1 had 114 (four): svg_layernorm_modulate_forward
+// fell from 0.41 to 0.62 ms at Wan 720p (profiles/r01f_bench_glue.json, r05n_bench.json hbm_kernels).
+template <int NCH, int LN>
 __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
             for (int j = 0; j < 8; ++j) x[i][j] = 0.f;
         }
     }
-    if (p.do_ln == 2) {
+    if constexpr (LN == 2) {
         float s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
                 }
             }
         }
-    } else if (p.do_ln) {
+    } else if constexpr (LN == 1) {
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
@@ -177,7 +180,13 @@ static int launch_row_glue(const GlueParams& p, hipStream_t st) {
     if (!dt_ok(p.x_dt) || !dt_ok(p.y_dt)) return SVG_ERR_UNSUPPORTED;
     const int need = (p.N / 8 + 63) / 64;
     const dim3 grid((p.M + 3) / 4), block(256);
-#define SVG_GLUE(NC) if (need <= NC) { hipLaunchKernelGGL(row_glue_kernel<NC>, grid, block, 0, st, p); return launch_status(); }
+#define SVG_GLUE(NC)                                                                                          \
+    if (need <= NC) {                                                                                         \
+        if (p.do_ln == 2) hipLaunchKernelGGL((row_glue_kernel<NC, 2>), grid, block, 0, st, p);                \
+        else if (p.do_ln == 1) hipLaunchKernelGGL((row_glue_kernel<NC, 1>), grid, block, 0, st, p);           \
+        else hipLaunchKernelGGL((row_glue_kernel<NC, 0>), grid, block, 0, st, p);                             \
+        return launch_status();                                                                               \
+    }
     SVG_GLUE(2) SVG_GLUE(4) SVG_GLUE(6) SVG_GLUE(8) SVG_GLUE(10) SVG_GLUE(12) SVG_GLUE(16)
 #undef SVG_GLUE
     return SVG_ERR_UNSUPPORTED;
