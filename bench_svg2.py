@@ -138,6 +138,21 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
             times["attention"].append(t[2].elapsed_time(t[3]))
             times["total"].append(t[0].elapsed_time(t[3]))
         dens = density_calculation(dmap, q_sizes, k_sizes)
+    # shader clock the power management grants the attention kernel: three more launches of the last step's call beside the library's clock probe
+    attention_sclk_mhz = None
+    if not a.materialize:
+        try:
+            probe = nat.ClockProbe(q.device)
+            probe.start(max_ms=5000)
+            for _ in range(3):
+                nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
+                                       q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
+                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8)
+            probe.arm_stop()
+            attention_sclk_mhz = probe.result()
+        except Exception:  # noqa: BLE001  (a measurement aid: its failure must not cost the block)
+            attention_sclk_mhz = None
+        torch.cuda.synchronize()
     # spot rows of the last timed output against a torch fp32 statement of the op (text rows: the two pseudo clusters)
     qlab, klab = ql.view(H, V), kl.view(H, V)
     if ctx:
@@ -164,6 +179,7 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         "data": "synthetic (64-mode Gaussian mixture per head)",
         "spot_rows_rel_l2_vs_torch_fp32": round(spot, 6),
         "attention_frac_of_2500tflops_bf16": round(attn_flops / (ms["attention"] * 1e-3) / 1e12 / 2500.0, 4),
+        "attention_sclk_mhz": attention_sclk_mhz,     # granted shader clock during three attention launches (svg_debug_clock_probe); 2400 = nominal
         "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
     }
     traffic = _pmc_traffic(a.workload, a.fp8)
