@@ -134,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     //  elements of tile t with a second score set: 168 registers, one workgroup per CU, 0.70 instead of 0.57 ms per call; (ii) a rolling half-tile
     //  pipeline — the epilogue of one 32-centroid half between the MFMAs of the other — at 128 registers and two workgroups per CU: 0.56 ms, no gain.
     //  Four waves per SIMD already overlap one wave's epilogue with another's MFMAs; the matrix pipe is 0.41 busy because 43 % of the wave cycles
-    //  sit at the tile barrier / waitcnt, profiles/r05i_pmc_svg2_native.json.)
+    //  sit at waitcnt / barrier, profiles/r05i_pmc_svg2_native.json — and (iii) 128-centroid LDS stages, one barrier per two tiles: no gain either.)
     float best = -INFINITY;
     int best_idx = 0;
     for (int t = 0; t < nT; ++t) {
