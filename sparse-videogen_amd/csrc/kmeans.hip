@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) void csq_kernel(const T* __restrict__ c, float
     }
 }
 
+#ifdef SVG_KMEANS_TRACE
+static __device__ unsigned long long g_km_trace[8 * 8];   // diagnostics build: per wave of workgroup (7, 0): cycles in { init, mfma, epilogue, stage, barrier }, tiles
+#endif
 // ---- assignment: grid = (ceil(N / (NW*32)), B), block = NW*64 ----
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __restrict__ x, const T* __restrict__ cent,
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     }
     u32x4 creg[NCH];
     float sreg = 0.f;
+    bool sreg_ok = false;
     const int nT = (K + kBN - 1) / kBN;
     auto issue = [&](int t) {
 #pragma unroll
@@ -107,16 +111,18 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
             const int c = t * kBN + srow[i];
             creg[i] = *(const u32x4*)(cb + (size_t)(c < K ? c : 0) * D + scol[i] * 8);
         }
-        if (tid < kBN) {   // -|c|^2 / 2 (the accumulator's start value, see below); centroids behind K can never win
+        if (tid < kBN) {   // |c|^2, RAW: the multiply sits in write() — used here it makes hipcc wait (vmcnt(0)) for the loads it has just issued
             const int c = t * kBN + tid;
-            sreg = c < K ? -0.5f * csqb[c] : -INFINITY;
+            sreg = csqb[c < K ? c : 0];
+            sreg_ok = c < K;
         }
     };
     auto write = [&](int buf) {
         char* base = smem + buf * kStage;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) *(u32x4*)(base + k_dst[i]) = creg[i];
-        if (tid < kBN) *(float*)(base + L::kKBytes + tid * 4) = sreg;
+        // -|c|^2 / 2 (the accumulator's start value, see below); centroids behind K can never win
+        if (tid < kBN) *(float*)(base + L::kKBytes + tid * 4) = sreg_ok ? -0.5f * sreg : -INFINITY;
     };
 
     issue(0);
@@ -130,13 +136,20 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     // argmin_c |x - c|^2 = argmax_c (x.c - |c|^2 / 2): the accumulators start at -|c|^2 / 2, so an element of the epilogue is a
     // compare and two selects (the distance form — fma, clamp, bounds test, compare, two selects — made this kernel VALU-bound:
     // 192 VALU against 16 MFMAs per tile).  Ties keep the lowest index, like argmin.
-    // (Round 5, measured and removed — profiles/r05j_ab_kmeans_assign.txt, labels bit-identical in both: (i) the MFMAs of tile t + 1 between the epilogue
-    //  elements of tile t with a second score set: 168 registers, one workgroup per CU, 0.70 instead of 0.57 ms per call; (ii) a rolling half-tile
-    //  pipeline — the epilogue of one 32-centroid half between the MFMAs of the other — at 128 registers and two workgroups per CU: 0.56 ms, no gain.
-    //  Four waves per SIMD already overlap one wave's epilogue with another's MFMAs; the matrix pipe is 0.41 busy because 43 % of the wave cycles
-    //  sit at waitcnt / barrier, profiles/r05i_pmc_svg2_native.json — and (iii) 128-centroid LDS stages, one barrier per two tiles: no gain either.)
+    // Round 5 (profiles/r05r_kmeans_assign_trace.txt, r05j_ab_kmeans_assign.txt; labels bit-identical throughout).  The per-phase trace (-DSVG_KMEANS_TRACE) found
+    // the MFMA phase at 1050 - 1240 cycles for 512 of matrix work (one fragment pair in flight) and the loads of tile t + 2 waited out in the iteration that
+    // issued them (the -|c|^2 / 2 multiply consumed its load at once): both fixed below — 3040 -> 2640 cycles per tile, 0.55 -> 0.525 ms per call.  What bounds
+    // the kernel now is the arg-max epilogue: per SIMD and tile four waves need 2048 cycles of matrix pipe and ~4000 of vector issue (3 VALU per score).
+    // Measured and removed: a second score set (168 registers: slower), a half-tile pipeline, 128-centroid stages (no gain: neither overlap nor the
+    // barrier was the problem).
     float best = -INFINITY;
     int best_idx = 0;
+#ifdef SVG_KMEANS_TRACE
+    unsigned long long tr[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define KM_TICK(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr[i] += now_ - tl; tl = now_; }
+#else
+#define KM_TICK(i)
+#endif
     for (int t = 0; t < nT; ++t) {
         const int buf = t & 1;
         const char* kbuf = smem + buf * kStage;
@@ -152,33 +165,75 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
             }
         float tb;
         int ti;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        KM_TICK(0)
+        // centroid fragments two k-steps ahead of their MFMAs (hipcc's own schedule kept ONE pair in flight and waited for it in front of
+        // every MFMA: 1050 - 1240 cycles for 512 cycles of matrix work per tile, profiles/r05r_kmeans_assign_trace.txt)
+        constexpr int kAhead = 2;
+        V8 af[kAhead + 1][2];
+        auto afetch = [&](int ks) {
             const int cch = ((2 * ks + g) ^ ksw0) << 4;
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const V8 a = *(const V8*)(kbuf + (32 * bb + ql) * L::kRowBytes + cch);
-                s[bb] = E::mfma(a, xf[ks], s[bb]);
+            for (int bb = 0; bb < 2; ++bb) af[ks % (kAhead + 1)][bb] = *(const V8*)(kbuf + (32 * bb + ql) * L::kRowBytes + cch);
+        };
+#pragma unroll
+        for (int ks = 0; ks < kAhead; ++ks) afetch(ks);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + kAhead < KS) afetch(ks + kAhead);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) s[bb] = E::mfma(af[ks % (kAhead + 1)][bb], xf[ks], s[bb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef SVG_KMEANS_TRACE
+        asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+#endif
+        KM_TICK(1)
+        // four independent chains of eight elements (ascending index inside a chain), merged in index order with the same strict compare:
+        // the result of the one 32-step chain — lowest index wins ties — at a quarter of its dependent latency (3 dependent VALU per step:
+        // 665 - 860 cycles per tile in the trace)
+        float cb_[4];
+        int ci_[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int bb = ch >> 1, r0 = (ch & 1) * 8;
+            cb_[ch] = s[bb][r0];
+            ci_[ch] = 32 * bb + 8 * (r0 >> 2) + (r0 & 3) + 4 * g;
+#pragma unroll
+            for (int r = r0 + 1; r < r0 + 8; ++r) {
+                const int c = 32 * bb + 8 * (r >> 2) + (r & 3);   // + 4 g: tile-local centroid index, ascending in (bb, r)
+                const bool upd = s[bb][r] > cb_[ch];
+                cb_[ch] = upd ? s[bb][r] : cb_[ch];
+                ci_[ch] = upd ? c + 4 * g : ci_[ch];
             }
         }
-        tb = s[0][0];
-        ti = 4 * g;
+        tb = cb_[0];
+        ti = ci_[0];
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int r = (bb == 0 ? 1 : 0); r < 16; ++r) {
-                const int c = 32 * bb + 8 * (r >> 2) + (r & 3);   // + 4 g: tile-local centroid index, ascending in (bb, r)
-                const bool upd = s[bb][r] > tb;
-                tb = upd ? s[bb][r] : tb;
-                ti = upd ? c + 4 * g : ti;
-            }
+        for (int ch = 1; ch < 4; ++ch) {
+            const bool upd = cb_[ch] > tb;
+            tb = upd ? cb_[ch] : tb;
+            ti = upd ? ci_[ch] : ti;
+        }
         const bool upd = tb > best;
         best = upd ? tb : best;
         best_idx = upd ? t * kBN + ti : best_idx;
+#ifdef SVG_KMEANS_TRACE
+        asm volatile("" : "+v"(best), "+v"(best_idx));
+#endif
+        KM_TICK(2)
         if (t + 1 < nT) write(buf ^ 1);
         if (t + 2 < nT) issue(t + 2);
+        KM_TICK(3)
         __syncthreads();
+        KM_TICK(4)
     }
+#ifdef SVG_KMEANS_TRACE
+    if (blockIdx.x == 7 && blockIdx.y == 0 && lane == 0) {
+        for (int i = 0; i < 5; ++i) g_km_trace[wave * 8 + i] = tr[i];
+        g_km_trace[wave * 8 + 5] = (unsigned long long)nT;
+    }
+#endif
     // the two lanes of a point cover disjoint centroid subsets: merge, lowest index wins ties
     const float ob = __shfl_xor(best, 32);
     const int oi = __shfl_xor(best_idx, 32);
@@ -343,6 +398,12 @@ __global__ __launch_bounds__(256) void kmeans_select_kernel(const T* __restrict_
 }  // namespace svg
 
 using namespace svg;
+
+#ifdef SVG_KMEANS_TRACE
+extern "C" int svg_debug_kmeans_trace(uint64_t* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_km_trace), sizeof(uint64_t) * 64) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int svg_kmeans_xsq(const void* x, float* xsq, int32_t B, int32_t N, int32_t D, int32_t dtype, void* stream) {
     if (!x || !xsq || B <= 0 || N <= 0) return SVG_ERR_BAD_ARG;

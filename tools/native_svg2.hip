@@ -257,6 +257,18 @@ int main(int argc, char** argv) {
     kmeans_pair(50);
     HIP_OK(hipEventRecord(i1, st));
 
+    if (auto kmtrace = (int (*)(uint64_t*))dlsym(so, "svg_debug_kmeans_trace")) {   // -DSVG_KMEANS_TRACE builds: phases of the LAST assignment launch (k side, K = KC)
+        HIP_OK(hipStreamSynchronize(st));
+        uint64_t tr[64];
+        if (kmtrace(tr) == 0) {
+            fprintf(stderr, "kmeans assign trace (workgroup 7 of head 0, cycles per tile): wave  init  mfma  epilogue  stage  barrier  [tiles]\n");
+            for (int w = 0; w < 8; ++w) {
+                const double nt = (double)std::max<uint64_t>(tr[w * 8 + 5], 1);
+                fprintf(stderr, "  wave %d  %7.0f %7.0f %7.0f %7.0f %7.0f  [%llu]\n", w, tr[w * 8] / nt, tr[w * 8 + 1] / nt, tr[w * 8 + 2] / nt, tr[w * 8 + 3] / nt,
+                        tr[w * 8 + 4] / nt, (unsigned long long)tr[w * 8 + 5]);
+            }
+        }
+    }
     const int total = warm + reps;
     std::vector<hipEvent_t> ev(4 * total);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
