@@ -10,7 +10,9 @@
 // every role emits un-normalised fp32 partials (O, m, l) per sampled row, and a small second kernel merges the chunks,
 // normalises and reduces the MSE.  (The first version ran the roles as three workgroups, grid.z = 3: K/V staged three times,
 // 1.26 ms per call at Hunyuan 720p.)
+#include <type_traits>
 #include "attn_core.h"
+#include "attn_m16.h"
 
 namespace svg {
 
@@ -250,6 +252,7 @@ struct ProfilePolicy {
 //  tile a masked role does not need still pays the element predicate, which the lock-step body skips.)
 #ifdef SVG_PROF_TRACE
 static __device__ unsigned long long g_prof_trace[2048 * 4];   // diagnostics build: per workgroup { start, end (s_memtime), hw id, chunk << 16 | head }
+static __device__ unsigned long long g_prof_phase[2048 * 4];   // second form, wave 0: ticks in { DMA wait + barrier, scores + softmax, P V, tiles }
 #endif
 template <typename T, int D>
 __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename ProfilePolicy<T, D>::Params prm) {
@@ -270,6 +273,349 @@ __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename 
         }
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second form (round 5, head_dim 128): ONE score tile for all three outputs.  The golden rows and the rows under the two masks are the SAME
+// 64 sampled query rows against the SAME keys: S = Q K^T is computed once per tile, exponentiated once against the golden rows' running
+// maximum (a masked softmax may use any reference >= its own maximum: numerator and denominator scale together), and the two masks only select
+// which probabilities enter their P V and their row sum.  Workgroup = 4 waves x 16 sampled rows on v_mfma_f32_16x16x32 (the fragment layouts,
+// LDS images, swizzle and LDS-DMA staging of attn_m16.h); per tile and wave 16 MFMAs for S^T and 16 per output that sees the tile (a V^T fragment
+// read feeds up to three MFMAs).  ~200 registers and 64 KiB of LDS: two workgroups per CU, so one workgroup's softmax overlaps the other's MFMAs —
+// the first form (three roles x two waves of the lock-step body, each role its own S, 225 registers, ONE workgroup per CU in two rounds) took
+// 0.53 - 0.57 ms per call at HunyuanVideo 720p, every tile waiting out its own QK -> softmax -> PV chain (profiles/r05k_profiler_ab.txt).
+// Partials (O, m, l per sampled row, output and KV chunk) in the layout of the first form: profile_combine_kernel is unchanged.
+#ifndef SVG_P16_VG
+#define SVG_P16_VG 4
+#endif
+// torch: (q @ k^T) rounds to the input dtype, "/ sqrt(D)" rounds again (ProfilePolicy::score_fixup) — for a pair of scores: bf16 converts two
+// values per instruction and widens back with a shift / a mask
+template <typename T>
+__device__ __forceinline__ void p16_fixup_pair(float& a, float& b, float fs) {
+    if constexpr (std::is_same_v<T, __bf16>) {
+        using v2 = __bf16 __attribute__((ext_vector_type(2)));
+        auto rnd = [](float& x, float& y) {
+            const v2 r = {(__bf16)x, (__bf16)y};
+            const uint32_t w = __builtin_bit_cast(uint32_t, r);
+            x = __builtin_bit_cast(float, w << 16);
+            y = __builtin_bit_cast(float, w & 0xffff0000u);
+        };
+        rnd(a, b);
+        a *= fs, b *= fs;
+        rnd(a, b);
+    } else {
+        a = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(Elt<T>::from_float(a)) * fs));
+        b = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(Elt<T>::from_float(b)) * fs));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolicy<T, 128>::Params prm) {
+    using Pol = ProfilePolicy<T, 128>;
+    using E = Elt<T>;
+    using M = Mfma16<T>;
+    using V8 = typename E::v8;
+    constexpr int D = 128, KS = D / 32, NDB = D / 16;
+    constexpr int kImg = kBN * D * 2, kStage = 2 * kImg;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (prm.skip && prm.skip[0] != 0) return;
+#ifdef SVG_PROF_TRACE
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tr_wait = 0, tr_sm = 0, tr_pv = 0, tr_mark = tr_t0;
+#define P16_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tr_mark; tr_mark = now_; }
+#else
+#define P16_MARK(acc)
+#endif
+    const int head = blockIdx.x, chunk = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int g4 = lane >> 4, n16 = lane & 15;
+    const int ntiles = (prm.S + kBN - 1) / kBN;
+    const int t0 = chunk * prm.tiles_per_chunk;
+    const int nT = max(0, min(prm.tiles_per_chunk, ntiles - t0));
+    const T* __restrict__ qb = prm.q + (size_t)head * prm.S * D;
+    const T* __restrict__ kb_ = prm.k + (size_t)head * prm.S * D;
+    const T* __restrict__ vb = prm.v + (size_t)head * prm.S * D;
+
+    // The sampled rows in the order of their coordinate under the second mask (token-major in every model of the reference): a wave's 16 rows
+    // then sit close in that coordinate and the mask's tiles outside their common band are skipped (sampled in random order, 16 rows' bands
+    // cover nearly every tile).  The squared errors are summed over the rows: their order is free.  Rank by counting, through LDS.
+    {
+        const int mine = lane < prm.R ? (int)prm.rows[lane] : 0;
+        const int key = lane < prm.R ? Pol::coord(prm, prm.var[1], mine) : 0x7fffffff;
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int kj = __builtin_amdgcn_readlane(key, j);
+            rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+        }
+        if (wave == 0) ((int*)smem)[rank] = mine;
+        __syncthreads();
+    }
+    // this lane's sampled row (rows >= R do not exist: they read row 0 and are never stored)
+    const int r = wave * 16 + n16;
+    const bool have = r < prm.R;
+    const int qrow = have ? ((const int*)smem)[r] : 0;
+    __syncthreads();    // (the staging below reuses the bytes)
+    V8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qb + (size_t)qrow * D + ks * 32 + g4 * 8);
+
+    // the two masks' per-lane / per-wave state, as ProfilePolicy::init computes it (variant 1 <- var[0], variant 2 <- var[1])
+    typename Pol::Ctx mc[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        typename Pol::Ctx& c = mc[v];
+        c.head = head, c.variant = v + 1, c.chunk = chunk, c.t0 = t0, c.nT = nT;
+        c.pv = prm.var[v];
+        c.qx = Pol::coord(prm, c.pv, qrow) - c.pv.origin;
+        c.qtext = have && ((unsigned)(qrow - c.pv.text_lo) < (unsigned)(c.pv.text_hi - c.pv.text_lo));
+        const int blk = c.qx >> 7;
+        int lo = have ? blk : (1 << 28), hi = have ? blk : -(1 << 28), anyt = c.qtext;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+            anyt |= __shfl_xor(anyt, o);
+        }
+        c.xlo_blk = __builtin_amdgcn_readfirstlane(lo), c.xhi_blk = __builtin_amdgcn_readfirstlane(hi);
+        c.any_text = __builtin_amdgcn_readfirstlane(anyt);
+        c.tk0 = 0, c.f0 = 0, c.p0 = 0;
+        c.ystride = c.pv.coord == 1 ? prm.F : 1;
+        c.ybase = 0, c.g4F = 4 * g4 * c.ystride;     // (this layout: a lane's keys of a 16-key block are 4 g4 + [0, 4))
+        const int x = c.qx, span = c.pv.span;
+        const bool xdom = have && ((unsigned)x < (unsigned)span);
+        const int ylo = ((x >> 7) - c.pv.band_blocks + 1) * 128, yhi = ((x >> 7) + c.pv.band_blocks) * 128;
+        const int a0 = max(ylo, 0), a1 = min(yhi, span);
+        c.fa0 = a0, c.falen = xdom ? (unsigned)max(a1 - a0, 0) : 0u;
+        c.fblen = (xdom && c.pv.sink_cols > 0) ? (unsigned)min(c.pv.sink_cols, span) : 0u;
+        if (c.qtext) c.fa0 = -(1 << 30), c.falen = 0xFFFFFFFFu;
+    }
+
+    // ---- LDS-DMA staging: wave w moves key group w (16 keys) of a tile, all four 64-byte d-blocks, K and V ----
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned vsw = (unsigned)((lane >> 4) & 1) << 1;
+    const unsigned col_v = ((lane & 3) ^ vsw) * 16u;
+    const int krow = 16 * wave + (lane >> 2);
+    auto dma_tile = [&](int t) {
+        const int l = (t0 + t) * kBN + krow;
+        const unsigned nphys = (unsigned)(l < prm.S ? l : 0);    // rows behind the sequence: masked below (the last tile is never FULL)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t & 1) * kStage) + (unsigned)(j * (kBN * 64) + wave * 1024));
+            const unsigned vo = (nphys * (unsigned)(2 * D)) | (unsigned)(j * 64) | col_v;
+            asm volatile("s_mov_b32 m0, %0\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %2\n\t"
+                         "s_add_u32 m0, m0, %4\n\t"
+                         "s_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %3"
+                         :
+                         : "s"(st), "v"(vo), "s"(kb_), "s"(vb), "n"(kImg)
+                         : "memory", "scc");
+        }
+    };
+    const int k_lane = n16 * 64 + ((g4 ^ (((n16 >> 2) & 1) << 1)) << 4);
+    const int v_lane0 = kImg + (4 * g4 + (n16 >> 2)) * 64 + (((g4 & 1) * 16) + 4 * (n16 & 3)) * 2;
+    const int v_lane1 = v_lane0 ^ 32;
+    auto kfrag = [&](const char* st, int kblk, int ks) -> V8 { return *(const V8*)(st + k_lane + ks * (kBN * 64) + kblk * 1024); };
+    auto vfrag = [&](const char* st, int kc, int db) -> V8 {
+        const char* vbase = st + ((db & 1) ? v_lane1 : v_lane0) + (db >> 1) * (kBN * 64) + (32 * kc) * 64;
+        const i16x4 lo = lds_read_tr16(vbase);
+        const i16x4 hi = lds_read_tr16(vbase + 16 * 64);
+        const i16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(V8, both);
+    };
+
+    float m_run = -INFINITY, l_run[3] = {0.f, 0.f, 0.f};
+    f32x4 acc[3][NDB];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) acc[o][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c_log2 = prm.scale_log2;
+
+    if (nT > 0) dma_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nT; ++t) {
+        P16_MARK(tr_wait)
+        if (t + 1 < nT) dma_tile(t + 1);      // into the stage every wave finished reading one barrier ago
+        const char* st = smem + (t & 1) * kStage;
+        const int k0 = (t0 + t) * kBN;
+        int cls[3];     // (a wave without sampled rows — R < 64 — walks the tiles like the others and stores nothing)
+        cls[0] = (k0 + kBN <= prm.S) ? TILE_FULL : TILE_PARTIAL;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            int c = __builtin_amdgcn_readfirstlane(Pol::classify(prm, mc[v], k0, wave * 16));   // (wave-uniform: branches, not exec masks)
+            // a fast tile (64 keys at coordinates ybase + [0, 63] * ystride, none of them text) farther than the band from every row of the wave
+            const typename Pol::Ctx& x = mc[v];
+            if (c == TILE_PARTIAL_FAST && !x.any_text && x.ybase >= x.pv.sink_cols) {
+                const int b0 = x.ybase >> 7, b1 = (x.ybase + 63 * x.ystride) >> 7;
+                if (b0 - x.xhi_blk >= x.pv.band_blocks || x.xlo_blk - b1 >= x.pv.band_blocks) c = TILE_SKIP;
+            }
+            cls[v + 1] = c;
+        }
+        {
+            // ---- S^T = K Q^T (lane: query row n16, keys 16 kb + 4 g4 + [0, 4)) ----
+            f32x4 sc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {   // K fragments two 32-wide d-blocks deep (all sixteen at once is what the scheduler does on its own: 64 registers)
+                V8 kf[2][4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) kf[0][b] = kfrag(st, b, 0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) kf[(ks + 1) & 1][b] = kfrag(st, b, ks + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) sc[b] = M::mfma(kf[ks & 1][b], qf[ks], sc[b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // torch's rounding of the scores (emulate), the keys behind the sequence, the lane's maximum: uniform branches, packed pairs
+            if (prm.emulate) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float s0 = sc[b][0], s1 = sc[b][1], s2 = sc[b][2], s3 = sc[b][3];
+                    p16_fixup_pair<T>(s0, s1, prm.fix_scale);
+                    p16_fixup_pair<T>(s2, s3, prm.fix_scale);
+                    sc[b] = f32x4{s0, s1, s2, s3};
+                }
+            }
+            if (cls[0] != TILE_FULL) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[b][j] = (k0 + 16 * b + 4 * g4 + j < prm.S) ? sc[b][j] : -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+            for (int b = 1; b < 4; ++b) mx = fmaxf(fmaxf(mx, sc[b][0]), fmaxf(fmaxf(sc[b][1], sc[b][2]), sc[b][3]));
+            // the running maximum moves in a few tiles per row (a record among ~S / 64 tile maxima): only then the cross-lane reduction, the
+            // exponential of the step and the rescaling of the 96 accumulators — the same numbers as updating every tile (a step of 0 is exact)
+            if (__any(mx * c_log2 > m_run)) {
+                asm volatile("" ::: "memory");
+                const float m_new = fmaxf(m_run, quad_group_max(mx) * c_log2);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // (m_new is finite: a tile holds at least one key of the sequence)
+                m_run = m_new;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    l_run[o] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[o][db][j] *= alpha;
+                }
+            }
+            const float m_use = m_run;
+            // ---- probabilities (once), the masks' selections, row sums ----
+            V8 pf[3][2];
+            float pr[16];
+            float psum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pr[4 * b + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][j], c_log2, -m_use));
+                    psum[0] += pr[4 * b + j];
+                    pf[0][b >> 1][4 * (b & 1) + j] = E::from_float(pr[4 * b + j]);
+                }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                // the tile's class is wave-uniform: one branch per mask and tile, the element predicate inside it branch-free
+                auto select = [&](auto pred) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float pm = pred(16 * b + j) ? pr[4 * b + j] : 0.f;    // key offset inside the tile without the lane's 4 g4
+                            psum[v + 1] += pm;
+                            pf[v + 1][b >> 1][4 * (b & 1) + j] = E::from_float(pm);
+                        }
+                };
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 1)
+                if (cls[v + 1] != TILE_SKIP) select([&](int) { return true; });
+#else
+                if (cls[v + 1] == TILE_PARTIAL_FAST) select([&](int off) { return Pol::allowed_fast(prm, mc[v], off); });
+                else if (cls[v + 1] != TILE_SKIP) select([&](int off) { return Pol::allowed(prm, mc[v], 0, k0 + off + 4 * g4); });
+#endif
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) l_run[o] += psum[o];
+            P16_MARK(tr_sm)
+            // ---- O^T += V^T P^T for every output that sees the tile ----
+            {   // V^T fragments in groups of G 16-wide d-blocks, two groups in flight; a masked output's MFMAs of a group behind ONE uniform branch
+                // (if-then around in-place accumulators: no copies.  Whole-pass forms per combination cost 40 register moves per tile and spills.)
+                constexpr int G = SVG_P16_VG, NG = 2 * NDB / G;
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 2)
+                const bool s1 = false, s2 = false;
+#else
+                const bool s1 = cls[1] != TILE_SKIP, s2 = cls[2] != TILE_SKIP;
+#endif
+                V8 vf[2][G];
+#pragma unroll
+                for (int i = 0; i < G; ++i) vf[0][i] = vfrag(st, 0, i);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int i = 0; i < G; ++i) vf[(g + 1) & 1][i] = vfrag(st, ((g + 1) * G + i) / NDB, ((g + 1) * G + i) % NDB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) acc[0][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[0][(g * G + i) / NDB], acc[0][(g * G + i) % NDB]);
+                    if (s1) {
+#pragma unroll
+                        for (int i = 0; i < G; ++i) acc[1][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[1][(g * G + i) / NDB], acc[1][(g * G + i) % NDB]);
+                    }
+                    if (s2) {
+#pragma unroll
+                        for (int i = 0; i < G; ++i) acc[2][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[2][(g * G + i) / NDB], acc[2][(g * G + i) % NDB]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            P16_MARK(tr_pv)
+        }
+#if !(defined(SVG_P16_ABL) && (SVG_P16_ABL & 4))
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads();
+    }
+#ifdef SVG_PROF_TRACE
+    if (threadIdx.x == 0) {
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (wg < 2048) {
+            g_prof_trace[wg * 4 + 0] = tr_t0;
+            g_prof_trace[wg * 4 + 1] = __builtin_amdgcn_s_memtime();
+            g_prof_trace[wg * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+            g_prof_trace[wg * 4 + 3] = ((unsigned long long)blockIdx.y << 16) | blockIdx.x;
+            g_prof_phase[wg * 4 + 0] = tr_wait, g_prof_phase[wg * 4 + 1] = tr_sm, g_prof_phase[wg * 4 + 2] = tr_pv, g_prof_phase[wg * 4 + 3] = nT;
+        }
+    }
+#endif
+#undef P16_MARK
+    // ---- partials: output 0 golden, 1 under var[0], 2 under var[1] (store_partial's layout) ----
+    if (have) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float* dst = prm.part + ((((size_t)o * prm.BH + head) * prm.n_chunks + chunk) * kProfMaxRows + r) * (D + 4);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) *(f32x4*)(dst + 16 * db + 4 * g4) = acc[o][db];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float l_tot = quad_group_sum(l_run[o]);
+        if (have && g4 == 0) {
+            float* dst = prm.part + ((((size_t)o * prm.BH + head) * prm.n_chunks + chunk) * kProfMaxRows + r) * (D + 4);
+            dst[D] = m_run;
+            dst[D + 1] = l_tot;
+        }
+    }
 }
 
 // merge the split-KV partials, normalise, and reduce squared errors.  grid = (kProfRowGroups, BH), block = 256:
@@ -385,6 +731,19 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     }
     p.part = (float*)ws;
     p.skip = skip;
+#ifndef SVG_PROF_FIRST_FORM
+    if constexpr (D == 128) {   // second form: one score tile for the three outputs, two workgroups per CU
+        constexpr int lds16 = 2 * 2 * kBN * 128 * 2;   // two stages of a K and a V image
+        auto kern16 = profile16_kernel<T>;
+        hipError_t e16 = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+        if (e16 != hipSuccess) {
+            g_last_hip_error = (int)e16;
+            return SVG_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern16, dim3(BH, p.n_chunks), dim3(256), lds16, st, p);
+    } else
+#endif
+    {
     const int lds = attn_lds_bytes<D, kProfNW>();
     auto kern = profile_attn_kernel<T, D>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -393,6 +752,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
         return SVG_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
+    }
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
                        R, p.n_chunks, p.emulate, skip);
@@ -409,6 +769,10 @@ using namespace svg;
 extern "C" int svg_debug_prof_trace(uint64_t* out, int n_workgroups) {
     if (!out || n_workgroups <= 0 || n_workgroups > 2048) return SVG_ERR_BAD_ARG;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_trace), (size_t)n_workgroups * 4 * sizeof(uint64_t)) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
+}
+extern "C" int svg_debug_prof_phase(uint64_t* out, int n_workgroups) {
+    if (!out || n_workgroups <= 0 || n_workgroups > 2048) return SVG_ERR_BAD_ARG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_phase), (size_t)n_workgroups * 4 * sizeof(uint64_t)) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
 }
 #endif
 
