@@ -252,7 +252,7 @@ struct ProfilePolicy {
 //  tile a masked role does not need still pays the element predicate, which the lock-step body skips.)
 #ifdef SVG_PROF_TRACE
 static __device__ unsigned long long g_prof_trace[2048 * 4];   // diagnostics build: per workgroup { start, end (s_memtime), hw id, chunk << 16 | head }
-static __device__ unsigned long long g_prof_phase[2048 * 4];   // second form, wave 0: ticks in { DMA wait + barrier, scores + softmax, P V, tiles }
+static __device__ unsigned long long g_prof_phase[2048 * 8];   // second form, wave 0: ticks in { DMA wait + barrier, scores + softmax, P V, tiles }
 #endif
 template <typename T, int D>
 __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename ProfilePolicy<T, D>::Params prm) {
@@ -288,6 +288,17 @@ __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename 
 #ifndef SVG_P16_VG
 #define SVG_P16_VG 4
 #endif
+#ifndef SVG_P16_KAHEAD
+#define SVG_P16_KAHEAD 1
+#endif
+#ifdef SVG_P16_NOSB
+#define P16_SB
+#else
+#define P16_SB __builtin_amdgcn_sched_barrier(0)
+#endif
+using p16_i32x4 = int __attribute__((ext_vector_type(4)));
+constexpr int kP16Win = 128;                                         // tiles per fill of a wave's class table
+constexpr int kP16LdsBytes = 2 * 2 * kBN * 128 * 2 + 4 * kP16Win * 16;   // two stages of a K and a V image + the four waves' class tables
 // torch: (q @ k^T) rounds to the input dtype, "/ sqrt(D)" rounds again (ProfilePolicy::score_fixup) — for a pair of scores: bf16 converts two
 // values per instruction and widens back with a shift / a mask
 template <typename T>
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     if (prm.skip && prm.skip[0] != 0) return;
 #ifdef SVG_PROF_TRACE
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tr_wait = 0, tr_sm = 0, tr_pv = 0, tr_mark = tr_t0;
+    unsigned long long tr_wait = 0, tr_sm = 0, tr_pv = 0, tr_qk = 0, tr_fix = 0, tr_exp = 0, tr_mark = tr_t0;
 #define P16_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tr_mark; tr_mark = now_; }
 #else
 #define P16_MARK(acc)
@@ -425,7 +436,13 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
         return __builtin_bit_cast(V8, both);
     };
 
-    float m_run = -INFINITY, l_run[3] = {0.f, 0.f, 0.f};
+    // row sums on the matrix pipe (an all-ones A fragment: every row of D is the column sum of P^T — of the P the numerator sees, rounded to T), as
+    // attn_m16.h ships it: 2 MFMAs per output and tile instead of 16 additions and a cross-lane reduction at the end
+    float m_run = -INFINITY;
+    f32x4 acc_l[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    V8 ones8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones8[i] = E::from_float(1.f);
     f32x4 acc[3][NDB];
 #pragma unroll
     for (int o = 0; o < 3; ++o)
@@ -433,50 +450,91 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
         for (int db = 0; db < NDB; ++db) acc[o][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c_log2 = prm.scale_log2;
 
+    int* const tab = (int*)(smem + 2 * kStage) + wave * (kP16Win * 4);
+    auto fill_classes = [&](int win0) {
+#pragma unroll
+        for (int i = 0; i < kP16Win / 64; ++i) {
+            const int tl = win0 + lane + 64 * i;
+            p16_i32x4 e = {TILE_SKIP, 0, TILE_SKIP, 0};
+            if (tl < nT) {
+                const int kk = (t0 + tl) * kBN;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    typename Pol::Ctx x = mc[v];
+                    int c = Pol::classify(prm, x, kk, wave * 16);
+                    // a fast tile (64 keys at coordinates ybase + [0, 63] * ystride, none of them text) farther than the band from every row of the wave
+                    if (c == TILE_PARTIAL_FAST && !x.any_text && x.ybase >= x.pv.sink_cols) {
+                        const int b0 = x.ybase >> 7, b1 = (x.ybase + 63 * x.ystride) >> 7;
+                        if (b0 - x.xhi_blk >= x.pv.band_blocks || x.xlo_blk - b1 >= x.pv.band_blocks) c = TILE_SKIP;
+                    }
+                    e[2 * v] = c, e[2 * v + 1] = x.ybase;
+                }
+            }
+            *(p16_i32x4*)(tab + (lane + 64 * i) * 4) = e;
+        }
+    };
     if (nT > 0) dma_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the q fragments are consumed here as far as the compiler's counter bookkeeping goes: left pending into the loop, their first use there gets
+    //  an s_waitcnt vmcnt(0) — which waits for the tile prefetch just issued, the whole HBM latency every tile: 2900 of a tile's 7300 cycles)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
     for (int t = 0; t < nT; ++t) {
         P16_MARK(tr_wait)
+#if !(defined(SVG_P16_ABL) && (SVG_P16_ABL & 256))
         if (t + 1 < nT) dma_tile(t + 1);      // into the stage every wave finished reading one barrier ago
+#endif
         const char* st = smem + (t & 1) * kStage;
         const int k0 = (t0 + t) * kBN;
+        // the tile's class under the two masks and its first coordinate, from the wave's table (filled 128 tiles at a time, a tile per lane: as
+        // scalar code per tile and wave the classification was ~250 instructions of a tile's ~950)
+        if ((t & (kP16Win - 1)) == 0) fill_classes(t);
         int cls[3];     // (a wave without sampled rows — R < 64 — walks the tiles like the others and stores nothing)
         cls[0] = (k0 + kBN <= prm.S) ? TILE_FULL : TILE_PARTIAL;
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            int c = __builtin_amdgcn_readfirstlane(Pol::classify(prm, mc[v], k0, wave * 16));   // (wave-uniform: branches, not exec masks)
-            // a fast tile (64 keys at coordinates ybase + [0, 63] * ystride, none of them text) farther than the band from every row of the wave
-            const typename Pol::Ctx& x = mc[v];
-            if (c == TILE_PARTIAL_FAST && !x.any_text && x.ybase >= x.pv.sink_cols) {
-                const int b0 = x.ybase >> 7, b1 = (x.ybase + 63 * x.ystride) >> 7;
-                if (b0 - x.xhi_blk >= x.pv.band_blocks || x.xlo_blk - b1 >= x.pv.band_blocks) c = TILE_SKIP;
-            }
-            cls[v + 1] = c;
+        {
+            const p16_i32x4 e = *(const p16_i32x4*)(tab + (t & (kP16Win - 1)) * 4);
+            cls[1] = __builtin_amdgcn_readfirstlane(e[0]), mc[0].ybase = __builtin_amdgcn_readfirstlane(e[1]);
+            cls[2] = __builtin_amdgcn_readfirstlane(e[2]), mc[1].ybase = __builtin_amdgcn_readfirstlane(e[3]);
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 16)
+            cls[1] = cls[2] = TILE_SKIP;
+#endif
         }
         {
             // ---- S^T = K Q^T (lane: query row n16, keys 16 kb + 4 g4 + [0, 4)) ----
             f32x4 sc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {   // K fragments two 32-wide d-blocks deep (all sixteen at once is what the scheduler does on its own: 64 registers)
-                V8 kf[2][4];
+            {   // K fragments kKA 32-wide d-blocks ahead (all sixteen at once is what the scheduler does on its own: 64 registers)
+                constexpr int kKA = SVG_P16_KAHEAD;
+                V8 kf[kKA + 1][4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) kf[0][b] = kfrag(st, b, 0);
+                for (int a = 0; a < kKA; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) kf[a][b] = kfrag(st, b, a);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks + 1 < KS) {
+                    if (ks + kKA < KS) {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) kf[(ks + 1) & 1][b] = kfrag(st, b, ks + 1);
+                        for (int b = 0; b < 4; ++b) kf[(ks + kKA) % (kKA + 1)][b] = kfrag(st, b, ks + kKA);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    P16_SB;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) sc[b] = M::mfma(kf[ks & 1][b], qf[ks], sc[b]);
-                    __builtin_amdgcn_sched_barrier(0);
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 64)
+                    for (int b = 0; b < 4; ++b) sc[b] += f32x4{kf[ks % (kKA + 1)][b][0], 0.f, 0.f, 0.f} * f32x4{qf[ks][0], 1.f, 1.f, 1.f};
+#else
+                    for (int b = 0; b < 4; ++b) sc[b] = M::mfma(kf[ks % (kKA + 1)][b], qf[ks], sc[b]);
+#endif
+                    P16_SB;
                 }
             }
+            P16_MARK(tr_qk)
             // torch's rounding of the scores (emulate), the keys behind the sequence, the lane's maximum: uniform branches, packed pairs
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 32)
+            if (false) {
+#else
             if (prm.emulate) {
+#endif
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     float s0 = sc[b][0], s1 = sc[b][1], s2 = sc[b][2], s3 = sc[b][3];
@@ -503,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                 m_run = m_new;
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    l_run[o] *= alpha;
+                    acc_l[o][0] *= alpha;
 #pragma unroll
                     for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -511,18 +569,22 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                 }
             }
             const float m_use = m_run;
+            P16_MARK(tr_fix)
             // ---- probabilities (once), the masks' selections, row sums ----
             V8 pf[3][2];
             float pr[16];
-            float psum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 8)
+                    pr[4 * b + j] = __builtin_fmaf(sc[b][j], c_log2, -m_use);
+#else
                     pr[4 * b + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][j], c_log2, -m_use));
-                    psum[0] += pr[4 * b + j];
+#endif
                     pf[0][b >> 1][4 * (b & 1) + j] = E::from_float(pr[4 * b + j]);
                 }
+            P16_MARK(tr_exp)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
                 // the tile's class is wave-uniform: one branch per mask and tile, the element predicate inside it branch-free
@@ -532,19 +594,31 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float pm = pred(16 * b + j) ? pr[4 * b + j] : 0.f;    // key offset inside the tile without the lane's 4 g4
-                            psum[v + 1] += pm;
                             pf[v + 1][b >> 1][4 * (b & 1) + j] = E::from_float(pm);
                         }
                 };
 #if defined(SVG_P16_ABL) && (SVG_P16_ABL & 1)
                 if (cls[v + 1] != TILE_SKIP) select([&](int) { return true; });
 #else
-                if (cls[v + 1] == TILE_PARTIAL_FAST) select([&](int off) { return Pol::allowed_fast(prm, mc[v], off); });
-                else if (cls[v + 1] != TILE_SKIP) select([&](int off) { return Pol::allowed(prm, mc[v], 0, k0 + off + 4 * g4); });
+                if (cls[v + 1] == TILE_PARTIAL_FAST) {
+                    // allowed_fast with the lane's part hoisted; a mask without sink columns (every model but the 5-D Cog masks) has one interval
+                    const int yb = mc[v].ybase + mc[v].g4F - mc[v].fa0, ys = mc[v].ystride;
+                    const unsigned fal = mc[v].falen, fbl = mc[v].fblen;
+                    if (mc[v].pv.sink_cols > 0) {
+                        const int fa0 = mc[v].fa0;
+                        select([&](int off) { return ((unsigned)(yb + off * ys) < fal) | ((unsigned)(yb + fa0 + off * ys) < fbl); });
+                    } else {
+                        select([&](int off) { return (unsigned)(yb + off * ys) < fal; });
+                    }
+                }
+                else if (cls[v + 1] != TILE_SKIP) {
+                    (void)Pol::classify(prm, mc[v], k0, wave * 16);    // (the general predicate's per-tile decomposition: tk0, f0, p0)
+                    int kb = k0 + 4 * g4;
+                    asm volatile("" : "+v"(kb));   // (opaque: or the optimiser computes the two masks' common sub-tests for every tile, ahead of the branch)
+                    select([&](int off) { return Pol::allowed(prm, mc[v], 0, kb + off); });
+                }
 #endif
             }
-#pragma unroll
-            for (int o = 0; o < 3; ++o) l_run[o] += psum[o];
             P16_MARK(tr_sm)
             // ---- O^T += V^T P^T for every output that sees the tile ----
             {   // V^T fragments in groups of G 16-wide d-blocks, two groups in flight; a masked output's MFMAs of a group behind ONE uniform branch
@@ -564,18 +638,25 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
                         for (int i = 0; i < G; ++i) vf[(g + 1) & 1][i] = vfrag(st, ((g + 1) * G + i) / NDB, ((g + 1) * G + i) % NDB);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    P16_SB;
 #pragma unroll
+#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 128)
+                    for (int i = 0; i < G; ++i) acc[0][(g * G + i) % NDB][0] += (float)vf[g & 1][i][0] * (float)pf[0][(g * G + i) / NDB][0];
+#else
                     for (int i = 0; i < G; ++i) acc[0][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[0][(g * G + i) / NDB], acc[0][(g * G + i) % NDB]);
+#endif
+                    if ((g * G) % NDB == 0) acc_l[0] = M::mfma(ones8, pf[0][(g * G) / NDB], acc_l[0]);
                     if (s1) {
+                        if ((g * G) % NDB == 0) acc_l[1] = M::mfma(ones8, pf[1][(g * G) / NDB], acc_l[1]);
 #pragma unroll
                         for (int i = 0; i < G; ++i) acc[1][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[1][(g * G + i) / NDB], acc[1][(g * G + i) % NDB]);
                     }
                     if (s2) {
+                        if ((g * G) % NDB == 0) acc_l[2] = M::mfma(ones8, pf[2][(g * G) / NDB], acc_l[2]);
 #pragma unroll
                         for (int i = 0; i < G; ++i) acc[2][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[2][(g * G + i) / NDB], acc[2][(g * G + i) % NDB]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    P16_SB;
                 }
             }
             P16_MARK(tr_pv)
@@ -593,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
             g_prof_trace[wg * 4 + 1] = __builtin_amdgcn_s_memtime();
             g_prof_trace[wg * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
             g_prof_trace[wg * 4 + 3] = ((unsigned long long)blockIdx.y << 16) | blockIdx.x;
-            g_prof_phase[wg * 4 + 0] = tr_wait, g_prof_phase[wg * 4 + 1] = tr_sm, g_prof_phase[wg * 4 + 2] = tr_pv, g_prof_phase[wg * 4 + 3] = nT;
+            g_prof_phase[wg * 8 + 0] = tr_wait, g_prof_phase[wg * 8 + 1] = tr_sm, g_prof_phase[wg * 8 + 2] = tr_pv, g_prof_phase[wg * 8 + 3] = nT;
+            g_prof_phase[wg * 8 + 4] = tr_qk, g_prof_phase[wg * 8 + 5] = tr_fix, g_prof_phase[wg * 8 + 6] = tr_exp, g_prof_phase[wg * 8 + 7] = 0;
         }
     }
 #endif
@@ -609,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        const float l_tot = quad_group_sum(l_run[o]);
+        const float l_tot = acc_l[o][0];
         if (have && g4 == 0) {
             float* dst = prm.part + ((((size_t)o * prm.BH + head) * prm.n_chunks + chunk) * kProfMaxRows + r) * (D + 4);
             dst[D] = m_run;
@@ -733,7 +815,11 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     p.skip = skip;
 #ifndef SVG_PROF_FIRST_FORM
     if constexpr (D == 128) {   // second form: one score tile for the three outputs, two workgroups per CU
-        constexpr int lds16 = 2 * 2 * kBN * 128 * 2;   // two stages of a K and a V image
+#ifdef SVG_P16_LDS_BYTES
+        constexpr int lds16 = SVG_P16_LDS_BYTES;       // (diagnostics: 98304 leaves room for ONE workgroup per CU)
+#else
+        constexpr int lds16 = kP16LdsBytes;
+#endif
         auto kern16 = profile16_kernel<T>;
         hipError_t e16 = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
         if (e16 != hipSuccess) {
@@ -772,7 +858,7 @@ extern "C" int svg_debug_prof_trace(uint64_t* out, int n_workgroups) {
 }
 extern "C" int svg_debug_prof_phase(uint64_t* out, int n_workgroups) {
     if (!out || n_workgroups <= 0 || n_workgroups > 2048) return SVG_ERR_BAD_ARG;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_phase), (size_t)n_workgroups * 4 * sizeof(uint64_t)) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_phase), (size_t)n_workgroups * 8 * sizeof(uint64_t)) == hipSuccess ? SVG_OK : SVG_ERR_LAUNCH;
 }
 #endif
 

@@ -401,11 +401,13 @@ int main(int argc, char** argv) {
         }
         if (auto pphase = (int (*)(uint64_t*, int))dlsym(so, "svg_debug_prof_phase")) {   // second form: where wave 0 of the workgroups spent its ticks
             const int nwg = 2048;
-            std::vector<uint64_t> ph((size_t)nwg * 4);
+            std::vector<uint64_t> ph((size_t)nwg * 8);
             if (pphase(ph.data(), nwg) == 0) {
-                double w = 0, sm = 0, pv = 0, tiles = 0;
-                for (int i = 0; i < nwg; ++i) w += (double)ph[4 * i], sm += (double)ph[4 * i + 1], pv += (double)ph[4 * i + 2], tiles += (double)ph[4 * i + 3];
-                if (tiles > 0) fprintf(stderr, "prof phases (wave 0, ticks per tile): wait+barrier %.1f  scores+softmax %.1f  PV %.1f  (tiles %.0f)\n", w / tiles, sm / tiles, pv / tiles, tiles);
+                double v[8] = {0};
+                for (int i = 0; i < nwg; ++i) for (int j = 0; j < 8; ++j) v[j] += (double)ph[8 * i + j];
+                const double tiles = v[3];
+                if (tiles > 0) fprintf(stderr, "prof phases (wave 0, ticks per tile): wait+barrier %.1f | scores %.1f  rounding+max %.1f  exp+pack %.1f  masks %.1f | PV %.1f  (tiles %.0f)\n",
+                                       v[0] / tiles, v[4] / tiles, v[5] / tiles, v[6] / tiles, v[1] / tiles, v[2] / tiles, tiles);
             }
         }
         auto num = [](float x) { char buf[32]; if (x != x) return std::string("null"); snprintf(buf, sizeof buf, "%.6e", x); return std::string(buf); };
