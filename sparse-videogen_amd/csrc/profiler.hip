@@ -276,29 +276,31 @@ __global__ __launch_bounds__(kProfNW * 64, 2) void profile_attn_kernel(typename 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Second form (round 5, head_dim 128): ONE score tile for all three outputs.  The golden rows and the rows under the two masks are the SAME
-// 64 sampled query rows against the SAME keys: S = Q K^T is computed once per tile, exponentiated once against the golden rows' running
-// maximum (a masked softmax may use any reference >= its own maximum: numerator and denominator scale together), and the two masks only select
-// which probabilities enter their P V and their row sum.  Workgroup = 4 waves x 16 sampled rows on v_mfma_f32_16x16x32 (the fragment layouts,
-// LDS images, swizzle and LDS-DMA staging of attn_m16.h); per tile and wave 16 MFMAs for S^T and 16 per output that sees the tile (a V^T fragment
-// read feeds up to three MFMAs).  ~200 registers and 64 KiB of LDS: two workgroups per CU, so one workgroup's softmax overlaps the other's MFMAs —
-// the first form (three roles x two waves of the lock-step body, each role its own S, 225 registers, ONE workgroup per CU in two rounds) took
-// 0.53 - 0.57 ms per call at HunyuanVideo 720p, every tile waiting out its own QK -> softmax -> PV chain (profiles/r05k_profiler_ab.txt).
+// Second form (round 5): ONE score tile for all three outputs.  The golden rows and the rows under the two masks are the SAME 64 sampled
+// query rows against the SAME keys: S = Q K^T is computed once per tile, exponentiated once against the golden rows' running maximum (a masked
+// softmax may use any reference >= its own maximum: numerator and denominator scale together), and the two masks only select which
+// probabilities enter their P V and their row sum.  Workgroup = 4 waves x 16 sampled rows on v_mfma_f32_16x16x32 (the fragment layouts, LDS
+// images, swizzle and LDS-DMA staging of attn_m16.h); per tile and wave 16 MFMAs for S^T and 16 + 2 per output that sees the tile (a V^T fragment
+// read feeds up to three MFMAs; the row sums ride the matrix pipe).  ~225 registers, 72 KiB of LDS: two workgroups per CU.
+//   * the sampled rows are ranked by their coordinate under the second mask, so a wave's 16 rows sit close in it and its tiles outside their
+//     common band are skipped (in sampling order 16 rows' bands cover nearly every tile);
+//   * a tile's class under each mask and its first coordinate come from a per-wave LDS table (128 tiles per fill, a tile per lane): as scalar
+//     code per tile and wave the classification was ~250 of a tile's ~950 instructions;
+//   * the class is wave-uniform: one branch per mask and tile, the element predicate inside it branch-free (one interval test without sink
+//     columns); the running maximum, the exponential of its step and the rescaling of the 108 accumulators only in the tiles where it moves.
+// HunyuanVideo 720p: 0.345 ms against 0.60 ms for the first form (three roles x two waves of the lock-step body, each role its own S, ONE
+// workgroup per CU in two rounds); with the golden output alone 0.31 ms, which is the time of its loads alone: removing the rounding, the
+// exponentials, the QK or the P V MFMAs changes nothing, removing the loads gives 0.18 ms, the loads without any arithmetic take 0.309 ms whether
+// an instruction moves 16 x 64 B or 1 KiB contiguous, and two tiles of K in flight instead of one gain 1.4 % (profiles/r05zj_profiler_bound_ablations.txt).
 // Partials (O, m, l per sampled row, output and KV chunk) in the layout of the first form: profile_combine_kernel is unchanged.
-#ifndef SVG_P16_VG
-#define SVG_P16_VG 4
-#endif
-#ifndef SVG_P16_KAHEAD
-#define SVG_P16_KAHEAD 1
-#endif
-#ifdef SVG_P16_NOSB
-#define P16_SB
-#else
-#define P16_SB __builtin_amdgcn_sched_barrier(0)
+// -DSVG_P16_ABL=<bits> (timing only, results wrong by construction): 1 no mask predicates, 2 no P V of the masked outputs, 4 no wait on the staged
+// tile, 8 no loads, 16 no arithmetic in the tile loop.
+#ifndef SVG_P16_ABL
+#define SVG_P16_ABL 0
 #endif
 using p16_i32x4 = int __attribute__((ext_vector_type(4)));
-constexpr int kP16Win = 128;                                         // tiles per fill of a wave's class table
-constexpr int kP16LdsBytes = 2 * 2 * kBN * 128 * 2 + 4 * kP16Win * 16;   // two stages of a K and a V image + the four waves' class tables
+constexpr int kP16Win = 128;                                          // tiles per fill of a wave's class table
+constexpr int p16_lds_bytes(int D) { return 2 * 2 * kBN * D * 2 + 4 * kP16Win * 16; }   // two stages of a K and a V image + the four waves' tables
 // torch: (q @ k^T) rounds to the input dtype, "/ sqrt(D)" rounds again (ProfilePolicy::score_fixup) — for a pair of scores: bf16 converts two
 // values per instruction and widens back with a shift / a mask
 template <typename T>
@@ -319,19 +321,19 @@ __device__ __forceinline__ void p16_fixup_pair(float& a, float& b, float fs) {
         b = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(Elt<T>::from_float(b)) * fs));
     }
 }
-template <typename T>
-__global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolicy<T, 128>::Params prm) {
-    using Pol = ProfilePolicy<T, 128>;
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolicy<T, D>::Params prm) {
+    using Pol = ProfilePolicy<T, D>;
     using E = Elt<T>;
     using M = Mfma16<T>;
     using V8 = typename E::v8;
-    constexpr int D = 128, KS = D / 32, NDB = D / 16;
+    constexpr int KS = D / 32, NDB = D / 16;
     constexpr int kImg = kBN * D * 2, kStage = 2 * kImg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (prm.skip && prm.skip[0] != 0) return;
 #ifdef SVG_PROF_TRACE
     const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();
-    unsigned long long tr_wait = 0, tr_sm = 0, tr_pv = 0, tr_qk = 0, tr_fix = 0, tr_exp = 0, tr_mark = tr_t0;
+    unsigned long long tr_wait = 0, tr_sm = 0, tr_pv = 0, tr_qk = 0, tr_fix = 0, tr_mark = tr_t0;
 #define P16_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tr_mark; tr_mark = now_; }
 #else
 #define P16_MARK(acc)
@@ -346,9 +348,8 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     const T* __restrict__ kb_ = prm.k + (size_t)head * prm.S * D;
     const T* __restrict__ vb = prm.v + (size_t)head * prm.S * D;
 
-    // The sampled rows in the order of their coordinate under the second mask (token-major in every model of the reference): a wave's 16 rows
-    // then sit close in that coordinate and the mask's tiles outside their common band are skipped (sampled in random order, 16 rows' bands
-    // cover nearly every tile).  The squared errors are summed over the rows: their order is free.  Rank by counting, through LDS.
+    // The sampled rows in the order of their coordinate under the second mask (token-major in every model of the reference).  The squared
+    // errors are summed over the rows: their order is free.  Rank by counting, through LDS.
     {
         const int mine = lane < prm.R ? (int)prm.rows[lane] : 0;
         const int key = lane < prm.R ? Pol::coord(prm, prm.var[1], mine) : 0x7fffffff;
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qb + (size_t)qrow * D + ks * 32 + g4 * 8);
 
-    // the two masks' per-lane / per-wave state, as ProfilePolicy::init computes it (variant 1 <- var[0], variant 2 <- var[1])
+    // the two masks' per-lane / per-wave state, as ProfilePolicy::init computes it (output 1 <- var[0], output 2 <- var[1])
     typename Pol::Ctx mc[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
         if (c.qtext) c.fa0 = -(1 << 30), c.falen = 0xFFFFFFFFu;
     }
 
-    // ---- LDS-DMA staging: wave w moves key group w (16 keys) of a tile, all four 64-byte d-blocks, K and V ----
+    // ---- LDS-DMA staging: wave w moves key group w (16 keys) of a tile, every 64-byte d-block, K and V ----
     const unsigned lds0 = (unsigned)(size_t)smem;
     const unsigned vsw = (unsigned)((lane >> 4) & 1) << 1;
     const unsigned col_v = ((lane & 3) ^ vsw) * 16u;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
         const int l = (t0 + t) * kBN + krow;
         const unsigned nphys = (unsigned)(l < prm.S ? l : 0);    // rows behind the sequence: masked below (the last tile is never FULL)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < D / 32; ++j) {
             const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t & 1) * kStage) + (unsigned)(j * (kBN * 64) + wave * 1024));
             const unsigned vo = (nphys * (unsigned)(2 * D)) | (unsigned)(j * 64) | col_v;
             asm volatile("s_mov_b32 m0, %0\n\t"
@@ -436,20 +437,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
         return __builtin_bit_cast(V8, both);
     };
 
-    // row sums on the matrix pipe (an all-ones A fragment: every row of D is the column sum of P^T — of the P the numerator sees, rounded to T), as
-    // attn_m16.h ships it: 2 MFMAs per output and tile instead of 16 additions and a cross-lane reduction at the end
-    float m_run = -INFINITY;
-    f32x4 acc_l[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    V8 ones8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones8[i] = E::from_float(1.f);
-    f32x4 acc[3][NDB];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) acc[o][db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float c_log2 = prm.scale_log2;
-
+    // ---- the wave's class table: { class under mask 0, first coordinate, class under mask 1, first coordinate } per tile of the window ----
     int* const tab = (int*)(smem + 2 * kStage) + wave * (kP16Win * 4);
     auto fill_classes = [&](int win0) {
 #pragma unroll
@@ -473,22 +461,33 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
             *(p16_i32x4*)(tab + (lane + 64 * i) * 4) = e;
         }
     };
+
+    // row sums on the matrix pipe (an all-ones A fragment: every row of D is the column sum of P^T — of the P the numerator sees, rounded to T), as
+    // attn_m16.h ships it: 2 MFMAs per output and tile instead of 16 additions and a cross-lane reduction at the end
+    float m_run = -INFINITY;
+    f32x4 acc_l[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    V8 ones8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones8[i] = E::from_float(1.f);
+    f32x4 acc[3][NDB];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) acc[o][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float c_log2 = prm.scale_log2;
+
     if (nT > 0) dma_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // (the q fragments are consumed here as far as the compiler's counter bookkeeping goes: left pending into the loop, their first use there gets
-    //  an s_waitcnt vmcnt(0) — which waits for the tile prefetch just issued, the whole HBM latency every tile: 2900 of a tile's 7300 cycles)
+    //  an s_waitcnt vmcnt(0) — which waits for the tile prefetch just issued)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     __syncthreads();
     for (int t = 0; t < nT; ++t) {
         P16_MARK(tr_wait)
-#if !(defined(SVG_P16_ABL) && (SVG_P16_ABL & 256))
-        if (t + 1 < nT) dma_tile(t + 1);      // into the stage every wave finished reading one barrier ago
-#endif
+        if (!(SVG_P16_ABL & 8) && t + 1 < nT) dma_tile(t + 1);      // into the stage every wave finished reading one barrier ago
         const char* st = smem + (t & 1) * kStage;
         const int k0 = (t0 + t) * kBN;
-        // the tile's class under the two masks and its first coordinate, from the wave's table (filled 128 tiles at a time, a tile per lane: as
-        // scalar code per tile and wave the classification was ~250 instructions of a tile's ~950)
         if ((t & (kP16Win - 1)) == 0) fill_classes(t);
         int cls[3];     // (a wave without sampled rows — R < 64 — walks the tiles like the others and stores nothing)
         cls[0] = (k0 + kBN <= prm.S) ? TILE_FULL : TILE_PARTIAL;
@@ -496,45 +495,31 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
             const p16_i32x4 e = *(const p16_i32x4*)(tab + (t & (kP16Win - 1)) * 4);
             cls[1] = __builtin_amdgcn_readfirstlane(e[0]), mc[0].ybase = __builtin_amdgcn_readfirstlane(e[1]);
             cls[2] = __builtin_amdgcn_readfirstlane(e[2]), mc[1].ybase = __builtin_amdgcn_readfirstlane(e[3]);
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 16)
-            cls[1] = cls[2] = TILE_SKIP;
-#endif
         }
-        {
+        if (!(SVG_P16_ABL & 16)) {
             // ---- S^T = K Q^T (lane: query row n16, keys 16 kb + 4 g4 + [0, 4)) ----
             f32x4 sc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {   // K fragments kKA 32-wide d-blocks ahead (all sixteen at once is what the scheduler does on its own: 64 registers)
-                constexpr int kKA = SVG_P16_KAHEAD;
-                V8 kf[kKA + 1][4];
+            {   // K fragments one 32-wide d-block ahead (all sixteen at once is what the scheduler does on its own: 64 registers)
+                V8 kf[2][4];
 #pragma unroll
-                for (int a = 0; a < kKA; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) kf[a][b] = kfrag(st, b, a);
+                for (int b = 0; b < 4; ++b) kf[0][b] = kfrag(st, b, 0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks + kKA < KS) {
+                    if (ks + 1 < KS) {
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) kf[(ks + kKA) % (kKA + 1)][b] = kfrag(st, b, ks + kKA);
+                        for (int b = 0; b < 4; ++b) kf[(ks + 1) & 1][b] = kfrag(st, b, ks + 1);
                     }
-                    P16_SB;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 64)
-                    for (int b = 0; b < 4; ++b) sc[b] += f32x4{kf[ks % (kKA + 1)][b][0], 0.f, 0.f, 0.f} * f32x4{qf[ks][0], 1.f, 1.f, 1.f};
-#else
-                    for (int b = 0; b < 4; ++b) sc[b] = M::mfma(kf[ks % (kKA + 1)][b], qf[ks], sc[b]);
-#endif
-                    P16_SB;
+                    for (int b = 0; b < 4; ++b) sc[b] = M::mfma(kf[ks & 1][b], qf[ks], sc[b]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             P16_MARK(tr_qk)
             // torch's rounding of the scores (emulate), the keys behind the sequence, the lane's maximum: uniform branches, packed pairs
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 32)
-            if (false) {
-#else
             if (prm.emulate) {
-#endif
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     float s0 = sc[b][0], s1 = sc[b][1], s2 = sc[b][2], s3 = sc[b][3];
@@ -553,9 +538,9 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
             for (int b = 1; b < 4; ++b) mx = fmaxf(fmaxf(mx, sc[b][0]), fmaxf(fmaxf(sc[b][1], sc[b][2]), sc[b][3]));
             // the running maximum moves in a few tiles per row (a record among ~S / 64 tile maxima): only then the cross-lane reduction, the
-            // exponential of the step and the rescaling of the 96 accumulators — the same numbers as updating every tile (a step of 0 is exact)
+            // exponential of the step and the rescaling of the accumulators — the same numbers as updating every tile (a step of 0 is exact)
             if (__any(mx * c_log2 > m_run)) {
-                asm volatile("" ::: "memory");
+                asm volatile("" ::: "memory");   // (keeps the branch: x * 1 is exact, so the optimiser would rather multiply every tile)
                 const float m_new = fmaxf(m_run, quad_group_max(mx) * c_log2);
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // (m_new is finite: a tile holds at least one key of the sequence)
                 m_run = m_new;
@@ -570,24 +555,18 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
             }
             const float m_use = m_run;
             P16_MARK(tr_fix)
-            // ---- probabilities (once), the masks' selections, row sums ----
+            // ---- probabilities (once), the masks' selections ----
             V8 pf[3][2];
             float pr[16];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 8)
-                    pr[4 * b + j] = __builtin_fmaf(sc[b][j], c_log2, -m_use);
-#else
                     pr[4 * b + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[b][j], c_log2, -m_use));
-#endif
                     pf[0][b >> 1][4 * (b & 1) + j] = E::from_float(pr[4 * b + j]);
                 }
-            P16_MARK(tr_exp)
 #pragma unroll
             for (int v = 0; v < 2; ++v) {
-                // the tile's class is wave-uniform: one branch per mask and tile, the element predicate inside it branch-free
                 auto select = [&](auto pred) {
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -597,10 +576,9 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                             pf[v + 1][b >> 1][4 * (b & 1) + j] = E::from_float(pm);
                         }
                 };
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 1)
-                if (cls[v + 1] != TILE_SKIP) select([&](int) { return true; });
-#else
-                if (cls[v + 1] == TILE_PARTIAL_FAST) {
+                if (SVG_P16_ABL & 1) {
+                    if (cls[v + 1] != TILE_SKIP) select([&](int) { return true; });
+                } else if (cls[v + 1] == TILE_PARTIAL_FAST) {
                     // allowed_fast with the lane's part hoisted; a mask without sink columns (every model but the 5-D Cog masks) has one interval
                     const int yb = mc[v].ybase + mc[v].g4F - mc[v].fa0, ys = mc[v].ystride;
                     const unsigned fal = mc[v].falen, fbl = mc[v].fblen;
@@ -610,25 +588,19 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                     } else {
                         select([&](int off) { return (unsigned)(yb + off * ys) < fal; });
                     }
-                }
-                else if (cls[v + 1] != TILE_SKIP) {
+                } else if (cls[v + 1] != TILE_SKIP) {
                     (void)Pol::classify(prm, mc[v], k0, wave * 16);    // (the general predicate's per-tile decomposition: tk0, f0, p0)
                     int kb = k0 + 4 * g4;
                     asm volatile("" : "+v"(kb));   // (opaque: or the optimiser computes the two masks' common sub-tests for every tile, ahead of the branch)
                     select([&](int off) { return Pol::allowed(prm, mc[v], 0, kb + off); });
                 }
-#endif
             }
             P16_MARK(tr_sm)
             // ---- O^T += V^T P^T for every output that sees the tile ----
-            {   // V^T fragments in groups of G 16-wide d-blocks, two groups in flight; a masked output's MFMAs of a group behind ONE uniform branch
+            {   // V^T fragments in groups of four 16-wide d-blocks, two groups in flight; a masked output's MFMAs of a group behind ONE uniform branch
                 // (if-then around in-place accumulators: no copies.  Whole-pass forms per combination cost 40 register moves per tile and spills.)
-                constexpr int G = SVG_P16_VG, NG = 2 * NDB / G;
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 2)
-                const bool s1 = false, s2 = false;
-#else
-                const bool s1 = cls[1] != TILE_SKIP, s2 = cls[2] != TILE_SKIP;
-#endif
+                constexpr int G = 4, NG = 2 * NDB / G;
+                const bool s1 = !(SVG_P16_ABL & 2) && cls[1] != TILE_SKIP, s2 = !(SVG_P16_ABL & 2) && cls[2] != TILE_SKIP;
                 V8 vf[2][G];
 #pragma unroll
                 for (int i = 0; i < G; ++i) vf[0][i] = vfrag(st, 0, i);
@@ -638,13 +610,9 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
                         for (int i = 0; i < G; ++i) vf[(g + 1) & 1][i] = vfrag(st, ((g + 1) * G + i) / NDB, ((g + 1) * G + i) % NDB);
                     }
-                    P16_SB;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-#if defined(SVG_P16_ABL) && (SVG_P16_ABL & 128)
-                    for (int i = 0; i < G; ++i) acc[0][(g * G + i) % NDB][0] += (float)vf[g & 1][i][0] * (float)pf[0][(g * G + i) / NDB][0];
-#else
                     for (int i = 0; i < G; ++i) acc[0][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[0][(g * G + i) / NDB], acc[0][(g * G + i) % NDB]);
-#endif
                     if ((g * G) % NDB == 0) acc_l[0] = M::mfma(ones8, pf[0][(g * G) / NDB], acc_l[0]);
                     if (s1) {
                         if ((g * G) % NDB == 0) acc_l[1] = M::mfma(ones8, pf[1][(g * G) / NDB], acc_l[1]);
@@ -656,14 +624,12 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
 #pragma unroll
                         for (int i = 0; i < G; ++i) acc[2][(g * G + i) % NDB] = M::mfma(vf[g & 1][i], pf[2][(g * G + i) / NDB], acc[2][(g * G + i) % NDB]);
                     }
-                    P16_SB;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             P16_MARK(tr_pv)
         }
-#if !(defined(SVG_P16_ABL) && (SVG_P16_ABL & 4))
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+        if (!(SVG_P16_ABL & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #ifdef SVG_PROF_TRACE
@@ -675,27 +641,22 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
             g_prof_trace[wg * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
             g_prof_trace[wg * 4 + 3] = ((unsigned long long)blockIdx.y << 16) | blockIdx.x;
             g_prof_phase[wg * 8 + 0] = tr_wait, g_prof_phase[wg * 8 + 1] = tr_sm, g_prof_phase[wg * 8 + 2] = tr_pv, g_prof_phase[wg * 8 + 3] = nT;
-            g_prof_phase[wg * 8 + 4] = tr_qk, g_prof_phase[wg * 8 + 5] = tr_fix, g_prof_phase[wg * 8 + 6] = tr_exp, g_prof_phase[wg * 8 + 7] = 0;
+            g_prof_phase[wg * 8 + 4] = tr_qk, g_prof_phase[wg * 8 + 5] = tr_fix, g_prof_phase[wg * 8 + 6] = 0, g_prof_phase[wg * 8 + 7] = 0;
         }
     }
 #endif
 #undef P16_MARK
-    // ---- partials: output 0 golden, 1 under var[0], 2 under var[1] (store_partial's layout) ----
+    // ---- partials: output 0 golden, 1 under var[0], 2 under var[1] (store_partial's layout; the row sum is the same in the four lanes of a row) ----
     if (have) {
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             float* dst = prm.part + ((((size_t)o * prm.BH + head) * prm.n_chunks + chunk) * kProfMaxRows + r) * (D + 4);
 #pragma unroll
             for (int db = 0; db < NDB; ++db) *(f32x4*)(dst + 16 * db + 4 * g4) = acc[o][db];
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float l_tot = acc_l[o][0];
-        if (have && g4 == 0) {
-            float* dst = prm.part + ((((size_t)o * prm.BH + head) * prm.n_chunks + chunk) * kProfMaxRows + r) * (D + 4);
-            dst[D] = m_run;
-            dst[D + 1] = l_tot;
+            if (g4 == 0) {
+                dst[D] = m_run;
+                dst[D + 1] = acc_l[o][0];
+            }
         }
     }
 }
@@ -715,22 +676,38 @@ __global__ __launch_bounds__(256) void profile_combine_kernel(const float* __res
     float sq[2] = {0.f, 0.f};
     float bad[2] = {0.f, 0.f};
     constexpr int DS = D + 4;
+    const size_t cs = (size_t)kProfMaxRows * DS;
+    // the chunks' weights 2^(m_c - M) and the denominators once per (output, row) — a chunk per lane — instead of per element (every one of a row's
+    // D threads re-read its chunks' m twice and l once: 0.033 ms of a 0.355 ms call); the sums in the same order as before: the same bits
+    constexpr int kRowsPer = (kProfMaxRows + kProfRowGroups - 1) / kProfRowGroups;
+    __shared__ float wsh[3][kRowsPer][64], lws[3][kRowsPer][64], lsh[3][kRowsPer];
+    const int nrows = max(r1 - r0, 0);
+    for (int pi = tid >> 6; pi < 3 * nrows; pi += 4) {
+        const int v = pi / nrows, rr = pi - v * nrows, c = tid & 63;
+        const float* base = part + ((((size_t)v * BH + h) * n_chunks) * kProfMaxRows + r0 + rr) * DS;
+        const float mc = c < n_chunks ? base[c * cs + D] : -INFINITY;
+        const float M = wave_max(mc);
+        const float w = (mc == -INFINITY) ? 0.f : exp2f(mc - M);
+        wsh[v][rr][c] = w;
+        lws[v][rr][c] = c < n_chunks ? base[c * cs + D + 1] * w : 0.f;
+    }
+    __syncthreads();
+    if (tid < 3 * nrows) {
+        const int v = tid / nrows, rr = tid - v * nrows;
+        float L = 0.f;
+        for (int c = 0; c < n_chunks; ++c) L += lws[v][rr][c];
+        lsh[v][rr] = L;
+    }
+    __syncthreads();
     for (int e = r0 * D + tid; e < r1 * D; e += 256) {
         const int row = e / D, d = e - row * D;
         float o[3];
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
             const float* base = part + ((((size_t)v * BH + h) * n_chunks) * kProfMaxRows + row) * DS;
-            const size_t cs = (size_t)kProfMaxRows * DS;
-            float M = -INFINITY;
-            for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, base[c * cs + D]);
-            float L = 0.f, acc = 0.f;
-            for (int c = 0; c < n_chunks; ++c) {
-                const float mc = base[c * cs + D];
-                const float w = (mc == -INFINITY) ? 0.f : exp2f(mc - M);
-                L += base[c * cs + D + 1] * w;
-                acc += base[c * cs + d] * w;
-            }
+            const float L = lsh[v][row - r0];
+            float acc = 0.f;
+            for (int c = 0; c < n_chunks; ++c) acc += base[c * cs + d] * wsh[v][row - r0][c];
             // a row whose mask admits no key is NaN in the reference (softmax over all -inf)
             o[v] = (L > 0.f) ? acc / L : __builtin_nanf("");
             if (emulate) o[v] = Elt<T>::to_float(Elt<T>::from_float(o[v]));
@@ -782,7 +759,7 @@ static int prof_chunks(int BH, int S) {
     n = n > ntiles ? ntiles : n;
     n = n > 64 ? 64 : n;
 #ifdef SVG_PROF_CHUNKS_ENV
-    if (const char* e = getenv("SVG_PROF_CHUNKS")) n = std::max(1, std::min(atoi(e), ntiles));   // (A/B builds only)
+    if (const char* e = getenv("SVG_PROF_CHUNKS")) n = std::max(1, std::min(std::min(atoi(e), ntiles), 64));   // (A/B builds only)
 #endif
     return n;
 }
@@ -814,22 +791,18 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     p.part = (float*)ws;
     p.skip = skip;
 #ifndef SVG_PROF_FIRST_FORM
-    if constexpr (D == 128) {   // second form: one score tile for the three outputs, two workgroups per CU
-#ifdef SVG_P16_LDS_BYTES
-        constexpr int lds16 = SVG_P16_LDS_BYTES;       // (diagnostics: 98304 leaves room for ONE workgroup per CU)
-#else
-        constexpr int lds16 = kP16LdsBytes;
-#endif
-        auto kern16 = profile16_kernel<T>;
+    {   // second form: one score tile for the three outputs, two workgroups per CU
+        constexpr int lds16 = p16_lds_bytes(D);
+        auto kern16 = profile16_kernel<T, D>;
         hipError_t e16 = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
         if (e16 != hipSuccess) {
             g_last_hip_error = (int)e16;
             return SVG_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern16, dim3(BH, p.n_chunks), dim3(256), lds16, st, p);
-    } else
-#endif
-    {
+    }
+#else
+    {   // first form (A/B builds): three roles x two waves of the lock-step body
     const int lds = attn_lds_bytes<D, kProfNW>();
     auto kern = profile_attn_kernel<T, D>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -839,6 +812,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     }
     hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
     }
+#endif
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
                        R, p.n_chunks, p.emulate, skip);

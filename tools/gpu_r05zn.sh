@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 5, GPU call zn: online profiler, second form for both head dims against the first form (same tree, -DSVG_PROF_FIRST_FORM): ms and mse on the
+# five geometries, the profiler / processor tests, kernel trace
+tag=${1:-r05zn}; O=gpurun_out/$tag; mkdir -p $O
+export TMPDIR=/tmp
+R=$PWD
+for g in hy720p wan720p hy480p cog15 cog480p; do for l in libsvgattn libsvgattn_prof1; do timeout 60 tools/native_harness --lib sparse-videogen_amd/lib/$l.so --geom $g --profiler --reps 10 > $O/prof_${g}_$l.json 2> $O/prof_${g}_$l.err; echo "$g $l rc=$? $(python3 -c "
+import json; d=json.load(open('$O/prof_${g}_$l.json')); print(d['ms_mean'], d['gbps'], d['mse_sum'], d['mse0'], d['mse_bits'])")"; done; done 2>&1 | tee $O/ab.txt
+timeout 900 python -m pytest tests -m gpu -q -k "profil or sample_mse or mse or processor" -p no:cacheprovider 2>&1 | tail -5 | tee $O/pytest_profiler.txt
+(cd /tmp && timeout 60 rocprofv3 --kernel-trace --stats -d $R/$O/kt_prof -o kt -- $R/tools/native_harness --lib $R/sparse-videogen_amd/lib/libsvgattn.so --geom hy720p --profiler --reps 5 > $R/$O/kt_prof.log 2>&1)
+timeout 20 python3 tools/rocprof_summary.py $(find $O/kt_prof -name "*.db" | head -1) $O/profiler_kernel_trace.txt; head -6 $O/profiler_kernel_trace.txt | cut -c1-150
