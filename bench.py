@@ -337,6 +337,7 @@ def main():
         q_tok = (q_tok.float() * nat.softmax_q_scale(D)).to(q_tok.dtype)
     LN2 = math.log(2.0)
     ev_p0, ev_p1 = [], []
+    ev_q0, ev_q1 = [], []
 
     def step(timed: bool):
         if world > 1:   # inbound exchange: token shards -> this rank's heads over the full sequence
@@ -346,7 +347,13 @@ def main():
                 else:
                     tokens_to_heads(x_tok, S, unit=TOKEN_UNIT, head_lists=head_lists, presorted=True, out=x[0])
         if not a.no_profiler:
+            if timed:
+                ev_q0.append(torch.cuda.Event(enable_timing=True))
+                ev_q0[-1].record()
             mse = nat.sample_mse(q_att[0], k[0], v[0], rows, prof, sm_scale=LN2 if a.prescaled else None)
+            if timed:
+                ev_q1.append(torch.cuda.Event(enable_timing=True))
+                ev_q1[-1].record()
             _ = mse.argmin(0)  # best_mask_idx (kept on device; the bench uses the fixed alternating pattern)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
@@ -561,6 +568,17 @@ def main():
             },
             "clock": clock_info,   # sustained shader clock during the timed steps (the 2.5 PFLOP/s peak is quoted at 2.4 GHz)
         }
+        if ev_q0:
+            # the layer-call's other kernel, HBM-bound: K and V of every head streamed once for the 64 sampled rows.  The same
+            # K / V stream by LDS-DMA with no arithmetic takes 0.309 ms at this geometry (4.7 TB/s, profiles/r05zj_profiler_bound_ablations.txt)
+            prof_ms = sum(x.elapsed_time(y) for x, y in zip(ev_q0, ev_q1)) / len(ev_q0)
+            kv_bytes = 2.0 * Hl * S * D * 2
+            out["online_profiler"] = {
+                "kernels": "profile16_kernel + profile_combine_kernel + profile_finalize_kernel (svg_sample_mse)",
+                "ms": round(prof_ms, 4), "algorithmic_bytes": kv_bytes, "GBs": round(kv_bytes / prof_ms / 1e6, 1),
+                "frac_of_8TBs": round(kv_bytes / prof_ms / 1e6 / 8000.0, 4), "bound": "hbm",
+                "reference": "svg/models/hyvideo/attention.py:376-399 (sample_mse), svg/models/hyvideo/utils.py:47-93 (the two masks)",
+            }
         if a.prescaled:
             out["config"]["q_prescaled"] = "--prescaled: q carries sm_scale * log2(e), as the fused prologue writes it under prescale_q = True (opt-in; default: plain q)"
             ob = nat.band_attention(q[:, :2].contiguous(), k[:, :2].contiguous(), v[:, :2].contiguous(), mask,

@@ -181,6 +181,9 @@ def test_bench_line_with_extras_has_no_error_key():
     for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p", "hbm_kernels"):
         assert key in d, sorted(d)
     _check_hbm_block(d["hbm_kernels"])
+    op = d["online_profiler"]     # the layer-call's HBM-bound kernel: K and V of every head once
+    assert op["ms"] > 0 and op["bound"] == "hbm" and abs(op["GBs"] - op["algorithmic_bytes"] / op["ms"] / 1e6) <= 0.01 * op["GBs"] + 0.1
+    assert abs(op["frac_of_8TBs"] - op["GBs"] / 8000.0) < 1e-3 and "svg/" in op["reference"]
     assert d["svg2_wan720p"]["ms"]["total"] > 0 and d["svg2_wan720p_fp8"]["ms"]["total"] > 0
     assert d["denoise_step_hy720p"]["denoise_steps_per_s"] > 0
 
