@@ -553,7 +553,11 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                         for (int j = 0; j < 4; ++j) acc[o][db][j] *= alpha;
                 }
             }
-            const float m_use = m_run;
+            // The masked outputs share the golden rows' reference: a mask whose best key scores far below the row's overall maximum sees small
+            // probabilities.  The reference sits 60 binades under the maximum (p <= 2^60; sums of 2^17 keys times |v| stay below 2^90), so a masked
+            // row only loses keys more than 186 binades = 129 in logit under the overall maximum — then its sum is 0 and the MSE NaN like a row
+            // without visible keys.  A power of two: every number of the kernel scales exactly, the results are bit for bit those without it.
+            const float m_use = m_run - 60.f;
             P16_MARK(tr_fix)
             // ---- probabilities (once), the masks' selections ----
             V8 pf[3][2];

@@ -657,6 +657,31 @@ def test_sample_mse(nat, model):
     assert got32.argmin(0)[0] == 1 and got32.argmin(0)[1] == 0  # temporal head / spatial head as constructed
 
 
+@pytest.mark.parametrize("model,D,R,dtype", [("hy", 128, 64, torch.bfloat16), ("cog", 64, 5, torch.bfloat16), ("wan", 128, 17, torch.float16)])
+def test_sample_mse_many_heads_one_chunk(nat, model, D, R, dtype):
+    """512 heads: ONE KV chunk per head of 134 tiles, so a wave's class table (128 tiles per fill) is refilled inside the loop; full and nearly
+    empty row sets (waves without sampled rows), fp16.  8 distinct heads repeated 64 times: every replica must give the same bits."""
+    torch.manual_seed(16)
+    F_, P_, ctx, Hd, rep = 5, 1700, 32, 8, 64
+    ctx = 0 if model == "wan" else ctx
+    S = F_ * P_ + ctx
+    assert (S + 63) // 64 > 128
+    q, k, v = (torch.randn(1, Hd, S, D) for _ in range(3))
+    vid0 = ctx if model == "cog" else 0
+    pos = torch.randn(P_, D)
+    k[0, 0, vid0:vid0 + F_ * P_] += 3 * pos.repeat(F_, 1)
+    q[0, 0, vid0:vid0 + F_ * P_] += 3 * pos.repeat(F_, 1)
+    q, k, v = (x.to(dtype) for x in (q, k, v))
+    lo = ctx if model == "cog" else 0
+    rows = torch.randint(lo, lo + F_ * P_, (R,))
+    masks = list(O.profile_masks(model, ctx, F_, P_))
+    ref32 = O.sample_mse_fp32(q, k, v, rows, masks)[:, 0]
+    qq, kk, vv = (dev(x[0]).repeat(rep, 1, 1).contiguous() for x in (q, k, v))
+    got = nat.sample_mse(qq, kk, vv, dev(rows), _prof_desc(nat, model, ctx, F_, P_, False)).cpu().view(2, rep, Hd)
+    assert torch.equal(got, got[:, :1].expand_as(got)), "replicas of the same head differ"
+    torch.testing.assert_close(got[:, 0], ref32, rtol=3e-2, atol=1e-6)
+
+
 def test_sample_mse_golden_reference_processor(nat, golden):
     """Against Hunyuan_SVGAttn_Processor2_0.sample_mse of the reference itself (bf16 torch ops)."""
     F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
