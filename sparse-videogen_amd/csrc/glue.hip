@@ -69,11 +69,10 @@ __device__ __forceinline__ void store8(void* base, size_t elem, int dt, const fl
 // LN: p.do_ln as a compile-time constant — with the three normalisation forms behind run-time branches of one kernel the hidden-size-5120
 // instance needed 182 registers (two waves per SIMD) where the LayerNorm-only kernel of round 1 had 114 (four): svg_layernorm_modulate_forward
 // fell from 0.41 to 0.62 ms at Wan 720p (profiles/r01f_bench_glue.json, r05n_bench.json hbm_kernels).
-template <int NCH, int LN>
-__global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
+// MOD_LDS: scale / shift come from the workgroup's LDS copy `mod` ((1 + scale) and shift as 16-byte pieces, piece h of chunk c at
+// (h * nchunks + c) for (1 + scale), behind 2 * nchunks pieces for shift: consecutive lanes read consecutive pieces).
+template <int NCH, int LN, bool MOD_LDS>
+__device__ __forceinline__ void row_glue_body(const GlueParams& p, int row, int lane, const f32x4* mod) {
     const int nchunks = p.N / 8;
     const size_t rbase = (size_t)row * p.N;
     float x[NCH][8];
@@ -146,7 +145,14 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
         if (c >= nchunks) continue;
-        if (p.scale) {
+        if constexpr (MOD_LDS) {
+            const f32x4 s0 = mod[c], s1 = mod[nchunks + c], h0 = mod[2 * nchunks + c], h1 = mod[3 * nchunks + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[i][j] = x[i][j] * s0[j] + h0[j], x[i][4 + j] = x[i][4 + j] * s1[j] + h1[j];
+            store8(p.y, rbase + (size_t)c * 8, p.y_dt, x[i]);
+            __builtin_amdgcn_sched_barrier(0);   // (or every chunk's four LDS reads are hoisted to the top: 16 registers each, 218 at hidden size 5120)
+            continue;
+        } else if (p.scale) {
             float sc[8], sh[8];
             load8(p.scale, mrow + (size_t)c * 8, SVG_DTYPE_F32, sc);
             load8(p.shift, mrow + (size_t)c * 8, SVG_DTYPE_F32, sh);
@@ -155,6 +161,36 @@ __global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
         }
         store8(p.y, rbase + (size_t)c * 8, p.y_dt, x[i]);
     }
+}
+
+template <int NCH, int LN>
+__global__ __launch_bounds__(256) void row_glue_kernel(GlueParams p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    row_glue_body<NCH, LN, false>(p, row, threadIdx.x & 63, nullptr);
+}
+
+// The modulated forms (round 5): a row's scale and shift are 64 bytes of fp32 per 16-byte chunk of x — three times the row's own traffic through the
+// vector memory path, every row again: svg_modulate_shift_forward alone took 0.397 ms at Wan's [75600, 5120] where LayerNorm alone takes 0.314 (a
+// copy 0.308).  Here a workgroup of 8 waves copies (1 + scale) and shift of its batch to LDS (8 N bytes) once for its 8 rows, one wave per row as
+// above: an eighth of that traffic.  The same numbers: 1 + scale is formed once per workgroup instead of per row.
+constexpr int kGlueLdsWaves = 8;
+template <int NCH, int LN>
+__global__ __launch_bounds__(kGlueLdsWaves * 64) void row_glue_lds_kernel(GlueParams p) {
+    extern __shared__ __attribute__((aligned(16))) char glue_smem[];
+    f32x4* mod = (f32x4*)glue_smem;
+    const int nchunks = p.N / 8, batch = blockIdx.y;
+    const f32x4* sc = (const f32x4*)(p.scale + (size_t)batch * p.N);
+    const f32x4* sh = (const f32x4*)(p.shift + (size_t)batch * p.N);
+    for (int i = threadIdx.x; i < 2 * nchunks; i += kGlueLdsWaves * 64) {    // piece i of the row: chunk i / 2, half i % 2
+        const f32x4 a = sc[i];
+        mod[(i & 1) * nchunks + (i >> 1)] = f32x4{1.0f + a[0], 1.0f + a[1], 1.0f + a[2], 1.0f + a[3]};
+        mod[2 * nchunks + (i & 1) * nchunks + (i >> 1)] = sh[i];
+    }
+    __syncthreads();
+    // (one row per wave, no row loop: with a grid-stride loop around the body hipcc needs 218 registers at hidden size 5120 instead of 116)
+    const int row = batch * p.rows_per_batch + blockIdx.x * kGlueLdsWaves + (threadIdx.x >> 6);
+    if (row < (batch + 1) * p.rows_per_batch) row_glue_body<NCH, LN, true>(p, row, threadIdx.x & 63, mod);
 }
 
 // y = residual + x * gate, 8 elements per thread
@@ -180,6 +216,22 @@ static int launch_row_glue(const GlueParams& p, hipStream_t st) {
     if (!dt_ok(p.x_dt) || !dt_ok(p.y_dt)) return SVG_ERR_UNSUPPORTED;
     const int need = (p.N / 8 + 63) / 64;
     const dim3 grid((p.M + 3) / 4), block(256);
+    // modulated, a workgroup full of rows per batch, and the LDS copy fits three times into a CU: the LDS form
+    const int lds_bytes = 2 * p.N * (int)sizeof(float);
+    if (p.scale && p.rows_per_batch >= kGlueLdsWaves && lds_bytes <= 49152) {
+        const int batches = p.M / p.rows_per_batch;
+        const int per_batch = (p.rows_per_batch + kGlueLdsWaves - 1) / kGlueLdsWaves;
+        const dim3 g2(per_batch, batches), b2(kGlueLdsWaves * 64);
+#define SVG_GLUE_LDS(NC)                                                                                      \
+    if (need <= NC) {                                                                                         \
+        if (p.do_ln == 2) hipLaunchKernelGGL((row_glue_lds_kernel<NC, 2>), g2, b2, lds_bytes, st, p);         \
+        else if (p.do_ln == 1) hipLaunchKernelGGL((row_glue_lds_kernel<NC, 1>), g2, b2, lds_bytes, st, p);    \
+        else hipLaunchKernelGGL((row_glue_lds_kernel<NC, 0>), g2, b2, lds_bytes, st, p);                      \
+        return launch_status();                                                                               \
+    }
+        SVG_GLUE_LDS(2) SVG_GLUE_LDS(4) SVG_GLUE_LDS(6) SVG_GLUE_LDS(8) SVG_GLUE_LDS(10) SVG_GLUE_LDS(12) SVG_GLUE_LDS(16)
+#undef SVG_GLUE_LDS
+    }
 #define SVG_GLUE(NC)                                                                                          \
     if (need <= NC) {                                                                                         \
         if (p.do_ln == 2) hipLaunchKernelGGL((row_glue_kernel<NC, 2>), grid, block, 0, st, p);                \

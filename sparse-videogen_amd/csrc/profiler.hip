@@ -554,10 +554,12 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
                 }
             }
             // The masked outputs share the golden rows' reference: a mask whose best key scores far below the row's overall maximum sees small
-            // probabilities.  The reference sits 60 binades under the maximum (p <= 2^60; sums of 2^17 keys times |v| stay below 2^90), so a masked
-            // row only loses keys more than 186 binades = 129 in logit under the overall maximum — then its sum is 0 and the MSE NaN like a row
-            // without visible keys.  A power of two: every number of the kernel scales exactly, the results are bit for bit those without it.
-            const float m_use = m_run - 60.f;
+            // probabilities.  The reference sits kBias binades under the maximum — bf16: 60 (p <= 2^60; sums of 2^17 keys times |v| stay below
+            // 2^90), a masked row only loses keys more than 186 binades = 129 in logit under the overall maximum; fp16: 15 (p <= 2^15 < 65504),
+            // 39 binades = 27 in logit.  Below that its sum is 0 and the MSE NaN like a row without visible keys.  A power of two: every
+            // number of the kernel scales exactly, the results are bit for bit those without it.
+            constexpr float kBias = std::is_same_v<T, __bf16> ? 60.f : 15.f;
+            const float m_use = m_run - kBias;
             P16_MARK(tr_fix)
             // ---- probabilities (once), the masks' selections ----
             V8 pf[3][2];
