@@ -63,9 +63,7 @@ __device__ __forceinline__ void store8(void* base, size_t elem, int dt, const fl
 }
 
 // one wave per row; lane l owns the 8-element chunks l, l + 64, ... (NCH of them at most)
-// (Round 5: svg_layernorm_modulate_forward runs at 2.5 TB/s at Wan's hidden size (0.62 ms for [75600, 5120] bf16) where the gate-residual kernel reaches
-//  6.0: a row's scale and shift come from global memory as four 16-byte fp32 loads per 16-byte chunk of x, behind the statistics, at two waves per SIMD
-//  (182 registers).  Staging scale / shift in LDS once per workgroup of 32 rows was measured: 256 registers, one wave per SIMD, 0.99 ms — removed.)
+// (The modulated forms take scale / shift from an LDS copy when the launch allows it: row_glue_lds_kernel below.)
 // LN: p.do_ln as a compile-time constant — with the three normalisation forms behind run-time branches of one kernel the hidden-size-5120
 // instance needed 182 registers (two waves per SIMD) where the LayerNorm-only kernel of round 1 had 114 (four): svg_layernorm_modulate_forward
 // fell from 0.41 to 0.62 ms at Wan 720p (profiles/r01f_bench_glue.json, r05n_bench.json hbm_kernels).
