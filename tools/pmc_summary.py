@@ -5,14 +5,19 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 out = sys.argv[1]
+want = os.environ.get("PMC_KERNEL", "")     # substring of the kernel name to summarise (default: the attention kernels)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "?")
-        if "attn_" not in k or "profile" in k:
+        if want:
+            if want not in k:
+                continue
+        elif "attn_" not in k or "profile" in k:
             continue
         agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
