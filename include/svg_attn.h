@@ -198,7 +198,12 @@ int svg_varblock_attention(const void* q, const void* k, const void* v, void* o,
  * the reference masks (Wan sink columns, Cog's un-offset spatial band and text-less temporal mask) are expressed
  * through svg_profile_variant_t.  A sampled row whose mask admits no key yields NaN like the reference's softmax
  * over all -inf.  out_mse: device float [2, BH].
- * workspace: svg_sample_mse_workspace_bytes(BH, R, D).
+ * Numerics (csrc/profiler.hip, second form): one score tile serves the dense rows and both masks — the masked softmaxes use
+ * the dense rows' running maximum as their reference (exact in real arithmetic; a masked row loses keys that score more than
+ * 129 (bf16; fp16: 27) in logit below the row's overall maximum), and a row's denominator is the sum of the probabilities as
+ * the numerator sees them (rounded to the input dtype).  The rows are processed in the order of their coordinate under mask 1;
+ * the result does not depend on the order they are passed in (up to fp32 summation order over rows).
+ * workspace: svg_sample_mse_workspace_bytes(BH, R, D, S).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct svg_profile_variant {
     int32_t coord;        /* 0: indices as stored (frame-major); 1: token-major (p*F + f) inside the video range */
