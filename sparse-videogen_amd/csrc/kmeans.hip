@@ -241,7 +241,11 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     if (g == 0 && n < N) labels[(size_t)b * N + n] = best_idx;
 }
 
-// ---- centroid update: grid = (K, B), block = 256 = 16 row slots x 16 lanes (D = 128) / 32 x 8 (D = 64) ----
+// ---- centroid update: grid = (groups, B), block = 256 = 16 row slots x 16 lanes (D = 128) / 32 x 8 (D = 64); a workgroup walks clusters
+// k = blockIdx.x, + gridDim.x, ... of its batch.  (Until round 5 one workgroup per cluster: at K = 1000 that is 40000 workgroups of ~75 rows whose
+// lifetime is three dependent latencies — count / offset, row indices, rows — 0.36 ms per call at Wan 720p where the K = 300 side, HBM-bound, takes
+// 0.16.  Now the next cluster's count, offset and first four row indices per slot are fetched while the current one is summed.  The order of every
+// sum is unchanged: the same bits.)
 template <typename T, int D>
 __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict__ x, const T* __restrict__ c_old,
                                                             T* __restrict__ c_new, const int32_t* __restrict__ sorted_idx,
@@ -252,59 +256,102 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict_
     constexpr int SLOTS = 256 / LPR;
     __shared__ float red[SLOTS][D + 4];
     __shared__ float nrm[4];
-    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int slot = tid / LPR, li = tid - slot * LPR;
-    const int cnt = counts[(size_t)b * K + k];
-    const int start = offsets[(size_t)b * off_batch_stride + k];
     const T* xb = x + (size_t)b * N * D;
-    const int32_t* sidx = sorted_idx + (size_t)b * N + start;
-    float acc[8];
+    const int32_t* sidx_b = sorted_idx + (size_t)b * N;
+    using V8 = typename Elt<T>::v8;
+    int k = blockIdx.x;
+    if (k >= K) return;
+    int cnt = counts[(size_t)b * K + k];
+    int start = offsets[(size_t)b * off_batch_stride + k];
+    int pre[4];     // the slot's first four row indices of the cluster (rows slot, slot + SLOTS, ...)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // four rows of a slot in flight (index loads, then row loads); summed in the order a one-row loop sums them
-    int r = slot;
-    {
+    for (int u = 0; u < 4; ++u) pre[u] = (slot + u * SLOTS < cnt) ? sidx_b[start + slot + u * SLOTS] : 0;
+    for (;;) {
+        const int kn = k + (int)gridDim.x;
+        int cnt_n = 0, start_n = 0;
+        if (kn < K) {
+            cnt_n = counts[(size_t)b * K + kn];
+            start_n = offsets[(size_t)b * off_batch_stride + kn];
+        }
+        const int32_t* sidx = sidx_b + start;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        // four rows of a slot in flight (index loads, then row loads); summed in the order a one-row loop sums them
+        int r = slot;
+        {
 #pragma clang fp reassociate(off)
-        using V8 = typename Elt<T>::v8;
-        for (; r + 3 * SLOTS < cnt; r += 4 * SLOTS) {
-            int row[4];
+            if (r + 3 * SLOTS < cnt) {     // the first batch: its indices are here already
+                V8 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) row[u] = sidx[r + u * SLOTS];
-            V8 v[4];
+                for (int u = 0; u < 4; ++u) v[u] = *(const V8*)(xb + (size_t)pre[u] * D + li * 8);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const V8*)(xb + (size_t)row[u] * D + li * 8);
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                    for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[u][j]);
+                r += 4 * SLOTS;
+                for (; r + 3 * SLOTS < cnt; r += 4 * SLOTS) {
+                    int row[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[u][j]);
+                    for (int u = 0; u < 4; ++u) row[u] = sidx[r + u * SLOTS];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *(const V8*)(xb + (size_t)row[u] * D + li * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[u][j]);
+                }
+                for (; r < cnt; r += SLOTS) {
+                    const V8 w = *(const V8*)(xb + (size_t)sidx[r] * D + li * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(w[j]);
+                }
+            } else {                       // at most three rows for this slot, all of them prefetched
+                V8 v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (slot + u * SLOTS < cnt) v[u] = *(const V8*)(xb + (size_t)pre[u] * D + li * 8);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (slot + u * SLOTS < cnt) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[u][j]);
+                    }
+            }
         }
-        for (; r < cnt; r += SLOTS) {
-            const V8 v = *(const V8*)(xb + (size_t)sidx[r] * D + li * 8);
+        // the next cluster's first indices: in flight during the reduction below
+        if (kn < K) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += Elt<T>::to_float(v[j]);
+            for (int u = 0; u < 4; ++u) pre[u] = (slot + u * SLOTS < cnt_n) ? sidx_b[start_n + slot + u * SLOTS] : 0;
         }
-    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[slot][li * 8 + j] = acc[j];
-    __syncthreads();
-    float d2 = 0.f;
-    if (tid < D) {
-        float s = 0.f;
-        for (int sl = 0; sl < SLOTS; ++sl) s += red[sl][tid];  // fixed order -> deterministic
-        const size_t o = ((size_t)b * K + k) * D + tid;
-        const float oldv = Elt<T>::to_float(c_old[o]);
-        // ref: svg/kmeans_utils.py:416-421 sums / clamp(count,1), empty cluster keeps the old centroid, cast to x.dtype
-        const T nv = cnt > 0 ? Elt<T>::from_float(s / (float)cnt) : c_old[o];
-        c_new[o] = nv;
-        const float df = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(nv) - oldv));
-        d2 = df * df;
-    }
-    d2 = wave_sum(d2);
-    if ((tid & 63) == 0) nrm[tid >> 6] = d2;
-    __syncthreads();
-    if (tid == 0) {
-        const float nr = sqrtf(nrm[0] + nrm[1] + nrm[2] + nrm[3]);
-        atomicMax((int*)(shift + b), __float_as_int(nr));  // non-negative floats order like ints
+        for (int j = 0; j < 8; ++j) red[slot][li * 8 + j] = acc[j];
+        __syncthreads();
+        float d2 = 0.f;
+        if (tid < D) {
+            float s = 0.f;
+            for (int sl = 0; sl < SLOTS; ++sl) s += red[sl][tid];  // fixed order -> deterministic
+            const size_t o = ((size_t)b * K + k) * D + tid;
+            const float oldv = Elt<T>::to_float(c_old[o]);
+            // ref: svg/kmeans_utils.py:416-421 sums / clamp(count,1), empty cluster keeps the old centroid, cast to x.dtype
+            const T nv = cnt > 0 ? Elt<T>::from_float(s / (float)cnt) : c_old[o];
+            c_new[o] = nv;
+            const float df = Elt<T>::to_float(Elt<T>::from_float(Elt<T>::to_float(nv) - oldv));
+            d2 = df * df;
+        }
+        d2 = wave_sum(d2);
+        if ((tid & 63) == 0) nrm[tid >> 6] = d2;
+        __syncthreads();
+        if (tid == 0) {
+            const float nr = sqrtf(nrm[0] + nrm[1] + nrm[2] + nrm[3]);
+            atomicMax((int*)(shift + b), __float_as_int(nr));  // non-negative floats order like ints
+        }
+        if (kn >= K) break;
+        k = kn, cnt = cnt_n, start = start_n;
+        // (red / nrm of this cluster are read before the barriers above; the next writes to red come after the second one, the next write to
+        //  nrm after the next cluster's first barrier: tid 0 has read nrm by then only if it passed that barrier too — it has: same barrier)
     }
 }
 
@@ -334,7 +381,14 @@ static int run_kmeans_update(const void* x, const void* c_in, void* c_out, const
     if (rc) return rc;
     (void)hipMemsetAsync(shift, 0, (size_t)B * sizeof(float), st);
     const int nchunks = (N + 1023) / 1024;
-    hipLaunchKernelGGL((kmeans_update_kernel<T, D>), dim3(K, B), dim3(256), 0, st, (const T*)x, (const T*)c_in, (T*)c_out,
+    // workgroups per batch: three per CU over the whole launch.  Measured at Wan 720p (40 heads, K = 300 and 1000 on two streams, the 2-iteration
+    // stage): 6 per head 3.49 ms, 8 3.27, 12 3.14, 16 3.05, 20 3.02, 26 3.13, 32 3.17, 52 3.22, 100 3.36, one per cluster 3.37; the kernel of
+    // round 4 (one workgroup per cluster, no prefetch) 3.39 (profiles/r05zw_kmeans_update_groups.txt).  SVG_KMEANS_UPDATE_GROUPS: A/B builds
+    int groups = std::max(1, std::min(K, (3 * kNumCU + B - 1) / B));
+#ifdef SVG_KMEANS_UPDATE_GROUPS_ENV
+    if (const char* e = getenv("SVG_KMEANS_UPDATE_GROUPS")) groups = std::max(1, std::min(K, atoi(e)));
+#endif
+    hipLaunchKernelGGL((kmeans_update_kernel<T, D>), dim3(groups, B), dim3(256), 0, st, (const T*)x, (const T*)c_in, (T*)c_out,
                        sorted_idx, (const int32_t*)sort_ws, counts, shift, N, K, (size_t)nchunks * K);
     return launch_status();
 }
