@@ -4,12 +4,16 @@
 // profiling masks of get_attention_mask (hyvideo/utils.py:47-93, wan/utils.py:63-110, cog/utils.py:61-88).
 //
 // The reference materialises two [10000, S] fp32 masks (4.8 GB each) and runs three full softmaxes in torch.
-// Here the masks are analytic predicates and the three variants are three wave roles of ONE workgroup that shares
-// attn_core.h: grid = (BH, kv_chunks); waves 0-1 compute the golden rows, waves 2-3 the rows under mask 1, waves 4-5 under
-// mask 0 (waves 6-7 only help staging) on the SAME staged K/V tiles, so a chunk of K/V is read and staged once (split-KV);
-// every role emits un-normalised fp32 partials (O, m, l) per sampled row, and a small second kernel merges the chunks,
-// normalises and reduces the MSE.  (The first version ran the roles as three workgroups, grid.z = 3: K/V staged three times,
-// 1.26 ms per call at Hunyuan 720p.)
+// Here the masks are analytic predicates (ProfilePolicy below: tile classification + element predicate) and K / V are streamed once per
+// call: grid = (BH, kv_chunks), every workgroup emits un-normalised fp32 partials (O, m, l) per sampled row, output and chunk (split-KV),
+// profile_combine_kernel merges the chunks, normalises and reduces the squared errors, profile_finalize_kernel writes mse[2][BH].
+// Two forms of the attention kernel:
+//   profile16_kernel     (shipped, round 5)  ONE score tile for the golden rows and both masks, 4 waves x 16 rows on 16x16x32 MFMAs, two
+//                        workgroups per CU — see the note above the kernel;
+//   profile_attn_kernel  (-DSVG_PROF_FIRST_FORM, A/B builds)  the three outputs as three wave roles of one workgroup on attn_core.h's
+//                        lock-step body: waves 0-1 the golden rows, 2-3 the rows under mask 1, 4-5 under mask 0 on the SAME staged K / V
+//                        tiles, each role its own scores.  (Before that: three workgroups, grid.z = 3, K / V staged three times, 1.26 ms per
+//                        call at HunyuanVideo 720p; the role form 0.78 -> 0.60 ms; the shipped one 0.32.)
 #include <type_traits>
 #include "attn_core.h"
 #include "attn_m16.h"
