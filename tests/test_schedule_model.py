@@ -166,6 +166,107 @@ def test_profile_predicates_equal_reference_masks(model, ctx, F_, P_):
             assert torch.equal(got, m[q] != 0), f"{model} variant coord={var[0]} row {q}"
 
 
+# ---- profiler tile classes of the second form (csrc/profiler.hip: ProfilePolicy::classify, allowed_fast, profile16_kernel's row ranking and
+#      its skip of fast tiles outside the band of a wave's rows) ----
+def _asr7(v):
+    return v >> 7            # Python's >> on a negative int is the arithmetic shift the kernel's `>> 7` on int is
+
+
+def prof_coord(i, vid0, F_, P_, var):
+    coord = var[0]
+    if coord == 1 and 0 <= i - vid0 < F_ * P_:
+        f, pp = divmod(i - vid0, P_)
+        return vid0 + pp * F_ + f
+    return i
+
+
+def prof_wave_state(rows, vid0, F_, P_, var):
+    """per-wave / per-row state of profile16_kernel for one mask: (xlo_blk, xhi_blk, any_text, [(fa0, falen, fblen)] per row)"""
+    coord, origin, span, bb, sink, tlo, thi = var
+    blks, lanes, any_text = [], [], False
+    for q in rows:
+        x = prof_coord(q, vid0, F_, P_, var) - origin
+        qtext = tlo <= q < thi
+        any_text |= qtext
+        blks.append(_asr7(x))
+        xdom = 0 <= x < span
+        a0, a1 = max((_asr7(x) - bb + 1) * 128, 0), min((_asr7(x) + bb) * 128, span)
+        falen = max(a1 - a0, 0) if xdom else 0
+        fblen = min(sink, span) if (xdom and sink > 0) else 0
+        lanes.append((-(1 << 30), 1 << 32, fblen) if qtext else (a0, falen, fblen))
+    return min(blks), max(blks), any_text, lanes
+
+
+def prof_classify(k0, S, vid0, F_, P_, var, xlo_blk, xhi_blk, any_text):
+    """-> (class, ybase, ystride): 0 SKIP, 2 PARTIAL (general predicate), 3 PARTIAL_FAST — ProfilePolicy::classify plus the second form's skip"""
+    coord, origin, span, bb, sink, tlo, thi = var
+    V, BN = F_ * P_, 64
+    k1 = min(k0 + BN, S)
+    cls, ybase, ystride = 2, 0, (F_ if coord == 1 else 1)
+    if coord == 0:
+        text_keys = k0 < thi and k1 > tlo
+        if not any_text and not text_keys:
+            y0, y1 = k0 - origin, k1 - 1 - origin
+            outside = y1 < 0 or y0 >= span
+            far = (_asr7(y0) - xhi_blk >= bb) or (xlo_blk - _asr7(y1) >= bb)
+            if outside or (far and y0 >= sink and y0 >= 0):
+                return 0, 0, ystride
+        if not text_keys and k0 + BN <= S and k0 - origin >= 0 and k0 + BN - origin <= span:
+            cls, ybase = 3, k0 - origin
+    else:
+        i0 = max(k0 - vid0, 0)
+        f0 = i0 // P_
+        p0 = i0 - f0 * P_
+        text_keys = k0 < thi and k0 + BN > tlo
+        if k0 >= vid0 and k0 + BN <= vid0 + V and k0 + BN <= S and p0 + BN <= P_ and not text_keys:
+            cls, ybase = 3, vid0 + p0 * F_ + f0 - origin
+    if cls == 3 and not any_text and ybase >= sink:      # profile16_kernel: a fast tile farther than the band from every row of the wave
+        b0, b1 = _asr7(ybase), _asr7(ybase + 63 * ystride)
+        if b0 - xhi_blk >= bb or xlo_blk - b1 >= bb:
+            cls = 0
+    return cls, ybase, ystride
+
+
+@pytest.mark.parametrize("model,ctx,F_,P_", [("hy", 16, 4, 140), ("wan", 0, 4, 140), ("cog", 16, 4, 140), ("cog", 26, 3, 200),
+                                            ("hy", 40, 5, 100), ("wan", 0, 3, 260), ("hy", 64, 6, 330), ("wan", 0, 7, 192)])
+@pytest.mark.parametrize("R,seed", [(64, 0), (37, 1), (5, 2)])
+def test_profile_tile_classes_against_reference_masks(model, ctx, F_, P_, R, seed):
+    """The index logic of the online profiler's second form against the reference's materialised masks: rows ranked by their coordinate
+    under the second mask and cut into waves of 16; for every wave, mask and 64-key tile a SKIP class means no row of the wave sees a
+    key of the tile, a FAST class means the two interval tests give exactly the mask's elements, anything else falls to the general
+    predicate (test above)."""
+    S = F_ * P_ + ctx
+    vid0, variants = prof_variants(model, ctx, F_, P_)
+    masks = [m != 0 for m in O.profile_masks(model, ctx, F_, P_)]
+    gen = torch.Generator().manual_seed(seed)
+    lo, hi = (vid0, S) if model == "cog" else (0, S)
+    rows = torch.randint(lo, hi, (R,), generator=gen).tolist()
+    order = sorted(range(R), key=lambda i: (prof_coord(rows[i], vid0, F_, P_, variants[1]), i))     # rank by counting, ties by lane
+    ranked = [rows[i] for i in order]
+    n_skip = n_fast = 0
+    for w0 in range(0, R, 16):
+        wave_rows = ranked[w0:w0 + 16]
+        for var, m in zip(variants, masks):
+            xlo, xhi, any_text, lanes = prof_wave_state(wave_rows, vid0, F_, P_, var)
+            for k0 in range(0, S, 64):
+                cls, ybase, ys = prof_classify(k0, S, vid0, F_, P_, var, xlo, xhi, any_text)
+                sub = torch.stack([m[q, k0:min(k0 + 64, S)] for q in wave_rows])
+                if cls == 0:
+                    n_skip += 1
+                    assert not sub.any(), f"{model} coord={var[0]} wave {w0} tile {k0}: SKIP tile has an allowed key"
+                elif cls == 3:
+                    n_fast += 1
+                    assert sub.shape[1] == 64
+                    for (fa0, falen, fblen), want in zip(lanes, sub):
+                        got = torch.tensor([(0 <= ybase + off * ys - fa0 < falen) or (0 <= ybase + off * ys < fblen) for off in range(64)])
+                        assert torch.equal(got, want), f"{model} coord={var[0]} wave {w0} tile {k0}: fast predicate differs from the mask"
+                else:
+                    for q, want in zip(wave_rows, sub):
+                        got = torch.tensor([prof_allowed(q, k, S, vid0, F_, P_, var) for k in range(k0, min(k0 + 64, S))])
+                        assert torch.equal(got, want)
+    assert n_fast > 0
+
+
 # ---- variable-block policy: run list and row cursor (csrc/attention.hip VarblockPolicy::init / kv_phys_at) ----
 def vb_run_list(map_row, k_off):
     """host model of the LDS run list of one block-row: the active non-empty key blocks in ascending order as
