@@ -425,7 +425,48 @@ def profile_masks(model: str, context_length: int, num_frame: int, frame_size: i
     raise ValueError(model)
 
 
-def sample_mse(q, k, v, sampled_rows, masks):
+def profile_mask_rows(model: str, context_length: int, num_frame: int, frame_size: int, rows) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rows `rows` of the two masks of `profile_masks`, each [len(rows), S] float, without the [S, S] tensors (at HunyuanVideo 720p one
+    of them is 56 GB).  Same references: every entry is the blocked band `|i // 128 - j // 128| < thres` evaluated at the coordinates the
+    permutation `reshape(P, F, P, F).permute(1, 0, 3, 2)` assigns to (row, column) — temporal[f P + p, f' P + p'] = band[p F + f, p' F + f']
+    — plus the models' all-ones text rows / columns and sink columns.  tests/test_oracle_golden.py holds it to `profile_masks` entry for
+    entry at small sizes (and through it to the reference's own get_attention_mask outputs in tests/golden)."""
+    F_, P_ = num_frame, frame_size
+    V = F_ * P_
+    S = V + context_length
+    r = torch.as_tensor(rows, dtype=torch.long)[:, None]
+    c = torch.arange(S)[None, :]
+
+    def tm(x):      # token-major coordinate of a frame-major video index
+        return (x % P_) * F_ + x // P_
+
+    def blk_band(i, j, thres):
+        return ((i // 128) - (j // 128)).abs() < thres
+
+    if model == "hy":
+        th = (P_ * 1.5) // 128
+        vid = (r < V) & (c < V)
+        sp = torch.where(vid, blk_band(r, c, th), torch.ones(1, dtype=torch.bool))
+        tp = torch.where(vid, blk_band(tm(r), tm(c), th), torch.ones(1, dtype=torch.bool))
+        return sp.float(), tp.float()
+    if model == "wan":
+        assert context_length == 0
+        th = (P_ * 2) // 128
+        sp = blk_band(r, c, th) | (c < P_)
+        tp = blk_band(tm(r), tm(c), th) | (tm(c) < P_)
+        return sp.float(), tp.float()
+    if model == "cog":
+        ctx = context_length
+        th = (P_ * 1.5) // 128
+        nb128 = min(S, math.ceil(V / 128) * 128)
+        sp = (r < ctx) | (c < ctx) | ((r < nb128) & (c < nb128) & blk_band(r, c, th))
+        rv, cv = (r - ctx).clamp(min=0), (c - ctx).clamp(min=0)
+        tp = (r >= ctx) & (c >= ctx) & blk_band(tm(rv), tm(cv), th)
+        return sp.float(), tp.float()
+    raise ValueError(model)
+
+
+def sample_mse(q, k, v, sampled_rows, masks, rows_gathered: bool = False):
     """ref: sample_mse svg/models/hyvideo/attention.py:376-399, computed in the input dtype exactly like the reference
     (bf16 matmul outputs, bf16 softmax outputs).  masks: two [rows_available, S] float masks.  -> [2, cfg, H]"""
     cfg, H, S, D = q.shape
@@ -434,16 +475,16 @@ def sample_mse(q, k, v, sampled_rows, masks):
     golden = torch.matmul(F.softmax(scores, dim=-1), v)
     out = torch.zeros(len(masks), cfg, H, dtype=q.dtype)
     for i, m in enumerate(masks):
-        sm = m[sampled_rows, :]
+        sm = m if rows_gathered else m[sampled_rows, :]      # rows_gathered: masks are already [len(sampled_rows), S] (profile_mask_rows)
         w = F.softmax(scores.masked_fill(sm == 0, float("-inf")), dim=-1)
         hs = torch.matmul(w, v)
         out[i] = torch.mean((hs - golden) ** 2, dim=(2, 3))
     return out
 
 
-def sample_mse_fp32(q, k, v, sampled_rows, masks):
+def sample_mse_fp32(q, k, v, sampled_rows, masks, rows_gathered: bool = False):
     """Same quantity in fp32 throughout (what the HIP profiler computes with emulate_bf16 = 0)."""
-    return sample_mse(q.float(), k.float(), v.float(), sampled_rows, masks)
+    return sample_mse(q.float(), k.float(), v.float(), sampled_rows, masks, rows_gathered)
 
 
 # =====================================================================================================================

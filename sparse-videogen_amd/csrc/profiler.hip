@@ -8,9 +8,9 @@
 // call: grid = (BH, kv_chunks), every workgroup emits un-normalised fp32 partials (O, m, l) per sampled row, output and chunk (split-KV),
 // profile_combine_kernel merges the chunks, normalises and reduces the squared errors, profile_finalize_kernel writes mse[2][BH].
 // Two forms of the attention kernel:
-//   profile16_kernel     (shipped, round 5)  ONE score tile for the golden rows and both masks, 4 waves x 16 rows on 16x16x32 MFMAs, two
+//   profile16_kernel     (bf16, round 5)  ONE score tile for the golden rows and both masks, 4 waves x 16 rows on 16x16x32 MFMAs, two
 //                        workgroups per CU — see the note above the kernel;
-//   profile_attn_kernel  (-DSVG_PROF_FIRST_FORM, A/B builds)  the three outputs as three wave roles of one workgroup on attn_core.h's
+//   profile_attn_kernel  (fp16; -DSVG_PROF_FIRST_FORM: both types)  the three outputs as three wave roles of one workgroup on attn_core.h's
 //                        lock-step body: waves 0-1 the golden rows, 2-3 the rows under mask 1, 4-5 under mask 0 on the SAME staged K / V
 //                        tiles, each role its own scores.  (Before that: three workgroups, grid.z = 3, K / V staged three times, 1.26 ms per
 //                        call at HunyuanVideo 720p; the role form 0.78 -> 0.60 ms; the shipped one 0.32.)
@@ -800,8 +800,16 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
     }
     p.part = (float*)ws;
     p.skip = skip;
-#ifndef SVG_PROF_FIRST_FORM
-    {   // second form: one score tile for the three outputs, two workgroups per CU
+    // bf16: the second form.  fp16: the first form — the second one exponentiates the masked rows against the golden rows' maximum, and an fp16
+    // probability only reaches 39 binades (27 in logit) below it: a sampled row whose best in-mask key sits further down would lose its row sum
+    // (NaN for the whole head, where the reference is finite).  bf16 probabilities reach 186 binades (129 in logit); the first form keeps a
+    // running maximum per output.  -DSVG_PROF_FIRST_FORM: the first form for both (A/B builds).
+#ifdef SVG_PROF_FIRST_FORM
+    constexpr bool kSecondForm = false;
+#else
+    constexpr bool kSecondForm = std::is_same_v<T, __bf16>;
+#endif
+    if constexpr (kSecondForm) {   // one score tile for the three outputs, two workgroups per CU
         constexpr int lds16 = p16_lds_bytes(D);
         auto kern16 = profile16_kernel<T, D>;
         hipError_t e16 = hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
@@ -810,19 +818,16 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
             return SVG_ERR_LAUNCH;
         }
         hipLaunchKernelGGL(kern16, dim3(BH, p.n_chunks), dim3(256), lds16, st, p);
+    } else {   // three roles x two waves of the lock-step body, each role its own scores and running maximum
+        const int lds = attn_lds_bytes<D, kProfNW>();
+        auto kern = profile_attn_kernel<T, D>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            g_last_hip_error = (int)e;
+            return SVG_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
     }
-#else
-    {   // first form (A/B builds): three roles x two waves of the lock-step body
-    const int lds = attn_lds_bytes<D, kProfNW>();
-    auto kern = profile_attn_kernel<T, D>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-        g_last_hip_error = (int)e;
-        return SVG_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(kern, dim3(BH, p.n_chunks), dim3(kProfNW * 64), lds, st, p);
-    }
-#endif
     float* sq_part = (float*)ws + (size_t)3 * BH * p.n_chunks * kProfMaxRows * (D + 4);
     hipLaunchKernelGGL((profile_combine_kernel<T, D>), dim3(kProfRowGroups, BH), dim3(256), 0, st, (const float*)ws, sq_part, BH,
                        R, p.n_chunks, p.emulate, skip);

@@ -151,3 +151,80 @@ def test_fullsize_spot_rows_wan_cog(model):
         got = om[0, h].float().cpu()[rows]     # om is in logical order for both heads
         torch.testing.assert_close(got, ref, atol=1e-2, rtol=1e-2)
         assert ((got - ref).norm() / ref.norm()).item() < 3e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# online profiler (sample_mse) at the production geometries against the oracle: the kernel was rewritten in
+# round 5 and was held to the oracle only at S <= 8532.  A full profiling mask is [S, S] (56 GB at HunyuanVideo 720p): the oracle
+# evaluates the sampled ROWS of the two masks (O.profile_mask_rows == rows of O.profile_masks, tests/test_oracle_golden.py).
+# ref: svg/models/hyvideo/attention.py:376-399, svg/models/hyvideo/utils.py:47-93 (wan/utils.py:63-110, cog/utils.py:61-88)
+# ---------------------------------------------------------------------------------------------------------
+PROFILE_GEOM = {
+    # name: (oracle model, BH, D, F, P, ctx, sampled rows, sample_max_row)   — the install hooks' numbers
+    "hy720p": ("hy", 24, 128, 33, 3600, 256, 64, 10000),
+    "wan720p": ("wan", 40, 128, 21, 3600, 0, 64, 10000),
+    "cog15_768p": ("cog", 96, 64, 11, 4080, 226, 32, 45106),        # cfg 2 x 48 heads
+}
+
+
+def _profile_desc(nat, model, ctx, F2, P2, emulate):
+    V2 = F2 * P2
+    pv = nat.ProfileVariant
+    if model == "hy":
+        bb = int((P2 * 1.5) // 128)
+        var, vid0 = (pv(0, 0, V2, bb, 0, V2, V2 + ctx), pv(1, 0, V2, bb, 0, V2, V2 + ctx)), 0
+    elif model == "wan":
+        bb = int((P2 * 2) // 128)
+        var, vid0 = (pv(0, 0, V2, bb, P2, 0, 0), pv(1, 0, V2, bb, P2, 0, 0)), 0
+    else:
+        bb = int((P2 * 1.5) // 128)
+        span = min(V2 + ctx, math.ceil(V2 / 128) * 128)
+        var, vid0 = (pv(0, 0, span, bb, 0, 0, ctx), pv(1, ctx, V2, bb, 0, 0, 0)), ctx
+    d = nat.ProfileDesc(vid0, F2, P2, int(emulate))
+    d.variant[0], d.variant[1] = var
+    return d
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("name", sorted(PROFILE_GEOM))
+def test_fullsize_sample_mse_vs_oracle(name, dtype):
+    """every head of the model at full sequence length; structured data (even heads: q / k share a per-POSITION component — most of a
+    row's softmax mass sits on its position in the other frames, the temporal mask's keys; odd heads: a per-FRAME component — the mass
+    sits in the row's own frame, the spatial mask's) so that both decisions occur; mse within 3e-2 of the fp32 oracle and the same
+    argmin on every head"""
+    from svg import _native as nat
+
+    nat.load()
+    model, BH, D_, F2, P2, ctx, R, max_row = PROFILE_GEOM[name]
+    V2 = F2 * P2
+    S2 = V2 + ctx
+    vid0 = ctx if model == "cog" else 0
+    g = torch.Generator(device="cuda").manual_seed(23)
+    q, k, v = (torch.randn(BH, S2, D_, device="cuda", generator=g) for _ in range(3))
+    pos = torch.randn(BH, 1, P2, D_, device="cuda", generator=g)
+    frm = torch.randn(BH, F2, 1, D_, device="cuda", generator=g)
+    kind = torch.arange(BH, device="cuda") % 2
+    add = (pos * (kind == 0)[:, None, None, None] + frm * (kind == 1)[:, None, None, None]).reshape(BH, V2, D_)   # +sqrt(D) in logit
+    q[:, vid0:vid0 + V2] += add
+    k[:, vid0:vid0 + V2] += add
+    del add
+    q, k, v = (x.to(dtype) for x in (q, k, v))
+    rows = torch.randint(vid0, min(max_row, vid0 + V2), (R,), generator=torch.Generator().manual_seed(5))
+    got = nat.sample_mse(q, k, v, rows.cuda(), _profile_desc(nat, model, ctx, F2, P2, False)).cpu()
+    got_em = nat.sample_mse(q, k, v, rows.cuda(), _profile_desc(nat, model, ctx, F2, P2, True)).cpu()
+    masks = list(O.profile_mask_rows(model, ctx, F2, P2, rows))
+    ref = torch.empty(2, BH)
+    for h0 in range(0, BH, 8):      # 8 heads at a time: the fp32 scores of all 96 CogVideoX heads would be 1.1 GB, fine, but q/k/v in fp32 too
+        sl = slice(h0, min(BH, h0 + 8))
+        ref[:, sl] = O.sample_mse_fp32(q[None, sl].cpu(), k[None, sl].cpu(), v[None, sl].cpu(), rows, masks, True)[:, 0]
+    assert torch.isfinite(ref).all() and torch.isfinite(got).all() and torch.isfinite(got_em).all()
+    torch.testing.assert_close(got, ref, rtol=3e-2, atol=1e-7)
+    assert torch.all((ref[0] - ref[1]).abs() > 0.1 * ref.max(0).values), "the case is built so that no head is a near-tie"
+    assert torch.equal(got.argmin(0), ref.argmin(0))
+    assert torch.equal(got_em.argmin(0), ref.argmin(0))     # the torch-rounding emulation (the reference computes in the 16-bit type) decides alike
+    best = ref.argmin(0)
+    assert torch.equal(best, (torch.arange(BH) % 2 == 0).long()), "even heads temporal, odd heads spatial, as constructed"
+    # (a head's MSE under its RIGHT mask can be ~1e-7 — the mask holds nearly all of the softmax mass —: errors are shown against the
+    #  tolerance the assertion above applies, rtol * |ref| + atol, 1.0 = at the bound)
+    print(f"[sample_mse {name} {dtype}] temporal heads {int(best.sum())} / {BH}; worst |got - ref| / (3e-2 |ref| + 1e-7) = "
+          f"{((got - ref).abs() / (3e-2 * ref.abs() + 1e-7)).max().item():.3f}; mse range {ref.min().item():.2e} .. {ref.max().item():.2e}")

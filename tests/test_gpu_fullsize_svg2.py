@@ -172,3 +172,56 @@ def test_svg2_production_labels_partition(case):
         assert torch.equal(c["qidx"][h, :V].cpu().long(), O.stable_argsort(lab))
         n = CASES[c["name"]][6]
         assert torch.equal(c["q_sizes"][h, :n].cpu().long(), torch.bincount(lab, minlength=n))
+
+
+def _bf16_ulp(x):
+    return torch.exp2(torch.floor(torch.log2(x.abs().clamp(min=2.0 ** -126))) - 7)
+
+
+def test_kmeans_production_size_vs_oracle():
+    """Two Lloyd iterations of the Wan 2.1 720p k-side k-means (N = 75600, K = 1000, D = 128; two heads) from the deterministic init
+    (first K rows) against O.kmeans_iter, step by step on the HIP path's own previous state (run(m - 1)'s centroids
+    are exactly what iteration m assigns with): labels equal to the oracle's argmin or a rounding-level near-tie (the two distances
+    within 1e-2 relative: the bf16 norm rounding of SURVEY hazard 4), counts == bincount, sorted indices == stable argsort, centroids
+    within ONE bf16 ulp of the fp32-sum update of those labels (the order of the fp32 sums is the only freedom), empty clusters keep
+    their centroid.  The walking update kernel (round 5) had no oracle at this size.
+    ref: svg/kmeans_utils.py:629-643 (_euclid_iter), :375-421 (sorted centroid update), :684-733 (loop)."""
+    from svg import _native as nat
+    from svg.kmeans_utils import batch_kmeans_Euclid
+
+    nat.load()
+    B, N, K, D = 2, 75600, 1000, 128
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    xd = clustered(B, N, D, 64, gen)
+    c0d = xd[:, :K].clone()
+    c0d[:, [7, K - 1]] *= 3          # two centroids outside the data: empty clusters
+    x, prev = xd.cpu(), c0d.cpu()
+    xsq = O.kmeans_xsq(x)
+    total_mism = 0
+    for m in (1, 2):
+        lab, cent, cnt, nit, sidx = batch_kmeans_Euclid(xd, K, max_iters=m, init_centroids=c0d, return_sorted_indices=True, check_every=0)
+        assert int(nit) == m
+        lab, cent, cnt, sidx = lab.cpu(), cent.cpu(), cnt.cpu(), sidx.cpu()
+        for b in range(B):      # one head at a time: [N, K] fp32 distances are 302 MB
+            dist = O.kmeans_distances(x[b:b + 1], xsq[b:b + 1], prev[b:b + 1])[0]
+            ref_lab = dist.argmin(-1)
+            mism = lab[b] != ref_lab
+            d_got = dist.gather(1, lab[b][:, None])[:, 0]
+            d_ref = dist.min(-1).values
+            assert mism.float().mean() < 5e-3, mism.float().mean()
+            assert torch.all((d_got - d_ref)[mism] <= 1e-2 * d_ref[mism].clamp(min=1.0))
+            total_mism += int(mism.sum())
+        c_ref, cnt_ref = O.kmeans_update(x, lab, prev)
+        assert torch.equal(cnt, cnt_ref)
+        assert torch.equal(sidx.long(), O.stable_argsort(lab))
+        empty = cnt_ref == 0
+        assert int(empty.sum()) >= 2 * B and torch.equal(cent[empty], prev[empty])
+        # the oracle's update rounds the fp32 mean once; a different fp32 summation order may cross one rounding boundary
+        sums = torch.zeros(B, K, D).scatter_add_(1, lab[..., None].expand(-1, -1, D), x.float())
+        mean = torch.where(empty[..., None], prev.float(), sums / cnt_ref.float().clamp(min=1)[..., None])
+        err = (cent.float() - mean).abs()
+        assert torch.all(err <= _bf16_ulp(mean) * 0.5 * 1.02 + 1e-6), (err / _bf16_ulp(mean)).max()   # correctly rounded up to the sums' order
+        assert torch.all((cent.float() - c_ref.float()).abs() <= _bf16_ulp(c_ref.float())), "more than one bf16 ulp from the oracle's centroids"
+        assert (cent != c_ref).float().mean() < 2e-2
+        prev = cent
+    print(f"[kmeans Wan 720p k-side, 2 heads x 2 iterations] near-tie labels that differ from the oracle's argmin: {total_mism} of {2 * B * N}")

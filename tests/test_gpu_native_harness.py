@@ -35,7 +35,7 @@ CASES = [
     ["--geom", "small64", "--switch", "1", "--flags", "one"],   # ... dense side: the placement flags must be ignored
     ["--geom", "cog480p", "--heads", "4"],                      # production sequence length of CogVideoX-v1 480p, four heads
     ["--geom", "small", "--fill", "zero"],                      # all-zero operands (the schedule-only ceiling runs of profiles/r05a_*): output exactly 0
-    ["--geom", "small", "--band", "256"],                       # band override (tools/gpu_r05a.sh band sweep)
+    ["--geom", "small", "--band", "256"],                       # band override (tools/history/r05/gpu_r05a.sh band sweep)
 ]
 
 

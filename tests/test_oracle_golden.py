@@ -77,6 +77,24 @@ def test_profile_masks_bit_exact(golden):
     assert torch.equal(tp != 0, unbits(golden["prof_cog_temporal"], S))
 
 
+@pytest.mark.parametrize("model,ctx,F_,P_", [("hy", 32, 5, 300), ("hy", 7, 3, 130), ("wan", 0, 5, 300), ("wan", 0, 4, 257),
+                                             ("cog", 32, 5, 300), ("cog", 17, 3, 200), ("cog", 226, 2, 135)])
+def test_profile_mask_rows_equals_profile_masks(model, ctx, F_, P_):
+    """the rows-only statement of the profiling masks (what the production-size GPU tests use: a full mask is 56 GB at HunyuanVideo 720p)
+    equals the rows of the full masks, which the golden vectors above pin to the reference's get_attention_mask"""
+    S = F_ * P_ + ctx
+    rows = torch.cat([torch.randint(0, S, (97,), generator=torch.Generator().manual_seed(S)),
+                      torch.tensor([0, S - 1, ctx, max(ctx - 1, 0), F_ * P_ - 1, min(F_ * P_, S - 1)])])
+    full = O.profile_masks(model, ctx, F_, P_)
+    part = O.profile_mask_rows(model, ctx, F_, P_, rows)
+    for a, b in zip(full, part):
+        assert torch.equal(a[rows], b)
+    q, k, v = (torch.randn(1, 2, S, 32, generator=torch.Generator().manual_seed(i)) for i in range(3))
+    lo = ctx if model == "cog" else 0
+    vr = rows[(rows >= lo) & (rows < lo + F_ * P_)]
+    assert torch.equal(O.sample_mse(q, k, v, vr, list(full)), O.sample_mse(q, k, v, vr, list(O.profile_mask_rows(model, ctx, F_, P_, vr)), True))
+
+
 def test_sample_mse_matches_reference_processor(golden):
     F_, P_, ctx, L, S, Sw = (int(x) for x in golden["mask_geom"])
     torch.manual_seed(0)

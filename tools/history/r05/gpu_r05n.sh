@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5 validation pass on a GPU box (python): the GPU suite, the default bench line, the reference's complete varblock grid, then the torch-free
-# harness pass (timing, kernel trace, PMC) on the same box.     gpurun --timeout 2700 -- 'bash tools/gpu_r05n.sh <tag>'
+# harness pass (timing, kernel trace, PMC) on the same box.     gpurun --timeout 2700 -- 'bash tools/history/r05/gpu_r05n.sh <tag>'
 tag=${1:-r05n}; O=gpurun_out/$tag; mkdir -p $O
 export TMPDIR=/tmp
 t0=$(date +%s)

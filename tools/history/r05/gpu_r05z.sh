@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5 final pass on a GPU box: the GPU suite, the default bench line, the same command under rocprofv3 --kernel-trace --stats, the torch-free harness
-# pass with the PMC sets, the SVG2 PMC passes.     gpurun --timeout 2700 -- 'bash tools/gpu_r05z.sh <tag>'
+# pass with the PMC sets, the SVG2 PMC passes.     gpurun --timeout 2700 -- 'bash tools/history/r05/gpu_r05z.sh <tag>'
 tag=${1:-r05z}; O=gpurun_out/$tag; mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
@@ -25,4 +25,4 @@ PY
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/kt -o $tag -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-dense --no-svg2 --no-step --no-ab --no-hbm > $R/$O/bench_under_rocprof.json 2>/dev/null)
 python3 tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -1) $O/bench_kernel_trace.txt; head -6 $O/bench_kernel_trace.txt | cut -c1-170
 bash tools/gpu_native_pass.sh ${tag} 2>&1 | head -8
-bash tools/gpu_r05i.sh ${tag}_svg2 2>&1 | grep "varblock_attn" | cut -c1-400
+bash tools/history/r05/gpu_r05i.sh ${tag}_svg2 2>&1 | grep "varblock_attn" | cut -c1-400

@@ -2,7 +2,7 @@
 # Round 5, GPU call zs: Wan block glue with scale / shift from LDS: the glue tests, the parts' timing, bench_hbm rows
 tag=${1:-r05zs}; O=gpurun_out/$tag; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_glue.py tests/test_gpu_triton_golden.py -m gpu -q -p no:cacheprovider 2>&1 | tail -4 | tee $O/pytest_glue.txt
-bash tools/gpu_r05zr.sh $tag 2>&1 | tail -4
+bash tools/history/r05/gpu_r05zr.sh $tag 2>&1 | tail -4
 timeout 300 python bench_hbm.py --reps 20 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
