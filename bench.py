@@ -41,6 +41,9 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+# what every fp8 block of the line says about itself (README: configs[4] was measured and closed in round 5)
+FP8_STATUS = ("closed: not usable (8.8 % rel. L2 against the 16-bit kernel on SVG2; no e4m3 / int8 form inside 3 % with a projected gain, "
+              "profiles/r05l_fp8_int8_precision_study.txt) - a measurement, not an option")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "sparse-videogen_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -661,6 +664,7 @@ def main():
             pre = sum(evs[2 * i].elapsed_time(evs[2 * i + 1]) for i in range(3)) / 3
             tot = evs[0].elapsed_time(evs[6]) / 3
             out["fp8_hy720p"] = {
+                "status": FP8_STATUS,
                 "what": "the headline layer-call's attention with e4m3 q, k, v, probabilities (svg_band_attention_fp8); bf16 in / out",
                 "prepass_ms": round(pre, 3), "kernel_ms": round(tot - pre, 3), "attention_ms": round(tot, 3),
                 "kernel_tflops": round(flops_call / ((tot - pre) * 1e-3) / 1e12, 1),
@@ -769,9 +773,20 @@ def main():
                 if os.environ.get("SVG_BENCH_TEST_BREAK_EXTRAS"):    # test hook (tests/test_gpu_bench_contract.py): the failure path below
                     raise RuntimeError("SVG_BENCH_TEST_BREAK_EXTRAS")
                 out[key] = bench_svg2.measure(svg2_wl, steps=svg2_steps, warmup=1, fp8=f8)
+                if f8 and key.endswith("_fp8"):
+                    out[key]["status"] = FP8_STATUS
             except Exception as e:  # noqa: BLE001
                 out[key] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 failed_extras.append(key)
+        if extras_full and not fp8:
+            # the SAP layer-call of HunyuanVideo 720p (QC 400, KC 1000 + the prompt / unused-prompt pseudo clusters of dynamic_map_post_processing,
+            # ref svg/models/hyvideo/attention.py:657-702, scripts/hyvideo/hyvideo_t2v_720p_sap.sh:12-17)
+            try:
+                out["svg2_hy720p"] = bench_svg2.measure("hy720p", steps=2, warmup=1)
+            except Exception as e:  # noqa: BLE001
+                out["svg2_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+                failed_extras.append("svg2_hy720p")
+            torch.cuda.empty_cache()
     if world == 1 and not a.no_step and (extras_full or extras_small):
         # BASELINE.json configs[3] at N = 1: a measured denoise step of the synthetic 60-block HunyuanVideo stack (GEMMs + glue +
         # attention), sparse and dense; `denoise_steps_per_s` here is measured, unlike attention_only_steps_per_s above
@@ -786,6 +801,21 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             failed_extras.append("denoise_step_hy720p")
+        torch.cuda.empty_cache()
+        # BASELINE.json configs[2], the metric's second half: a measured denoise step of the synthetic 40-block Wan 2.1 14B stack with SVG2 / SAP
+        # attention (block glue, RMSNorm-across-heads + complex-RoPE prologue, warm-started two-stream k-means, block map, variable-block
+        # attention together), sparse and dense (bench_step.measure_wan)
+        try:
+            import bench_step
+
+            if extras_full:
+                out["denoise_step_wan720p_svg2"] = bench_step.measure_wan(steps=2, warmup=1)
+            else:
+                out["denoise_step_wan720p_svg2"] = bench_step.measure_wan(
+                    steps=1, warmup=0, geo=bench_step.WanGeo(F=5, P=600, hid=512, heads=4, hd=128, ffn=1024, text=64, layers=2, qc=20, kc=40))
+        except Exception as e:  # noqa: BLE001
+            out["denoise_step_wan720p_svg2"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            failed_extras.append("denoise_step_wan720p_svg2")
         torch.cuda.empty_cache()
     if world == 1 and not a.no_hbm and (extras_full or extras_small):
         # the HBM-bound rows of SURVEY §8(d) (placement, inverse placement, SVG2 gather / scatter, label sort, prologue, block glue) at
@@ -816,6 +846,20 @@ def main():
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 out["denoise_step_hy720p"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            raise
+        # BASELINE.json configs[2] at N > 1: the Wan 2.1 SVG2 step, tokens/N + heads/N (40 heads: N in 2, 4, 8), k-means stopping rule all-reduced
+        torch.cuda.empty_cache()
+        try:
+            if a.workload == "hy720p":
+                sw = bench_step.measure_wan(steps=2, warmup=1, rank=rank, world=world, kinds=("sparse",), host_staged=smoke)
+            else:
+                sw = bench_step.measure_wan(steps=1, warmup=0, rank=rank, world=world, kinds=("sparse",), host_staged=smoke,
+                                            geo=bench_step.WanGeo(F=5, P=600, hid=512, heads=4, hd=128, ffn=1024, text=64, layers=2, qc=20, kc=40))
+            if rank == 0:
+                out["denoise_step_wan720p_svg2"] = sw
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                out["denoise_step_wan720p_svg2"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             raise
     if world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(H, D, S)

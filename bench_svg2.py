@@ -150,6 +150,8 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
                                        q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8)
             probe.arm_stop()
             attention_sclk_mhz = probe.result()
+            if attention_sclk_mhz is not None and not 400.0 <= attention_sclk_mhz <= 2450.0:
+                attention_sclk_mhz = None     # the probe wave did not run beside the launches (this kernel fills every wave slot): no reading
         except Exception:  # noqa: BLE001  (a measurement aid: its failure must not cost the block)
             attention_sclk_mhz = None
         torch.cuda.synchronize()

@@ -103,7 +103,11 @@ struct BandPolicy {
             const int b2 = b - nh;
             const int full = ((p.nqt * p.BH - nh) / (kNumXCD * 32)) * (kNumXCD * 32);
             int w2 = b2;
+#ifdef SVG_BAND_NO_XCD_SWIZZLE      // A/B builds: dispatch id = work id (the hardware's round-robin then hands NEIGHBOURING q-tiles to DIFFERENT XCDs)
+            if (false) {
+#else
             if (b2 < full) {
+#endif
                 const int xcd = b2 % kNumXCD, s = b2 / kNumXCD;
                 w2 = (s / 32) * (kNumXCD * 32) + xcd * 32 + (s % 32);
             }

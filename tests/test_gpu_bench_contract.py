@@ -16,20 +16,24 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "data", "config", "roofline", "cpu_baseline"}
 
 
-_CHECKSUMS = {}   # bench.py --workload tiny: output_checksum by run ("n1", "n2", "n2_fallback") — the same inputs at every world size
-
-
 def _last_json(out: str):
     lines = [l for l in out.strip().splitlines() if l.startswith("{")]
     assert lines, out[-2000:]
     return json.loads(lines[-1])
 
 
-def test_bench_single_gpu_json_line():
+@pytest.fixture(scope="module")
+def one_rank_line():
+    """the one-rank `bench.py --workload tiny` line, run once per module: the reference `output_checksum` of the N-rank runs (the inputs are
+    seeded per global head, so every world size must leave the same bytes) — a fixture, so that any test of this module runs alone or in any order"""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = _last_json(r.stdout)
+    return _last_json(r.stdout)
+
+
+def test_bench_single_gpu_json_line(one_rank_line):
+    d = one_rank_line
     assert KEYS <= set(d), sorted(KEYS - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["dtype"] == "bf16"
     assert d["value"] > 0 and d["ms_per_step"] > 0
@@ -37,10 +41,9 @@ def test_bench_single_gpu_json_line():
     assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
     assert len(d["output_checksum"]) == 16
-    _CHECKSUMS["n1"] = d["output_checksum"]
 
 
-def test_bench_two_rank_control_flow_smoke():
+def test_bench_two_rank_control_flow_smoke(one_rank_line):
     env = dict(os.environ, SVG_BENCH_SMOKE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "tiny"]
@@ -52,14 +55,15 @@ def test_bench_two_rank_control_flow_smoke():
     ex = d["exchange"]
     assert ex["rccl_ranks_seen"] == 2 and ex["fallback_to_chunk_launches"] is False and ex["waiter_timeouts_in_timed_steps"] == 0
     assert ex["inbound_bytes_received_per_rank"] > 0 and ex["outbound_bytes_received_per_rank"] > 0
-    _CHECKSUMS["n2"] = d["output_checksum"]
-    if "n1" in _CHECKSUMS:   # the gathered output of the two-rank run == the one-rank run's, bit for bit (inputs are seeded per global head)
-        assert d["output_checksum"] == _CHECKSUMS["n1"], (d["output_checksum"], _CHECKSUMS["n1"])
+    # the gathered output of the two-rank run == the one-rank run's, bit for bit (inputs are seeded per global head)
+    assert d["output_checksum"] == one_rank_line["output_checksum"], (d["output_checksum"], one_rank_line["output_checksum"])
     sd = d["denoise_step_hy720p"]     # the token-sharded denoise step at N = 2 (reduced stack on the tiny workload)
     assert sd["n_gpus"] == 2 and sd["sparse_step"]["ms"] > 0 and sd["sparse_step"]["rccl_bytes_received_per_step_this_rank"] > 0
+    sw = d["denoise_step_wan720p_svg2"]   # the Wan SVG2 step, token- / head-sharded at N = 2
+    assert sw["n_gpus"] == 2 and sw["sparse_step"]["ms"] > 0 and sw["sparse_step"]["rccl_bytes_received_per_step_this_rank"] > 0
 
 
-def test_bench_two_rank_watchdog_falls_back():
+def test_bench_two_rank_watchdog_falls_back(one_rank_line):
     """Waiters that never see their count (test hook) give up at their deadline during warm-up; the bench then switches to one
     launch per chunk of heads on every rank, says so, and still produces a checked result (the smoke run's poisoned-output test)."""
     env = dict(os.environ, SVG_BENCH_SMOKE="1", SVG_BENCH_TEST_STUCK_WAITER="1", SVG_BENCH_WAITER_TIMEOUT_MS="20")
@@ -71,11 +75,8 @@ def test_bench_two_rank_watchdog_falls_back():
     ex = d["exchange"]
     assert ex["fallback_to_chunk_launches"] is True and ex["waiter_timeouts_in_timed_steps"] == 0
     assert "per chunk" in ex["outbound"]
-    # the fallback path (one launch + all-gather per chunk of heads) leaves the same bytes as the overlapped path and as the one-rank run
-    for other in ("n2", "n1"):
-        if other in _CHECKSUMS:
-            assert d["output_checksum"] == _CHECKSUMS[other], (other, d["output_checksum"], _CHECKSUMS[other])
-    assert _CHECKSUMS, "run the whole module: the one-rank / overlapped two-rank tests provide the reference checksum"
+    # the fallback path (one launch + all-gather per chunk of heads) leaves the same bytes as the one-rank run (and so as the overlapped path)
+    assert d["output_checksum"] == one_rank_line["output_checksum"], (d["output_checksum"], one_rank_line["output_checksum"])
 
 
 def test_bench_fp8_line():
@@ -109,6 +110,40 @@ def test_bench_step_two_rank_smoke():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", str(ROOT / "bench_step.py"), "--gpus", "2", "--tiny", "--layers-double", "1", "--layers-single", "1",
            "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and "tokens/2" in d["parallelism"] and "gloo" in d["exchange_backend"]
+    for kind in ("sparse_step", "dense_step"):
+        assert d[kind]["ms"] > 0 and d[kind]["rccl_bytes_received_per_step_this_rank"] > 0
+    assert d["denoise_steps_per_s"] > 0
+
+
+def test_bench_step_wan_small_stack():
+    """bench_step.measure_wan (what bench.py embeds as `denoise_step_wan720p_svg2`, BASELINE.json configs[2]) on a 3-block stack of a small
+    geometry: layer 0 dense, layers 1-2 SVG2 with the k-means init in the first sparse step and the warm start after it; both kinds of step,
+    the stage breakdown sums to the step."""
+    sys.path.insert(0, str(ROOT))
+    import bench_step
+
+    geo = bench_step.WanGeo(F=5, P=600, hid=512, heads=4, hd=128, ffn=1024, text=64, layers=3, qc=20, kc=40)
+    d = bench_step.measure_wan(steps=1, warmup=0, geo=geo)
+    assert not _error_keys(d), _error_keys(d)
+    for kind in ("sparse_step", "dense_step"):
+        b = d[kind]["step_breakdown_ms"]
+        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflop_this_rank"] > 0
+        assert {"gemm", "glue", "prologue", "self_attention", "cross_attention"} <= set(b)
+        assert abs(sum(b.values()) - d[kind]["ms"]) < 0.05 * d[kind]["ms"] + 0.1
+    assert d["denoise_steps_per_s"] > 0 and d["first_sparse_step_ms_with_kmeans_init"] > 0 and d["n_gpus"] == 1
+
+
+def test_bench_step_wan_two_rank_smoke():
+    """bench_step.py --model wan720p --gpus 2: the Wan SVG2 step token-sharded / head-sharded over two ranks on cuda:0 (gloo through host memory):
+    control flow — exchanges, the all-reduced k-means stopping rule, the final all-gather.  Equality with the one-process step:
+    tests/test_step_sharding_cpu.py::test_wan_svg2_token_sharded_step_equals_single_process."""
+    env = dict(os.environ, SVG_BENCH_SMOKE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", str(ROOT / "bench_step.py"), "--gpus", "2", "--tiny", "--model", "wan720p", "--steps", "1", "--warmup", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
@@ -178,8 +213,11 @@ def test_bench_line_with_extras_has_no_error_key():
     assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-1500:])
     d = _last_json(r.stdout)
     assert not _error_keys(d), _error_keys(d)
-    for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p", "hbm_kernels"):
+    for key in ("svg2_wan720p", "svg2_wan720p_fp8", "denoise_step_hy720p", "denoise_step_wan720p_svg2", "hbm_kernels"):
         assert key in d, sorted(d)
+    assert d["svg2_wan720p_fp8"]["status"].startswith("closed") and d["denoise_step_hy720p"]["fp8_attention"]["status"].startswith("closed")
+    assert "denoise_steps_per_s_fp8_attention" not in d["denoise_step_hy720p"] and "denoise_steps_per_s_video_average" not in d["denoise_step_hy720p"]
+    assert d["denoise_step_wan720p_svg2"]["denoise_steps_per_s"] > 0 and d["denoise_step_wan720p_svg2"]["sparse_step"]["step_breakdown_ms"]["gemm"] > 0
     _check_hbm_block(d["hbm_kernels"])
     op = d["online_profiler"]     # the layer-call's HBM-bound kernel: K and V of every head once
     assert op["ms"] > 0 and op["bound"] == "hbm" and abs(op["GBs"] - op["algorithmic_bytes"] / op["ms"] / 1e6) <= 0.01 * op["GBs"] + 0.1

@@ -94,3 +94,62 @@ def test_production_token_shards_are_balanced():
         assert max(sizes) * world / geo.S <= 1.01, (world, sizes)
     frames = [b - a for a, b in (D.token_range(geo.S, r, 8, unit=geo.P) for r in range(8))]
     assert max(frames) * 8 / geo.S > 1.2      # what the frame-granular split cost
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the Wan 2.1 SVG2 step (bench_step.run_step_wan, BASELINE.json configs[2]) token-sharded over 2 ranks == one process
+# ---------------------------------------------------------------------------------------------------------
+def _wan_geo():
+    _setup_paths()
+    import bench_step
+
+    return bench_step.WanGeo(F=4, P=40, hid=4 * 32, heads=4, hd=32, ffn=96, text=12, layers=2, qc=4, kc=6, unit=8, iter_step=2)
+
+
+def _wan_single(sparse):
+    _setup_paths()
+    import bench_step
+    from step_ops_torch import WanTorchOps
+
+    geo = _wan_geo()
+    st = bench_step.WanStack(torch.device("cpu"), geo, dtype=torch.float32)
+    x = torch.randn(geo.V, geo.hid, generator=torch.Generator().manual_seed(1)) * 0.5
+    ops = WanTorchOps(geo)
+    outs = [bench_step.run_step_wan(st, x, sparse, 1, ops, None) for _ in range(2)]     # two steps: the second one warm-starts the k-means
+    return outs, x
+
+
+def _wan_worker(rank, world, port, sparse, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    _setup_paths()
+    import bench_step
+    from step_ops_torch import WanTorchOps
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    geo = _wan_geo()
+    refs, x = _wan_single(sparse)
+    st = bench_step.WanStack(torch.device("cpu"), geo, dtype=torch.float32)
+    sh = bench_step.Sharding(geo, rank, world, torch.device("cpu"), torch.float32)
+    ops = WanTorchOps(geo)
+    ok = True
+    for ref in refs:
+        y = bench_step.run_step_wan(st, x[sh.a:sh.b].contiguous(), sparse, 1, ops, sh)
+        full, _ = sh.gather_tokens(y)
+        ok = ok and tuple(y.shape) == (sh.b - sh.a, geo.hid) and torch.allclose(y, ref[sh.a:sh.b], atol=3e-5, rtol=3e-5)
+        ok = ok and torch.allclose(full, ref, atol=3e-5, rtol=3e-5)
+    Hl = geo.heads // world     # 2 layers x (3 inbound + 1 outbound) all-to-alls in the last step
+    ok = ok and sh.nt == 0 and sh.nv == sh.b - sh.a
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,sparse", [(2, True), (2, False), (4, True)])
+def test_wan_svg2_token_sharded_step_equals_single_process(world, sparse):
+    """layer 0 dense, layer 1 SVG2 (k-means per head from the head's own first rows -> block map -> variable-block attention), cross attention over
+    replicated text tokens, two consecutive steps (warm start): every rank's token shard and the gathered hidden states equal the one-process step"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29750 + world * 5 + int(sparse)
+    mp.spawn(_wan_worker, args=(world, port, sparse, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -2,8 +2,9 @@
 # The 1 -> 8 GPU curve of BASELINE.json configs[3] in one command, for the first minutes on an 8-GPU MI355X node (no node was available to any
 # round so far: NOT RUN ON HARDWARE; its pieces are exercised at N = 2 on one GPU over gloo by tests/test_gpu_bench_contract.py).
 #   bash tools/scale_run.sh [out_dir] [Ns, default "1 2 4 8"]
-# For every N: `bench.py --gpus N` (the SVG1 layer-call, head-sharded with the overlapped all-gather) and `bench_step.py --gpus N` (the
-# token-sharded denoise step) under torch.distributed.run over RCCL; then checks
+# For every N: `bench.py --gpus N` (the SVG1 layer-call, head-sharded with the overlapped all-gather), `bench_step.py --gpus N` (the
+# token-sharded HunyuanVideo SVG1 denoise step) and `bench_step.py --model wan720p --gpus N` (the Wan 2.1 SVG2 denoise step, configs[2]) under
+# torch.distributed.run over RCCL; then checks
 #   * exchange.rccl_ranks_seen == N (every rank of the communicator answered an all-reduce),
 #   * output_checksum(N) == output_checksum(1): the gathered layer-call output is the one-rank output bit for bit (inputs are seeded per global head),
 #   * no waiter timed out / no fallback to chunk launches (reported, not fatal),
@@ -18,11 +19,14 @@ for N in $NS; do
   if [ "$N" = 1 ]; then
     python bench.py --gpus 1 --steps 10 --warmup 3 --no-svg2 --no-hbm > "$OUT/bench_$N.json" 2> "$OUT/bench_$N.err"
     python bench_step.py --steps 3 --warmup 1 > "$OUT/step_$N.json" 2> "$OUT/step_$N.err"
+    python bench_step.py --model wan720p --steps 2 --warmup 1 > "$OUT/step_wan_$N.json" 2> "$OUT/step_wan_$N.err"
   else
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus "$N" --steps 10 --warmup 3 \
       > "$OUT/bench_$N.json" 2> "$OUT/bench_$N.err"
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 1)) bench_step.py --gpus "$N" --steps 3 --warmup 1 \
       > "$OUT/step_$N.json" 2> "$OUT/step_$N.err"
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 50)) bench_step.py --model wan720p --gpus "$N" --steps 2 --warmup 1 \
+      > "$OUT/step_wan_$N.json" 2> "$OUT/step_wan_$N.err"
   fi
   echo "N=$N bench rc=$? (logs: $OUT/bench_$N.err, $OUT/step_$N.err)" >&2
 done
@@ -58,6 +62,8 @@ for n in ns:
                 row["error"] = "gathered output differs from the one-rank run"; bad += 1
     sd = (s or {})
     row["denoise_steps_per_s"] = sd.get("denoise_steps_per_s", (b.get("denoise_step_hy720p") or {}).get("denoise_steps_per_s"))
+    sw = last_json(f"{out}/step_wan_{n}.json") or {}
+    row["denoise_steps_per_s_wan720p_svg2"] = sw.get("denoise_steps_per_s", (b.get("denoise_step_wan720p_svg2") or {}).get("denoise_steps_per_s"))
     print(json.dumps(row))
 sys.exit(1 if bad else 0)
 PY
