@@ -216,7 +216,8 @@ static int launch_row_glue(const GlueParams& p, hipStream_t st) {
     const dim3 grid((p.M + 3) / 4), block(256);
     // modulated, a workgroup full of rows per batch, and the LDS copy fits three times into a CU: the LDS form
     const int lds_bytes = 2 * p.N * (int)sizeof(float);
-    if (p.scale && p.rows_per_batch >= kGlueLdsWaves && lds_bytes <= 49152) {
+    // (batches ride grid.y: more than 65535 of them — tiny batches of a huge M — take the plain form below, as before round 5)
+    if (p.scale && p.rows_per_batch >= kGlueLdsWaves && lds_bytes <= 49152 && p.M / p.rows_per_batch <= 65535) {
         const int batches = p.M / p.rows_per_batch;
         const int per_batch = (p.rows_per_batch + kGlueLdsWaves - 1) / kGlueLdsWaves;
         const dim3 g2(per_batch, batches), b2(kGlueLdsWaves * 64);

@@ -5,6 +5,8 @@ import torch.nn as nn
 
 
 class RMSNorm(nn.Module):
+    svg_rmsnorm_compatible = True     # x * rsqrt(mean(x^2) + eps) * weight, like diffusers' RMSNorm (see WanAttn processors' get_qk_norm)
+
     def __init__(self, dim, eps=1e-6):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(dim))

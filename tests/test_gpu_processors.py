@@ -176,6 +176,54 @@ def _clustered(H, N, D, modes, gen):
     return torch.gather(centers, 1, lab[..., None].expand(-1, -1, D)) + 0.4 * torch.randn(H, N, D, generator=gen)
 
 
+def test_kmeans_clustering_two_streams_equals_one_stream():
+    """`_core.kmeans_clustering` runs the q-side Lloyd loop on a side stream beside the k side (KMEANS_TWO_STREAMS, the default).
+    Several layers and steps — the init call of every layer (random points drawn from the same torch seed), then two warm-started calls on
+    drifting data, with allocator churn in between (tensors freed on the main stream while the side stream's outputs are still in use) —
+    give bit-identical labels, centroids, sizes, iteration counts and sorted indices with the switch on and off.
+    Memory: the q-side outputs come from the side stream's allocator pool and are record_stream'ed to the main stream, so their blocks
+    return to the pool only after the main stream's pending work — at Wan 2.1 720p (40 heads) that is 12 MB of labels + 12 MB of sorted
+    indices + 3 MB of centroids per layer-call held a little longer, not a growing footprint (asserted below on the allocator's counters)."""
+    from svg.models import _core
+
+    H, N, D, QC, KC = 4, 6000, 128, 24, 40
+    gen = torch.Generator().manual_seed(5)
+    base_q, base_k = _clustered(H, N, D, 16, gen), _clustered(H, N, D, 16, gen)
+
+    def run(two_streams):
+        old = _core.KMEANS_TWO_STREAMS
+        _core.KMEANS_TWO_STREAMS = two_streams
+        try:
+            store = _core.CentroidStore()
+            outs = []
+            g2 = torch.Generator().manual_seed(9)
+            for step in range(3):
+                drift = 0.05 * step
+                for layer in range(3):
+                    q = (base_q + drift * torch.randn(H, N, D, generator=g2) + 0.01 * layer)[None].to(DT).cuda()
+                    k = (base_k + drift * torch.randn(H, N, D, generator=g2) - 0.01 * layer)[None].to(DT).cuda()
+                    torch.manual_seed(100 + layer)                     # the init call's random points (svg/kmeans_utils.py:706-709)
+                    junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")   # allocator churn on the main stream
+                    (ql, qc, qs, qit, qidx), (kl, kc, ks, kit, kidx) = _core.kmeans_clustering(store, layer, q, k, QC, KC, 5, 2)
+                    del junk
+                    outs.append([t.clone() if isinstance(t, torch.Tensor) else torch.tensor(t) for t in (ql, qc, qs, qit, qidx, kl, kc, ks, kit, kidx)])
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            _core.KMEANS_TWO_STREAMS = old
+
+    a = run(True)
+    mem_after_first = torch.cuda.memory_reserved()
+    b = run(False)
+    a2 = run(True)
+    assert len(a) == len(b) == 9
+    for call, (x, y, z) in enumerate(zip(a, b, a2)):
+        for i, (t1, t2, t3) in enumerate(zip(x, y, z)):
+            assert torch.equal(t1.cpu(), t2.cpu()), (call, i)
+            assert torch.equal(t1.cpu(), t3.cpu()), (call, i)
+    assert torch.cuda.memory_reserved() <= mem_after_first + (256 << 20), "repeated two-stream calls must not grow the reserved memory"
+
+
 @pytest.mark.parametrize("model", ["hy", "wan"])
 def test_svg2_core_against_oracle_and_dense(model):
     """SVG2 sparse branch: (a) top_p = 1 keeps every block -> must equal dense attention (permutation invariance);

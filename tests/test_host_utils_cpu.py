@@ -69,6 +69,28 @@ def test_wan_qk_norm_accepts_rms_norm_only():
     with pytest.raises(ValueError):
         P(0).get_qk_norm(a, x, x)
 
+    # a class that is merely CALLED RMSNorm (a third-party module with other semantics) is not diffusers' RMSNorm: rejected too
+    class RMSNorm(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.weight, self.eps = torch.nn.Parameter(torch.ones(16)), 1e-6
+
+        def forward(self, t):
+            return t * (1 + self.weight)
+
+    a.norm_q = RMSNorm()
+    with pytest.raises(ValueError):
+        P(0).get_qk_norm(a, x, x)
+    # ... unless it lives in diffusers' modules (recognised by name: diffusers is not a dependency here) or declares the semantics
+    RMSNorm.svg_rmsnorm_compatible = True
+    q, _ = P(0).get_qk_norm(a, x, x)
+    torch.testing.assert_close(q, a.norm_q(x))                           # (CPU tensors: the module's own forward)
+    Fake = type("RMSNorm", (torch.nn.Module,), {"__module__": "diffusers.models.normalization", "forward": lambda self, t: t * 2.0})
+    a.norm_q = Fake()
+    a.norm_q.weight, a.norm_q.eps = torch.nn.Parameter(torch.ones(16)), 1e-6
+    q, _ = P(0).get_qk_norm(a, x, x)
+    torch.testing.assert_close(q, x * 2.0)
+
 
 def test_token_range_units():
     from svg.distributed import token_range
