@@ -75,9 +75,40 @@ F_, P_, CTX, L = HY720P.F, HY720P.P, HY720P.ctx, HY720P.L
 V, S = HY720P.V, HY720P.S
 
 
+TUNED_GEMMS = ROOT / "sparse-videogen_amd" / "tuning" / "tunableop_mi355x.csv"
+_TUNED = {"loaded": None}
+
+
+def enable_tuned_gemms():
+    """Solution selection for four GEMM shapes of the HunyuanVideo stack where torch's default hipBLASLt pick loses 4 - 27 % on MI355X
+    (sparse-videogen_amd/tuning/README.md): a TunableOp results file, read with tuning OFF — shapes without an entry keep the default pick, and
+    TunableOp rejects the file on any other library stack (its validators).  SVG_STEP_TUNABLEOP=0: skip."""
+    if _TUNED["loaded"] is not None:
+        return _TUNED["loaded"]
+    ok = False
+    if os.environ.get("SVG_STEP_TUNABLEOP", "1") != "0" and TUNED_GEMMS.exists() and hasattr(torch.cuda, "tunable"):
+        try:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.tuning_enable(False)
+            torch.cuda.tunable.record_untuned_enable(False)
+            ok = bool(torch.cuda.tunable.read_file(str(TUNED_GEMMS)))
+            if not ok:
+                torch.cuda.tunable.enable(False)
+        except Exception:  # noqa: BLE001
+            ok = False
+    _TUNED["loaded"] = ok
+    return ok
+
+
 def gemm_backend_info():
     """which BLAS the GEMMs of the step run on, as far as torch tells (the kernels' names are in the committed rocprofv3 trace of a step)"""
     info = {"library": "unknown"}
+    info["tunableop_file_loaded"] = bool(_TUNED["loaded"])
+    if _TUNED["loaded"]:
+        try:
+            info["tunableop_solutions"] = {r[1]: r[2] for r in torch.cuda.tunable.get_results()}
+        except Exception:  # noqa: BLE001
+            pass
     try:
         info["library"] = str(torch.backends.cuda.preferred_blas_library()).split(".")[-1]
     except Exception:  # noqa: BLE001
@@ -388,6 +419,7 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
             group=None, kinds=("sparse", "dense", "sparse_fp8"), host_staged: bool = False):
     from svg.models import _core as core
 
+    enable_tuned_gemms()
     dev = torch.device("cuda", torch.cuda.current_device())
     st = Stack(n_double, n_single, dev, geo)
     n_layers = n_double + n_single
@@ -595,13 +627,11 @@ class WanHipOps:
     def rms(self, x, w):                        # RMSNorm across all heads, before the head split — wan/attention.py:105-120
         return self.nat.rmsnorm_forward(x, w, 1e-6)
 
-    def prologue(self, st, q_buf, k_buf, v_buf, pos0, n):
-        """normalised projections [1, S_r, hid] -> head-major q, k (complex RoPE at positions pos0 ..) and v [1, H, S_r, hd]"""
-        g = self.geo
-        q, k = self.nat.qk_norm_rope_transpose(q_buf, k_buf, g.heads, g.heads, 0, None, None, None, None, 1e-6, 2,
+    def prologue(self, blk, st, q_buf, k_buf, v_buf, pos0, n):
+        """projection outputs [1, S_r, hid] -> head-major q, k, v [1, H, S_r, hd]: RMSNorm across all heads + complex RoPE at positions
+        pos0 .. + transpose in ONE pass (svg_rmsnorm_rope_transpose — what WanAttn_*Processor.get_fused_prologue runs)"""
+        return self.nat.rmsnorm_rope_transpose(q_buf, k_buf, v_buf, self.geo.heads, blk["nq"], blk["nk"], 1e-6, 2,
                                                st.rot_real[pos0:pos0 + n].contiguous(), st.rot_imag[pos0:pos0 + n].contiguous(), 0, n)
-        v, _ = self.nat.qk_norm_rope_transpose(v_buf, None, g.heads, 0)
-        return q, k, v
 
     def self_attention(self, q, k, v, layer: int, sparse: bool, head_shard=None):
         g = self.geo
@@ -660,8 +690,7 @@ def run_step_wan(st: WanStack, x, sparse_step: bool, first_layers_fp: int, ops, 
             q_buf, k_buf, v_buf = lin(b["bq"], xn, b["wq"].t()), lin(b["bk"], xn, b["wk"].t()), lin(b["bv"], xn, b["wv"].t())
             st.gemm_flops += 2.0 * Sr * hid * hid * 3
         with sec("prologue"):
-            q_buf, k_buf = ops.rms(q_buf, b["nq"]), ops.rms(k_buf, b["nk"])
-            q, k, v = ops.prologue(st, q_buf[None], k_buf[None], v_buf[None], pos0, Sr)
+            q, k, v = ops.prologue(b, st, q_buf[None], k_buf[None], v_buf[None], pos0, Sr)
         with sec("exchange"):
             if sharded:
                 q, k, v = (sh.to_heads(t[0], i)[None] for i, t in enumerate((q, k, v)))
@@ -711,6 +740,7 @@ def measure_wan(steps: int = 2, warmup: int = 1, geo: WanGeo = WAN720P, rank: in
     """Wan 2.1 720p SVG2 denoise step: 1 dense + 39 SAP layers (first_layers_fp = 0.03, wan_t2v_720p_sap.sh:4-5); the FIRST sparse step
     of a video runs the 50-iteration k-means init in every layer (reported as `first_sparse_step`), later steps 2 warm-started
     iterations.  Dense comparator: all 40 layers dense (the first first_times_fp = 0.2 * 50 = 10 steps of a video)."""
+    enable_tuned_gemms()
     dev = torch.device("cuda", torch.cuda.current_device())
     st = WanStack(dev, geo, layers=layers)
     n_layers = len(st.blocks)

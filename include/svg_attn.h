@@ -349,6 +349,18 @@ int svg_qk_norm_rope_transpose_qscale(const void* q_in, const void* k_in, void* 
                                       const float* cos_or_real, const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi,
                                       float q_scale, void* stream);
 
+/* The Wan 2.1 prologue in ONE pass (round 6): RMSNorm across ALL heads in the reference's Triton form (svg_rmsnorm_forward's arithmetic over
+ * the H * D row) -> rotary embedding of positions [rope_lo, rope_hi) -> head-major transpose for q and k, and the plain transpose of v, in one
+ * launch.  Replaces, bit for bit, svg_rmsnorm_forward(q), svg_rmsnorm_forward(k), svg_qk_norm_rope_transpose(q, k, norm 0, rope), the transpose
+ * of v — i.e. the reference's get_qk_norm (triton_rmsnorm_forward) + get_transpose_qkv (three `.transpose(1, 2).contiguous()`) +
+ * get_rotary_emb (_kernels.apply_qk_rope_inplace_cossin_complex): svg/models/wan/attention.py:99-148.  q_in / k_in / v_in: token-major
+ * [bsz, S, H * D] (any of them may be NULL); outputs head-major [bsz, H, S, D]; weights [H * D] of w_dtype or NULL; H * D <= 8192;
+ * q_scale as in svg_qk_norm_rope_qscale. */
+int svg_rmsnorm_rope_transpose(const void* q_in, const void* k_in, const void* v_in, void* q_out, void* k_out, void* v_out, int32_t bsz,
+                               int32_t H, int32_t S, int32_t D, int32_t dtype, const void* q_weight, const void* k_weight,
+                               int32_t w_dtype, float eps, int32_t rope_kind, const float* cos_or_real, const float* sin_or_imag,
+                               int32_t rope_lo, int32_t rope_hi, float q_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Transformer-block glue of the Wan blocks, rows of [M, N], N % 8 == 0, N <= 8192; dtypes per tensor
  * (SVG_DTYPE_BF16 / F16 / F32); scale, shift, gate are fp32 [M / rows_per_batch, N] (one row per batch element).

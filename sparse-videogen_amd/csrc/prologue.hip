@@ -191,9 +191,207 @@ static int launch_prologue(const PrologueParams& p, int bsz, int D, int dtype, h
     return SVG_ERR_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Wan 2.1 prologue in ONE pass: RMSNorm ACROSS ALL HEADS (the reference's Triton form: fp32 x * rstd * w over the H * D row, one rounding) ->
+// rotary embedding -> head-major transpose, for q and k, plus the plain transpose of v in the same launch.
+// ref: svg/models/wan/attention.py:99-148 — get_qk_norm (triton_rmsnorm_forward, :105-120), get_transpose_qkv (:122-133: three
+//      `.transpose(1, 2).contiguous()` copies), get_rotary_emb (:135-140: _kernels.apply_qk_rope_inplace_cossin_complex) — three passes over q
+//      and k and one over v there (and in this library until round 6: svg_rmsnorm_forward + svg_qk_norm_rope_transpose).
+// One wave per token row: lane l owns the 16-byte chunks l, l + 64, ... of the row (exactly svg_rmsnorm_forward's layout and summation order:
+// the same rstd, bit for bit), which live in registers between the statistics and the output; chunk c of the row is chunk c % (D / 8) of
+// head c / (D / 8), and 64 % (D / 8) == 0, so ALL of a lane's chunks sit at the same channels of their heads: one rotary-table read per
+// lane and row.  The normalised value is rounded to T before the rotation, as the unfused sequence leaves it in memory: the result equals
+// svg_rmsnorm_forward -> svg_qk_norm_rope_transpose bit for bit.  HBM traffic: every tensor read once, written once.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct RmsAllParams {
+    const void* q_in;    // [bsz, S, H * D] token-major projection outputs (k_in, v_in may be null)
+    const void* k_in;
+    const void* v_in;
+    void* q_out;         // [bsz, H, S, D]
+    void* k_out;
+    void* v_out;
+    const void* qw;      // [H * D] weights (dtype w_dt), may be null (= ones)
+    const void* kw;
+    int w_dt;
+    int H, S, bsz;
+    float eps;
+    int rope;
+    const float* cs;
+    const float* sn;
+    int rope_lo, rope_hi;
+    float q_scale;
+};
+
+template <typename T, int D, int NCH>
+__global__ __launch_bounds__(256) void rmsall_rope_transpose_kernel(RmsAllParams p) {
+    using E = Elt<T>;
+    using V8 = typename E::v8;
+    constexpr int LPR = D / 8;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)p.bsz * p.S) return;
+    const int b = (int)(row / p.S), pos = (int)(row - (long long)b * p.S);
+    const int N = p.H * D, nchunks = N / 8;
+    const int cih = lane % LPR;                      // the lane's chunk inside a head (the same for all its chunks)
+    const bool rot = p.rope != kRopeNone && pos >= p.rope_lo && pos < p.rope_hi;
+    float cs[8], sn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 1.f, sn[j] = 0.f;
+    if (rot) {
+        const size_t r = (size_t)(pos - p.rope_lo);
+        if (p.rope == kRopeCosSin) {
+            const f32x4* pc = (const f32x4*)(p.cs + r * D + cih * 8);
+            const f32x4* ps = (const f32x4*)(p.sn + r * D + cih * 8);
+            const f32x4 c0 = pc[0], c1 = pc[1], s0 = ps[0], s1 = ps[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = c0[j], cs[4 + j] = c1[j], sn[j] = s0[j], sn[4 + j] = s1[j];
+        } else {
+            const f32x4 fr = *(const f32x4*)(p.cs + r * (D / 2) + cih * 4);
+            const f32x4 fi = *(const f32x4*)(p.sn + r * (D / 2) + cih * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = fr[j], sn[j] = fi[j];
+        }
+    }
+    auto out_ptr = [&](void* base, int c) -> T* {   // chunk c of the token row -> its place in the head-major tensor
+        const int head = c / LPR;
+        return (T*)base + (((size_t)b * p.H + head) * p.S + pos) * D + cih * 8;
+    };
+    auto run = [&](const T* in, T* out, const void* wgt, const float oscale) {
+        const T* src = in + (size_t)row * N;
+        V8 xin[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) xin[i] = *(const V8*)(src + (size_t)c * 8);
+        }
+        float x[NCH][8];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[i][j] = (lane + 64 * i < nchunks) ? E::to_float(xin[i][j]) : 0.f;
+        // svg_rmsnorm_forward (glue.hip, row_glue_body<NCH, 2>): the same sum, the same order
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s2 += x[i][j] * x[i][j];
+        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)N + p.eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c >= nchunks) continue;
+            float w[8];
+            if (wgt) {
+                if (p.w_dt == SVG_DTYPE_F32) {
+                    const f32x4* pw = (const f32x4*)((const float*)wgt + (size_t)c * 8);
+                    const f32x4 a = pw[0], d = pw[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = a[j], w[4 + j] = d[j];
+                } else if (p.w_dt == SVG_DTYPE_BF16) {
+                    const bf16x8 a = *(const bf16x8*)((const __bf16*)wgt + (size_t)c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (float)a[j];
+                } else {
+                    const f16x8 a = *(const f16x8*)((const _Float16*)wgt + (size_t)c * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (float)a[j];
+                }
+            }
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = x[i][j] * rstd;
+                y[j] = E::to_float(E::from_float(wgt ? xh * w[j] : xh));      // the rounding svg_rmsnorm_forward stores
+            }
+            V8 o;
+            if (rot && p.rope == kRopeCosSin) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const float a = y[2 * k2], bq = y[2 * k2 + 1];
+                    o[2 * k2] = E::from_float((a * cs[2 * k2] + (-bq) * sn[2 * k2]) * oscale);
+                    o[2 * k2 + 1] = E::from_float((bq * cs[2 * k2 + 1] + a * sn[2 * k2 + 1]) * oscale);
+                }
+            } else if (rot) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const double a = (double)y[2 * k2], bq = (double)y[2 * k2 + 1];
+                    const double fr = (double)cs[k2], fi = (double)sn[k2];
+                    o[2 * k2] = E::from_double((a * fr - bq * fi) * (double)oscale);
+                    o[2 * k2 + 1] = E::from_double((a * fi + bq * fr) * (double)oscale);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = E::from_float(y[j] * oscale);
+            }
+            *(V8*)out_ptr(out, c) = o;
+        }
+    };
+    if (p.q_in) run((const T*)p.q_in, (T*)p.q_out, p.qw, p.q_scale);
+    if (p.k_in) run((const T*)p.k_in, (T*)p.k_out, p.kw, 1.f);
+    if (p.v_in) {   // plain transpose
+        const T* src = (const T*)p.v_in + (size_t)row * N;
+        V8 xin[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) xin[i] = *(const V8*)(src + (size_t)c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) *(V8*)out_ptr(p.v_out, c) = xin[i];
+        }
+    }
+}
+
+template <typename T, int D>
+static int launch_rmsall(const RmsAllParams& p, hipStream_t st) {
+    const int need = (p.H * D / 8 + 63) / 64;
+    const long long rows = (long long)p.bsz * p.S;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define SVG_RMSALL(NC)                                                                              \
+    if (need <= NC) {                                                                               \
+        hipLaunchKernelGGL((rmsall_rope_transpose_kernel<T, D, NC>), grid, block, 0, st, p);        \
+        return launch_status();                                                                     \
+    }
+    SVG_RMSALL(2) SVG_RMSALL(4) SVG_RMSALL(6) SVG_RMSALL(10) SVG_RMSALL(16)
+#undef SVG_RMSALL
+    return SVG_ERR_UNSUPPORTED;
+}
+
 }  // namespace svg
 
 using namespace svg;
+
+extern "C" int svg_rmsnorm_rope_transpose(const void* q_in, const void* k_in, const void* v_in, void* q_out, void* k_out, void* v_out,
+                                          int32_t bsz, int32_t H, int32_t S, int32_t D, int32_t dtype, const void* q_weight,
+                                          const void* k_weight, int32_t w_dtype, float eps, int32_t rope_kind, const float* cos_or_real,
+                                          const float* sin_or_imag, int32_t rope_lo, int32_t rope_hi, float q_scale, void* stream) {
+    if (!q_in && !k_in && !v_in) return SVG_ERR_BAD_ARG;
+    if ((q_in && !q_out) || (k_in && !k_out) || (v_in && !v_out) || q_in == q_out || (k_in && k_in == k_out) || (v_in && v_in == v_out))
+        return SVG_ERR_BAD_ARG;
+    if (bsz <= 0 || H <= 0 || S <= 0 || !(q_scale > 0.f)) return SVG_ERR_BAD_ARG;
+    if ((int64_t)bsz * S > 0x7fffffffll * 4) return SVG_ERR_UNSUPPORTED;
+    if (rope_kind < 0 || rope_kind > 2) return SVG_ERR_BAD_ARG;
+    if (rope_kind != kRopeNone && (!cos_or_real || !sin_or_imag || rope_lo < 0 || rope_hi > S || rope_lo > rope_hi)) return SVG_ERR_BAD_ARG;
+    if (w_dtype != SVG_DTYPE_BF16 && w_dtype != SVG_DTYPE_F16 && w_dtype != SVG_DTYPE_F32) return SVG_ERR_UNSUPPORTED;
+    if ((int64_t)H * D > 8192) return SVG_ERR_UNSUPPORTED;
+    RmsAllParams p;
+    p.q_in = q_in, p.k_in = k_in, p.v_in = v_in, p.q_out = q_out, p.k_out = k_out, p.v_out = v_out;
+    p.qw = q_weight, p.kw = k_weight, p.w_dt = w_dtype, p.H = H, p.S = S, p.bsz = bsz, p.eps = eps;
+    p.rope = rope_kind, p.cs = cos_or_real, p.sn = sin_or_imag, p.rope_lo = rope_lo, p.rope_hi = rope_hi, p.q_scale = q_scale;
+    hipStream_t st = (hipStream_t)stream;
+#define SVG_RMSALL_D(T)                                            \
+    switch (D) {   /* the head sizes of the models that normalise across heads (Wan 2.1: 128); 64 for completeness */ \
+        case 64: return launch_rmsall<T, 64>(p, st);               \
+        case 128: return launch_rmsall<T, 128>(p, st);             \
+        default: return SVG_ERR_UNSUPPORTED;                       \
+    }
+    if (dtype == SVG_DTYPE_BF16) { SVG_RMSALL_D(__bf16) }
+    if (dtype == SVG_DTYPE_F16) { SVG_RMSALL_D(_Float16) }
+#undef SVG_RMSALL_D
+    return SVG_ERR_UNSUPPORTED;
+}
 
 extern "C" int svg_qk_norm_rope_qscale(void* q, void* k, int32_t bsz, int32_t Hq, int32_t Hkv, int32_t S, int32_t D, int32_t dtype,
                                        int32_t norm_kind, const void* q_weight, const void* q_bias, const void* k_weight,

@@ -106,6 +106,8 @@ SIGNATURES = {
                                           _VP, _I32, _I32, C.c_float, _VP]),
     "svg_qk_norm_rope_transpose_qscale": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP,
                                                     C.c_float, _I32, _VP, _VP, _I32, _I32, C.c_float, _VP]),
+    "svg_rmsnorm_rope_transpose": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _I32, C.c_float, _I32, _VP,
+                                             _VP, _I32, _I32, C.c_float, _VP]),
     "svg_head_placement": (C.c_int, [_VP, _VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "svg_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "svg_inverse_permute_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
@@ -866,6 +868,32 @@ def qk_norm_rope_transpose(q_in, k_in, heads_q: int, heads_k: int, norm_kind: in
                                                  _ptr(k_bias), float(eps), int(rope_kind), _ptr(cos), _ptr(sin), int(rope_lo),
                                                  int(rope_hi), float(q_scale), _stream()), "svg_qk_norm_rope_transpose")
     return q_out, k_out
+
+
+def rmsnorm_rope_transpose(q_in, k_in, v_in, heads: int, q_weight=None, k_weight=None, eps: float = 1e-6, rope_kind: int = 0, cos=None,
+                           sin=None, rope_lo: int = 0, rope_hi: Optional[int] = None, q_scale: float = 1.0):
+    """The Wan 2.1 prologue in one pass (svg_rmsnorm_rope_transpose): q_in / k_in / v_in [bsz, S, heads * D] token-major (k_in, v_in may be
+    None) -> (q, k, v) head-major [bsz, heads, S, D]; q and k RMS-normalised ACROSS ALL HEADS (the reference's Triton form, weights [heads * D])
+    and rotated, v transposed.  Bit-identical to rmsnorm_forward -> qk_norm_rope_transpose(norm 0, rope) and a transpose of v."""
+    lib = load()
+    _dev(q_in, k_in, v_in, q_weight, k_weight, cos, sin)
+    bsz, S, HD = q_in.shape
+    D = HD // heads
+    assert q_in.is_contiguous() and all(t is None or (t.shape == q_in.shape and t.dtype == q_in.dtype and t.is_contiguous()) for t in (k_in, v_in))
+    mk = lambda t: None if t is None else torch.empty((bsz, heads, S, D), dtype=q_in.dtype, device=q_in.device)  # noqa: E731
+    q_out, k_out, v_out = mk(q_in), mk(k_in), mk(v_in)
+    w = q_weight if q_weight is not None else k_weight
+    wdt = _GLUE_DT[w.dtype] if w is not None else 2
+    for t in (q_weight, k_weight):
+        assert t is None or (t.shape == (HD,) and t.is_contiguous() and _GLUE_DT[t.dtype] == wdt)
+    rope_hi = S if rope_hi is None else rope_hi
+    if rope_kind:
+        cols = D // 2 if rope_kind == 2 else D
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.shape == (rope_hi - rope_lo, cols) and sin.shape == cos.shape
+    _check(lib.svg_rmsnorm_rope_transpose(q_in.data_ptr(), _ptr(k_in), _ptr(v_in), q_out.data_ptr(), _ptr(k_out), _ptr(v_out), bsz, heads, S, D,
+                                          _dtype_code(q_in), _ptr(q_weight), _ptr(k_weight), wdt, float(eps), int(rope_kind), _ptr(cos),
+                                          _ptr(sin), int(rope_lo), int(rope_hi), float(q_scale), _stream()), "svg_rmsnorm_rope_transpose")
+    return q_out, k_out, v_out
 
 
 # ---- transformer-block glue (svg/kernels/triton/{layernorm,modulate}.py of the reference) ----

@@ -41,6 +41,27 @@ def apply_rotary_emb(query: torch.Tensor, key: torch.Tensor, freqs, q_scale: flo
     return rot(query), rot(key)
 
 
+def _is_rms(mod) -> bool:
+    """the reference takes torch.nn.RMSNorm or diffusers' RMSNorm (and their subclasses) and raises on anything else (ref :107-119).
+    diffusers is not a dependency here, so its class is recognised by NAME — of a class that lives in diffusers' own modules, or of one that
+    says it computes x * rsqrt(mean(x^2) + eps) * weight (`svg_rmsnorm_compatible = True`: the duck-typed stand-ins of the tests).  An
+    unrelated third-party class that merely happens to be called RMSNorm ((1 + weight) scaling, a bias, ...) is rejected like any other
+    module instead of being sent through the kernel."""
+    if isinstance(mod, torch.nn.RMSNorm):
+        return True
+    for c in type(mod).__mro__:
+        if c.__name__ == "RMSNorm" and (c.__module__.split(".")[0] == "diffusers" or getattr(c, "svg_rmsnorm_compatible", False)):
+            return getattr(mod, "weight", None) is not None
+    return False
+
+
+def _rms_kernel_ok(mod, x) -> bool:
+    """the HIP RMSNorm (weight and eps only, like the reference's kernel call :105-120) applies to this module and tensor"""
+    w = getattr(mod, "weight", None)
+    return bool(w is not None and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
+                and tuple(w.shape) == (x.shape[-1],) and getattr(mod, "eps", None) is not None and getattr(mod, "bias", None) is None)
+
+
 class WanAttn_SVGAttn_Processor2_0:
     """Sparse VideoGen 1 for Wan 2.1 (ref: wan/attention.py:77-328)."""
 
@@ -85,27 +106,12 @@ class WanAttn_SVGAttn_Processor2_0:
         # Wan normalises across all heads, before the head split, and the reference does it with its Triton RMSNorm kernel whatever the
         # module is (ref :105-120: `triton_rmsnorm_forward(query, attn.norm_q.weight, attn.norm_q.eps)` — fp32, one rounding), not with
         # the module's forward (diffusers rounds before the weight): same here on the GPU; other tensors take the module
-        def is_rms(mod):
-            # the reference takes torch.nn.RMSNorm or diffusers' RMSNorm (and their subclasses) and raises on anything else (:107-119).
-            # diffusers is not a dependency here, so its class is recognised by NAME — of a class that lives in diffusers' own modules, or of
-            # one that says it computes x * rsqrt(mean(x^2) + eps) * weight (`svg_rmsnorm_compatible = True`: the duck-typed stand-ins of the
-            # tests).  An unrelated third-party class that merely happens to be called RMSNorm ((1 + weight) scaling, a bias, ...) is rejected
-            # like any other module instead of being sent through the kernel.
-            if isinstance(mod, torch.nn.RMSNorm):
-                return True
-            for c in type(mod).__mro__:
-                if c.__name__ == "RMSNorm" and (c.__module__.split(".")[0] == "diffusers" or getattr(c, "svg_rmsnorm_compatible", False)):
-                    return getattr(mod, "weight", None) is not None
-            return False
-
         def norm(mod, x):
-            if not is_rms(mod):
+            if not _is_rms(mod):
                 raise ValueError(f"Unsupported norm type: {type(mod)}")
-            w = mod.weight
             # the reference's kernel call takes weight and eps only (:105-120); a module that also carries a bias runs its own forward
-            if (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192
-                    and w.shape == (x.shape[-1],) and getattr(mod, "eps", None) is not None and getattr(mod, "bias", None) is None):
-                return triton_rmsnorm_forward(x.contiguous(), w, mod.eps)
+            if _rms_kernel_ok(mod, x):
+                return triton_rmsnorm_forward(x.contiguous(), mod.weight, mod.eps)
             return mod(x)
 
         if getattr(attn, "norm_q", None) is not None:
@@ -126,6 +132,35 @@ class WanAttn_SVGAttn_Processor2_0:
             query, key = apply_rotary_emb(query, key, rotary_emb, q_scale=q_scale, scaled=flag)
             self._rope_scaled = bool(flag and flag[0])
         return query, key
+
+    fused_prologue = True    # self attention on the GPU: qk_norm + transpose + rotary_emb as ONE pass over q, k, v (svg_rmsnorm_rope_transpose)
+
+    @time_logging_decorator("Level 2 - qk_norm + transpose + rotary_emb (fused)")
+    def get_fused_prologue(self, attn, query, key, value, rotary_emb, q_scale: float = 1.0):
+        """get_qk_norm -> get_transpose_qkv -> get_rotary_emb in one kernel (bit-identical to the three steps on the HIP path; ref :99-148):
+        returns (q, k, v) head-major, or None when the pass does not apply — then the caller runs the three steps."""
+        if not self.fused_prologue or rotary_emb is None:
+            return None
+        nq, nk = getattr(attn, "norm_q", None), getattr(attn, "norm_k", None)
+        if nq is None or nk is None or not (_is_rms(nq) and _is_rms(nk)):
+            return None          # (an unsupported module raises in get_qk_norm, exactly as before)
+        ts = (query, key, value)
+        if not all(t.is_cuda and t.dim() == 3 and t.is_contiguous() and t.dtype == query.dtype and t.shape == query.shape for t in ts):
+            return None
+        if not (_rms_kernel_ok(nq, query) and _rms_kernel_ok(nk, key)) or float(nq.eps) != float(nk.eps):
+            return None
+        H = attn.heads
+        D = query.shape[-1] // H
+        if D not in (64, 128) or H * D != query.shape[-1]:
+            return None
+        fr, fi = rotary_emb if isinstance(rotary_emb, (tuple, list)) else (rotary_emb.real, rotary_emb.imag)
+        S = query.shape[1]
+        tb = _core._tables(fr, fi, S, D // 2, query.device)
+        if tb is None:
+            return None
+        dt = query.dtype
+        qw, kw = (m.weight.detach().to(device=query.device, dtype=dt).contiguous() for m in (nq, nk))
+        return _core._native.rmsnorm_rope_transpose(query, key, value, H, qw, kw, float(nq.eps), 2, tb[0], tb[1], 0, S, q_scale=q_scale)
 
     @time_logging_decorator("Level 2 - output")
     def get_o(self, attn, query, hidden_states, hidden_states_img):
@@ -148,12 +183,19 @@ class WanAttn_SVGAttn_Processor2_0:
         if encoder_hidden_states is None:
             encoder_hidden_states = hidden_states
         query, key, value = self.get_qkv(attn, hidden_states, encoder_hidden_states)
-        query, key = self.get_qk_norm(attn, query, key)
-        query, key, value = self.get_transpose_qkv(attn, query, key, value)
         q_scale = 1.0
-        if self.prescale_q and not cross and timestep is not None and rotary_emb is not None and _core.prescale_supported(query):
-            q_scale = _core._native.softmax_q_scale(query.shape[-1])     # a request: the RoPE pass reports whether it folded it in
-        query, key = self.get_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
+        D_head = query.shape[-1] // attn.heads
+        if (self.prescale_q and not cross and timestep is not None and rotary_emb is not None and query.is_cuda
+                and query.dtype in (torch.bfloat16, torch.float16) and D_head in (64, 128)):
+            q_scale = _core._native.softmax_q_scale(D_head)     # a request: the RoPE pass reports whether it folded it in
+        fused = None if cross else self.get_fused_prologue(attn, query, key, value, rotary_emb, q_scale)
+        if fused is not None:
+            query, key, value = fused
+            self._rope_scaled = q_scale != 1.0
+        else:
+            query, key = self.get_qk_norm(attn, query, key)
+            query, key, value = self.get_transpose_qkv(attn, query, key, value)
+            query, key = self.get_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
         hidden_states_img = None
         if encoder_hidden_states_img is not None:  # I2V: CLIP image tokens, small dense cross attention (ref :174-188)
             key_img = attn.norm_added_k(attn.add_k_proj(encoder_hidden_states_img))

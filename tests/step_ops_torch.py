@@ -61,8 +61,9 @@ class WanTorchOps:
         xf = x.float()
         return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()).to(x.dtype)
 
-    def prologue(self, st, q_buf, k_buf, v_buf, pos0, n):
+    def prologue(self, blk, st, q_buf, k_buf, v_buf, pos0, n):
         g = self.geo
+        q_buf, k_buf = self.rms(q_buf, blk["nq"]), self.rms(k_buf, blk["nk"])
         q, k, v = (b.unflatten(2, (g.heads, -1)).transpose(1, 2).contiguous() for b in (q_buf, k_buf, v_buf))
         re, im = st.rot_real[pos0:pos0 + n], st.rot_imag[pos0:pos0 + n]
         return O.rope_complex(q, re, im), O.rope_complex(k, re, im), v

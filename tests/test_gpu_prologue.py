@@ -198,3 +198,89 @@ def test_full_size_hunyuan_prologue(nat):
         pos = rows < S - L
         ref[:, :, pos] = O.rope_cossin(ref[:, :, pos], cos[rows[pos]].cpu(), sin[rows[pos]].cpu())
         ulp_equal(x1[:, :, rows], ref, 2e-3, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the Wan 2.1 prologue in one pass (svg_rmsnorm_rope_transpose, round 6): RMSNorm across ALL heads + RoPE + head-major transpose
+# ref: svg/models/wan/attention.py:99-148 (get_qk_norm / get_transpose_qkv / get_rotary_emb)
+# ---------------------------------------------------------------------------------------------------------
+def _triton_rmsnorm(x, w, eps):
+    """the reference's Triton RMSNorm (svg/kernels/triton/rmsnorm.py:8-48): fp32 x * rstd * w, ONE rounding"""
+    xf = x.float()
+    y = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return (y * w.float() if w is not None else y).to(x.dtype)
+
+
+@pytest.mark.parametrize("H,D,rope,dtype,wdt", [
+    (40, 128, 2, torch.bfloat16, torch.bfloat16),      # Wan 2.1 14B: 5120 = 640 chunks, ten per lane
+    (12, 128, 2, torch.bfloat16, torch.float32),       # Wan 2.1 1.3B: 1536 = 192 chunks; fp32 weights
+    (5, 64, 1, torch.float16, torch.float16),          # 40 chunks: lanes without a chunk; cos-sin table
+    (7, 128, 0, torch.bfloat16, torch.bfloat16),       # no rotation
+    (64, 128, 2, torch.float16, torch.float16),        # 8192: the largest row
+])
+def test_rmsnorm_rope_transpose_equals_the_three_passes(nat, H, D, rope, dtype, wdt):
+    """one launch == svg_rmsnorm_forward(q), svg_rmsnorm_forward(k), svg_qk_norm_rope_transpose(norm 0, rope), transpose(v) bit for bit
+    (partial rotation range, q_scale folded into q's last rounding), and == the torch statement of the reference's three steps"""
+    torch.manual_seed(H * D + rope)
+    bsz, S, lo, hi = 2, 333, 7, 301
+    q_in, k_in, v_in = (torch.randn(bsz, S, H * D).to(dtype).cuda() * 1.7 for _ in range(3))
+    qw, kw = (torch.randn(H * D).mul(0.3).add(1.0).to(wdt).cuda() for _ in range(2))
+    cols = D // 2 if rope == 2 else D
+    cs, sn = (torch.randn(hi - lo, cols).cuda(), torch.randn(hi - lo, cols).cuda()) if rope else (None, None)
+    for q_scale in (1.0, 0.1275):
+        q, k, v = nat.rmsnorm_rope_transpose(q_in, k_in, v_in, H, qw, kw, 1e-6, rope, cs, sn, lo, hi, q_scale=q_scale)
+        qn, kn = nat.rmsnorm_forward(q_in, qw, 1e-6), nat.rmsnorm_forward(k_in, kw, 1e-6)
+        q_ref, k_ref = nat.qk_norm_rope_transpose(qn, kn, H, H, 0, None, None, None, None, 1e-6, rope, cs, sn, lo, hi, q_scale=q_scale)
+        assert torch.equal(q, q_ref) and torch.equal(k, k_ref)
+        assert torch.equal(v, v_in.unflatten(2, (H, D)).transpose(1, 2).contiguous())
+    # partial calls: k or v absent, no weights
+    q1, k1, v1 = nat.rmsnorm_rope_transpose(q_in, None, None, H, qw, None, 1e-6, rope, cs, sn, lo, hi)
+    assert k1 is None and v1 is None
+    q2, _, _ = nat.rmsnorm_rope_transpose(q_in, k_in, v_in, H, qw, kw, 1e-6, rope, cs, sn, lo, hi)
+    assert torch.equal(q1, q2)
+    q3, _, _ = nat.rmsnorm_rope_transpose(q_in, None, None, H, None, None, 1e-6, 0)
+    assert torch.equal(q3, nat.rmsnorm_forward(q_in, None, 1e-6).unflatten(2, (H, D)).transpose(1, 2).contiguous())
+    # the reference's statement of the same three steps in torch (fp32 norm with one rounding; fp64 complex rotation)
+    ref = _triton_rmsnorm(q_in.cpu(), qw.cpu(), 1e-6).unflatten(2, (H, D)).transpose(1, 2).contiguous()
+    if rope == 2:
+        ref[:, :, lo:hi] = O.rope_complex(ref[:, :, lo:hi], cs.cpu(), sn.cpu())
+    elif rope == 1:
+        ref[:, :, lo:hi] = O.rope_cossin(ref[:, :, lo:hi], cs.cpu(), sn.cpu())
+    ulp_equal(q2, ref, 5e-3, 1, abs_ok=2e-2)
+
+
+def test_full_size_wan_prologue(nat):
+    """Wan 2.1 720p (S = 75600, 40 x 128): the fused pass equals the unfused sequence at full size; reports both times"""
+    torch.manual_seed(4)
+    H, S, D = 40, 75600, 128
+    dt = torch.bfloat16
+    q_in, k_in, v_in = (torch.randn(1, S, H * D, device="cuda", dtype=dt) for _ in range(3))
+    qw, kw = (torch.randn(H * D, device="cuda").mul(0.2).add(1.5).to(dt) for _ in range(2))
+    fr, fi = torch.randn(S, D // 2, device="cuda"), torch.randn(S, D // 2, device="cuda")
+
+    def fused():
+        return nat.rmsnorm_rope_transpose(q_in, k_in, v_in, H, qw, kw, 1e-6, 2, fr, fi, 0, S)
+
+    def unfused():
+        qn, kn = nat.rmsnorm_forward(q_in, qw, 1e-6), nat.rmsnorm_forward(k_in, kw, 1e-6)
+        q, k = nat.qk_norm_rope_transpose(qn, kn, H, H, 0, None, None, None, None, 1e-6, 2, fr, fi, 0, S)
+        v, _ = nat.qk_norm_rope_transpose(v_in, None, H, 0)
+        return q, k, v
+
+    a, b = fused(), unfused()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    del a, b
+    times = {}
+    for name, fn in (("fused", fused), ("unfused", unfused)):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) / 5
+    alg = 6 * S * H * D * 2      # q, k, v read once and written once
+    print(f"\n[wan 720p prologue] fused {times['fused']:.3f} ms = {alg / times['fused'] / 1e6:.0f} GB/s algorithmic; the three-pass sequence "
+          f"{times['unfused']:.3f} ms")
+    assert times["fused"] < times["unfused"]
