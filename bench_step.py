@@ -118,7 +118,7 @@ def gemm_backend_info():
     return info
 
 
-def gemm_shapes_tflops(shapes, reps=5, dtype=torch.bfloat16):
+def gemm_shapes_tflops(shapes, reps=20, dtype=torch.bfloat16):
     """per-shape rate of the step's GEMMs, each alone on the GPU: [(M, N, K)] -> {"MxNxK": TFLOP/s} (y[M, N] = x[M, K] @ w[N, K]^T)"""
     out = {}
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -126,7 +126,9 @@ def gemm_shapes_tflops(shapes, reps=5, dtype=torch.bfloat16):
         x = torch.randn(M, K, device=dev, dtype=dtype)
         w = torch.randn(N, K, device=dev, dtype=dtype)
         y = torch.empty(M, N, device=dev, dtype=dtype)
-        torch.mm(x, w.t(), out=y)
+        for _ in range(5):       # (the first launches of a shape after idle time run at a lower clock: 1085 vs 1290 TFLOP/s measured)
+            torch.mm(x, w.t(), out=y)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

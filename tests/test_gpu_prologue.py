@@ -246,7 +246,10 @@ def test_rmsnorm_rope_transpose_equals_the_three_passes(nat, H, D, rope, dtype, 
         ref[:, :, lo:hi] = O.rope_complex(ref[:, :, lo:hi], cs.cpu(), sn.cpu())
     elif rope == 1:
         ref[:, :, lo:hi] = O.rope_cossin(ref[:, :, lo:hi], cs.cpu(), sn.cpu())
-    ulp_equal(q2, ref, 5e-3, 1, abs_ok=2e-2)
+    # (the torch norm sums in another order: rstd may differ in its last fp32 bit, the rounded norm then by one ulp of T in a few elements, and
+    #  the rotation — table entries ~N(0, 1) here — multiplies that: the reference's own tolerance, and nearly all elements equal)
+    close(q2, ref)
+    ulp_equal(q2, ref, 5e-3, 4, abs_ok=6e-2)
 
 
 def test_full_size_wan_prologue(nat):
