@@ -43,6 +43,17 @@ __device__ __forceinline__ float group_sum(float v) {  // sum over the LPR conse
     return v;
 }
 
+// T(v * oscale) with the product ROUNDED TO fp32 FIRST, like torch's `(x.float() * s).to(T)`.  Without the fence hipcc picks, element by
+// element, between v_mul_f32 + v_cvt_f16_f32 and v_fma_mixlo_f16 (one instruction from the fp32 operands to the fp16 result) for T = fp16, and
+// the two do not agree bit for bit: two kernels that state the same arithmetic then differ in 0.1 % of the elements (found in round 6: the
+// fused Wan prologue against the unfused sequence, fp16, q_scale != 1).  bf16 has no such instruction; the fence is free there.
+template <typename E>
+__device__ __forceinline__ auto scaled_round(float v, float oscale) {
+    float t = v * oscale;
+    asm volatile("" : "+v"(t));
+    return E::from_float(t);
+}
+
 // One lane = 8 consecutive channels of one (batch, head, position) row; a wave covers 64 / (D / 8) consecutive positions;
 // the workgroup (4 waves) walks over all heads of Q and then of K for its positions, kUnroll rows in flight per lane.
 template <typename T, int D>
@@ -142,8 +153,8 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float a = x[2 * i], bq = x[2 * i + 1];
-                        out[2 * i] = E::from_float((a * cs[2 * i] + (-bq) * sn[2 * i]) * oscale);
-                        out[2 * i + 1] = E::from_float((bq * cs[2 * i + 1] + a * sn[2 * i + 1]) * oscale);
+                        out[2 * i] = scaled_round<E>(a * cs[2 * i] + (-bq) * sn[2 * i], oscale);
+                        out[2 * i + 1] = scaled_round<E>(bq * cs[2 * i + 1] + a * sn[2 * i + 1], oscale);
                     }
                 } else if (rot) {
                     // (x[2i] + i x[2i+1]) * (fr + i fi) in fp64 (the reference multiplies complex128 by complex64)
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void qk_prologue_kernel(PrologueParams p) {
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) out[j] = E::from_float(x[j] * oscale);
+                    for (int j = 0; j < 8; ++j) out[j] = scaled_round<E>(x[j], oscale);
                 }
                 if (valid && h0 + u < H) *(V8*)(row0 + (size_t)(h0 + u) * hstride) = out;
             }
@@ -308,8 +319,8 @@ __global__ __launch_bounds__(256) void rmsall_rope_transpose_kernel(RmsAllParams
 #pragma unroll
                 for (int k2 = 0; k2 < 4; ++k2) {
                     const float a = y[2 * k2], bq = y[2 * k2 + 1];
-                    o[2 * k2] = E::from_float((a * cs[2 * k2] + (-bq) * sn[2 * k2]) * oscale);
-                    o[2 * k2 + 1] = E::from_float((bq * cs[2 * k2 + 1] + a * sn[2 * k2 + 1]) * oscale);
+                    o[2 * k2] = scaled_round<E>(a * cs[2 * k2] + (-bq) * sn[2 * k2], oscale);
+                    o[2 * k2 + 1] = scaled_round<E>(bq * cs[2 * k2 + 1] + a * sn[2 * k2 + 1], oscale);
                 }
             } else if (rot) {
 #pragma unroll
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void rmsall_rope_transpose_kernel(RmsAllParams
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = E::from_float(y[j] * oscale);
+                for (int j = 0; j < 8; ++j) o[j] = scaled_round<E>(y[j], oscale);
             }
             *(V8*)out_ptr(out, c) = o;
         }
