@@ -194,7 +194,12 @@ class WanAttn_SVGAttn_Processor2_0:
             self._rope_scaled = q_scale != 1.0
         else:
             query, key = self.get_qk_norm(attn, query, key)
-            query, key, value = self.get_transpose_qkv(attn, query, key, value)
+            if cross and rotary_emb is None and query.is_cuda:
+                # cross attention (512 text keys, torch SDPA below): head views instead of three contiguous copies — the q copy alone is
+                # 2 x 774 MB of traffic per layer at Wan 2.1 720p; SDPA takes strided operands and returns q's layout
+                query, key, value = (x.unflatten(2, (attn.heads, -1)).transpose(1, 2) for x in (query, key, value))
+            else:
+                query, key, value = self.get_transpose_qkv(attn, query, key, value)
             query, key = self.get_rotary_emb(query, key, rotary_emb, q_scale=q_scale)
         hidden_states_img = None
         if encoder_hidden_states_img is not None:  # I2V: CLIP image tokens, small dense cross attention (ref :174-188)

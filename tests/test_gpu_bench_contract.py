@@ -131,7 +131,7 @@ def test_bench_step_wan_small_stack():
     assert not _error_keys(d), _error_keys(d)
     for kind in ("sparse_step", "dense_step"):
         b = d[kind]["step_breakdown_ms"]
-        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflop_this_rank"] > 0
+        assert d[kind]["ms"] > 0 and 0 < d[kind]["attention_share"] < 1 and d[kind]["gemm_tflops_this_rank"] > 0   # (the small stack's TFLOP round to 0.0)
         assert {"gemm", "glue", "prologue", "self_attention", "cross_attention"} <= set(b)
         assert abs(sum(b.values()) - d[kind]["ms"]) < 0.05 * d[kind]["ms"] + 0.1
     assert d["denoise_steps_per_s"] > 0 and d["first_sparse_step_ms_with_kmeans_init"] > 0 and d["n_gpus"] == 1
