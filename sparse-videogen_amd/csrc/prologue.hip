@@ -337,13 +337,12 @@ __global__ __launch_bounds__(256) void rmsall_rope_transpose_kernel(RmsAllParams
             *(V8*)out_ptr(out, c) = o;
         }
     };
-    // grid.y = which tensor: the three passes of a row are independent and run as three waves.  (Measured at Wan 720p: 1.04 - 1.13 ms = 4.1 - 4.5
-    // TB/s algorithmic either way, against 1.77 ms for the three-pass sequence; the stores are 256-byte segments — one head's row — per 16 lanes,
-    // where svg_qk_norm_rope_transpose writes 1 KB per wave and reaches 5.6 TB/s: staging the rows of a workgroup through LDS is what is left.)
-    const int which = blockIdx.y;
-    if (which == 0 && p.q_in) run((const T*)p.q_in, (T*)p.q_out, p.qw, p.q_scale);
-    if (which == 1 && p.k_in) run((const T*)p.k_in, (T*)p.k_out, p.kw, 1.f);
-    if (which == 2 && p.v_in) {   // plain transpose
+    // One wave takes its row through q, k and v in turn.  Measured at Wan 720p and NOT shipped (same boxes: the three-pass sequence took 1.77 ms on
+    // each): the three tensors as three waves (grid.y) 1.13 ms, that plus the rows of a workgroup staged through LDS so that a store instruction
+    // writes 1 KB of one head instead of 256-byte pieces of four heads 1.17 ms — against 1.04 ms for this form.
+    if (p.q_in) run((const T*)p.q_in, (T*)p.q_out, p.qw, p.q_scale);
+    if (p.k_in) run((const T*)p.k_in, (T*)p.k_out, p.kw, 1.f);
+    if (p.v_in) {   // plain transpose
         const T* src = (const T*)p.v_in + (size_t)row * N;
         V8 xin[NCH];
 #pragma unroll
@@ -363,7 +362,7 @@ template <typename T, int D>
 static int launch_rmsall(const RmsAllParams& p, hipStream_t st) {
     const int need = (p.H * D / 8 + 63) / 64;
     const long long rows = (long long)p.bsz * p.S;
-    const dim3 grid((unsigned)((rows + 3) / 4), 3), block(256);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define SVG_RMSALL(NC)                                                                              \
     if (need <= NC) {                                                                               \
         hipLaunchKernelGGL((rmsall_rope_transpose_kernel<T, D, NC>), grid, block, 0, st, p);        \
