@@ -346,6 +346,45 @@ def test_wan_and_cog_svg_processors_run_and_match():
     torch.testing.assert_close(out.float().cpu(), ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("hd,complex_table", [(128, False), (64, True)])
+def test_wan_fused_prologue_equals_the_three_steps(hd, complex_table):
+    """WanAttn_SVGAttn_Processor2_0: `fused_prologue` (qk_norm + transpose + rotary_emb in one kernel, svg_rmsnorm_rope_transpose) on and off give
+    the same processor output bit for bit — dense and sparse steps, rotary table as the (real, imag) pair of the patched model forward or as
+    diffusers' complex tensor — and the cross attention (head views instead of contiguous copies) equals the copying path."""
+    from svg.models.wan.attention import WanAttn_SVGAttn_Processor2_0 as WanP
+    from svg.models.wan.utils import generate_temporal_head_mask_mod as wan_mm
+
+    torch.manual_seed(8)
+    heads, F_, P_ = 3, 5, 160
+    dim, S = heads * hd, F_ * P_
+    WanP.context_length, WanP.num_frame, WanP.frame_size = 0, F_, P_
+    WanP.first_layers_fp, WanP.first_times_fp, WanP.num_sampled_rows, WanP.sample_mse_max_row = 0, 900.0, 16, 400
+    WanP.block_mask = wan_mm(0, 0, F_, P_, mul=1.2)
+    attn = Attention(dim, heads, qk_norm="rms", across_heads=True, dtype=DT).cuda()
+    with torch.no_grad():
+        attn.norm_q.weight.mul_(1.3).add_(0.1 * torch.randn_like(attn.norm_q.weight))
+        attn.norm_k.weight.mul_(0.8).add_(0.1 * torch.randn_like(attn.norm_k.weight))
+    attn.set_processor(WanP(0))
+    hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
+    enc = (torch.randn(1, 37, dim) * 0.3).to(DT).cuda()
+    ang = torch.rand(S, hd // 2) * 6.28
+    rope = torch.complex(ang.cos(), ang.sin())[None, None].cuda() if complex_table else (ang.cos().cuda(), ang.sin().cuda())
+    outs = {}
+    try:
+        for fused in (True, False):
+            WanP.fused_prologue = fused
+            with torch.no_grad():
+                torch.manual_seed(3)      # (the sampled rows of the online profiler)
+                sparse = attn(hidden, rotary_emb=rope, timestep=torch.tensor([100.0]))
+                dense = attn(hidden, rotary_emb=rope, timestep=torch.tensor([950.0]))
+                cross = attn(hidden, encoder_hidden_states=enc)
+            outs[fused] = (sparse.clone(), dense.clone(), cross.clone())
+    finally:
+        WanP.fused_prologue = True
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("hd", [64, 128])
 def test_wan_and_cog_prescaled_q_equals_plain_path(hd):
     """Wan / Cog SVG1 processors: prescale_q = True (opt-in — the HIP RoPE pass folds the softmax scale into its rounding of q, pre-scaled

@@ -100,3 +100,23 @@ def test_token_range_units():
     assert tr[0] == (0, 14976) and tr[-1][1] == S and all(tr[i][1] == tr[i + 1][0] for i in range(7))
     assert max(b - a for a, b in tr) * 8 / S < 1.01
     assert token_range(10, 0, 1) == (0, 10) and token_range(10, 2, 3, unit=4) == (8, 10)   # a trailing partial unit goes to the last rank
+
+
+def test_tuned_gemm_file_is_a_tunableop_results_file():
+    """sparse-videogen_amd/tuning/tunableop_mi355x.csv (bench_step.enable_tuned_gemms): TunableOp's validators first — it rejects the file on any
+    other library stack —, then one GemmTunableOp line per listed shape naming a library solution (no kernel of this repo)."""
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lines = (root / "sparse-videogen_amd" / "tuning" / "tunableop_mi355x.csv").read_text().strip().splitlines()
+    val = {l.split(",")[1] for l in lines if l.startswith("Validator,")}
+    assert {"PT_VERSION", "HIP_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= val
+    ops = [l.split(",") for l in lines if not l.startswith("Validator,")]
+    assert len(ops) == 4 and all(o[0] == "GemmTunableOp_BFloat16_TN" and o[2].startswith(("Gemm_Hipblaslt_", "Gemm_Rocblas_")) for o in ops)
+    assert {o[1].split("_")[1] for o in ops} == {"3072"}          # the four 3072-wide shapes of the HunyuanVideo stack
+    sys_path_added = str(root) not in __import__("sys").path
+    if sys_path_added:
+        __import__("sys").path.insert(0, str(root))
+    import bench_step
+
+    assert bench_step.TUNED_GEMMS.exists() and callable(bench_step.enable_tuned_gemms)
