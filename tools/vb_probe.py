@@ -7,6 +7,8 @@ a time —
                    rows in place (no index arrays): the kernel body and the run-list walk alone
     uniform_idx    the same plan with the rows behind a random permutation (q_row_idx / kv_row_idx): + the 256-byte row gather
     uniform_nbr    uniform, but neighbouring block-rows select nearly the same key blocks (what k-means clusters of one neighbourhood do)
+    uniformNNN     q-clusters of NNN rows each (64, 96, 128, 160, 192, 224): ONE partially filled q-tile per block-row — the cost of a tile iteration
+                   as a function of its fill (run with --variant 6: no remainder packing)
     ragged         the REAL cluster sizes of the bench pipeline (252 +- 124 rows) with the random quarter map, rows in place: + q-tile fill, packing
     real_noidx     the bench pipeline's sizes and map, q / k / v permuted beforehand (the reference's pipeline), rows in place
     real           the bench pipeline as shipped (fused gather / scatter)
@@ -95,9 +97,12 @@ def main():
     for case in a.cases.split(","):
         qq, kk, vv, qi, ki = q, k, v, None, None
         if case.startswith("uniform"):
-            QB = S // 256                       # 295 block-rows of 256 rows: 75520 rows
-            Sq = QB * 256
-            qs = torch.full((H, QB), 256, dtype=torch.int32, device=dev)
+            # uniform / uniform_idx / uniform_nbr: q-clusters of 256 rows; uniformNNN: of NNN rows (one partially filled q-tile each: what a
+            # tile iteration costs as a function of its fill — packing off, see --variant 6)
+            rows = int(case[len("uniform"):]) if case[len("uniform"):].isdigit() else 256
+            QB = S // rows
+            Sq = QB * rows
+            qs = torch.full((H, QB), rows, dtype=torch.int32, device=dev)
             ks = torch.full((H, KB), Sq // KB, dtype=torch.int32, device=dev)
             ks[:, : Sq - (Sq // KB) * KB] += 1
             dmap = random_quarter_map(QB, gen, dev, neighbours=case == "uniform_nbr")
