@@ -158,8 +158,10 @@ class WanAttn_SVGAttn_Processor2_0:
         tb = _core._tables(fr, fi, S, D // 2, query.device)
         if tb is None:
             return None
-        dt = query.dtype
-        qw, kw = (m.weight.detach().to(device=query.device, dtype=dt).contiguous() for m in (nq, nk))
+        # weights in their own dtype, as get_qk_norm hands them to the RMSNorm kernel (an fp32 weight is used in fp32 there too)
+        qw, kw = (m.weight.detach().to(device=query.device).contiguous() for m in (nq, nk))
+        if qw.dtype != kw.dtype or qw.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            return None
         return _core._native.rmsnorm_rope_transpose(query, key, value, H, qw, kw, float(nq.eps), 2, tb[0], tb[1], 0, S, q_scale=q_scale)
 
     @time_logging_decorator("Level 2 - output")

@@ -364,6 +364,8 @@ def test_wan_fused_prologue_equals_the_three_steps(hd, complex_table):
     with torch.no_grad():
         attn.norm_q.weight.mul_(1.3).add_(0.1 * torch.randn_like(attn.norm_q.weight))
         attn.norm_k.weight.mul_(0.8).add_(0.1 * torch.randn_like(attn.norm_k.weight))
+    if complex_table:      # norm weights kept in fp32 beside a 16-bit model: both paths use them in fp32
+        attn.norm_q.float(), attn.norm_k.float()
     attn.set_processor(WanP(0))
     hidden = (torch.randn(1, S, dim) * 0.3).to(DT).cuda()
     enc = (torch.randn(1, 37, dim) * 0.3).to(DT).cuda()
