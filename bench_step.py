@@ -237,8 +237,17 @@ class HipOps:
         q, k = self.nat.qk_norm_rope_transpose(q_buf, k_buf, g.heads, g.heads, 1, st.qn, None, st.kn, None, 1e-6, 1 if n_rot else 0,
                                                st.cos[pos0:pos0 + n_rot].contiguous() if n_rot else None,
                                                st.sin[pos0:pos0 + n_rot].contiguous() if n_rot else None, 0, n_rot, q_scale=self.q_scale)
+        if self.v_in_place:     # the attention kernels read v where the projection wrote it (svg_attn_layout_t): a view, no transpose copy
+            return q, k, v_buf.unflatten(2, (g.heads, -1)).transpose(1, 2)
         v, _ = self.nat.qk_norm_rope_transpose(v_buf, None, g.heads, 0)
         return q, k, v
+
+    v_in_place = False
+
+    def set_sharded(self, sharded: bool):
+        """one GPU, head_dim 128: v stays in the projection layout and o comes back token-major (svg.models._core.TOKEN_MAJOR_IO); the
+        head-sharded step exchanges contiguous head slices and keeps the copies"""
+        self.v_in_place = (not sharded) and self.core.TOKEN_MAJOR_IO and self.geo.hd == 128 and not self.prescale
 
     def attention(self, q, k, v, sparse: bool):
         """q, k, v [1, H_local, S, hd] -> o [1, H_local, S, hd]"""
@@ -328,6 +337,8 @@ def run_step(st: Stack, img, txt, sparse_step: bool, first_layers_fp: int, attn_
     sharded = sh is not None and sh.world > 1
     q_buf, k_buf, v_buf = (torch.empty(1, Sr, hid, device=img.device, dtype=img.dtype) for _ in range(3))
     layer = 0
+    if hasattr(ops, "set_sharded"):
+        ops.set_sharded(sharded)
 
     def proj(x_img, x_txt, wi, wt):
         with sec("gemm"):
@@ -355,7 +366,8 @@ def run_step(st: Stack, img, txt, sparse_step: bool, first_layers_fp: int, attn_
             if sharded:
                 o = sh.to_tokens(o[0])[None]                                     # [1, H, S_r, hd]
         with sec("prologue"):
-            o = o.transpose(1, 2).reshape(Sr, hid)      # head-major -> token-major for the output projection (one copy)
+            o = o.transpose(1, 2).reshape(Sr, hid)      # head-major -> token-major for the output projection (one copy; a view when the
+                                                        # attention wrote o token-major: svg.models._core.TOKEN_MAJOR_IO)
         if events:
             e1.record()
             attn_events.append((e0, e1))
@@ -632,8 +644,19 @@ class WanHipOps:
     def prologue(self, blk, st, q_buf, k_buf, v_buf, pos0, n):
         """projection outputs [1, S_r, hid] -> head-major q, k, v [1, H, S_r, hd]: RMSNorm across all heads + complex RoPE at positions
         pos0 .. + transpose in ONE pass (svg_rmsnorm_rope_transpose — what WanAttn_*Processor.get_fused_prologue runs)"""
-        return self.nat.rmsnorm_rope_transpose(q_buf, k_buf, v_buf, self.geo.heads, blk["nq"], blk["nk"], 1e-6, 2,
-                                               st.rot_real[pos0:pos0 + n].contiguous(), st.rot_imag[pos0:pos0 + n].contiguous(), 0, n)
+        vin = None if self.v_in_place else v_buf
+        q, k, v = self.nat.rmsnorm_rope_transpose(q_buf, k_buf, vin, self.geo.heads, blk["nq"], blk["nk"], 1e-6, 2,
+                                                  st.rot_real[pos0:pos0 + n].contiguous(), st.rot_imag[pos0:pos0 + n].contiguous(), 0, n)
+        if self.v_in_place:     # the attention kernels read v where the projection wrote it (svg_attn_layout_t): a view, no transpose copy
+            v = v_buf.unflatten(2, (self.geo.heads, -1)).transpose(1, 2)
+        return q, k, v
+
+    v_in_place = False
+
+    def set_sharded(self, sharded: bool):
+        """one GPU, head_dim 128: v stays in the projection layout and o comes back token-major (svg.models._core.TOKEN_MAJOR_IO); the
+        head-sharded step exchanges contiguous head slices and keeps the copies"""
+        self.v_in_place = (not sharded) and self.core.TOKEN_MAJOR_IO and self.geo.hd == 128
 
     def self_attention(self, q, k, v, layer: int, sparse: bool, head_shard=None):
         g = self.geo
@@ -682,6 +705,8 @@ def run_step_wan(st: WanStack, x, sparse_step: bool, first_layers_fp: int, ops, 
         head_shard = (sh.rank * Hl, (sh.rank + 1) * Hl, H)
     lin = torch.addmm
     text = st.text
+    if hasattr(ops, "set_sharded"):
+        ops.set_sharded(sharded)
 
     for layer, b in enumerate(st.blocks):
         m = b["mod"]
@@ -702,7 +727,8 @@ def run_step_wan(st: WanStack, x, sparse_step: bool, first_layers_fp: int, ops, 
             if sharded:
                 o = sh.to_tokens(o[0])[None]
         with sec("prologue"):
-            o = o.transpose(1, 2).reshape(Sr, hid)       # head-major -> token-major for the output projection (one copy)
+            o = o.transpose(1, 2).reshape(Sr, hid)       # head-major -> token-major for the output projection (one copy; a view when the
+                                                         # attention wrote o token-major: svg.models._core.TOKEN_MAJOR_IO)
         with sec("gemm"):
             o = lin(b["bo"], o, b["wo"].t())
             st.gemm_flops += 2.0 * Sr * hid * hid

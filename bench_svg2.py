@@ -127,9 +127,11 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
                                         k_sizes.view(H, KB).contiguous(), variant=a.variant)
             o = nat.permute_rows(op, qi, inverse=True)
         else:
+            # (rows_covered: the cluster sizes add up to S, so the wrapper skips the zero fill — what svg2_sparse_attention passes)
             o = nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dmap.view(H, QB, KB).contiguous(),
                                        q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8)
+                                       q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), variant=a.variant, fp8=a.fp8,
+                                       rows_covered=True)
         t[3].record()
         torch.cuda.synchronize()
         if it >= a.warmup:
@@ -155,6 +157,32 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         except Exception:  # noqa: BLE001  (a measurement aid: its failure must not cost the block)
             attention_sclk_mhz = None
         torch.cuda.synchronize()
+    # the same plan with v read in place from a projection's output [S, H * D] and o written token-major (svg_varblock_attention_strided:
+    # what the processors run on one GPU, svg.models._core.TOKEN_MAJOR_IO), beside the contiguous call with and without the zero fill
+    io_ab = None
+    if not a.materialize and not a.fp8 and a.variant == -1 and D == 128:
+        def _t(fn, n=3):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            for _ in range(n):
+                r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n, r
+        pa = (dmap.view(H, QB, KB).contiguous(), q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous())
+        pk = dict(q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous())
+        v_tok = v.transpose(1, 2).contiguous().transpose(1, 2)      # [1, H, S, D] view of a token-major [1, S, H * D] buffer
+        t_zero, o_zero = _t(lambda: nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), *pa, **pk))
+        t_cont, _ = _t(lambda: nat.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), *pa, rows_covered=True, **pk))
+        t_str, o_str = _t(lambda: nat.varblock_attention(q, k, v_tok, *pa, rows_covered=True, token_major_out=True, **pk))
+        t_vc, _ = _t(lambda: v_tok.contiguous())
+        t_oc, _ = _t(lambda: o_zero.view(1, H, S, D).transpose(1, 2).contiguous())
+        io_ab = {"contiguous_zero_filled_ms": round(t_zero, 3), "contiguous_ms": round(t_cont, 3), "v_in_place_o_token_major_ms": round(t_str, 3),
+                 "v_transpose_copy_ms": round(t_vc, 3), "o_transpose_copy_ms": round(t_oc, 3),
+                 "bit_identical": bool(torch.equal(o_str.reshape(H, S, D), o_zero.reshape(H, S, D)))}
+        del v_tok, o_str, o_zero
     # spot rows of the last timed output against a torch fp32 statement of the op (text rows: the two pseudo clusters)
     qlab, klab = ql.view(H, V), kl.view(H, V)
     if ctx:
@@ -184,6 +212,8 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
         "attention_sclk_mhz": attention_sclk_mhz,     # granted shader clock during three attention launches (svg_debug_clock_probe); 2400 = nominal
         "algorithmic_bytes": 4.0 * H * S * D * 2,     # q, k, v read once + o written once
     }
+    if io_ab is not None:
+        out["io_layout_ab"] = io_ab
     traffic = _pmc_traffic(a.workload, a.fp8)
     if traffic:
         out.update(traffic)

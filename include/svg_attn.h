@@ -132,6 +132,36 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
                        int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                        int32_t variant, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Strided tensors: attention straight out of / into the projection layout.
+ * ref: the reference's processors build q, k, v as `proj(x).unflatten(2, (heads, -1)).transpose(1, 2)` and hand the result back as
+ *      `hidden_states.transpose(1, 2).flatten(2, 3)` (svg/models/wan/attention.py:123-125,168-170, hyvideo/attention.py:83-85,202) —
+ *      flex_attention / flash-attn take the strided VIEWS, and what they cannot take is copied: one transpose copy per tensor and
+ *      layer (V in, O out: 2 x 2 x S x H x D x 2 bytes that carry no arithmetic).
+ * A tensor here is a [B, H, S, D] view whose last dimension is contiguous; strides are in ELEMENTS.  Head index bh = b * H + h with
+ * H = heads_per_batch (k / v of svg_varblock_attention_strided: kv_heads_per_batch).  The contiguous [BH, S, D] layout of every other
+ * entry point is { batch = H * S * D, head = S * D, row = D }; the projection layout [B, S, H * D] is { S * H * D, D, H * D }; a slice
+ * of a fused QKV projection [B, S, 3 * H * D] is { 3 * S * H * D, D, 3 * H * D } behind a base pointer moved to the slice.
+ * Requirements: base pointers and row strides multiples of 16 bytes; S * row stride * 2 < 2^32 for k and v (their LDS-DMA requests
+ * carry 32-bit byte offsets per head), row strides < 2^23 elements.  Head_dim 128 on the default schedule only (the 16x16x32 body,
+ * variant 0 / 8 of svg_band_attention, the default of svg_varblock_attention; svg_sample_mse: its second form, bf16); anything else
+ * returns SVG_ERR_UNSUPPORTED and the caller copies, as the reference does.  Results are bit-identical to the contiguous call on the
+ * same values (tests/test_gpu_strided.py).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct svg_tensor_strides {
+    int64_t batch, head, row;          /* element strides of a [B, H, S, D] view, stride(D) == 1 */
+} svg_tensor_strides_t;
+
+typedef struct svg_attn_layout {
+    int32_t heads_per_batch;           /* H of q / o (and of k / v unless kv_heads_per_batch says otherwise) */
+    int32_t kv_heads_per_batch;        /* 0: = heads_per_batch */
+    svg_tensor_strides_t q, k, v, o;
+} svg_attn_layout_t;
+
+int svg_band_attention_strided(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                               const svg_attn_layout_t* layout, void* stream);
+
 /* svg_band_attention for a q that already carries the softmax scale: q_scaled = q * sm_scale * log2(e), rounded ONCE to the 16-bit
  * type by whoever produced q (svg_qk_norm_rope* with q_scale — the processors' prologue — so no second rounding happens on that
  * path).  The kernel then starts its score accumulators at minus the row's softmax reference and the MFMAs deliver the exponent
@@ -186,6 +216,14 @@ int svg_varblock_attention(const void* q, const void* k, const void* v, void* o,
                            const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
                            const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
                            size_t workspace_bytes, int32_t variant, void* stream);
+/* svg_varblock_attention (variant -1) on strided q, k, v, o: svg_attn_layout_t above; heads_per_batch counts q heads,
+ * kv_heads_per_batch kv heads (0: heads_per_batch * Hkv / Hq).  Head_dim 128 and block-rows large enough for the default body
+ * (Sq >= 160 * QB), otherwise SVG_ERR_UNSUPPORTED. */
+int svg_varblock_attention_strided(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
+                                   int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
+                                   const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB, int32_t KB,
+                                   const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                                   size_t workspace_bytes, const svg_attn_layout_t* layout, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Online profiler (SVG1): mean-squared error of the two candidate masks on sampled query rows.
@@ -226,6 +264,12 @@ size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t D, int32_t 
 int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S,
                    int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* svg_sample_mse[_flagged] on strided q, k, v (svg_attn_layout_t above; layout->o is ignored).  skip_flag: NULL, or the device flag
+ * of svg_sample_mse_flagged.  bf16 only (the second form of the kernel); fp16 with row strides other than D: SVG_ERR_UNSUPPORTED. */
+int svg_sample_mse_strided(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S,
+                           int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
+                           void* workspace, size_t workspace_bytes, const int32_t* skip_flag, const svg_attn_layout_t* layout,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * flash-kmeans (Euclidean Lloyd iterations, batched over heads).
@@ -409,6 +453,11 @@ int svg_layernorm_modulate_forward_ex(const void* x, void* y, const void* weight
 int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                               const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream);
+/* svg_band_attention_switch on strided tensors (svg_attn_layout_t above; head_dim 128). */
+int svg_band_attention_switch_strided(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                      int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                      const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag,
+                                      const svg_attn_layout_t* layout, void* stream);
 int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S,
                            int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse,
                            void* workspace, size_t workspace_bytes, const int32_t* skip_flag, void* stream);

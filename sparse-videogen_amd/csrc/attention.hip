@@ -155,6 +155,7 @@ struct VarblockPolicy {
                                     // `partner` (same kv head) — "remainder packing", see varblock_pair_kernel
         const int32_t* q_row_idx;   // [Hq, Sq] or null
         const int32_t* kv_row_idx;  // [Hkv, Skv] or null
+        AttnLayout lay;             // strides of q, k, v, o (contiguous [H, S, D] unless the call came through svg_varblock_attention_strided)
     };
     struct Ctx {
         int hq, hkv, q0, q_end, nT, total;  // q rows [q0, q_end) in permuted coordinates; total = active keys
@@ -284,10 +285,14 @@ struct VarblockPolicy {
         return true;
     }
 
-    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.hq * p.Sq * D; }
-    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.hkv * p.Skv * D; }
-    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.hkv * p.Skv * D; }
-    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.hq * p.Sq * D; }
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + layout_head_off(p.lay.q_bs, p.lay.q_hs, p.lay.hpb_q, c.hq); }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + layout_head_off(p.lay.k_bs, p.lay.k_hs, p.lay.hpb_kv, c.hkv); }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + layout_head_off(p.lay.v_bs, p.lay.v_hs, p.lay.hpb_kv, c.hkv); }
+    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + layout_head_off(p.lay.o_bs, p.lay.o_hs, p.lay.hpb_q, c.hq); }
+    static __device__ __forceinline__ int q_rs(const Params& p) { return p.lay.q_rs; }   // row strides in elements (attn_m16.h only, see BandPolicy)
+    static __device__ __forceinline__ int k_rs(const Params& p) { return p.lay.k_rs; }
+    static __device__ __forceinline__ int v_rs(const Params& p) { return p.lay.v_rs; }
+    static __device__ __forceinline__ int o_rs(const Params& p) { return p.lay.o_rs; }
 
     // (the "logical" index of a query row is its row inside the tile here: all the mask needs is which member it belongs to)
     static __device__ __forceinline__ int q_logical(const Ctx&, int row) { return row; }
@@ -899,6 +904,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
     }
     if (variant == kBandAuto) variant = band_default(D);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
+    if (opts.strided && variant != kBandM16) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
     if (dtype == SVG_DTYPE_BF16 && D == 64) return FN<__bf16, 64>(__VA_ARGS__);                 \
@@ -953,6 +959,17 @@ extern "C" int svg_band_attention(const void* q, const void* k, const void* v, v
     const int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
     if (rc != SVG_OK) return rc;
     return band_dispatch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, variant, BandOpts(), (hipStream_t)stream);
+}
+
+extern "C" int svg_band_attention_strided(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                          int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                          const svg_attn_layout_t* layout, void* stream) {
+    int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
+    if (rc != SVG_OK) return rc;
+    BandOpts opts;
+    opts.strided = true;
+    if (rc = layout_from_abi(layout, BH, BH, S, S, D, q, k, v, o, opts.lay); rc != SVG_OK) return rc;
+    return band_dispatch(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, kBandAuto, opts, (hipStream_t)stream);
 }
 
 extern "C" int svg_band_attention_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,
@@ -1042,19 +1059,26 @@ extern "C" int svg_wait_counters_deadline(const int32_t* counters, int32_t n, in
     return launch_status();
 }
 
-extern "C" int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
-                                         int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
-                                         const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream) {
+// svg_band_attention_switch (layout == nullptr: contiguous [BH, S, D] tensors) and svg_band_attention_switch_strided
+static int band_switch_entry(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D, int32_t dtype,
+                             float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const svg_band_mask_t* alt_mask,
+                             const int32_t* use_alt_flag, const svg_attn_layout_t* layout, void* stream) {
     if (!alt_mask || !use_alt_flag) return SVG_ERR_BAD_ARG;
     int rc = band_check_args(q, k, v, o, BH, S, D, mask, perm);
     if (rc == SVG_OK) rc = band_check_args(q, k, v, o, BH, S, D, alt_mask, nullptr);
     if (rc != SVG_OK) return rc;
+    BandOpts opts;
+    if (layout) {
+        if (D != 128) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
+        opts.strided = true;
+        if (rc = layout_from_abi(layout, BH, BH, S, S, D, q, k, v, o, opts.lay); rc != SVG_OK) return rc;
+    }
     if (D == 128 && (dtype == SVG_DTYPE_BF16 || dtype == SVG_DTYPE_F16)) {   // the default schedule of this head size (attn_m16.h)
         auto go = [&](auto t_c) -> int {
             using T = decltype(t_c);
             using Pol = BandPolicy<T, 128, 8, false>;
-            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
-            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
+            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr, opts);
             auto kern = band_attn_m16_switch_kernel<T>;
             if (const int r2 = configure_lds((const void*)kern, attn_m16_lds_bytes()); r2 != SVG_OK) return r2;
             hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_m16_lds_bytes(), (hipStream_t)stream, a, b, use_alt_flag);
@@ -1076,6 +1100,20 @@ extern "C" int svg_band_attention_switch(const void* q, const void* k, const voi
         return dtype == SVG_DTYPE_BF16 ? go(__bf16{}) : go(_Float16{});
     }
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                         int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                         const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream) {
+    return band_switch_entry(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, alt_mask, use_alt_flag, nullptr, stream);
+}
+
+extern "C" int svg_band_attention_switch_strided(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
+                                                 int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
+                                                 const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag,
+                                                 const svg_attn_layout_t* layout, void* stream) {
+    if (!layout) return SVG_ERR_BAD_ARG;
+    return band_switch_entry(q, k, v, o, BH, S, D, dtype, sm_scale, mask, perm, alt_mask, use_alt_flag, layout, stream);
 }
 
 extern "C" int svg_band_attention_switch_prescaled(const void* q_scaled, const void* k, const void* v, void* o, int32_t BH, int32_t S,
@@ -1160,7 +1198,8 @@ template <typename T, int D, int NW>
 static int run_varblock(const void* q, const void* k, const void* v, void* o, int Hq, int Hkv, int Sq, int Skv,
                         float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int QB,
                         int KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* ws, bool block_row_order, bool trace,
-                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0, bool body_m16 = false) {
+                        hipStream_t st, const F8GArgs* f8 = nullptr, int order_mode = 0, bool body_m16 = false,
+                        const AttnLayout* lay = nullptr) {
     // body_m16 (NW == -8, head_dim 128): the two-phase body on 16x16x32 MFMAs (attn_m16.h) instead of the 32x32x16 one
     int32_t* q_off = (int32_t*)ws;
     int32_t* tile_off = q_off + (size_t)Hkv * (QB + 1);
@@ -1180,6 +1219,7 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
         p.scale_log2 = sm_scale * 1.4426950408889634f;
         p.block_map = block_map, p.q_off = q_off, p.k_off = k_off, p.tile_off = toff;
         p.q_row_idx = q_row_idx, p.kv_row_idx = kv_row_idx;
+        p.lay = lay ? *lay : contiguous_layout(Hq, Hkv, Sq, Skv, D);
         p.order = nullptr;
         if constexpr (NW == -8 || NW == -9) {
             const int group = Hq / Hkv;
@@ -1278,16 +1318,22 @@ static int run_varblock(const void* q, const void* k, const void* v, void* o, in
 }
 }  // namespace svg
 
-extern "C" int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv,
-                                      int32_t Sq, int32_t Skv, int32_t D, int32_t dtype, float sm_scale,
-                                      const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB,
-                                      int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
-                                      size_t workspace_bytes, int32_t variant, void* stream) {
+// svg_varblock_attention (abi_layout == nullptr: contiguous [H, S, D] tensors) and svg_varblock_attention_strided
+static int varblock_entry(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq, int32_t Skv, int32_t D,
+                          int32_t dtype, float sm_scale, const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes,
+                          int32_t QB, int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                          size_t workspace_bytes, int32_t variant, const svg_attn_layout_t* abi_layout, void* stream) {
     if (!q || !k || !v || !o || !block_map || !q_sizes || !k_sizes || !workspace) return SVG_ERR_BAD_ARG;
     if (Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Sq <= 0 || Skv <= 0 || QB <= 0 || KB <= 0) return SVG_ERR_BAD_ARG;
     if (KB > kVbMaxKB) return SVG_ERR_UNSUPPORTED;
     if ((int64_t)Skv * D * 2 >= (1ll << 32) || (int64_t)Sq * D * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq)) return SVG_ERR_WORKSPACE;
+    AttnLayout lay_storage;
+    const AttnLayout* lay = nullptr;
+    if (abi_layout) {
+        if (const int rc = layout_from_abi(abi_layout, Hq, Hkv, Sq, Skv, D, q, k, v, o, lay_storage); rc != SVG_OK) return rc;
+        lay = &lay_storage;
+    }
     hipStream_t st = (hipStream_t)stream;
     // variant 0: 4 waves, 128-row q tiles; 1: 8 waves, 256-row q tiles; 2: mixed (full 256-row tiles on 8 waves, rest on 4)
     // (6 = 3: the longest-first order is the default again — the similarity order, variant 7, raised the L2 hit rate from 31 % to 48 %
@@ -1298,7 +1344,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     if (variant == 8 || variant == 9) variant = 3;
     const bool block_row_order = (variant == 4), trace = (variant == 5);
     const int order_mode = variant == 7 ? 2 : (variant == 6 ? 1 : 0);   // 0: longest-first + remainder packing, 1: longest-first, 2: similarity order
-#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode, body_m16
+#define SVG_VB_ARGS q, k, v, o, Hq, Hkv, Sq, Skv, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx, workspace, block_row_order, trace, st, nullptr, order_mode, body_m16, lay
 #define SVG_VB_DISPATCH(T)                                                                       \
     if (D == 128) {                                                                              \
         if (variant == 2) return run_varblock<T, 128, 0>(SVG_VB_ARGS);                           \
@@ -1315,6 +1361,7 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
     const bool body_m16 = (variant >= 3 && D == 128 && !force_pp2);
+    if (lay && !(body_m16 && !trace)) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {
@@ -1323,6 +1370,25 @@ extern "C" int svg_varblock_attention(const void* q, const void* k, const void* 
 #undef SVG_VB_ARGS
 #undef SVG_VB_DISPATCH
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_varblock_attention(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv,
+                                      int32_t Sq, int32_t Skv, int32_t D, int32_t dtype, float sm_scale,
+                                      const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB,
+                                      int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                                      size_t workspace_bytes, int32_t variant, void* stream) {
+    return varblock_entry(q, k, v, o, Hq, Hkv, Sq, Skv, D, dtype, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx,
+                          workspace, workspace_bytes, variant, nullptr, stream);
+}
+
+extern "C" int svg_varblock_attention_strided(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv,
+                                              int32_t Sq, int32_t Skv, int32_t D, int32_t dtype, float sm_scale,
+                                              const uint8_t* block_map, const int32_t* q_sizes, const int32_t* k_sizes, int32_t QB,
+                                              int32_t KB, const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
+                                              size_t workspace_bytes, const svg_attn_layout_t* layout, void* stream) {
+    if (!layout) return SVG_ERR_BAD_ARG;
+    return varblock_entry(q, k, v, o, Hq, Hkv, Sq, Skv, D, dtype, sm_scale, block_map, q_sizes, k_sizes, QB, KB, q_row_idx, kv_row_idx,
+                          workspace, workspace_bytes, -1, layout, stream);
 }
 
 extern "C" size_t svg_varblock_attention_fp8_workspace_bytes(int32_t Hq, int32_t Hkv, int32_t QB, int32_t KB, int32_t Sq, int32_t Skv,

@@ -151,7 +151,6 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     P::kv_cursor_init(prm, ctx, cur, krow);
     const unsigned vsw = (unsigned)((lane >> 4) & 1) << 1;                       // ((key >> 2) & 1) << 1 of this lane's key row: the chunk XOR of BOTH images
     const unsigned col_v = (unsigned)(dma_db0 * 64 + (((lane & 3) ^ vsw) * 16));
-    const unsigned k_xor = 0u;                                                   // (the K source address is the V one: the same swizzle)
     const unsigned lds_piece = lds0 + (unsigned)(dma_db0 * (kBN * 64) + dma_kg * 1024);
     int nphys = 0, nnext = 0;
     auto resolve = [&](int t, auto guard_c) {
@@ -160,22 +159,25 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     };
     constexpr std::true_type kGuarded{};
     auto take = [&]() { nphys = nnext; };
+    // byte offsets of a key row inside its head: row * (row stride in bytes) + the lane's 16-byte column.  The row strides are kernel
+    // arguments (svg_attn_layout_t: 2 D for contiguous heads, H * D or 3 * H * D elements for k / v read in place from a projection's
+    // output) — one v_mad_u32_u24 per tensor and tile (rows and byte strides are below 2^24, the products below 2^32: layout_from_abi)
+    const unsigned k_rsb = (unsigned)P::k_rs(prm) * 2u, v_rsb = (unsigned)P::v_rs(prm) * 2u;
     auto dma_piece = [&](int t, auto j_c) {
         constexpr int j = decltype(j_c)::value;
         const unsigned st = __builtin_amdgcn_readfirstlane(lds_piece + (unsigned)((t % NS) * kStage) + j * (kBN * 64));
-        const unsigned vo = ((unsigned)nphys * (unsigned)(2 * D)) | col_v;
-        unsigned kvo;
-        const unsigned kx = k_xor;
+        const unsigned ko = __umul24((unsigned)nphys, k_rsb) + col_v;
+        const unsigned vo = __umul24((unsigned)nphys, v_rsb) + col_v;
         const char* const kbp = (const char*)kb_ + j * 64;
         const char* const vbp = (const char*)vb + j * 64;
-        asm volatile("s_mov_b32 m0, %1\n\t"
-                     "v_xor_b32 %0, %2, %3\n\t"
-                     "global_load_lds_dwordx4 %0, %4\n\t"
-                     "s_add_u32 m0, m0, %6\n\t"
+        asm volatile("s_mov_b32 m0, %0\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, %5"
-                     : "=&v"(kvo)
-                     : "s"(st), "v"(vo), "v"(kx), "s"(kbp), "s"(vbp), "n"(kImg)
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_add_u32 m0, m0, %5\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %4"
+                     :
+                     : "s"(st), "v"(ko), "v"(vo), "s"(kbp), "s"(vbp), "n"(kImg)
                      : "memory", "scc");
     };
     auto dma_issue = [&](int t) {
@@ -200,7 +202,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
         const int row_in_wg = wave * 32 + rb * 16 + n16;
         const int qp = P::q_phys(prm, ctx, row_in_wg);
         q_log[rb] = P::q_logical(ctx, row_in_wg);
-        const T* qrow = qb + (size_t)(qp >= 0 ? qp : 0) * D + g4 * 8;
+        const T* qrow = qb + (size_t)(qp >= 0 ? qp : 0) * P::q_rs(prm) + g4 * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const Q8*)(qrow + ks * 32);
         P::row_intervals(prm, ctx, q_log[rb], m_a0[rb], m_alen[rb], m_b0[rb], m_blen[rb]);
@@ -559,6 +561,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     T* __restrict__ ob = P::o_base(prm, ctx);
+    const int o_rs = P::o_rs(prm);
     constexpr int kLanesPerRow = D * 2 / 8;
     constexpr int kRowsPerPass = 64 / kLanesPerRow;
     const int sub = lane / kLanesPerRow;
@@ -570,7 +573,7 @@ __device__ __forceinline__ void attn_body_m16(const typename P::Params& prm, cha
     for (int i = 0; i < 32 / kRowsPerPass; ++i) {
         const int rr = i * kRowsPerPass + sub;
         const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
-        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+        if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * o_rs) + colb) = val;
     }
     P::notify(prm, ctx);
 }

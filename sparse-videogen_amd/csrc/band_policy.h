@@ -15,6 +15,8 @@ struct BandOpts {
     bool prescaled = false;    // q carries sm_scale * log2(e) (svg_band_attention_prescaled; two-phase body only)
     bool trace = false;        // diagnostics builds: the traced kernel (svg_debug_pp_trace)
     int trace_abl = 0;         // ... and its timing ablation
+    bool strided = false;      // `lay` describes the tensors (svg_band_attention_strided); otherwise contiguous [BH, S, D]
+    AttnLayout lay{};
 };
 
 // =====================================================================================================
@@ -22,6 +24,7 @@ struct BandOpts {
 // =====================================================================================================
 template <typename T, int D, int NW, bool SKEW, int ABL = 0, int RB = 1, int SUBS = 1>
 struct BandPolicy {
+    static constexpr int kHeadDim = D;
     static constexpr int kSubTiles = SUBS;   // 64-key tiles per LDS stage / barrier
     static constexpr int kPrefetch = (ABL == 12) ? 3 : (ABL == 13 ? 2 : 1);  // operand ring depth (k-steps / MFMA steps ahead)
     static constexpr bool kFixup = false;
@@ -60,6 +63,7 @@ struct BandPolicy {
         // start exchanging it while the launch is still working on the next heads (dispatch is head-major)
         int32_t* done;             // int32 [BH * done_nseg + BH]: segment counters, then one hidden counter per head (see notify)
         int done_nseg, done_tps;   // counters per head: segment of q-tile qt (row order) = min(qt / done_tps, done_nseg - 1)
+        AttnLayout lay;            // strides of q, k, v, o (contiguous [BH, S, D] unless the call came through a *_strided entry point)
     };
     struct Ctx {
         int head, qt, q0, q_end, nT, perm;
@@ -175,10 +179,15 @@ struct BandPolicy {
         return true;
     }
 
-    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + layout_head_off(p.lay.q_bs, p.lay.q_hs, p.lay.hpb_q, c.head); }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + layout_head_off(p.lay.k_bs, p.lay.k_hs, p.lay.hpb_kv, c.head); }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + layout_head_off(p.lay.v_bs, p.lay.v_hs, p.lay.hpb_kv, c.head); }
+    static __device__ __forceinline__ T* o_base(const Params& p, const Ctx& c) { return p.o + layout_head_off(p.lay.o_bs, p.lay.o_hs, p.lay.hpb_q, c.head); }
+    // row strides in elements (attn_m16.h; every other body addresses rows at stride D and the host refuses anything else for it)
+    static __device__ __forceinline__ int q_rs(const Params& p) { return p.lay.q_rs; }
+    static __device__ __forceinline__ int k_rs(const Params& p) { return p.lay.k_rs; }
+    static __device__ __forceinline__ int v_rs(const Params& p) { return p.lay.v_rs; }
+    static __device__ __forceinline__ int o_rs(const Params& p) { return p.lay.o_rs; }
 
     static __device__ __forceinline__ int q_logical(const Ctx& c, int row) { return c.q0 + row; }
     static __device__ __forceinline__ bool wave_active(const Ctx& c, int wrow0) { return c.q0 + wrow0 < c.q_end; }
@@ -417,6 +426,7 @@ inline typename Pol::Params make_band_params(const void* q, const void* k, const
                                              const svg_band_mask_t* mask, const svg_perm_desc_t* perm, const BandOpts& opts = BandOpts()) {
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v, p.o = (T*)o;
+    p.lay = opts.strided ? opts.lay : contiguous_layout(BH, BH, S, S, Pol::kHeadDim);
     p.S = S, p.BH = BH, p.nqt = (S + Pol::BM - 1) / Pol::BM;
     p.scale_log2 = sm_scale * 1.4426950408889634f;
     p.real_len = mask->real_len, p.band = mask->band;

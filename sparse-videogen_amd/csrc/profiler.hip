@@ -62,6 +62,7 @@ struct ProfilePolicy {
         float fix_scale;    // sm_scale when emulate
         int emulate;
         const int64_t* rows;
+        AttnLayout lay;     // strides of q, k, v (svg_sample_mse_strided; row strides other than D: the second form only)
         int vid0, F, P, V;
         ProfVariant var[2];
         float* part;        // [3][BH][n_chunks][kProfMaxRows][D + 4]
@@ -140,9 +141,9 @@ struct ProfilePolicy {
         }
         return true;
     }
-    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + (size_t)c.head * p.S * D; }
-    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + (size_t)c.head * p.S * D; }
+    static __device__ __forceinline__ const T* q_base(const Params& p, const Ctx& c) { return p.q + layout_head_off(p.lay.q_bs, p.lay.q_hs, p.lay.hpb_q, c.head); }
+    static __device__ __forceinline__ const T* k_base(const Params& p, const Ctx& c) { return p.k + layout_head_off(p.lay.k_bs, p.lay.k_hs, p.lay.hpb_kv, c.head); }
+    static __device__ __forceinline__ const T* v_base(const Params& p, const Ctx& c) { return p.v + layout_head_off(p.lay.v_bs, p.lay.v_hs, p.lay.hpb_kv, c.head); }
 
     // workgroup row -> sampled row of its role
     static __device__ __forceinline__ bool exists(const Params& p, int row) {
@@ -348,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     const int ntiles = (prm.S + kBN - 1) / kBN;
     const int t0 = chunk * prm.tiles_per_chunk;
     const int nT = max(0, min(prm.tiles_per_chunk, ntiles - t0));
-    const T* __restrict__ qb = prm.q + (size_t)head * prm.S * D;
-    const T* __restrict__ kb_ = prm.k + (size_t)head * prm.S * D;
-    const T* __restrict__ vb = prm.v + (size_t)head * prm.S * D;
+    const T* __restrict__ qb = prm.q + layout_head_off(prm.lay.q_bs, prm.lay.q_hs, prm.lay.hpb_q, head);
+    const T* __restrict__ kb_ = prm.k + layout_head_off(prm.lay.k_bs, prm.lay.k_hs, prm.lay.hpb_kv, head);
+    const T* __restrict__ vb = prm.v + layout_head_off(prm.lay.v_bs, prm.lay.v_hs, prm.lay.hpb_kv, head);
 
     // The sampled rows in the order of their coordinate under the second mask (token-major in every model of the reference).  The squared
     // errors are summed over the rows: their order is free.  Rank by counting, through LDS.
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     __syncthreads();    // (the staging below reuses the bytes)
     V8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qb + (size_t)qrow * D + ks * 32 + g4 * 8);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qb + (size_t)qrow * prm.lay.q_rs + ks * 32 + g4 * 8);
 
     // the two masks' per-lane / per-wave state, as ProfilePolicy::init computes it (output 1 <- var[0], output 2 <- var[1])
     typename Pol::Ctx mc[2];
@@ -411,21 +412,24 @@ __global__ __launch_bounds__(256, 2) void profile16_kernel(typename ProfilePolic
     const unsigned vsw = (unsigned)((lane >> 4) & 1) << 1;
     const unsigned col_v = ((lane & 3) ^ vsw) * 16u;
     const int krow = 16 * wave + (lane >> 2);
+    const unsigned k_rsb = (unsigned)prm.lay.k_rs * 2u, v_rsb = (unsigned)prm.lay.v_rs * 2u;
     auto dma_tile = [&](int t) {
         const int l = (t0 + t) * kBN + krow;
         const unsigned nphys = (unsigned)(l < prm.S ? l : 0);    // rows behind the sequence: masked below (the last tile is never FULL)
 #pragma unroll
         for (int j = 0; j < D / 32; ++j) {
             const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((t & 1) * kStage) + (unsigned)(j * (kBN * 64) + wave * 1024));
-            const unsigned vo = (nphys * (unsigned)(2 * D)) | (unsigned)(j * 64) | col_v;
+            // row * (row stride in bytes, a kernel argument: svg_attn_layout_t) + the d-block + the lane's 16-byte column
+            const unsigned ko = __umul24(nphys, k_rsb) + ((unsigned)(j * 64) | col_v);
+            const unsigned vo = __umul24(nphys, v_rsb) + ((unsigned)(j * 64) | col_v);
             asm volatile("s_mov_b32 m0, %0\n\t"
                          "s_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %2\n\t"
-                         "s_add_u32 m0, m0, %4\n\t"
+                         "global_load_lds_dwordx4 %1, %3\n\t"
+                         "s_add_u32 m0, m0, %5\n\t"
                          "s_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %3"
+                         "global_load_lds_dwordx4 %2, %4"
                          :
-                         : "s"(st), "v"(vo), "s"(kb_), "s"(vb), "n"(kImg)
+                         : "s"(st), "v"(ko), "v"(vo), "s"(kb_), "s"(vb), "n"(kImg)
                          : "memory", "scc");
         }
     };
@@ -776,10 +780,11 @@ static int prof_chunks(int BH, int S) {
 
 template <typename T, int D>
 static int run_profile(const void* q, const void* k, const void* v, const int64_t* rows, int R, int BH, int S, float sm_scale,
-                       const svg_profile_desc_t* pd, float* out_mse, void* ws, const int32_t* skip, hipStream_t st) {
+                       const svg_profile_desc_t* pd, float* out_mse, void* ws, const int32_t* skip, const AttnLayout* lay, hipStream_t st) {
     using Pol = ProfilePolicy<T, D>;
     typename Pol::Params p;
     p.q = (const T*)q, p.k = (const T*)k, p.v = (const T*)v;
+    p.lay = lay ? *lay : contiguous_layout(BH, BH, S, S, D);
     p.S = S, p.BH = BH, p.R = R;
     p.n_chunks = prof_chunks(BH, S);
     const int ntiles = (S + kBN - 1) / kBN;
@@ -809,6 +814,7 @@ static int run_profile(const void* q, const void* k, const void* v, const int64_
 #else
     constexpr bool kSecondForm = std::is_same_v<T, __bf16>;
 #endif
+    if (!kSecondForm && !p.lay.rows_contiguous(D)) return SVG_ERR_UNSUPPORTED;   // row strides: the second form only (svg_attn_layout_t)
     if constexpr (kSecondForm) {   // one score tile for the three outputs, two workgroups per CU
         constexpr int lds16 = p16_lds_bytes(D);
         auto kern16 = profile16_kernel<T, D>;
@@ -856,10 +862,10 @@ extern "C" size_t svg_sample_mse_workspace_bytes(int32_t BH, int32_t R, int32_t 
     return ((size_t)3 * BH * prof_chunks(BH, S) * kProfMaxRows * (D + 4) + (size_t)BH * kProfRowGroups * 4) * sizeof(float);
 }
 
-extern "C" int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
-                                      int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
-                                      float* out_mse, void* workspace, size_t workspace_bytes, const int32_t* skip_flag,
-                                      void* stream) {
+// svg_sample_mse[_flagged] (abi_layout == nullptr: contiguous [BH, S, D] tensors) and svg_sample_mse_strided
+static int sample_mse_entry(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH, int32_t S, int32_t D,
+                            int32_t dtype, float sm_scale, const svg_profile_desc_t* prof, float* out_mse, void* workspace,
+                            size_t workspace_bytes, const int32_t* skip_flag, const svg_attn_layout_t* abi_layout, void* stream) {
     if (!q || !k || !v || !rows || !prof || !out_mse || !workspace) return SVG_ERR_BAD_ARG;
     if (R <= 0 || BH <= 0 || S <= 0) return SVG_ERR_BAD_ARG;
     if (R > kProfMaxRows) return SVG_ERR_UNSUPPORTED;
@@ -867,14 +873,37 @@ extern "C" int svg_sample_mse_flagged(const void* q, const void* k, const void* 
         if (prof->variant[i].coord == 1 && prof->frame_size < kBN) return SVG_ERR_UNSUPPORTED;  // one-wrap stepping
     if (workspace_bytes < svg_sample_mse_workspace_bytes(BH, R, D, S)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    AttnLayout lay_storage;
+    const AttnLayout* lay = nullptr;
+    if (abi_layout) {   // (o is not a tensor of this call: q stands in for the alignment test)
+        svg_attn_layout_t a = *abi_layout;
+        a.o = a.q;
+        if (const int rc = layout_from_abi(&a, BH, BH, S, S, D, q, k, v, q, lay_storage); rc != SVG_OK) return rc;
+        lay = &lay_storage;
+    }
     if (dtype == SVG_DTYPE_BF16) {
-        if (D == 128) return run_profile<__bf16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
-        if (D == 64) return run_profile<__bf16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
+        if (D == 128) return run_profile<__bf16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, lay, st);
+        if (D == 64) return run_profile<__bf16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, lay, st);
     } else if (dtype == SVG_DTYPE_F16) {
-        if (D == 128) return run_profile<_Float16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
-        if (D == 64) return run_profile<_Float16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, st);
+        if (D == 128) return run_profile<_Float16, 128>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, lay, st);
+        if (D == 64) return run_profile<_Float16, 64>(q, k, v, rows, R, BH, S, sm_scale, prof, out_mse, workspace, skip_flag, lay, st);
     }
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_sample_mse_flagged(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
+                                      int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
+                                      float* out_mse, void* workspace, size_t workspace_bytes, const int32_t* skip_flag,
+                                      void* stream) {
+    return sample_mse_entry(q, k, v, rows, R, BH, S, D, dtype, sm_scale, prof, out_mse, workspace, workspace_bytes, skip_flag, nullptr, stream);
+}
+
+extern "C" int svg_sample_mse_strided(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,
+                                      int32_t S, int32_t D, int32_t dtype, float sm_scale, const svg_profile_desc_t* prof,
+                                      float* out_mse, void* workspace, size_t workspace_bytes, const int32_t* skip_flag,
+                                      const svg_attn_layout_t* layout, void* stream) {
+    if (!layout) return SVG_ERR_BAD_ARG;
+    return sample_mse_entry(q, k, v, rows, R, BH, S, D, dtype, sm_scale, prof, out_mse, workspace, workspace_bytes, skip_flag, layout, stream);
 }
 
 extern "C" int svg_sample_mse(const void* q, const void* k, const void* v, const int64_t* rows, int32_t R, int32_t BH,

@@ -99,4 +99,50 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int kNumXCD = 8;
 constexpr int kNumCU = 256;
 
+// Where the four tensors of an attention call live (kernel-argument form of svg_attn_layout_t, strides in ELEMENTS): element
+// (bh, s, :) of tensor x starts at x + (bh / hpb) * x_bs + (bh % hpb) * x_hs + s * x_rs.  The contiguous [BH, S, D] layout is
+// { hpb = BH, hs = S * D, rs = D }.  Head and batch strides reach every attention body through the policies' *_base(); ROW strides
+// other than D exist in the 16x16x32 body (attn_m16.h) and the online profiler's second form only — the host side refuses them elsewhere.
+struct AttnLayout {
+    int hpb_q, hpb_kv;
+    long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs, o_bs, o_hs;
+    int q_rs, k_rs, v_rs, o_rs;
+    bool rows_contiguous(int D) const { return q_rs == D && k_rs == D && v_rs == D && o_rs == D; }
+};
+inline AttnLayout contiguous_layout(int Hq, int Hkv, long long Sq, long long Skv, int D) {
+    AttnLayout l;
+    l.hpb_q = Hq > 0 ? Hq : 1, l.hpb_kv = Hkv > 0 ? Hkv : 1;
+    l.q_bs = l.o_bs = (long long)Hq * Sq * D, l.k_bs = l.v_bs = (long long)Hkv * Skv * D;
+    l.q_hs = l.o_hs = Sq * D, l.k_hs = l.v_hs = Skv * D;
+    l.q_rs = l.k_rs = l.v_rs = l.o_rs = D;
+    return l;
+}
+// svg_attn_layout_t -> AttnLayout with the checks of the header (16-byte rows, 32-bit LDS-DMA offsets for k / v, 23-bit row strides).
+inline int layout_from_abi(const svg_attn_layout_t* a, int Hq, int Hkv, long long Sq, long long Skv, int D, const void* q, const void* k,
+                           const void* v, const void* o, AttnLayout& l) {
+    if (!a) return SVG_ERR_BAD_ARG;
+    const int hq = a->heads_per_batch, hkv = a->kv_heads_per_batch > 0 ? a->kv_heads_per_batch : (int)((long long)hq * Hkv / (Hq > 0 ? Hq : 1));
+    if (hq <= 0 || hkv <= 0 || Hq % hq != 0 || Hkv % hkv != 0 || Hq / hq != Hkv / hkv) return SVG_ERR_BAD_ARG;
+    l.hpb_q = hq, l.hpb_kv = hkv;
+    const svg_tensor_strides_t* s4[4] = {&a->q, &a->k, &a->v, &a->o};
+    const void* p4[4] = {q, k, v, o};
+    for (int i = 0; i < 4; ++i) {
+        const svg_tensor_strides_t& s = *s4[i];
+        if (s.row < D || s.head < 0 || s.batch < 0) return SVG_ERR_BAD_ARG;
+        if (s.row % 8 != 0 || s.head % 8 != 0 || s.batch % 8 != 0 || ((size_t)p4[i] & 15) != 0) return SVG_ERR_UNSUPPORTED;
+        if (s.row >= (1ll << 23)) return SVG_ERR_UNSUPPORTED;
+    }
+    if (Skv * a->k.row * 2 >= (1ll << 32) || Skv * a->v.row * 2 >= (1ll << 32)) return SVG_ERR_UNSUPPORTED;
+    if (Sq >= (1ll << 24) || Skv >= (1ll << 24)) return SVG_ERR_UNSUPPORTED;
+    l.q_bs = a->q.batch, l.q_hs = a->q.head, l.q_rs = (int)a->q.row;
+    l.k_bs = a->k.batch, l.k_hs = a->k.head, l.k_rs = (int)a->k.row;
+    l.v_bs = a->v.batch, l.v_hs = a->v.head, l.v_rs = (int)a->v.row;
+    l.o_bs = a->o.batch, l.o_hs = a->o.head, l.o_rs = (int)a->o.row;
+    return SVG_OK;
+}
+__device__ __forceinline__ size_t layout_head_off(long long bs, long long hs, int hpb, int head) {
+    const int b = head / hpb;   // (wave-uniform: scalar unit, once per workgroup)
+    return (size_t)b * (size_t)bs + (size_t)(head - b * hpb) * (size_t)hs;
+}
+
 }  // namespace svg

@@ -75,6 +75,18 @@ class ProfileDesc(C.Structure):
 
 _I32, _I64, _F32, _VP, _SZ = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
+
+class TensorStrides(C.Structure):
+    """svg_tensor_strides_t: element strides of a [B, H, S, D] view whose last dimension is contiguous."""
+    _fields_ = [("batch", C.c_int64), ("head", C.c_int64), ("row", C.c_int64)]
+
+
+class AttnLayout(C.Structure):
+    """svg_attn_layout_t (include/svg_attn.h): where q, k, v, o of a *_strided attention call live."""
+    _fields_ = [("heads_per_batch", C.c_int32), ("kv_heads_per_batch", C.c_int32), ("q", TensorStrides), ("k", TensorStrides),
+                ("v", TensorStrides), ("o", TensorStrides)]
+
+
 # name -> (restype, argtypes); must list every symbol include/svg_attn.h declares (tests check this)
 SIGNATURES = {
     "svg_abi_version": (C.c_int, []),
@@ -115,6 +127,14 @@ SIGNATURES = {
     "svg_argsort_labels": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_band_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
                                      C.POINTER(PermDesc), _I32, _VP]),
+    "svg_band_attention_strided": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                             C.POINTER(PermDesc), C.POINTER(AttnLayout), _VP]),
+    "svg_band_attention_switch_strided": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _F32, C.POINTER(BandMask),
+                                                    C.POINTER(PermDesc), C.POINTER(BandMask), _VP, C.POINTER(AttnLayout), _VP]),
+    "svg_varblock_attention_strided": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _VP, _VP,
+                                                 _I32, _I32, _VP, _VP, _VP, _SZ, C.POINTER(AttnLayout), _VP]),
+    "svg_sample_mse_strided": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, C.POINTER(ProfileDesc), _VP, _VP,
+                                         _SZ, _VP, C.POINTER(AttnLayout), _VP]),
     "svg_band_attention_prescaled": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask), C.POINTER(PermDesc), _VP]),
     "svg_band_attention_switch_prescaled": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, C.POINTER(BandMask),
                                                       C.POINTER(PermDesc), C.POINTER(BandMask), _VP, _VP]),
@@ -224,12 +244,61 @@ def _dev(*ts: torch.Tensor) -> None:
             raise RuntimeError("libsvgattn ops need contiguous tensors")
 
 
+def _gpu(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libsvgattn ops need GPU (HIP) tensors; there is no CPU fallback for the sparse path")
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------------
+# strided attention tensors (svg_attn_layout_t): q / k / v read where a projection wrote them, o written where the output projection
+# reads it — the reference's processors hand flex_attention / flash-attn `proj(x).unflatten(2, (H, -1)).transpose(1, 2)` VIEWS and
+# copy what those cannot take (wan/attention.py:123-125,168-170)
+# ------------------------------------------------------------------------------------------------------
+def _view4(t: torch.Tensor) -> torch.Tensor:
+    """[B, H, S, D] view of a [B, H, S, D] or [BH, S, D] tensor (no copy)."""
+    return t if t.dim() == 4 else t.unsqueeze(0)
+
+
+def _strided_ok(t4: torch.Tensor, dma: bool = False) -> bool:
+    """Can a *_strided entry point read / write this [B, H, S, D] view in place?  (layout_from_abi, csrc/svg_common.h)"""
+    B, H, S, D = t4.shape
+    st = t4.stride()
+    if st[3] != 1 or t4.data_ptr() % 16 != 0 or st[2] < D or st[2] >= (1 << 23):
+        return False
+    if any(x % 8 != 0 or x < 0 for x in st[:3]):
+        return False
+    return (not dma) or S * st[2] * 2 < (1 << 32)   # k / v: 32-bit byte offsets per head in the LDS-DMA requests
+
+
+def _is_dense4(t4: torch.Tensor) -> bool:
+    """contiguous [B, H, S, D]: what every entry point without `_strided` takes"""
+    return t4.is_contiguous()
+
+
+def attn_layout(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, o4: torch.Tensor) -> AttnLayout:
+    ts = [TensorStrides(t.stride(0), t.stride(1), t.stride(2)) for t in (q4, k4, v4, o4)]
+    return AttnLayout(q4.shape[1], k4.shape[1], *ts)
+
+
+def token_major_empty(like4: torch.Tensor) -> torch.Tensor:
+    """An uninitialised [B, H, S, D] tensor stored token-major ([B, S, H, D] in memory): `out.transpose(1, 2).flatten(2, 3)` — what
+    every processor of the reference does with the attention output before the output projection — is then a view, not a copy."""
+    B, H, S, D = like4.shape
+    return torch.empty((B, S, H, D), dtype=like4.dtype, device=like4.device).permute(0, 2, 1, 3)
+
+
+def strided_attention_supported(q: torch.Tensor, variant: int = 0) -> bool:
+    """The *_strided entry points exist for the default schedule at head_dim 128 (the 16x16x32 body)."""
+    return q.shape[-1] == 128 and variant == 0 and q.dtype in (torch.bfloat16, torch.float16)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -284,26 +353,46 @@ def argsort_labels(labels: torch.Tensor, K: int):
 def band_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, sm_scale: Optional[float] = None,
                    head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1,
                    frame_size: int = 1, variant: int = 0, out: Optional[torch.Tensor] = None,
-                   done: Optional[torch.Tensor] = None, done_nseg: int = 1, q_prescaled: bool = False) -> torch.Tensor:
-    """q, k, v: [B, H, S, D] (or [BH, S, D]) contiguous bf16/fp16 GPU tensors -> o of the same shape.
+                   done: Optional[torch.Tensor] = None, done_nseg: int = 1, q_prescaled: bool = False,
+                   token_major_out: bool = False) -> torch.Tensor:
+    """q, k, v: [B, H, S, D] (or [BH, S, D]) bf16/fp16 GPU tensors -> o of the same shape.
+    Strided views (last dimension contiguous — e.g. `proj(x).unflatten(2, (H, -1)).transpose(1, 2)`, or a slice of a fused QKV
+    projection) are read in place by svg_band_attention_strided where it exists (head_dim 128, default schedule, plain q, no completion
+    counters) and copied otherwise, as the reference does.  token_major_out: the result is a [B, H, S, D] tensor stored [B, S, H, D]
+    (token_major_empty), so the processors' `.transpose(1, 2).flatten(2, 3)` is a view.
     q_prescaled: q already carries sm_scale * log2(e) (SOFTMAX_Q_SCALE(D) for the default scale; what qk_norm_rope*(q_scale=...)
     writes): svg_band_attention_prescaled, default schedule only.
     done: int32 [BH * (done_nseg + 1)] zeroed completion counters (svg_band_attention_notify[_seg]; see band_notify_target /
     band_notify_layout / wait_counters / notify_counters): counter (h, s) at done[h * done_nseg + s], the last BH words are scratch
     of the library (hidden per-head counters of heads that run with the fused layout permutation)."""
     lib = load()
-    _dev(q, k, v, head_perm_flag)
+    _dev(head_perm_flag)
+    _gpu(q, k, v, out)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
     S, D = q.shape[-2], q.shape[-1]
     BH = q.numel() // (S * D)
-    o = torch.empty_like(q) if out is None else out
-    _dev(o)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
     perm = None
     if head_perm_flag is not None:
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    dense_in = q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and (out is None or out.is_contiguous())
+    if (not dense_in or (token_major_out and out is None)) and done is None and not q_prescaled and strided_attention_supported(q, variant):
+        q4, k4, v4 = _view4(q), _view4(k), _view4(v)
+        o4 = _view4(out) if out is not None else (token_major_empty(q4) if token_major_out else torch.empty(q4.shape, dtype=q.dtype, device=q.device))
+        if _strided_ok(q4) and _strided_ok(k4, True) and _strided_ok(v4, True) and _strided_ok(o4) and o4.shape == q4.shape:
+            lay = attn_layout(q4, k4, v4, o4)
+            rc = lib.svg_band_attention_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o4.data_ptr(), BH, S, D, _dtype_code(q), scale,
+                                                C.byref(mask), C.byref(perm) if perm is not None else None, C.byref(lay), _stream())
+            _check(rc, "svg_band_attention_strided")
+            return out if out is not None else (o4 if q.dim() == 4 else o4.squeeze(0))
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()   # (what no strided entry point takes is copied, as the reference does)
+    if out is not None and not out.is_contiguous():
+        out.copy_(band_attention(q, k, v, mask, sm_scale, head_perm_flag, vid0, num_frame, frame_size, variant, None, done, done_nseg,
+                                 q_prescaled))
+        return out
+    o = torch.empty_like(q) if out is None else out
     if q_prescaled and done is not None:
         _dev(done)
         assert done.dtype == torch.int32 and done.is_contiguous() and variant == 0 and sm_scale is None
@@ -455,24 +544,41 @@ def wait_counters(counters: torch.Tensor, target: int, timeout_ms: int = 0, time
 def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: BandMask, alt_mask: BandMask,
                           use_alt_flag: torch.Tensor, sm_scale: Optional[float] = None,
                           head_perm_flag: Optional[torch.Tensor] = None, vid0: int = 0, num_frame: int = 1, frame_size: int = 1,
-                          out: Optional[torch.Tensor] = None, q_prescaled: bool = False) -> torch.Tensor:
+                          out: Optional[torch.Tensor] = None, q_prescaled: bool = False, token_major_out: bool = False) -> torch.Tensor:
     """band_attention with a device-side switch: `use_alt_flag` (int32 [1] on the GPU) != 0 selects `alt_mask` without the head
     placement, otherwise `mask` with it (svg_band_attention_switch) — no host read of the flag.
-    q_prescaled: q carries sm_scale * log2(e) (svg_band_attention_switch_prescaled, D = 128)."""
+    q_prescaled: q carries sm_scale * log2(e) (svg_band_attention_switch_prescaled, D = 128).
+    Strided views / token_major_out: as band_attention (svg_band_attention_switch_strided: head_dim 128, plain q)."""
     lib = load()
-    _dev(q, k, v, head_perm_flag, use_alt_flag)
+    _dev(head_perm_flag, use_alt_flag)
+    _gpu(q, k, v, out)
     assert q.shape == k.shape == v.shape and q.dtype == k.dtype == v.dtype
     assert use_alt_flag.dtype == torch.int32 and use_alt_flag.numel() >= 1
     S, D = q.shape[-2], q.shape[-1]
     BH = q.numel() // (S * D)
-    o = torch.empty_like(q) if out is None else out
-    _dev(o)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
     perm = None
     if head_perm_flag is not None:
         flag = head_perm_flag.to(torch.int64).contiguous()
         assert flag.numel() == BH
         perm = PermDesc(flag.data_ptr(), vid0, num_frame, frame_size)
+    dense_in = q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and (out is None or out.is_contiguous())
+    if (not dense_in or (token_major_out and out is None)) and not q_prescaled and strided_attention_supported(q):
+        q4, k4, v4 = _view4(q), _view4(k), _view4(v)
+        o4 = _view4(out) if out is not None else (token_major_empty(q4) if token_major_out else torch.empty(q4.shape, dtype=q.dtype, device=q.device))
+        if _strided_ok(q4) and _strided_ok(k4, True) and _strided_ok(v4, True) and _strided_ok(o4) and o4.shape == q4.shape:
+            lay = attn_layout(q4, k4, v4, o4)
+            rc = lib.svg_band_attention_switch_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o4.data_ptr(), BH, S, D, _dtype_code(q),
+                                                       scale, C.byref(mask), C.byref(perm) if perm is not None else None,
+                                                       C.byref(alt_mask), use_alt_flag.data_ptr(), C.byref(lay), _stream())
+            _check(rc, "svg_band_attention_switch_strided")
+            return out if out is not None else (o4 if q.dim() == 4 else o4.squeeze(0))
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    if out is not None and not out.is_contiguous():
+        out.copy_(band_attention_switch(q, k, v, mask, alt_mask, use_alt_flag, sm_scale, head_perm_flag, vid0, num_frame, frame_size, None,
+                                        q_prescaled))
+        return out
+    o = torch.empty_like(q) if out is None else out
     if q_prescaled:
         assert sm_scale is None, "q_prescaled: the scale lives in q"
         rc = lib.svg_band_attention_switch_prescaled(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), BH, S, D, _dtype_code(q),
@@ -490,15 +596,23 @@ def band_attention_switch(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mas
 def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_map: torch.Tensor, q_sizes: torch.Tensor,
                        k_sizes: torch.Tensor, sm_scale: Optional[float] = None, q_row_idx: Optional[torch.Tensor] = None,
                        kv_row_idx: Optional[torch.Tensor] = None, variant: int = -1, fp8: bool = False,
-                       workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q: [Hq, Sq, D], k/v: [Hkv, Skv, D]; block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] / [Hkv, KB].
+                       workspace: Optional[torch.Tensor] = None, token_major_out: bool = False,
+                       rows_covered: bool = False) -> torch.Tensor:
+    """q: [Hq, Sq, D], k/v: [Hkv, Skv, D] (or [B, H, S, D]: heads = B * H); block_map bool [Hkv, QB, KB]; sizes int32 [Hkv, QB] /
+    [Hkv, KB].  -> o of q's shape.
     fp8=True: e4m3 QK^T / PV (svg_varblock_attention_fp8, D = 128, default schedule only).
     workspace: optional uint8 GPU tensor of svg_varblock_workspace_bytes(...) bytes for the 16-bit call (tests read the launch
-    order back from it; see varblock_launch_order)."""
+    order back from it; see varblock_launch_order).
+    Strided views / token_major_out: as band_attention (svg_varblock_attention_strided: head_dim 128, variant -1 on block-rows large
+    enough for the default body, 16-bit).
+    rows_covered: the caller guarantees sum(q_sizes[h]) == Sq for every head (k-means cluster sizes do), so every output row is
+    written by the kernel and the output is not zero-filled first (a 2 S H D-byte memset per call otherwise)."""
     lib = load()
-    _dev(q, k, v, block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
-    Hq, Sq, D = q.shape
-    Hkv, Skv, _ = k.shape
+    _dev(block_map, q_sizes, k_sizes, q_row_idx, kv_row_idx)
+    _gpu(q, k, v)
+    Sq, D = q.shape[-2], q.shape[-1]
+    Skv = k.shape[-2]
+    Hq, Hkv = q.numel() // (Sq * D), k.numel() // (Skv * D)
     QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
     assert block_map.shape == (Hkv, QB, KB) and block_map.dtype in (torch.bool, torch.uint8)
     assert q_sizes.dtype == torch.int32 and k_sizes.dtype == torch.int32
@@ -506,8 +620,27 @@ def varblock_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, block_
         assert q_row_idx.dtype == torch.int32 and q_row_idx.shape == (Hq, Sq)
     if kv_row_idx is not None:
         assert kv_row_idx.dtype == torch.int32 and kv_row_idx.shape == (Hkv, Skv)
-    o = torch.zeros_like(q) if q_row_idx is None else torch.zeros_like(q)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    dense_in = q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    if (not dense_in or token_major_out) and not fp8 and variant == -1 and strided_attention_supported(q) and Sq >= 160 * QB:
+        q4, k4, v4 = _view4(q), _view4(k), _view4(v)
+        o4 = token_major_empty(q4) if token_major_out else torch.empty(q4.shape, dtype=q.dtype, device=q.device)
+        if _strided_ok(q4) and _strided_ok(k4, True) and _strided_ok(v4, True) and _strided_ok(o4):
+            if not rows_covered:
+                o4.zero_()
+            need = int(lib.svg_varblock_workspace_bytes(Hq, Hkv, QB, KB, Sq))
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device) if workspace is None else workspace
+            _dev(ws)
+            assert ws.dtype == torch.uint8 and ws.numel() >= need
+            lay = attn_layout(q4, k4, v4, o4)
+            rc = lib.svg_varblock_attention_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), o4.data_ptr(), Hq, Hkv, Sq, Skv, D,
+                                                    _dtype_code(q), scale, block_map.data_ptr(), q_sizes.data_ptr(), k_sizes.data_ptr(),
+                                                    QB, KB, _ptr(q_row_idx), _ptr(kv_row_idx), ws.data_ptr(), ws.numel(), C.byref(lay),
+                                                    _stream())
+            _check(rc, "svg_varblock_attention_strided")
+            return o4 if q.dim() == 4 else o4.squeeze(0)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()   # (what the strided entry point does not take is copied)
+    o = torch.empty_like(q) if rows_covered else torch.zeros_like(q)
     if fp8:
         need = int(lib.svg_varblock_attention_fp8_workspace_bytes(Hq, Hkv, QB, KB, Sq, Skv, D))
         if need == 0:
@@ -601,15 +734,31 @@ def clear_workspace_cache() -> None:
 
 def sample_mse(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rows: torch.Tensor, prof: ProfileDesc,
                sm_scale: Optional[float] = None, skip_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q,k,v [BH, S, D]; rows int64 [R] (device) -> mse float32 [2, BH].  skip_flag (int32 [1] on the GPU) != 0: the kernels
-    return at once and the result is undefined (a dense step does not use it)."""
+    """q,k,v [BH, S, D] (or [B, H, S, D]: BH = B * H); rows int64 [R] (device) -> mse float32 [2, BH].  skip_flag (int32 [1] on the
+    GPU) != 0: the kernels return at once and the result is undefined (a dense step does not use it).
+    Strided views are read in place by svg_sample_mse_strided (bf16: the second form of the kernel) and copied otherwise."""
     lib = load()
-    _dev(q, k, v, rows, skip_flag)
-    BH, S, D = q.shape
+    _dev(rows, skip_flag)
+    _gpu(q, k, v)
+    S, D = q.shape[-2], q.shape[-1]
+    BH = q.numel() // (S * D)
     R = rows.numel()
     out = torch.empty((2, BH), dtype=torch.float32, device=q.device)
     ws = torch.empty(lib.svg_sample_mse_workspace_bytes(BH, R, D, S), dtype=torch.uint8, device=q.device)
     scale = float(sm_scale) if sm_scale is not None else 1.0 / (D ** 0.5)
+    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()) and q.dtype == torch.bfloat16:
+        q4, k4, v4 = _view4(q), _view4(k), _view4(v)
+        if _strided_ok(q4) and _strided_ok(k4, True) and _strided_ok(v4, True):
+            if skip_flag is not None:
+                assert skip_flag.dtype == torch.int32
+                out.zero_()
+            lay = attn_layout(q4, k4, v4, q4)
+            rc = lib.svg_sample_mse_strided(q.data_ptr(), k.data_ptr(), v.data_ptr(), rows.data_ptr(), R, BH, S, D, _dtype_code(q), scale,
+                                            C.byref(prof), out.data_ptr(), ws.data_ptr(), ws.numel(), _ptr(skip_flag), C.byref(lay),
+                                            _stream())
+            _check(rc, "svg_sample_mse_strided")
+            return out
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     if skip_flag is not None:
         assert skip_flag.dtype == torch.int32
         out.zero_()

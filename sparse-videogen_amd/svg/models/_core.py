@@ -75,6 +75,13 @@ def is_full_attention(layer_idx: int, timestep, first_layers_fp, first_times_fp)
 
 LN2 = 0.6931471805599453   # sm_scale of a kernel that applies sm_scale * log2(e) itself to a q that already carries the softmax scale
 
+# Attention straight out of / into the projection layout (include/svg_attn.h, svg_attn_layout_t): q / k / v views that are not
+# contiguous (a `proj(x).unflatten(2, (H, -1)).transpose(1, 2)` the caller did not copy) are read in place, and the result comes back as a
+# [cfg, H, S, D] tensor STORED token-major, so that the processors' `hidden_states.transpose(1, 2).flatten(2, 3)` (ref:
+# wan/attention.py:168-170, hyvideo/attention.py:202) is a view instead of a 2 S H D-byte copy.  Head_dim 128, one GPU (the head-sharded
+# path gathers contiguous head slices); anything else falls back to copies inside svg/_native.py.  False: every output is contiguous.
+TOKEN_MAJOR_IO = True
+
 
 @time_logging_decorator("Level 3 - Dense Flash Attention")
 def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, valid_len: Optional[int] = None,
@@ -86,7 +93,7 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, valid_len
     if q.is_cuda:
         real = S if valid_len is None else int(valid_len)
         mask = _native.BandMask(real_len=real, band=S + 1, colfull_lo=0, colfull_hi=0, rowfull_lo=0, rowfull_hi=0)
-        return _native.band_attention(q.contiguous(), k.contiguous(), v.contiguous(), mask, q_prescaled=q_prescaled)
+        return _native.band_attention(q, k, v, mask, q_prescaled=q_prescaled, token_major_out=TOKEN_MAJOR_IO and not _dist.active())
     assert not q_prescaled, "a pre-scaled q only exists on the GPU path"
     if valid_len is None or valid_len >= S:
         return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
@@ -113,8 +120,7 @@ def sample_mse(q, k, v, geo: Geometry, prof: "_native.ProfileDesc", num_sampled_
     cfg, H, S, D = q.shape
     n = min(num_sampled_rows, S)
     rows = torch.randint(low=0, high=sample_max_row, size=(n,), generator=generator)
-    mses = _native.sample_mse(q.reshape(cfg * H, S, D), k.reshape(cfg * H, S, D), v.reshape(cfg * H, S, D),
-                              rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag,
+    mses = _native.sample_mse(q, k, v, rows.to(q.device, non_blocking=True), prof, skip_flag=skip_flag,   # (4-D views: no reshape copy)
                               sm_scale=LN2 if q_prescaled else None)   # (the profiler multiplies its scale by log2(e) itself)
     return mses.reshape(2, cfg, H).to(q.dtype)
 
@@ -173,12 +179,12 @@ def svg1_attention_device_switch(q, k, v, geo: Geometry, mask: "_native.BandMask
         return _dist.run_sharded(lambda qh, kh, vh: svg1_attention_device_switch(
             qh, kh, vh, geo, mask, dense_mask, prof, num_sampled_rows, sample_max_row, dense_flag, _local=True,
             q_prescaled=q_prescaled), (q, k, v), _dist.current_group())
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, skip_flag=dense_flag, generator=_switch_generator(),
                       q_prescaled=q_prescaled)
     best_mask_idx = torch.argmin(mses, dim=0)
     out = _native.band_attention_switch(q, k, v, mask, dense_mask, dense_flag, head_perm_flag=best_mask_idx, vid0=geo.vid0,
-                                        num_frame=geo.num_frame, frame_size=geo.frame_size, q_prescaled=q_prescaled)
+                                        num_frame=geo.num_frame, frame_size=geo.frame_size, q_prescaled=q_prescaled,
+                                        token_major_out=TOKEN_MAJOR_IO and not _local)
     return out, torch.where(dense_flag.reshape(()) != 0, torch.full_like(best_mask_idx, -1), best_mask_idx)
 
 
@@ -194,17 +200,17 @@ def svg1_sparse_attention(q, k, v, geo: Geometry, mask: "_native.BandMask", prof
         return _dist.run_sharded(lambda qh, kh, vh: svg1_sparse_attention(
             qh, kh, vh, geo, mask, prof, num_sampled_rows, sample_max_row, fused, _local=True, q_prescaled=q_prescaled), (q, k, v),
             _dist.current_group())
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     mses = sample_mse(q, k, v, geo, prof, num_sampled_rows, sample_max_row, q_prescaled=q_prescaled)
     best_mask_idx = torch.argmin(mses, dim=0)  # [cfg, H] int64; NaN wins like torch.argmin in the reference
     pk = dict(head_perm_flag=best_mask_idx, vid0=geo.vid0, num_frame=geo.num_frame, frame_size=geo.frame_size)
     if fused:
         with time_logging_decorator("Level 3 - sparse_flex_attention"):
             if _use_fp8(q):   # (the fp8 pre-pass folds whatever scale it is given into its quantisation of q)
-                out = _native.band_attention_fp8(q, k, v, mask, sm_scale=LN2 if q_prescaled else None, **pk)
+                out = _native.band_attention_fp8(q.contiguous(), k.contiguous(), v.contiguous(), mask, sm_scale=LN2 if q_prescaled else None, **pk)
             else:
-                out = _native.band_attention(q, k, v, mask, q_prescaled=q_prescaled, **pk)
+                out = _native.band_attention(q, k, v, mask, q_prescaled=q_prescaled, token_major_out=TOKEN_MAJOR_IO and not _local, **pk)
         return out, best_mask_idx
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     qo, ko, vo = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     with time_logging_decorator("Level 3 - fast_sparse_head_placement"):
         _native.head_placement([q, k, v], [qo, ko, vo], best_mask_idx, geo.context_length, geo.num_frame, geo.frame_size,
@@ -324,7 +330,7 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
     assert cfg == 1, "Batch size must be 1 for kmeans block sparse attention"
     assert not geo.text_first, "SVG2 is defined for text-last models (Hunyuan, Wan)"
     V, ctx = geo.video_length, geo.context_length
-    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    q, k = q.contiguous(), k.contiguous()   # (the k-means reads them as [H, N, D]; v may stay a strided view: only the attention kernel reads it)
     qv = q[:, :, :V].contiguous() if ctx else q
     kv = k[:, :, :V].contiguous() if ctx else k
     with time_logging_decorator("Level 3 - semantic aware permutation"):
@@ -341,9 +347,12 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
                                                                                 prompt_length)
     QB, KB = q_sizes.shape[-1], k_sizes.shape[-1]
     f8 = _use_fp8(q)
-    out = _native.varblock_attention(q.view(H, S, D), k.view(H, S, D), v.view(H, S, D), dyn_map.view(H, QB, KB).contiguous(),
+    # (rows_covered: the cluster sizes of every head add up to S — k-means counts over the V video tokens plus the text pseudo-clusters of
+    #  dynamic_map_post_processing — so the kernel writes every output row and the wrapper skips the zero fill)
+    out = _native.varblock_attention(q, k, v, dyn_map.view(H, QB, KB).contiguous(),
                                      q_sizes.view(H, QB).contiguous(), k_sizes.view(H, KB).contiguous(),
-                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), fp8=f8)
+                                     q_row_idx=qidx.contiguous(), kv_row_idx=kidx.contiguous(), fp8=f8,
+                                     token_major_out=TOKEN_MAJOR_IO and _head_shard is None, rows_covered=True)
     if logging_file is not None:
         from .context import timestep_value
 
@@ -353,7 +362,7 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
         if _head_shard is None or torch.distributed.get_rank(_dist.current_group()) == 0:
             DENSITY_LOG.push(logging_file, {"timestep": timestep_value(timestep) if timestep is not None else None,
                                             "layer": layer_idx}, densities)
-    return out.view(cfg, H, S, D)
+    return out.reshape(cfg, H, S, D)   # (a view in either storage order: cfg == 1)
 
 
 class _DensityLog:
@@ -508,6 +517,16 @@ def prescale_supported(query) -> bool:
     return bool(query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and query.shape[-1] in (64, 128))
 
 
+def value_in_place(value: torch.Tensor, heads: int):
+    """The v projection's output [bsz, S, heads * D] as the [bsz, heads, S, D] VIEW the attention kernels read in place
+    (svg_attn_layout_t; TOKEN_MAJOR_IO, one GPU, head_dim 128, 16-bit, on the GPU) — or None: the caller makes the head-major copy."""
+    if not (TOKEN_MAJOR_IO and value.is_cuda and value.dim() == 3 and value.is_contiguous() and not _dist.active()):
+        return None
+    if value.dtype not in (torch.bfloat16, torch.float16) or value.shape[-1] != heads * 128:
+        return None
+    return value.unflatten(2, (heads, -1)).transpose(1, 2)
+
+
 def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin, rope_lo: int, rope_hi: int,
                          complex_pairs: bool = False, q_scale: float = 1.0):
     """Projection outputs [bsz, S, heads * D] -> head-major q, k, v [bsz, heads, S, D] with QK-norm + RoPE applied to q, k in
@@ -535,5 +554,7 @@ def qkv_from_projections(query, key, value, heads: int, norm_q, norm_k, cos, sin
         rk = 2 if complex_pairs else 1
     q, k = _native.qk_norm_rope_transpose(query, key, heads, heads, kind, qw, qb, kw, kb, eps, rk, tb[0], tb[1], rope_lo, rope_hi,
                                           q_scale=q_scale)   # q_scale != 1: q leaves the prologue carrying the softmax scale
-    v, _ = _native.qk_norm_rope_transpose(value, None, heads, 0)
+    v = value_in_place(value, heads) if q_scale == 1.0 else None   # (a pre-scaled q takes the entry points without strides)
+    if v is None:
+        v, _ = _native.qk_norm_rope_transpose(value, None, heads, 0)
     return q, k, v

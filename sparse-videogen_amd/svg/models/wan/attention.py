@@ -162,7 +162,11 @@ class WanAttn_SVGAttn_Processor2_0:
         qw, kw = (m.weight.detach().to(device=query.device).contiguous() for m in (nq, nk))
         if qw.dtype != kw.dtype or qw.dtype not in (torch.bfloat16, torch.float16, torch.float32):
             return None
-        return _core._native.rmsnorm_rope_transpose(query, key, value, H, qw, kw, float(nq.eps), 2, tb[0], tb[1], 0, S, q_scale=q_scale)
+        # v: read in place by the attention kernels where they take strides (a view of the projection's output), else transposed in the same pass
+        vv = _core.value_in_place(value, H) if q_scale == 1.0 else None
+        q, k, v = _core._native.rmsnorm_rope_transpose(query, key, None if vv is not None else value, H, qw, kw, float(nq.eps), 2, tb[0], tb[1],
+                                                       0, S, q_scale=q_scale)
+        return q, k, (vv if vv is not None else v)
 
     @time_logging_decorator("Level 2 - output")
     def get_o(self, attn, query, hidden_states, hidden_states_img):

@@ -90,6 +90,9 @@ def test_struct_layouts():
     assert ctypes.sizeof(_native.PermDesc) == 24 and _native.PermDesc.vid0.offset == 8
     assert ctypes.sizeof(_native.ProfileVariant) == 28
     assert ctypes.sizeof(_native.ProfileDesc) == 16 + 2 * 28
+    # svg_attn_layout_t: two int32, then four { batch, head, row } int64 triples (include/svg_attn.h)
+    assert ctypes.sizeof(_native.TensorStrides) == 24 and ctypes.sizeof(_native.AttnLayout) == 8 + 4 * 24
+    assert _native.AttnLayout.q.offset == 8 and _native.AttnLayout.o.offset == 8 + 3 * 24 and _native.TensorStrides.row.offset == 16
 
 
 def test_argument_validation_returns_error_codes():
