@@ -143,10 +143,10 @@ int svg_band_attention(const void* q, const void* k, const void* v, void* o, int
  * entry point is { batch = H * S * D, head = S * D, row = D }; the projection layout [B, S, H * D] is { S * H * D, D, H * D }; a slice
  * of a fused QKV projection [B, S, 3 * H * D] is { 3 * S * H * D, D, 3 * H * D } behind a base pointer moved to the slice.
  * Requirements: base pointers and row strides multiples of 16 bytes; S * row stride * 2 < 2^32 for k and v (their LDS-DMA requests
- * carry 32-bit byte offsets per head), row strides < 2^23 elements.  Head_dim 128 on the default schedule only (the 16x16x32 body,
- * variant 0 / 8 of svg_band_attention, the default of svg_varblock_attention; svg_sample_mse: its second form, bf16); anything else
- * returns SVG_ERR_UNSUPPORTED and the caller copies, as the reference does.  Results are bit-identical to the contiguous call on the
- * same values (tests/test_gpu_strided.py).
+ * carry 32-bit byte offsets per head), row strides < 2^23 elements.  The default schedules only — the two-phase bodies: 16x16x32 at
+ * head_dim 128, 32x32x16 at head_dim 64 (variant 0 of svg_band_attention, the default of svg_varblock_attention on block-rows large
+ * enough for it; svg_sample_mse: its second form, bf16); anything else returns SVG_ERR_UNSUPPORTED and the caller copies, as the
+ * reference does.  Results are bit-identical to the contiguous call on the same values (tests/test_gpu_strided.py).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct svg_tensor_strides {
     int64_t batch, head, row;          /* element strides of a [B, H, S, D] view, stride(D) == 1 */
@@ -217,7 +217,7 @@ int svg_varblock_attention(const void* q, const void* k, const void* v, void* o,
                            const int32_t* q_row_idx, const int32_t* kv_row_idx, void* workspace,
                            size_t workspace_bytes, int32_t variant, void* stream);
 /* svg_varblock_attention (variant -1) on strided q, k, v, o: svg_attn_layout_t above; heads_per_batch counts q heads,
- * kv_heads_per_batch kv heads (0: heads_per_batch * Hkv / Hq).  Head_dim 128 and block-rows large enough for the default body
+ * kv_heads_per_batch kv heads (0: heads_per_batch * Hkv / Hq).  Block-rows large enough for the default (two-phase) body
  * (Sq >= 160 * QB), otherwise SVG_ERR_UNSUPPORTED. */
 int svg_varblock_attention_strided(const void* q, const void* k, const void* v, void* o, int32_t Hq, int32_t Hkv, int32_t Sq,
                                    int32_t Skv, int32_t D, int32_t dtype, float sm_scale, const uint8_t* block_map,
@@ -453,7 +453,7 @@ int svg_layernorm_modulate_forward_ex(const void* x, void* y, const void* weight
 int svg_band_attention_switch(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                               int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                               const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag, void* stream);
-/* svg_band_attention_switch on strided tensors (svg_attn_layout_t above; head_dim 128). */
+/* svg_band_attention_switch on strided tensors (svg_attn_layout_t above). */
 int svg_band_attention_switch_strided(const void* q, const void* k, const void* v, void* o, int32_t BH, int32_t S, int32_t D,
                                       int32_t dtype, float sm_scale, const svg_band_mask_t* mask, const svg_perm_desc_t* perm,
                                       const svg_band_mask_t* alt_mask, const int32_t* use_alt_flag,

@@ -904,7 +904,7 @@ static int band_dispatch(const void* q, const void* k, const void* v, void* o, i
     }
     if (variant == kBandAuto) variant = band_default(D);
     if (opts.done && band_waves_per_tile(variant) < 0) return SVG_ERR_UNSUPPORTED;
-    if (opts.strided && variant != kBandM16) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
+    if (opts.strided && variant != kBandM16 && variant != kBandPingPong) return SVG_ERR_UNSUPPORTED;   // strided tensors: the two-phase bodies only (see svg_attn_layout_t)
 #define SVG_BAND_TD(FN, ...)                                                                    \
     if (dtype == SVG_DTYPE_BF16 && D == 128) return FN<__bf16, 128>(__VA_ARGS__);               \
     if (dtype == SVG_DTYPE_BF16 && D == 64) return FN<__bf16, 64>(__VA_ARGS__);                 \
@@ -1068,8 +1068,7 @@ static int band_switch_entry(const void* q, const void* k, const void* v, void* 
     if (rc == SVG_OK) rc = band_check_args(q, k, v, o, BH, S, D, alt_mask, nullptr);
     if (rc != SVG_OK) return rc;
     BandOpts opts;
-    if (layout) {
-        if (D != 128) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
+    if (layout) {   // (both switch kernels run a two-phase body: strides as in svg_band_attention_strided)
         opts.strided = true;
         if (rc = layout_from_abi(layout, BH, BH, S, S, D, q, k, v, o, opts.lay); rc != SVG_OK) return rc;
     }
@@ -1090,8 +1089,8 @@ static int band_switch_entry(const void* q, const void* k, const void* v, void* 
         auto go = [&](auto t_c) -> int {
             using T = decltype(t_c);
             using Pol = BandPolicy<T, 64, 8, false>;
-            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm);
-            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr);
+            const typename Pol::Params a = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, mask, perm, opts);
+            const typename Pol::Params b = make_band_params<Pol, T>(q, k, v, o, BH, S, sm_scale, alt_mask, nullptr, opts);
             auto kern = band_attn_pp2_switch64_kernel<T>;
             if (const int r2 = configure_lds((const void*)kern, attn_pp2_lds_bytes<64>()); r2 != SVG_OK) return r2;
             hipLaunchKernelGGL(kern, dim3(std::max(a.nqt, b.nqt) * BH), dim3(512), attn_pp2_lds_bytes<64>(), (hipStream_t)stream, a, b, use_alt_flag);
@@ -1361,7 +1360,7 @@ static int varblock_entry(const void* q, const void* k, const void* v, void* o, 
     // (Wan 720p, 252-row clusters: 40.4 ms; lock-step 8 waves 45.5, 4 waves 47.7, mixed 46.9), 128-row tiles otherwise
     if (variant == -1) variant = ((int64_t)Sq >= (int64_t)160 * QB) ? 3 : 0;
     const bool body_m16 = (variant >= 3 && D == 128 && !force_pp2);
-    if (lay && !(body_m16 && !trace)) return SVG_ERR_UNSUPPORTED;   // strided tensors: the 16x16x32 body only (see svg_attn_layout_t)
+    if (lay && !(variant >= 3 && !trace)) return SVG_ERR_UNSUPPORTED;   // strided tensors: the two-phase bodies only (see svg_attn_layout_t)
     if (dtype == SVG_DTYPE_BF16) {
         SVG_VB_DISPATCH(__bf16)
     } else if (dtype == SVG_DTYPE_F16) {

@@ -626,6 +626,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     P::kv_cursor_init(prm, ctx, cur, krow);
     const unsigned col_v = (unsigned)(dma_db0 * 64 + (lane & 3) * 16);
     const unsigned k_xor = (unsigned)(((lane >> 4) & 3) << 4);
+    const unsigned col_k = col_v ^ k_xor;
+    const unsigned k_rsb = (unsigned)P::k_rs(prm) * 2u, v_rsb = (unsigned)P::v_rs(prm) * 2u;
     const unsigned lds_piece = lds0 + (unsigned)(dma_db0 * (kBN * 64) + dma_kg * 1024);
     // Physical rows are resolved one vector phase before they are requested (nnext -> nphys): for the variable-block policy
     // the resolve is itself a global index load, and this keeps its latency off the critical path.
@@ -645,20 +647,21 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         constexpr int j = decltype(j_c)::value;
         static_assert(2 * D >= 256 || NP == 1, "row offset | column offset");
         const unsigned st = __builtin_amdgcn_readfirstlane(lds_piece + (unsigned)((t % NS) * kStage) + j * (kBN * 64));
-        const unsigned vo = ((unsigned)nphys * (unsigned)(2 * D)) | col_v;
-        unsigned kvo;
-        const unsigned kx = k_xor;   // (locals: asm operands of a generic lambda do not capture implicitly)
+        // byte offset of the key row inside its head = row * (row stride in bytes, a kernel argument: svg_attn_layout_t — 2 D for contiguous
+        // heads) + the lane's 16-byte column (K: swizzled): one v_mad_u32_u24 per tensor (rows, strides < 2^24, products < 2^32: layout_from_abi)
+        const unsigned ko = __umul24((unsigned)nphys, k_rsb) + col_k;
+        const unsigned vo = __umul24((unsigned)nphys, v_rsb) + col_v;
         // (the d-block offset goes into the scalar base, loop-invariant — an instruction offset would also move the LDS address)
         const char* const kbp = (const char*)kb + j * 64;
         const char* const vbp = (const char*)vb + j * 64;
-        asm volatile("s_mov_b32 m0, %1\n\t"
-                     "v_xor_b32 %0, %2, %3\n\t"
-                     "global_load_lds_dwordx4 %0, %4\n\t"
-                     "s_add_u32 m0, m0, %6\n\t"
+        asm volatile("s_mov_b32 m0, %0\n\t"
                      "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, %5"
-                     : "=&v"(kvo)
-                     : "s"(st), "v"(vo), "v"(kx), "s"(kbp), "s"(vbp), "n"(kImg)
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "s_add_u32 m0, m0, %5\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %4"
+                     :
+                     : "s"(st), "v"(ko), "v"(vo), "s"(kbp), "s"(vbp), "n"(kImg)
                      : "memory", "scc");
     };
     auto dma_issue = [&](int t) {  // request this wave's pieces of tile t (t < nT, rows in nphys) into stage t % NS
@@ -674,9 +677,8 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         resolve(t, kGuarded);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const unsigned vo = (unsigned)nnext * (unsigned)(2 * D) + col_v + (unsigned)(j * 64);
-            kreg[j] = *(const u32x4*)((const char*)kb + (vo ^ k_xor));
-            vreg[j] = *(const u32x4*)((const char*)vb + vo);
+            kreg[j] = *(const u32x4*)((const char*)kb + (size_t)nnext * k_rsb + (col_k + (unsigned)(j * 64)));
+            vreg[j] = *(const u32x4*)((const char*)vb + (size_t)nnext * v_rsb + (col_v + (unsigned)(j * 64)));
         }
     };
     char* const piece_ptr = smem + dma_db0 * (kBN * 64) + dma_kg * 1024 + lane * 16;
@@ -712,7 +714,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
     const int q_log = P::q_logical(ctx, row_in_wg);
     V8 qf[KS];
     {
-        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * D + g * 8;
+        const T* qrow = qb + (size_t)(q_phys >= 0 ? q_phys : 0) * P::q_rs(prm) + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const V8*)(qrow + ks * 16);
     }
@@ -1124,7 +1126,7 @@ __device__ __forceinline__ void attn_body_pp2(const typename P::Params& prm, cha
         for (int i = 0; i < 32 / kRowsPerPass; ++i) {
             const int rr = i * kRowsPerPass + sub;
             const u32x2 val = *(const u32x2*)(erow + rr * kEpiStride + colb);
-            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * D) + colb) = val;
+            if (ephys[i] >= 0) *(u32x2*)((char*)(ob + (size_t)ephys[i] * P::o_rs(prm)) + colb) = val;
         }
         P::notify(prm, ctx);   // completion counter of the policy (band attention: per head, for an exchange that overlaps the launch)
         if constexpr (TRACE) {

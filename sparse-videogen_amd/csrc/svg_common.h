@@ -102,7 +102,8 @@ constexpr int kNumCU = 256;
 // Where the four tensors of an attention call live (kernel-argument form of svg_attn_layout_t, strides in ELEMENTS): element
 // (bh, s, :) of tensor x starts at x + (bh / hpb) * x_bs + (bh % hpb) * x_hs + s * x_rs.  The contiguous [BH, S, D] layout is
 // { hpb = BH, hs = S * D, rs = D }.  Head and batch strides reach every attention body through the policies' *_base(); ROW strides
-// other than D exist in the 16x16x32 body (attn_m16.h) and the online profiler's second form only — the host side refuses them elsewhere.
+// other than D exist in the two-phase bodies (attn_m16.h, attn_body_pp2 of attn_core.h) and the online profiler's second form only — the host
+// side refuses them elsewhere.
 struct AttnLayout {
     int hpb_q, hpb_kv;
     long long q_bs, q_hs, k_bs, k_hs, v_bs, v_hs, o_bs, o_hs;

@@ -297,8 +297,8 @@ def token_major_empty(like4: torch.Tensor) -> torch.Tensor:
 
 
 def strided_attention_supported(q: torch.Tensor, variant: int = 0) -> bool:
-    """The *_strided entry points exist for the default schedule at head_dim 128 (the 16x16x32 body)."""
-    return q.shape[-1] == 128 and variant == 0 and q.dtype in (torch.bfloat16, torch.float16)
+    """The *_strided entry points exist for the default schedules (the two-phase bodies: 16x16x32 at head_dim 128, 32x32x16 at 64)."""
+    return q.shape[-1] in (64, 128) and variant == 0 and q.dtype in (torch.bfloat16, torch.float16)
 
 
 # ------------------------------------------------------------------------------------------------------

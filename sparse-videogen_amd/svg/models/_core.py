@@ -78,7 +78,7 @@ LN2 = 0.6931471805599453   # sm_scale of a kernel that applies sm_scale * log2(e
 # Attention straight out of / into the projection layout (include/svg_attn.h, svg_attn_layout_t): q / k / v views that are not
 # contiguous (a `proj(x).unflatten(2, (H, -1)).transpose(1, 2)` the caller did not copy) are read in place, and the result comes back as a
 # [cfg, H, S, D] tensor STORED token-major, so that the processors' `hidden_states.transpose(1, 2).flatten(2, 3)` (ref:
-# wan/attention.py:168-170, hyvideo/attention.py:202) is a view instead of a 2 S H D-byte copy.  Head_dim 128, one GPU (the head-sharded
+# wan/attention.py:168-170, hyvideo/attention.py:202) is a view instead of a 2 S H D-byte copy.  The default schedules, one GPU (the head-sharded
 # path gathers contiguous head slices); anything else falls back to copies inside svg/_native.py.  False: every output is contiguous.
 TOKEN_MAJOR_IO = True
 
@@ -519,10 +519,10 @@ def prescale_supported(query) -> bool:
 
 def value_in_place(value: torch.Tensor, heads: int):
     """The v projection's output [bsz, S, heads * D] as the [bsz, heads, S, D] VIEW the attention kernels read in place
-    (svg_attn_layout_t; TOKEN_MAJOR_IO, one GPU, head_dim 128, 16-bit, on the GPU) — or None: the caller makes the head-major copy."""
+    (svg_attn_layout_t; TOKEN_MAJOR_IO, one GPU, head_dim 64 / 128, 16-bit, on the GPU) — or None: the caller makes the head-major copy."""
     if not (TOKEN_MAJOR_IO and value.is_cuda and value.dim() == 3 and value.is_contiguous() and not _dist.active()):
         return None
-    if value.dtype not in (torch.bfloat16, torch.float16) or value.shape[-1] != heads * 128:
+    if value.dtype not in (torch.bfloat16, torch.float16) or value.shape[-1] not in (heads * 64, heads * 128):
         return None
     return value.unflatten(2, (heads, -1)).transpose(1, 2)
 

@@ -76,8 +76,10 @@ class CogVideoX_SparseAttn_Processor2_0:
 
     def transpose_qkv(self, attn, query, key, value, batch_size):
         head_dim = key.shape[-1] // attn.heads
-        query, key, value = (x.view(batch_size, -1, attn.heads, head_dim).transpose(1, 2).contiguous()
-                             for x in (query, key, value))
+        # v: a view of the projection's output where the attention kernels read it in place (svg_attn_layout_t), a head-major copy otherwise
+        vv = _core.value_in_place(value, attn.heads) if not self.prescale_q else None
+        query, key = (x.view(batch_size, -1, attn.heads, head_dim).transpose(1, 2).contiguous() for x in (query, key))
+        value = vv if vv is not None else value.view(batch_size, -1, attn.heads, head_dim).transpose(1, 2).contiguous()
         return query, key, value, head_dim
 
     def get_o(self, attn, hidden_states, batch_size, head_dim):

@@ -39,11 +39,12 @@ def _is_token_major(o):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("fused_qkv", [False, True])
-@pytest.mark.parametrize("model", ["hy", "wan", "dense2"])
-def test_band_attention_strided_equals_contiguous(nat, model, fused_qkv, dtype):
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("model", ["hy", "wan", "cog", "dense2"])
+def test_band_attention_strided_equals_contiguous(nat, model, D, fused_qkv, dtype):
     F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3
     S, prm, mask, _ = _band_case(model, F_, P_, ctx, L, mul)
-    B, H, D = 2, 3, 128
+    B, H = 2, 3
     q, k, v = _proj_views(B, H, S, D, dtype, fused_qkv, seed=7)
     assert not v.is_contiguous()
     m = nat.BandMask(**prm)
@@ -60,10 +61,11 @@ def test_band_attention_strided_equals_contiguous(nat, model, fused_qkv, dtype):
         check_attn(o[:1], O.masked_attention(q[:1].float().cpu().to(dtype), k[:1].float().cpu().to(dtype), v[:1].float().cpu().to(dtype), mask), dtype)
 
 
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("model", ["hy", "cog"])
-def test_band_attention_strided_fused_placement(nat, model):
+def test_band_attention_strided_fused_placement(nat, model, D):
     """token-major heads (head_perm_flag) gather K / V rows and scatter O rows through the placement index AND the row strides"""
-    F_, P_, ctx, L, mul, D, H, B = 6, 130, 24, 7, 1.6, 128, 4, 2
+    F_, P_, ctx, L, mul, H, B = 6, 130, 24, 7, 1.6, 4, 2
     S, prm, mask, vid0 = _band_case(model, F_, P_, ctx, L, mul)
     q, k, v = _proj_views(B, H, S, D, torch.bfloat16, True, seed=3)
     best = dev(torch.tensor([[0, 1, 1, 0], [1, 0, 1, 1]]))
@@ -73,8 +75,9 @@ def test_band_attention_strided_fused_placement(nat, model):
     assert _is_token_major(o) and torch.equal(o, ref)
 
 
-def test_band_attention_switch_strided(nat):
-    F_, P_, ctx, L, mul, D, H, B = 5, 150, 40, 11, 2.3, 128, 3, 1
+@pytest.mark.parametrize("D", [128, 64])
+def test_band_attention_switch_strided(nat, D):
+    F_, P_, ctx, L, mul, H, B = 5, 150, 40, 11, 2.3, 3, 1
     S, prm, mask, vid0 = _band_case("hy", F_, P_, ctx, L, mul)
     q, k, v = _proj_views(B, H, S, D, torch.bfloat16, False, seed=11)
     m, dm = nat.BandMask(**prm), nat.BandMask(**O.dense_band_params(S, F_ * P_ + L))
@@ -88,9 +91,10 @@ def test_band_attention_switch_strided(nat):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("hq,hkv", [(4, 4), (8, 2)])
-def test_varblock_attention_strided_equals_contiguous(nat, hq, hkv, dtype):
-    S, D, MB, NB = 4096, 128, 12, 40
+def test_varblock_attention_strided_equals_contiguous(nat, hq, hkv, D, dtype):
+    S, MB, NB = 4096, 12, 40
     gen = torch.Generator().manual_seed(77 + hq)
     rsz, csz = random_partition_batch(S, MB, hkv, gen), random_partition_batch(S, NB, hkv, gen)
     bmap = torch.rand(hkv, MB, NB, generator=gen) > 0.5
@@ -123,10 +127,11 @@ def test_varblock_uncovered_rows_stay_zero_when_strided(nat):
     assert torch.equal(o[0], ref) and float(o[0, 0, 1300:].abs().max()) == 0.0
 
 
-def test_sample_mse_strided_equals_contiguous(nat):
+@pytest.mark.parametrize("D", [128, 64])
+def test_sample_mse_strided_equals_contiguous(nat, D):
     from svg.models.hyvideo.utils import profile_desc
 
-    F_, P_, ctx, D, H, B = 6, 260, 24, 128, 3, 2
+    F_, P_, ctx, H, B = 6, 260, 24, 3, 2
     S = F_ * P_ + ctx
     q, k, v = _proj_views(B, H, S, D, torch.bfloat16, True, seed=21)
     rows = dev(torch.randint(0, F_ * P_, (64,), generator=torch.Generator().manual_seed(1)))
@@ -143,11 +148,11 @@ def test_sample_mse_strided_equals_contiguous(nat):
 
 
 def test_strided_fallbacks_copy(nat):
-    """what no strided entry point takes is copied, as the reference does: head_dim 64, an explicit schedule, a pre-scaled q"""
+    """what no strided entry point takes is copied, as the reference does: an explicit schedule, a pre-scaled q"""
     F_, P_, ctx, L, mul = 5, 150, 40, 11, 2.3
     S, prm, mask, _ = _band_case("hy", F_, P_, ctx, L, mul)
     m = nat.BandMask(**prm)
-    for D, kw in ((64, {}), (128, dict(variant=2)), (128, dict(q_prescaled=True))):
+    for D, kw in ((64, dict(variant=3)), (128, dict(variant=2)), (128, dict(q_prescaled=True))):
         q, k, v = _proj_views(1, 3, S, D, torch.bfloat16, False, seed=D)
         ref = nat.band_attention(q.contiguous(), k.contiguous(), v.contiguous(), m, **kw)
         o = nat.band_attention(q, k, v, m, token_major_out=True, **kw)
@@ -156,7 +161,7 @@ def test_strided_fallbacks_copy(nat):
 
 def test_strided_abi_argument_checks(nat):
     """layout_from_abi (csrc/svg_common.h): strides that are not multiples of 16 bytes, rows shorter than D, k / v whose byte offsets do
-    not fit 32 bits, head_dim 64 -> error codes, no launch"""
+    not fit 32 bits -> error codes, no launch"""
     import ctypes as C
 
     lib = nat.load()
@@ -184,7 +189,15 @@ def test_strided_abi_argument_checks(nat):
     bad = nat.attn_layout(x, x, x, x)
     bad.heads_per_batch = 3
     assert call(bad) == -1
-    assert call(good, 64) == -2
+    torch.cuda.synchronize()
+    # the variable-block entry point on block-rows too small for the two-phase body: unsupported, the binding copies
+    H2, S2, QB, KB = 2, 512, 8, 8
+    ws = dev(torch.zeros(int(lib.svg_varblock_workspace_bytes(H2, H2, QB, KB, S2)), dtype=torch.uint8))
+    sz = dev(torch.full((H2, QB), S2 // QB, dtype=torch.int32))
+    bm = dev(torch.ones(H2, QB, KB, dtype=torch.uint8))
+    rc = lib.svg_varblock_attention_strided(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), H2, H2, S2, S2, D, 0, 0.1, bm.data_ptr(),
+                                            sz.data_ptr(), sz.data_ptr(), QB, KB, None, None, ws.data_ptr(), ws.numel(), C.byref(good), st)
+    assert rc == -2
     torch.cuda.synchronize()
 
 
@@ -212,7 +225,9 @@ def test_core_svg1_token_major_io(nat, monkeypatch):
     d = _core.dense_attention(q, k, v, valid_len=F_ * P_ + L)
     assert _is_token_major(d) and torch.equal(d, nat.band_attention(q, k, v.contiguous(), nat.BandMask(**O.dense_band_params(S, F_ * P_ + L))))
     assert _core.value_in_place(dev(torch.zeros(1, S, H * D, dtype=torch.bfloat16)), H) is not None
-    assert _core.value_in_place(dev(torch.zeros(1, S, H * 64, dtype=torch.bfloat16)), H) is None
+    assert _core.value_in_place(dev(torch.zeros(1, S, H * 64, dtype=torch.bfloat16)), H) is not None
+    assert _core.value_in_place(dev(torch.zeros(1, S, H * 32, dtype=torch.bfloat16)), H) is None
+    assert _core.value_in_place(dev(torch.zeros(1, S, H * D, dtype=torch.float32)), H) is None
 
 
 def test_core_svg2_token_major_io(nat, monkeypatch):
