@@ -210,6 +210,7 @@ class HipOps:
 
         nat.load()
         self.nat, self.core, self.geo, self.first_layers_fp = nat, core, geo, first_layers_fp
+        core.TOKEN_MAJOR_IO = bool(int(os.environ.get("SVG_STEP_TOKEN_MAJOR_IO", "1") or 1))   # 0: the copies of the reference's processors (A/B)
         width = sparsity_to_width(0.25, geo.ctx, geo.F, geo.P)
         self.band = math.floor(width * geo.P / 128) * 128
         Vv, Ll = geo.V, geo.L
@@ -492,8 +493,9 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
         res[kind] = {"ms": round(t, 2), "ms_all_steps": [round(x, 1) for x in times], "attention_ms": round(a, 2),
                      "attention_share": round(a / t, 4), "gemm_and_glue_ms": round(t - a, 2), "gemm_tflop_this_rank": round(gf / 1e12, 1),
                      "gemm_tflops_lower_bound_this_rank": round(gf / max((t - a) * 1e-3, 1e-9) / 1e12, 1),
-                     # where the step goes: attention = profiler + band kernel (or the dense kernel); prologue = fused QK-norm + RoPE + transpose,
-                     # V transpose, output transpose copy; glue = LayerNorm + modulate / gate-residual (libsvgattn); gemm = torch.mm (+ GELU in
+                     # where the step goes: attention = profiler + band kernel (or the dense kernel); prologue = fused QK-norm + RoPE + transpose
+                     # (one GPU, `token_major_io`: v stays in the projection layout and o is written token-major — no V transpose, no output
+                     # transpose copy; otherwise both are in this section); glue = LayerNorm + modulate / gate-residual (libsvgattn); gemm = torch.mm (+ GELU in
                      # the epilogue when `gelu_in_gemm_epilogue`); elementwise = what is left in torch (GELU pass if not fused, cat)
                      "step_breakdown_ms": brk,
                      "gemm_tflops_this_rank": round(gf / max(breakdowns[mid].get("gemm", 0.0) * 1e-3, 1e-9) / 1e12, 1)}
@@ -510,6 +512,7 @@ def measure(steps: int = 1, warmup: int = 1, n_double: int = 20, n_single: int =
         "steps": steps, "warmup": warmup, "n_gpus": world,
         "not_modelled": "patch / time / text embedders, final layer, scheduler, text encoder, VAE",
         "gelu_in_gemm_epilogue": bool(getattr(ops, "_fused_gelu", False)),
+        "token_major_io": bool(getattr(ops, "v_in_place", False)),     # v read in place, o written token-major (svg_attn_layout_t)
         "gemm_backend": gemm_backend_info(),
     }
     if world > 1:
@@ -625,6 +628,7 @@ class WanHipOps:
 
         nat.load()
         self.nat, self.core, self.geo, self.first_layers_fp = nat, core, geo, first_layers_fp
+        core.TOKEN_MAJOR_IO = bool(int(os.environ.get("SVG_STEP_TOKEN_MAJOR_IO", "1") or 1))   # 0: the copies of the reference's processors (A/B)
         self.cgeo = core.Geometry(0, geo.F, geo.P)
         self.store = core.CentroidStore()       # per-layer centroids: 50 iterations on a layer's first sparse call, 2 warm-started ones after
         self.logging_file = None                # set: the sparse layers append their block-map densities (the processors' logging_file)
@@ -862,10 +866,12 @@ def measure_wan(steps: int = 2, warmup: int = 1, geo: WanGeo = WAN720P, rank: in
                     f"min_kc_ratio {geo.min_kc_ratio}, {geo.iter_step} warm-started k-means iterations per layer and step)",
         "steps": steps, "warmup": warmup, "n_gpus": world,
         "step_breakdown_sections": "glue = LayerNorm + modulate / gate-residual kernels (libsvgattn); prologue = RMSNorm across heads, complex "
-                                   "RoPE + head-major transpose, output transpose; self_attention = k-means + block map + variable-block "
+                                   "RoPE + head-major transpose of q and k (v and o: in the projection layout when `token_major_io`, else a "
+                                   "transpose copy each), RMSNorm of the cross-attention q / k; self_attention = k-means + block map + variable-block "
                                    "attention (sparse layers) or the dense kernel; cross_attention = torch SDPA over the text tokens; gemm = "
                                    "torch.addmm (hipBLASLt), GELU in the epilogue where available; exchange = RCCL all-to-alls (N > 1)",
         "gelu_in_gemm_epilogue": bool(getattr(ops, "_fused_gelu", False)),
+        "token_major_io": bool(getattr(ops, "v_in_place", False)),     # v read in place, o written token-major (svg_attn_layout_t)
         "not_modelled": "patch / time / text embedders, final layer, scheduler, text encoder, VAE",
         "data": "synthetic: hidden states = 64-mode Gaussian mixture (centres x 1.5, spread 0.35, bench_svg2.py's statistics), QK-norm weights ~1.5, "
                 + ("rotary table = real positions" if st.rope == "real" else "rotary table at angle 0 (the RoPE kernel runs unchanged; random projection "
