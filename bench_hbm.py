@@ -121,6 +121,29 @@ def measure(size: str = "full", reps: int = 10, device: int = 0) -> dict:
         "svg/kernels/triton/modulate.py:91-160 (triton_modulate_gate_residual_forward), svg/models/wan/custom_models.py:60")
     del hs, att
     torch.cuda.empty_cache()
+    # ---- Wan 2.1 self-attention prologue (f1): RMSNorm across all heads + complex RoPE + head-major transpose in ONE pass; with v and o in the
+    #      projection layout (svg_attn_layout_t) only q and k go through it ----
+    qin, kin, vin = (torch.randn(1, Sw, hid, device=dev, dtype=dt) for _ in range(3))
+    qw, kw = (torch.randn(hid, device=dev).mul(0.2).add(1.5).to(dt) for _ in range(2))
+    fr, fi = torch.randn(Sw, Dw // 2, device=dev), torch.randn(Sw, Dw // 2, device=dev)
+    rope_bytes = 2 * Sw * (Dw // 2) * 4
+
+    def three_pass():
+        qn, kn = nat.rmsnorm_forward(qin, qw, 1e-6), nat.rmsnorm_forward(kin, kw, 1e-6)
+        nat.qk_norm_rope_transpose(qn, kn, Hw, Hw, 0, None, None, None, None, 1e-6, 2, fr, fi, 0, Sw)
+        nat.qk_norm_rope_transpose(vin, None, Hw, 0)
+
+    ms3 = _time(three_pass, reps)
+    pro = f"Wan 2.1 {'720p' if size == 'full' else 'toy'} q / k / v projections [1, {Sw}, {hid}] bf16 -> [1, {Hw}, {Sw}, {Dw}]"
+    rec("wan_rmsnorm_rope_transpose_qkv", "rmsall_rope_transpose_kernel (svg_rmsnorm_rope_transpose: q, k, v)", pro,
+        _time(lambda: nat.rmsnorm_rope_transpose(qin, kin, vin, Hw, qw, kw, 1e-6, 2, fr, fi, 0, Sw), reps), 6 * el * 2 + rope_bytes,
+        "svg/models/wan/attention.py:99-148 (get_qk_norm -> get_transpose_qkv -> get_rotary_emb: three passes)")
+    rows["wan_rmsnorm_rope_transpose_qkv"]["three_pass_sequence_ms"] = round(ms3, 4)
+    rec("wan_rmsnorm_rope_transpose_qk", "rmsall_rope_transpose_kernel (svg_rmsnorm_rope_transpose: q, k; v read in place by the attention kernels)", pro,
+        _time(lambda: nat.rmsnorm_rope_transpose(qin, kin, None, Hw, qw, kw, 1e-6, 2, fr, fi, 0, Sw), reps), 4 * el * 2 + rope_bytes,
+        "svg/models/wan/attention.py:123-125 with svg_attn_layout_t (one GPU): the value copy of get_transpose_qkv is not made")
+    del qin, kin, vin
+    torch.cuda.empty_cache()
     return {"what": "HBM-bound kernels of SURVEY §8(d): algorithmic bytes (rows read once + written once) / time", "size": size, "reps": reps,
             "peak_GBs": {"spec": PEAK_SPEC_GBS, "measured_copy_MI355X_MICROARCH": PEAK_COPY_GBS},
             "torch_copy_this_box": {"ms": round(ms_copy, 4), "GBs": round(copy_gbs, 1), "bytes": 2 * tensor_bytes},

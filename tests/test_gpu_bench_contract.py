@@ -183,7 +183,7 @@ def test_bench_svg2_measure_small(fp8):
 
 
 HBM_ROWS = ("placement_qkv", "inverse_placement_o", "qk_norm_rope_inplace", "qk_norm_rope_transpose", "label_sort", "svg2_gather",
-            "svg2_scatter", "layernorm_modulate", "modulate_gate_residual")
+            "svg2_scatter", "layernorm_modulate", "modulate_gate_residual", "wan_rmsnorm_rope_transpose_qkv", "wan_rmsnorm_rope_transpose_qk")
 
 
 def _check_hbm_block(block):
