@@ -114,6 +114,31 @@ def test_varblock_attention_strided_equals_contiguous(nat, hq, hkv, D, dtype):
         assert torch.equal(o3, ref)   # the partitions cover every row: no zero fill needed
 
 
+def test_varblock_rows_covered_with_keyless_block_rows(nat):
+    """rows_covered=True hands the kernel an uninitialised output: a block-row whose map row is empty (no key at all) still gets its tiles and
+    writes zeros, and so does a block-row whose only key blocks are empty clusters"""
+    S, D, H, MB, NB = 4096, 128, 2, 10, 16
+    gen = torch.Generator().manual_seed(9)
+    rsz = random_partition_batch(S, MB, H, gen)
+    csz = random_partition_batch(S, NB - 1, H, gen)
+    csz = torch.cat([csz, torch.zeros(H, 1, dtype=torch.int32)], dim=1)      # the last key cluster is empty
+    bmap = torch.rand(H, MB, NB, generator=gen) > 0.5
+    bmap[:, 3, :] = False                                                     # no key block at all
+    bmap[:, 6, :] = False
+    bmap[:, 6, NB - 1] = True                                                 # only the empty cluster
+    q, k, v = (dev(torch.randn(H, S, D, generator=gen).to(torch.bfloat16)) for _ in range(3))
+    args = (dev(bmap), dev(rsz), dev(csz))
+    ref = nat.varblock_attention(q, k, v, *args)                               # zero-filled output
+    poison = [dev(torch.full((H, S, D), float("nan")).to(torch.bfloat16)) for _ in range(3)]   # whatever torch.empty hands out next: NaNs
+    del poison
+    o = nat.varblock_attention(q, k, v, *args, rows_covered=True)
+    assert torch.equal(o, ref)
+    for h in range(H):
+        off = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), rsz[h].to(torch.int64)]), 0)
+        for i in (3, 6):
+            assert float(o[h, off[i]:off[i + 1]].float().abs().max()) == 0.0 if off[i + 1] > off[i] else True
+
+
 def test_varblock_uncovered_rows_stay_zero_when_strided(nat):
     """q_sizes that do not cover Sq: without rows_covered the wrapper zero-fills the token-major output like the contiguous one"""
     S, D, H = 2048, 128, 2
