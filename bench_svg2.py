@@ -98,7 +98,8 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
     # first call of a "layer": 50 k-means iterations from random points (reference: kmeans_iter_init = 50)
     e0, e1 = ev(), ev()
     e0.record()
-    _core.kmeans_clustering(store, 0, q[:, :, :V].contiguous(), k[:, :, :V].contiguous(), QC, KC, 50, 2)
+    # (the video tokens as views, like svg2_sparse_attention passes them: svg_kmeans_loop_strided reads heads S * D apart in place)
+    _core.kmeans_clustering(store, 0, q[:, :, :V], k[:, :, :V], QC, KC, 50, 2)
     e1.record()
     torch.cuda.synchronize()
     init_ms = e0.elapsed_time(e1)
@@ -107,8 +108,8 @@ def measure(workload="wan720p", steps=3, warmup=1, variant=-1, materialize=False
     dens = None
     for it in range(a.warmup + a.steps):
         t = [ev() for _ in range(4)]
-        qv = q[:, :, :V].contiguous() if ctx else q
-        kv = k[:, :, :V].contiguous() if ctx else k
+        qv = q[:, :, :V] if ctx else q
+        kv = k[:, :, :V] if ctx else k
         t[0].record()
         (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = _core.kmeans_clustering(store, 0, qv, kv, QC, KC, 50, 2)
         t[1].record()

@@ -310,6 +310,14 @@ size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t K, int32_t 
 int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
                     int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N, int32_t K,
                     int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace, size_t workspace_bytes, void* stream);
+/* svg_kmeans_loop on an x whose batches are `x_batch_stride` elements apart (rows of a batch contiguous, stride D): the video tokens of a
+ * [H, S, D] tensor with text tokens behind them — `q[:, :V]` — without the copy the reference makes (`query[:, :, :-context_length, :]`
+ * materialised by its Triton kernels' `.contiguous()`, svg/models/hyvideo/attention.py:592-599).  x_batch_stride >= N * D, a multiple of
+ * 8, x 16-byte aligned; no xsq argument (the assignment does not read |x|^2).  Same result as svg_kmeans_loop on the copy. */
+int svg_kmeans_loop_strided(const void* x, int64_t x_batch_stride, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
+                            int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
+                            int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Top-p block selection.

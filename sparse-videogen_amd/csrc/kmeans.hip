@@ -67,7 +67,7 @@ template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __restrict__ x, const T* __restrict__ cent,
                                                                     const float* __restrict__ xsq,
                                                                     const float* __restrict__ csq, int32_t* __restrict__ labels,
-                                                                    int N, int K) {
+                                                                    int N, int K, long long x_bs /* elements between the batches of x */) {
     using E = Elt<T>;
     using V8 = typename E::v8;
     using L = LdsLayout<D>;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64, 2) void kmeans_assign_kernel(const T* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int g = lane >> 5, ql = lane & 31;
     const int n = blockIdx.x * (NW * 32) + wave * 32 + ql;
-    const T* xb = x + (size_t)b * N * D;
+    const T* xb = x + (size_t)b * (size_t)x_bs;
     const T* cb = cent + (size_t)b * K * D;
     const float* csqb = csq + (size_t)b * K;
 
@@ -251,14 +251,14 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict_
                                                             T* __restrict__ c_new, const int32_t* __restrict__ sorted_idx,
                                                             const int32_t* __restrict__ offsets /* [B][nchunks][K], chunk 0 */,
                                                             const int32_t* __restrict__ counts, float* __restrict__ shift,
-                                                            int N, int K, size_t off_batch_stride) {
+                                                            int N, int K, size_t off_batch_stride, long long x_bs) {
     constexpr int LPR = D / 8;
     constexpr int SLOTS = 256 / LPR;
     __shared__ float red[SLOTS][D + 4];
     __shared__ float nrm[4];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int slot = tid / LPR, li = tid - slot * LPR;
-    const T* xb = x + (size_t)b * N * D;
+    const T* xb = x + (size_t)b * (size_t)x_bs;
     const int32_t* sidx_b = sorted_idx + (size_t)b * N;
     using V8 = typename Elt<T>::v8;
     int k = blockIdx.x;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const T* __restrict_
 // 375-421) as host functions of their own: svg_kmeans_iter runs one after the other, svg_kmeans_assign / svg_kmeans_update expose them
 template <typename T, int D>
 static int run_kmeans_assign(const void* x, const float* xsq, const void* c_in, int32_t* labels, int B, int N, int K, void* ws,
-                             hipStream_t st) {
+                             hipStream_t st, long long x_bs) {
     constexpr int NW = 8;
     float* csq = (float*)ws;
     hipLaunchKernelGGL((csq_kernel<T>), dim3(std::min<long long>(2048, ((long long)B * K + 15) / 16)), dim3(256), 0, st,
@@ -367,13 +367,13 @@ static int run_kmeans_assign(const void* x, const float* xsq, const void* c_in, 
     constexpr int lds = 2 * (LdsLayout<D>::kKBytes + kBN * 4);
     auto kern = kmeans_assign_kernel<T, D, NW>;
     hipLaunchKernelGGL(kern, dim3((N + NW * 32 - 1) / (NW * 32), B), dim3(NW * 64), lds, st, (const T*)x, (const T*)c_in, xsq,
-                       csq, labels, N, K);
+                       csq, labels, N, K, x_bs);
     return launch_status();
 }
 
 template <typename T, int D>
 static int run_kmeans_update(const void* x, const void* c_in, void* c_out, const int32_t* labels, int32_t* counts, int32_t* sorted_idx,
-                             float* shift, int B, int N, int K, void* ws, hipStream_t st) {
+                             float* shift, int B, int N, int K, void* ws, hipStream_t st, long long x_bs) {
     const size_t csq_bytes = ((size_t)B * K * sizeof(float) + 255) / 256 * 256;
     char* sort_ws = (char*)ws + csq_bytes;
     const size_t sort_bytes = svg_argsort_workspace_bytes(B, N, K);
@@ -389,17 +389,17 @@ static int run_kmeans_update(const void* x, const void* c_in, void* c_out, const
     if (const char* e = getenv("SVG_KMEANS_UPDATE_GROUPS")) groups = std::max(1, std::min(K, atoi(e)));
 #endif
     hipLaunchKernelGGL((kmeans_update_kernel<T, D>), dim3(groups, B), dim3(256), 0, st, (const T*)x, (const T*)c_in, (T*)c_out,
-                       sorted_idx, (const int32_t*)sort_ws, counts, shift, N, K, (size_t)nchunks * K);
+                       sorted_idx, (const int32_t*)sort_ws, counts, shift, N, K, (size_t)nchunks * K, x_bs);
     return launch_status();
 }
 
 template <typename T, int D>
 static int run_kmeans_iter(const void* x, const float* xsq, const void* c_in, void* c_out, int32_t* labels, int32_t* counts,
                            int32_t* sorted_idx, float* shift, int B, int N, int K, void* ws, size_t ws_bytes,
-                           hipStream_t st) {
+                           hipStream_t st, long long x_bs) {
     (void)ws_bytes;
-    if (const int rc = run_kmeans_assign<T, D>(x, xsq, c_in, labels, B, N, K, ws, st); rc != SVG_OK) return rc;
-    return run_kmeans_update<T, D>(x, c_in, c_out, labels, counts, sorted_idx, shift, B, N, K, ws, st);
+    if (const int rc = run_kmeans_assign<T, D>(x, xsq, c_in, labels, B, N, K, ws, st, x_bs); rc != SVG_OK) return rc;
+    return run_kmeans_update<T, D>(x, c_in, c_out, labels, counts, sorted_idx, shift, B, N, K, ws, st, x_bs);
 }
 
 // ---- the Lloyd loop on the device (svg_kmeans_loop): commit of one iteration's result under the reference's stopping rule ----
@@ -481,9 +481,11 @@ extern "C" size_t svg_kmeans_workspace_bytes(int32_t B, int32_t N, int32_t K, in
     return csq_bytes + svg_argsort_workspace_bytes(B, N, K);
 }
 
-extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, void* centroids_out,
-                               int32_t* labels, int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N,
-                               int32_t K, int32_t D, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+// one Lloyd iteration on x whose batches are x_bs elements apart (rows contiguous inside a batch): svg_kmeans_iter (x_bs = N * D) and the
+// iterations of svg_kmeans_loop[_strided]
+static int kmeans_iter_impl(const void* x, long long x_bs, const float* xsq, const void* centroids_in, void* centroids_out,
+                            int32_t* labels, int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N,
+                            int32_t K, int32_t D, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
     // (xsq may be NULL: the argmax form of the assignment does not use |x|^2 — see kmeans_assign_kernel; the parameter stays in the
     //  signature because the reference's distance form carries it, svg/kmeans_utils.py:704)
     if (!x || !centroids_in || !centroids_out || !labels || !counts || !sorted_idx || !shift || !workspace)
@@ -495,19 +497,26 @@ extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* cent
     if (dtype == SVG_DTYPE_BF16) {
         if (D == 128)
             return run_kmeans_iter<__bf16, 128>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
-                                                K, workspace, workspace_bytes, st);
+                                                K, workspace, workspace_bytes, st, x_bs);
         if (D == 64)
             return run_kmeans_iter<__bf16, 64>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K,
-                                               workspace, workspace_bytes, st);
+                                               workspace, workspace_bytes, st, x_bs);
     } else if (dtype == SVG_DTYPE_F16) {
         if (D == 128)
             return run_kmeans_iter<_Float16, 128>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
-                                                  K, workspace, workspace_bytes, st);
+                                                  K, workspace, workspace_bytes, st, x_bs);
         if (D == 64)
             return run_kmeans_iter<_Float16, 64>(x, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N,
-                                                 K, workspace, workspace_bytes, st);
+                                                 K, workspace, workspace_bytes, st, x_bs);
     }
     return SVG_ERR_UNSUPPORTED;
+}
+
+extern "C" int svg_kmeans_iter(const void* x, const float* xsq, const void* centroids_in, void* centroids_out,
+                               int32_t* labels, int32_t* counts, int32_t* sorted_idx, float* shift, int32_t B, int32_t N,
+                               int32_t K, int32_t D, int32_t dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return kmeans_iter_impl(x, (long long)N * D, xsq, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K, D, dtype,
+                            workspace, workspace_bytes, stream);
 }
 
 #define SVG_KM_DISPATCH(CALL)                                                                  \
@@ -527,7 +536,7 @@ extern "C" int svg_kmeans_assign(const void* x, const void* centroids, int32_t* 
     if (K > 8192) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_kmeans_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-#define SVG_KM_ASSIGN(T, DD) run_kmeans_assign<T, DD>(x, nullptr, centroids, labels, B, N, K, workspace, st)
+#define SVG_KM_ASSIGN(T, DD) run_kmeans_assign<T, DD>(x, nullptr, centroids, labels, B, N, K, workspace, st, (long long)N * DD)
     SVG_KM_DISPATCH(SVG_KM_ASSIGN)
 #undef SVG_KM_ASSIGN
 }
@@ -542,7 +551,7 @@ extern "C" int svg_kmeans_update(const void* x, const int32_t* labels, const voi
     if (K > 8192) return SVG_ERR_UNSUPPORTED;
     if (workspace_bytes < svg_kmeans_workspace_bytes(B, N, K, D)) return SVG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-#define SVG_KM_UPDATE(T, DD) run_kmeans_update<T, DD>(x, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K, workspace, st)
+#define SVG_KM_UPDATE(T, DD) run_kmeans_update<T, DD>(x, centroids_in, centroids_out, labels, counts, sorted_idx, shift, B, N, K, workspace, st, (long long)N * DD)
     SVG_KM_DISPATCH(SVG_KM_UPDATE)
 #undef SVG_KM_UPDATE
 }
@@ -556,10 +565,11 @@ extern "C" size_t svg_kmeans_loop_workspace_bytes(int32_t B, int32_t N, int32_t 
     return (it + 255) / 256 * 256 + 2 * a + c + sh + 256;
 }
 
-extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
-                               int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
-                               int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+// svg_kmeans_loop (x_bs = N * D) and svg_kmeans_loop_strided
+static int kmeans_loop_impl(const void* x, long long x_bs, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
+                            int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
+                            int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
+                            size_t workspace_bytes, void* stream) {
     if (!x || !c_init || !c_work_a || !c_work_b || !labels || !counts || !sorted_idx || !centroids_out || !n_iters || !workspace)
         return SVG_ERR_BAD_ARG;   // (xsq may be NULL, see svg_kmeans_iter)
     if (B <= 0 || N <= 0 || K <= 0 || max_iters <= 0) return SVG_ERR_BAD_ARG;
@@ -585,7 +595,7 @@ extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_in
     for (int it = 0; it < max_iters; ++it) {
         void* out = (it & 1) ? c_work_b : c_work_a;
         const int sel_out = (it & 1) ? 2 : 1;
-        const int rc = svg_kmeans_iter(x, xsq, cur, out, t_labels, t_counts, t_sorted, t_shift, B, N, K, D, dtype, it_ws, it_bytes, stream);
+        const int rc = kmeans_iter_impl(x, x_bs, xsq, cur, out, t_labels, t_counts, t_sorted, t_shift, B, N, K, D, dtype, it_ws, it_bytes, stream);
         if (rc != SVG_OK) return rc;
         hipLaunchKernelGGL(kmeans_commit_kernel, dim3(grid), dim3(256), 0, st, t_labels, t_sorted, t_counts, labels, sorted_idx, counts,
                            t_shift, state, bn, bk, B, tol, it, sel_cur, sel_out);
@@ -601,4 +611,21 @@ extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_in
                            (const _Float16*)c_work_b, (_Float16*)centroids_out, state, n8);
     if (hipMemcpyAsync(n_iters, state + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return SVG_ERR_LAUNCH;
     return launch_status();
+}
+
+extern "C" int svg_kmeans_loop(const void* x, const float* xsq, const void* c_init, void* c_work_a, void* c_work_b, int32_t* labels,
+                               int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters, int32_t B, int32_t N,
+                               int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    return kmeans_loop_impl(x, (long long)N * D, xsq, c_init, c_work_a, c_work_b, labels, counts, sorted_idx, centroids_out, n_iters, B, N, K, D,
+                            dtype, max_iters, tol, workspace, workspace_bytes, stream);
+}
+
+extern "C" int svg_kmeans_loop_strided(const void* x, int64_t x_batch_stride, const void* c_init, void* c_work_a, void* c_work_b,
+                                       int32_t* labels, int32_t* counts, int32_t* sorted_idx, void* centroids_out, int32_t* n_iters,
+                                       int32_t B, int32_t N, int32_t K, int32_t D, int32_t dtype, int32_t max_iters, float tol,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (x_batch_stride < (int64_t)N * D || x_batch_stride % 8 != 0 || ((size_t)x & 15) != 0) return x_batch_stride < (int64_t)N * D ? SVG_ERR_BAD_ARG : SVG_ERR_UNSUPPORTED;
+    return kmeans_loop_impl(x, (long long)x_batch_stride, nullptr, c_init, c_work_a, c_work_b, labels, counts, sorted_idx, centroids_out, n_iters,
+                            B, N, K, D, dtype, max_iters, tol, workspace, workspace_bytes, stream);
 }

@@ -172,6 +172,7 @@ SIGNATURES = {
     "svg_kmeans_update": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _SZ, _VP]),
     "svg_kmeans_loop_workspace_bytes": (_SZ, [_I32, _I32, _I32, _I32]),
     "svg_kmeans_loop": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _SZ, _VP]),
+    "svg_kmeans_loop_strided": (C.c_int, [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _F32, _VP, _SZ, _VP]),
     "svg_identify_dynamic_map": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _F32, _I32, _VP]),
     "svg_map_density": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
 }
@@ -846,10 +847,17 @@ def kmeans_loop(x: torch.Tensor, xsq: Optional[torch.Tensor], c_init: torch.Tens
     [B, K, D], counts int32 [B, K], n_iters int32 [] on the device, sorted_idx int32 [B, N]).  `work`: a WorkspaceCache (or None: fresh
     scratch per call) that keeps the scratch tensors of a (B, N, K, D) shape per device AND stream between calls."""
     lib = load()
-    _dev(x, xsq, c_init)
+    _dev(xsq, c_init)
+    _gpu(x)
     B, N, D = x.shape
     K = c_init.shape[1]
-    assert c_init.shape == (B, K, D) and c_init.dtype == x.dtype and c_init.is_contiguous() and x.is_contiguous()
+    assert c_init.shape == (B, K, D) and c_init.dtype == x.dtype and c_init.is_contiguous()
+    # x: contiguous, or batches further apart than N * D with contiguous rows inside (the video tokens `q[:, :V]` of a [H, S, D] tensor):
+    # svg_kmeans_loop_strided reads them in place
+    batch_strided = (not x.is_contiguous()) and x.stride(2) == 1 and x.stride(1) == D and x.stride(0) >= N * D and x.stride(0) % 8 == 0 \
+        and x.data_ptr() % 16 == 0
+    if not x.is_contiguous() and not batch_strided:
+        x = x.contiguous()
     key = WorkspaceCache.key("kmeans", B, N, K, D, x.dtype, device=x.device)
     w = None if work is None else work.get(key)
     if w is None:
@@ -862,6 +870,12 @@ def kmeans_loop(x: torch.Tensor, xsq: Optional[torch.Tensor], c_init: torch.Tens
     counts = torch.empty((B, K), dtype=torch.int32, device=x.device)
     cent = torch.empty_like(c_init)
     n_it = torch.zeros((), dtype=torch.int32, device=x.device)
+    if batch_strided:
+        rc = lib.svg_kmeans_loop_strided(x.data_ptr(), int(x.stride(0)), c_init.data_ptr(), w["ca"].data_ptr(), w["cb"].data_ptr(),
+                                         labels.data_ptr(), counts.data_ptr(), sorted_idx.data_ptr(), cent.data_ptr(), n_it.data_ptr(), B, N, K, D,
+                                         _dtype_code(x), int(max_iters), float(tol), w["ws"].data_ptr(), w["ws"].numel(), _stream())
+        _check(rc, "svg_kmeans_loop_strided")
+        return labels, cent, counts, n_it, sorted_idx
     rc = lib.svg_kmeans_loop(x.data_ptr(), _ptr(xsq), c_init.data_ptr(), w["ca"].data_ptr(), w["cb"].data_ptr(), labels.data_ptr(),
                              counts.data_ptr(), sorted_idx.data_ptr(), cent.data_ptr(), n_it.data_ptr(), B, N, K, D, _dtype_code(x),
                              int(max_iters), float(tol), w["ws"].data_ptr(), w["ws"].numel(), _stream())

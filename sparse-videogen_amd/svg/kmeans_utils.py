@@ -79,8 +79,11 @@ def batch_kmeans_Euclid(x, n_clusters, max_iters=100, tol=1e-4, init_centroids=N
     assert x.is_cuda, "batch_kmeans_Euclid requires GPU tensors"
     assert max_iters >= 1, "max_iters must be >= 1 (the reference raises NameError for 0)"
     B, N, D = x.shape
-    x = x.contiguous()
     loop_in_library = not check_every and shift_reduce is None and not verbose
+    # (the library loop reads batches that lie further apart than N * D in place — svg_kmeans_loop_strided: the video tokens of a
+    #  [H, S, D] tensor with text rows behind them; every other path takes the contiguous copy the reference makes)
+    if not (loop_in_library and x.dim() == 3 and x.stride(2) == 1 and x.stride(1) == D and x.stride(0) >= N * D):
+        x = x.contiguous()
     st = None
     if not loop_in_library:     # (the svg_kmeans_loop path keeps its own scratch: no KMeansState for it)
         key = _native.WorkspaceCache.key(B, N, n_clusters, D, x.dtype, device=x.device)

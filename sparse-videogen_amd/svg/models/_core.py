@@ -331,8 +331,11 @@ def svg2_sparse_attention(q, k, v, geo: Geometry, store: CentroidStore, layer_id
     assert not geo.text_first, "SVG2 is defined for text-last models (Hunyuan, Wan)"
     V, ctx = geo.video_length, geo.context_length
     q, k = q.contiguous(), k.contiguous()   # (the k-means reads them as [H, N, D]; v may stay a strided view: only the attention kernel reads it)
-    qv = q[:, :, :V].contiguous() if ctx else q
-    kv = k[:, :, :V].contiguous() if ctx else k
+    # the video tokens as VIEWS when the loop runs inside the library (svg_kmeans_loop_strided reads heads S * D apart in place); the
+    # head-sharded path (torch statement of the loop, all-reduced stopping rule) takes the copies the reference makes
+    in_place = ctx and cfg == 1 and _head_shard is None and not _dist.active()
+    qv = (q[:, :, :V] if in_place else q[:, :, :V].contiguous()) if ctx else q
+    kv = (k[:, :, :V] if in_place else k[:, :, :V].contiguous()) if ctx else k
     with time_logging_decorator("Level 3 - semantic aware permutation"):
         (ql, qc, qs, _, qidx), (kl, kc, ks, _, kidx) = kmeans_clustering(store, layer_idx, qv, kv, num_q_centroids,
                                                                          num_k_centroids, iter_init, iter_step,

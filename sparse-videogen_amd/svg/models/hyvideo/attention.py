@@ -322,8 +322,8 @@ class Hunyuan_SAPAttn_Processor2_0(Hunyuan_SVGAttn_Processor2_0):
         if _core.is_full_attention(self.layer_idx, timestep, self.first_layers_fp, self.first_times_fp):
             if self.zero_step_kmeans_init and query.is_cuda:
                 V = geo.video_length
-                _core.kmeans_clustering(self.centroid_store, layer_idx, query[:, :, :V].contiguous(),
-                                        key[:, :, :V].contiguous(), self.num_q_centroids, self.num_k_centroids,
+                _core.kmeans_clustering(self.centroid_store, layer_idx, query[:, :, :V], key[:, :, :V],   # (views: read in place)
+                                        self.num_q_centroids, self.num_k_centroids,
                                         self.kmeans_iter_init, self.kmeans_iter_step)
             valid = cu_max_seqlens[0] if cu_max_seqlens is not None and cu_max_seqlens[0] is not None else (
                 geo.video_length + self.prompt_length)

@@ -276,3 +276,61 @@ def test_core_svg2_token_major_io(nat, monkeypatch):
         torch.manual_seed(0)       # (the first call of a layer draws its initial centroids from the global generator)
         outs[on] = _core.svg2_sparse_attention(q, k, v if on else v.contiguous(), geo, store, 0, 16, 32, 0.9, 0.1, 3, 2)
     assert _is_token_major(outs[True]) and torch.equal(outs[True], outs[False]) and torch.isfinite(outs[True].float()).all()
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_kmeans_loop_batch_strided_equals_contiguous(nat, D):
+    """svg_kmeans_loop_strided: the video tokens `x[:, :V]` of a [H, S, D] tensor read in place (heads S * D apart) == the loop on the
+    contiguous copy the reference makes (svg/models/hyvideo/attention.py:592-599), bit for bit; through batch_kmeans_Euclid as well"""
+    from svg.kmeans_utils import batch_kmeans_Euclid
+
+    H, S, V, K = 3, 2304, 2048, 24
+    g = torch.Generator().manual_seed(3)
+    cent = torch.randn(8, D, generator=g) * 1.5
+    full = dev((cent[torch.randint(0, 8, (H, S), generator=g)] + 0.35 * torch.randn(H, S, D, generator=g)).to(torch.bfloat16))
+    xv = full[:, :V]                       # [H, V, D], stride (S * D, D, 1)
+    assert not xv.is_contiguous()
+    c0 = xv[:, :K].contiguous()
+    for iters in (1, 2, 5):
+        ref = nat.kmeans_loop(xv.contiguous(), None, c0, iters, 1e-4)
+        got = nat.kmeans_loop(xv, None, c0, iters, 1e-4)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), iters
+    a = batch_kmeans_Euclid(xv, K, max_iters=3, init_centroids=c0, return_sorted_indices=True, check_every=0)
+    b = batch_kmeans_Euclid(xv.contiguous(), K, max_iters=3, init_centroids=c0, return_sorted_indices=True, check_every=0)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # a batch stride below N * D or not a multiple of 8 elements is refused
+    import ctypes as C
+
+    lib = nat.load()
+    z = dev(torch.zeros(64, dtype=torch.uint8))
+    args = (c0.data_ptr(), c0.data_ptr(), c0.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), c0.data_ptr(), z.data_ptr(), H, V, K, D, 0, 1, 1e-4,
+            z.data_ptr(), 64, torch.cuda.current_stream().cuda_stream)
+    assert lib.svg_kmeans_loop_strided(xv.data_ptr(), V * D - 8, *args) == -1
+    assert lib.svg_kmeans_loop_strided(xv.data_ptr(), S * D + 4, *args) == -2
+
+
+def test_core_svg2_video_tokens_in_place(nat, monkeypatch):
+    """svg2_sparse_attention on a text-last model (HunyuanVideo): the k-means reads the video tokens of q and k as views — same output as
+    with the copies (the head-sharded path's form), bit for bit"""
+    from svg.models import _core
+
+    F_, P_, ctx, L, D, H = 4, 512, 64, 20, 128, 2
+    V = F_ * P_
+    S = V + ctx
+    geo = _core.Geometry(ctx, F_, P_)
+    g = torch.Generator().manual_seed(43)
+    cent = torch.randn(8, H * D, generator=g) * 1.5
+    x = cent[torch.randint(0, 8, (S,), generator=g)] + 0.35 * torch.randn(S, H * D, generator=g)
+    q, k, v = (dev((x @ torch.randn(H * D, H * D, generator=g) / (H * D) ** 0.5)[None].to(torch.bfloat16)).unflatten(2, (H, D)).transpose(1, 2)
+               for _ in range(3))
+    q, k = q.contiguous(), k.contiguous()
+    outs = []
+    real_loop = nat.kmeans_loop
+    for copies in (False, True):
+        if copies:   # what the path did before: contiguous copies of the video tokens
+            monkeypatch.setattr(nat, "kmeans_loop", lambda xx, *a, **kw: real_loop(xx.contiguous(), *a, **kw))
+        store = _core.CentroidStore()
+        torch.manual_seed(0)
+        outs.append(_core.svg2_sparse_attention(q, k, v, geo, store, 0, 12, 24, 0.9, 0.1, 3, 2, prompt_length=L))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
